@@ -1,0 +1,51 @@
+"""ctypes binding of libovis_hip.so (C ABI: include/ovis_hip.h).  No torch types cross it."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libovis_hip.so")
+
+OVIS_OK = 0
+_ERRORS = {-1: "OVIS_EINVAL (bad size or null pointer)",
+           -2: "OVIS_ENOSPC (workspace too small)",
+           -3: "OVIS_ERANGE (problem size not supported by the kernel)"}
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/ovis_hip.h declares
+SIGNATURES = {
+    "ovis_version": (ctypes.c_char_p, []),
+    "ovis_roi_align_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "ovis_roi_align_backward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "ovis_nms_workspace_bytes": (_sz, [_i]),
+    "ovis_nms_f32": (_i, [_vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp]),
+    "ovis_sigmoid_focal_loss_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),
+    "ovis_sigmoid_focal_loss_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(make -C cvpr22_cross_modal_pseudo_labeling_amd/csrc). There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc == OVIS_OK:
+        return
+    if rc < 0:
+        raise RuntimeError(f"{what}: {_ERRORS.get(rc, rc)}")
+    raise RuntimeError(f"{what}: HIP error {rc}")

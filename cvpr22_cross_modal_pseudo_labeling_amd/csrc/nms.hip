@@ -1,0 +1,237 @@
+// Greedy IoU non-maximum suppression for gfx950 (MI355X), fully device-resident.
+//
+// Reference behaviour: maskrcnn_benchmark/csrc/cuda/nms.cu:13-131 (64x64 IoU bitmask tiles,
+// then a *host* loop over an 18 MB D2H copy of the mask) and csrc/nms.h:10-28.
+// Here the same bitmask formulation is kept (it makes the result bit-exact by construction:
+// the IoU expression below is devIoU's, evaluated with FP contraction off), but
+//   * the score sort is a device radix sort (stable: ties keep the lower index first),
+//   * the sorted boxes are gathered on the fly, only the upper triangle of tiles is computed,
+//   * the sequential reduce runs on the device in ONE 1024-lane workgroup: wave 0 resolves a
+//     64-box chunk from its diagonal tile with scalar bit tricks (wave64 == one mask word),
+//     then all 16 waves OR the surviving rows into the LDS-resident `removed` words,
+//   * survivors are compacted in ascending ORIGINAL index order through an LDS bitmap, so
+//     the reference's final index sort (nms.cu:127-130) is not needed.
+// Nothing is copied to the host; the caller reads back one int32 (the count) if it needs
+// a dense result tensor.
+#include <hipcub/hipcub.hpp>
+
+#include "ovis_common.h"
+
+namespace {
+
+constexpr int kTile = 64;          // == wavefront size == bits per mask word
+constexpr int kReduceThreads = 1024;
+constexpr int kMaxBlocks = 2048;   // K <= 131072 (keeps the reduce kernel under 64 KB of LDS)
+
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
+  unsigned lo = __builtin_amdgcn_readlane((unsigned)v, lane);
+  unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ void iota_kernel(int* idx, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) idx[i] = i;
+}
+
+// devIoU (nms.cu:13-21) with the operand roles of the reference: a = higher-scored box.
+__device__ __forceinline__ float iou_xyxy(const float4 a, const float4 b) {
+  const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
+  const float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
+  const float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
+  const float inter = width * height;
+  const float sa = (a.z - a.x + 1.f) * (a.w - a.y + 1.f);
+  const float sb = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
+  return inter / (sa + sb - inter);
+}
+
+// grid (nb, nb); block (row_blk = y, col_blk = x), tiles below the diagonal exit.
+template <bool GE>
+__global__ __launch_bounds__(kTile) void nms_mask_kernel(const float4* __restrict__ boxes,
+                                                         const int* __restrict__ order, int K,
+                                                         int nb, float thr,
+                                                         unsigned long long* __restrict__ mask) {
+  const int row_blk = blockIdx.y, col_blk = blockIdx.x;
+  if (row_blk > col_blk) return;
+  __shared__ float4 col_boxes[kTile];
+  const int lane = threadIdx.x;
+  const int col = col_blk * kTile + lane;
+  if (col < K) col_boxes[lane] = boxes[order[col]];
+  __syncthreads();
+  const int row = row_blk * kTile + lane;
+  if (row >= K) return;
+  const float4 a = boxes[order[row]];
+  const int ncol = min(K - col_blk * kTile, kTile);
+  unsigned long long bits = 0;
+  const int start = (row_blk == col_blk) ? lane + 1 : 0;
+  for (int j = start; j < ncol; ++j) {
+    const float v = iou_xyxy(a, col_boxes[j]);
+    const bool hit = GE ? (v >= thr) : (v > thr);
+    if (hit) bits |= 1ull << j;
+  }
+  mask[(size_t)row * nb + col_blk] = bits;
+}
+
+__global__ __launch_bounds__(kReduceThreads) void nms_reduce_kernel(
+    const unsigned long long* __restrict__ mask, const int* __restrict__ order, int K, int nb,
+    long long* __restrict__ keep_out, int* __restrict__ num_keep) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];
+  unsigned long long* removed = sm;        // [nb] suppression bits per sorted position
+  unsigned long long* keepw = sm + nb;     // [nb] survivors per sorted position
+  unsigned long long* obits = sm + 2 * nb; // [nb] survivors per ORIGINAL index
+  int* part = (int*)(sm + 3 * nb);         // [kReduceThreads] scan scratch
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < nb; i += kReduceThreads) { removed[i] = 0; obits[i] = 0; }
+  __syncthreads();
+
+  for (int b = 0; b < nb; ++b) {
+    if (wave == 0) {
+      const int row = b * kTile + lane;
+      const unsigned long long diag = row < K ? mask[(size_t)row * nb + b] : 0ull;
+      const int nvalid = min(K - b * kTile, kTile);
+      const unsigned long long valid = nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+      unsigned long long alive = uniform64(~removed[b] & valid);
+      unsigned long long keep = 0;
+      while (alive) {
+        const int i = __builtin_ctzll(alive);
+        keep |= 1ull << i;
+        alive &= ~(readlane64(diag, i) | (1ull << i));
+      }
+      if (lane == 0) keepw[b] = keep;
+    }
+    __syncthreads();
+    const unsigned long long keep = uniform64(keepw[b]);
+    if (keep != 0) {
+      for (int j0 = b + 1; j0 < nb; j0 += kTile) {
+        const int j = j0 + lane;
+        unsigned long long acc = 0, kk = keep;
+        int rank = 0;
+        while (kk) {
+          const int i = __builtin_ctzll(kk);
+          kk &= kk - 1;
+          if (((rank++) & 15) == wave && j < nb) acc |= mask[(size_t)(b * kTile + i) * nb + j];
+        }
+        if (acc) atomicOr(&removed[j], acc);
+      }
+    }
+    __syncthreads();
+  }
+
+  // survivors -> bitmap indexed by original box index (ascending order comes for free)
+  for (int p = tid; p < K; p += kReduceThreads) {
+    if ((keepw[p >> 6] >> (p & 63)) & 1ull) {
+      const int o = order[p];
+      atomicOr(&obits[o >> 6], 1ull << (o & 63));
+    }
+  }
+  __syncthreads();
+  // exclusive scan of per-thread popcounts over contiguous word segments
+  const int seg = (nb + kReduceThreads - 1) / kReduceThreads;
+  const int w0 = tid * seg, w1 = min(nb, w0 + seg);
+  int cnt = 0;
+  for (int w = w0; w < w1; ++w) cnt += __popcll(obits[w]);
+  part[tid] = cnt;
+  __syncthreads();
+  for (int off = 1; off < kReduceThreads; off <<= 1) {
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int pos = part[tid] - cnt;
+  for (int w = w0; w < w1; ++w) {
+    unsigned long long bits = obits[w];
+    while (bits) {
+      const int i = __builtin_ctzll(bits);
+      bits &= bits - 1;
+      keep_out[pos++] = (long long)w * 64 + i;
+    }
+  }
+  if (tid == kReduceThreads - 1) *num_keep = part[tid];
+}
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct NmsLayout {
+  size_t keys_out, idx_in, order, cub_temp, cub_bytes, mask, total;
+};
+
+int nms_layout(int K, NmsLayout* L) {
+  const size_t nb = (size_t)ovis_ceil_div(K, kTile);
+  size_t cub_bytes = 0;
+  hipError_t e = hipcub::DeviceRadixSort::SortPairsDescending(
+      nullptr, cub_bytes, (const float*)nullptr, (float*)nullptr, (const int*)nullptr,
+      (int*)nullptr, K);
+  if (e != hipSuccess) return (int)e;
+  size_t off = 0;
+  L->keys_out = off; off = align256(off + sizeof(float) * (size_t)K);
+  L->idx_in = off;   off = align256(off + sizeof(int) * (size_t)K);
+  L->order = off;    off = align256(off + sizeof(int) * (size_t)K);
+  L->cub_temp = off; off = align256(off + cub_bytes);
+  L->cub_bytes = cub_bytes;
+  L->mask = off;     off = align256(off + sizeof(unsigned long long) * (size_t)K * nb);
+  L->total = off;
+  return OVIS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ovis_nms_workspace_bytes(int num_boxes) {
+  if (num_boxes <= 0) return 0;
+  NmsLayout L;
+  if (nms_layout(num_boxes, &L) != OVIS_OK) return 0;
+  return L.total;
+}
+
+extern "C" int ovis_nms_f32(const float* boxes, const float* scores, int num_boxes,
+                            float threshold, int ge_mode, void* workspace,
+                            size_t workspace_bytes, int64_t* keep_out, int32_t* num_keep,
+                            void* stream) {
+  if (num_boxes < 0 || !num_keep) return OVIS_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (num_boxes == 0) {
+    OVIS_HIP_TRY(hipMemsetAsync(num_keep, 0, sizeof(int32_t), s));
+    return OVIS_OK;
+  }
+  if (!boxes || !scores || !keep_out || !workspace) return OVIS_EINVAL;
+  const int K = num_boxes;
+  const int nb = ovis_ceil_div(K, kTile);
+  if (nb > kMaxBlocks) return OVIS_ERANGE;
+  NmsLayout L;
+  int rc = nms_layout(K, &L);
+  if (rc != OVIS_OK) return rc;
+  if (workspace_bytes < L.total) return OVIS_ENOSPC;
+  char* ws = (char*)workspace;
+  float* keys_out = (float*)(ws + L.keys_out);
+  int* idx_in = (int*)(ws + L.idx_in);
+  int* order = (int*)(ws + L.order);
+  unsigned long long* mask = (unsigned long long*)(ws + L.mask);
+
+  hipLaunchKernelGGL(iota_kernel, dim3(ovis_ceil_div(K, 256)), dim3(256), 0, s, idx_in, K);
+  OVIS_LAUNCH_CHECK();
+  size_t cub_bytes = L.cub_bytes;
+  OVIS_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(
+      (void*)(ws + L.cub_temp), cub_bytes, scores, keys_out, (const int*)idx_in, order, K, 0,
+      32, s));
+  dim3 grid(nb, nb);
+  if (ge_mode)
+    hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(kTile), 0, s, (const float4*)boxes,
+                       order, K, nb, threshold, mask);
+  else
+    hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(kTile), 0, s, (const float4*)boxes,
+                       order, K, nb, threshold, mask);
+  OVIS_LAUNCH_CHECK();
+  const size_t lds = sizeof(unsigned long long) * 3 * (size_t)nb + sizeof(int) * kReduceThreads;
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(kReduceThreads), lds, s, mask, order, K,
+                     nb, (long long*)keep_out, num_keep);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}

@@ -1,0 +1,442 @@
+// RoIAlign forward / backward for gfx950 (MI355X), fp32, NCHW.
+//
+// Semantics follow the reference kernels
+//   forward : maskrcnn_benchmark/csrc/cuda/ROIAlign_cuda.cu:16-122  (CPU twin cpu/ROIAlign_cpu.cpp:18-219)
+//   backward: maskrcnn_benchmark/csrc/cuda/ROIAlign_cuda.cu:125-254
+// but the work decomposition is MI355X-first:
+//
+//  * one workgroup owns (RoI r, a tile of CPB channels). Blocks are ordered channel-tile
+//    major so the ~2000 co-resident blocks all read the same few channel planes, which
+//    stay in the XCD L2s; HBM sees each feature byte once.
+//  * the RoI's bounding window of the feature map is staged into LDS for a batch of up to
+//    16 channels with row-contiguous global reads; the four bilinear taps of every sample
+//    are LDS gathers, never global gathers.
+//  * lane <-> output bin. The sample geometry (tap offsets + weights) is computed once per
+//    (lane, sample) and reused across the channel batch held in registers, so the inner
+//    loop is 4 ds_read + 8 VALU per (sample, channel).
+//  * each output plane (pooled_h*pooled_w floats) is written by consecutive lanes:
+//    stores are wave-contiguous; the 0.8 MB/RoI output stream is the HBM roofline term.
+//
+// The translation unit is compiled with -ffp-contract=off: the forward then performs the
+// exact IEEE operation sequence of the reference CPU kernel and is bit-identical to it.
+#include "ovis_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kCPB = 32;            // channels per block (forward and backward)
+constexpr int kMaxBatch = 16;       // channels staged per LDS batch
+constexpr int kFwdLdsFloats = 4352; // 17 KB window budget (>= 50*84 C4 map for 1 channel)
+
+struct RoiGeom {
+  int b;
+  float start_w, start_h, bin_w, bin_h;
+  int gh, gw;
+  float count;
+  int wy0, wy1, wx0, wx1;  // inclusive feature-map window touched by valid samples
+  bool empty;
+};
+
+// One axis of the reference's bilinear set-up (ROIAlign_cuda.cu:22-50): returns false for a
+// coordinate outside [-1, size]; otherwise low/high cell and the two lerp weights.
+__device__ __forceinline__ bool axis_sample(float v, int size, int& lo, int& hi, float& l,
+                                            float& h) {
+  if (v < -1.0f || v > (float)size) return false;
+  if (v <= 0.f) v = 0.f;
+  lo = (int)v;
+  if (lo >= size - 1) {
+    hi = lo = size - 1;
+    v = (float)lo;
+  } else {
+    hi = lo + 1;
+  }
+  l = v - (float)lo;
+  h = 1.f - l;
+  return true;
+}
+
+__device__ __forceinline__ int axis_low(float v, int size) {
+  if (v <= 0.f) return 0;
+  int lo = (int)v;
+  return lo >= size - 1 ? size - 1 : lo;
+}
+
+__device__ __forceinline__ float sample_coord(float start, int p, float bin, int i, int g) {
+  // ROIAlign_cuda.cu:109,112: start + p*bin + (i + .5f)*bin / g
+  return start + (float)p * bin + ((float)i + .5f) * bin / (float)g;
+}
+
+__device__ __forceinline__ RoiGeom make_geom(const float* __restrict__ roi, float scale, int H,
+                                             int W, int PH, int PW, int sampling_ratio,
+                                             int batch) {
+  RoiGeom g;
+  g.b = (int)roi[0];
+  g.start_w = roi[1] * scale;
+  g.start_h = roi[2] * scale;
+  float end_w = roi[3] * scale;
+  float end_h = roi[4] * scale;
+  float roi_w = fmaxf(end_w - g.start_w, 1.f);
+  float roi_h = fmaxf(end_h - g.start_h, 1.f);
+  g.bin_h = roi_h / (float)PH;
+  g.bin_w = roi_w / (float)PW;
+  g.gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_h / (float)PH);
+  g.gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_w / (float)PW);
+  g.count = (float)(g.gh * g.gw);
+  // Sample coordinates are monotone in (p, i), so the first / last sample bound them all.
+  float y_first = sample_coord(g.start_h, 0, g.bin_h, 0, g.gh);
+  float y_last = sample_coord(g.start_h, PH - 1, g.bin_h, g.gh - 1, g.gh);
+  float x_first = sample_coord(g.start_w, 0, g.bin_w, 0, g.gw);
+  float x_last = sample_coord(g.start_w, PW - 1, g.bin_w, g.gw - 1, g.gw);
+  bool finite = isfinite(y_first) && isfinite(y_last) && isfinite(x_first) && isfinite(x_last);
+  g.empty = !finite || g.b < 0 || g.b >= batch || g.gh <= 0 || g.gw <= 0 ||
+            y_last < -1.f || y_first > (float)H || x_last < -1.f || x_first > (float)W;
+  if (!g.empty) {
+    g.wy0 = axis_low(fmaxf(y_first, -1.f), H);
+    g.wx0 = axis_low(fmaxf(x_first, -1.f), W);
+    g.wy1 = min(axis_low(fminf(y_last, (float)H), H) + 1, H - 1);
+    g.wx1 = min(axis_low(fminf(x_last, (float)W), W) + 1, W - 1);
+  } else {
+    g.wy0 = g.wx0 = 0;
+    g.wy1 = g.wx1 = -1;
+  }
+  return g;
+}
+
+// ---------------------------------------------------------------------------------------
+// Forward
+// ---------------------------------------------------------------------------------------
+
+// Pool NCS channels whose window (origin oy,ox; row stride rs; channel stride cs) starts at
+// `src` (LDS window or, for windows too large for LDS, the global plane itself).
+template <int NCS>
+__device__ __forceinline__ void fwd_pool(const float* src, int cs, int rs, int oy, int ox,
+                                         const RoiGeom& g, int H, int W, int PH, int PW,
+                                         float* __restrict__ out_c0) {
+  const int PHPW = PH * PW;
+  for (int bin = threadIdx.x; bin < PHPW; bin += kThreads) {
+    const int ph = bin / PW;
+    const int pw = bin - ph * PW;
+    float acc[NCS];
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) acc[c] = 0.f;
+    for (int iy = 0; iy < g.gh; ++iy) {
+      const float y = sample_coord(g.start_h, ph, g.bin_h, iy, g.gh);
+      int yl, yh;
+      float ly, hy;
+      if (!axis_sample(y, H, yl, yh, ly, hy)) continue;
+      const int ryl = (yl - oy) * rs, ryh = (yh - oy) * rs;
+      for (int ix = 0; ix < g.gw; ++ix) {
+        const float x = sample_coord(g.start_w, pw, g.bin_w, ix, g.gw);
+        int xl, xh;
+        float lx, hx;
+        if (!axis_sample(x, W, xl, xh, lx, hx)) continue;
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        const int o1 = ryl + (xl - ox), o2 = ryl + (xh - ox);
+        const int o3 = ryh + (xl - ox), o4 = ryh + (xh - ox);
+#pragma unroll
+        for (int c = 0; c < NCS; ++c) {
+          const float* p = src + c * cs;
+          acc[c] += w1 * p[o1] + w2 * p[o2] + w3 * p[o3] + w4 * p[o4];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) out_c0[(long)c * PHPW + bin] = acc[c] / g.count;
+  }
+}
+
+template <int NCS>
+__device__ __forceinline__ void fwd_batch_lds(float* win, const float* __restrict__ plane_c0,
+                                              int HW, int W, int H, const RoiGeom& g, int wh,
+                                              int ww, int PH, int PW,
+                                              float* __restrict__ out_c0) {
+  const int warea = wh * ww;
+  const float inv_ww = 1.f / (float)ww;
+  for (int idx = threadIdx.x; idx < warea; idx += kThreads) {
+    const int y = (int)(((float)idx + 0.5f) * inv_ww);
+    const int x = idx - y * ww;
+    const float* p = plane_c0 + (long)(g.wy0 + y) * W + (g.wx0 + x);
+    float v[NCS];
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) v[c] = p[(long)c * HW];
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) win[c * warea + idx] = v[c];
+  }
+  __syncthreads();
+  fwd_pool<NCS>(win, warea, ww, g.wy0, g.wx0, g, H, W, PH, PW, out_c0);
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_kernel(
+    const float* __restrict__ in, const float* __restrict__ rois, float* __restrict__ out,
+    int R, int batch, int C, int H, int W, int PH, int PW, float scale, int sampling_ratio) {
+  __shared__ float win[kFwdLdsFloats];
+  const int r = blockIdx.x % R;
+  const int ct = blockIdx.x / R;
+  const int c_begin = ct * kCPB;
+  const int c_end = min(C, c_begin + kCPB);
+  const int PHPW = PH * PW;
+  const int HW = H * W;
+  const RoiGeom g = make_geom(rois + (long)r * 5, scale, H, W, PH, PW, sampling_ratio, batch);
+  float* out_r = out + (long)r * C * PHPW;
+
+  if (g.empty) {
+    // every sample is out of range (or the RoI is malformed): the reference emits zeros
+    const int n = (c_end - c_begin) * PHPW;
+    for (int i = threadIdx.x; i < n; i += kThreads) out_r[(long)c_begin * PHPW + i] = 0.f;
+    return;
+  }
+  const int wh = g.wy1 - g.wy0 + 1, ww = g.wx1 - g.wx0 + 1;
+  const int warea = wh * ww;
+  const int cs_max = min(kMaxBatch, kFwdLdsFloats / warea);
+  const float* img = in + (long)g.b * C * HW;
+
+  int c = c_begin;
+  while (c < c_end) {
+    const int left = c_end - c;
+    const float* plane = img + (long)c * HW;
+    float* o = out_r + (long)c * PHPW;
+    const int n = min(left, cs_max);
+    if (n >= 16) {
+      fwd_batch_lds<16>(win, plane, HW, W, H, g, wh, ww, PH, PW, o);
+      c += 16;
+    } else if (n >= 8) {
+      fwd_batch_lds<8>(win, plane, HW, W, H, g, wh, ww, PH, PW, o);
+      c += 8;
+    } else if (n >= 4) {
+      fwd_batch_lds<4>(win, plane, HW, W, H, g, wh, ww, PH, PW, o);
+      c += 4;
+    } else if (n >= 2) {
+      fwd_batch_lds<2>(win, plane, HW, W, H, g, wh, ww, PH, PW, o);
+      c += 2;
+    } else if (n == 1) {
+      fwd_batch_lds<1>(win, plane, HW, W, H, g, wh, ww, PH, PW, o);
+      c += 1;
+    } else {
+      // window larger than the LDS budget (very large feature maps): gather from global
+      fwd_pool<1>(plane, HW, W, 0, 0, g, H, W, PH, PW, o);
+      c += 1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward
+//
+// Bilinear average pooling is separable: out = Ay * win * Ax^T with Ay[ph][y] the summed row
+// weights of bin-row ph's samples and Ax[pw][x] likewise.  The gradient of the window is
+// Ay^T * G * Ax / count, which each lane evaluates for ONE window cell as a short gather
+// over the (ph, pw) bins that touch it -- no atomics inside the tile.  One fp32 atomic per
+// (window cell, channel) then folds the RoI's window into grad_input, instead of the
+// reference's four atomics per (bin, sample, channel).
+// ---------------------------------------------------------------------------------------
+
+template <int NCS>
+__device__ __forceinline__ void bwd_batch(const float* Ay, const float* Ax, const int* phlo,
+                                          const int* phhi, const int* pwlo, const int* pwhi,
+                                          float* G, const float* __restrict__ gout_c0,
+                                          float* __restrict__ gin_c0, int HW, int W,
+                                          const RoiGeom& g, int wh, int ww, int PH, int PW) {
+  const int PHPW = PH * PW;
+  const int n = NCS * PHPW;
+  for (int i = threadIdx.x; i < n; i += kThreads) G[i] = gout_c0[i];
+  __syncthreads();
+  const int warea = wh * ww;
+  const float inv_ww = 1.f / (float)ww;
+  for (int idx = threadIdx.x; idx < warea; idx += kThreads) {
+    const int y = (int)(((float)idx + 0.5f) * inv_ww);
+    const int x = idx - y * ww;
+    const int p0 = phlo[y], p1 = phhi[y], q0 = pwlo[x], q1 = pwhi[x];
+    if (p1 < p0 || q1 < q0) continue;
+    float s[NCS];
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) s[c] = 0.f;
+    for (int ph = p0; ph <= p1; ++ph) {
+      const float ay = Ay[ph * wh + y];
+      for (int pw = q0; pw <= q1; ++pw) {
+        const float w = ay * Ax[pw * ww + x];
+        const float* gp = G + ph * PW + pw;
+#pragma unroll
+        for (int c = 0; c < NCS; ++c) s[c] += w * gp[c * PHPW];
+      }
+    }
+    float* dst = gin_c0 + (long)(g.wy0 + y) * W + (g.wx0 + x);
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) atomicAdd(dst + (long)c * HW, s[c] / g.count);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kThreads) void roi_align_bwd_kernel(
+    const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gin,
+    int R, int batch, int C, int H, int W, int PH, int PW, float scale, int sampling_ratio) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // layout: Ay[PH*H] | Ax[PW*W] | phlo[H] phhi[H] pwlo[W] pwhi[W] | G[kMaxBatch*PH*PW]
+  float* Ay = smem;
+  float* Ax = Ay + PH * H;
+  int* phlo = (int*)(Ax + PW * W);
+  int* phhi = phlo + H;
+  int* pwlo = phhi + H;
+  int* pwhi = pwlo + W;
+  float* G = (float*)(pwhi + W);
+
+  const int r = blockIdx.x % R;
+  const int ct = blockIdx.x / R;
+  const int c_begin = ct * kCPB;
+  const int c_end = min(C, c_begin + kCPB);
+  const int PHPW = PH * PW;
+  const int HW = H * W;
+  const RoiGeom g = make_geom(rois + (long)r * 5, scale, H, W, PH, PW, sampling_ratio, batch);
+  if (g.empty) return;
+  const int wh = g.wy1 - g.wy0 + 1, ww = g.wx1 - g.wx0 + 1;
+
+  for (int i = threadIdx.x; i < PH * wh; i += kThreads) Ay[i] = 0.f;
+  for (int i = threadIdx.x; i < PW * ww; i += kThreads) Ax[i] = 0.f;
+  for (int i = threadIdx.x; i < wh; i += kThreads) { phlo[i] = 0x7fffffff; phhi[i] = -1; }
+  for (int i = threadIdx.x; i < ww; i += kThreads) { pwlo[i] = 0x7fffffff; pwhi[i] = -1; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < PH * g.gh; t += kThreads) {
+    const int ph = t / g.gh, iy = t - ph * g.gh;
+    int yl, yh;
+    float ly, hy;
+    if (axis_sample(sample_coord(g.start_h, ph, g.bin_h, iy, g.gh), H, yl, yh, ly, hy)) {
+      yl -= g.wy0; yh -= g.wy0;
+      atomicAdd(&Ay[ph * wh + yl], hy);
+      atomicAdd(&Ay[ph * wh + yh], ly);
+      atomicMin(&phlo[yl], ph); atomicMax(&phhi[yl], ph);
+      atomicMin(&phlo[yh], ph); atomicMax(&phhi[yh], ph);
+    }
+  }
+  for (int t = threadIdx.x; t < PW * g.gw; t += kThreads) {
+    const int pw = t / g.gw, ix = t - pw * g.gw;
+    int xl, xh;
+    float lx, hx;
+    if (axis_sample(sample_coord(g.start_w, pw, g.bin_w, ix, g.gw), W, xl, xh, lx, hx)) {
+      xl -= g.wx0; xh -= g.wx0;
+      atomicAdd(&Ax[pw * ww + xl], hx);
+      atomicAdd(&Ax[pw * ww + xh], lx);
+      atomicMin(&pwlo[xl], pw); atomicMax(&pwhi[xl], pw);
+      atomicMin(&pwlo[xh], pw); atomicMax(&pwhi[xh], pw);
+    }
+  }
+  __syncthreads();
+
+  const float* go_r = gout + (long)r * C * PHPW;
+  float* gin_b = gin + (long)g.b * C * HW;
+  int c = c_begin;
+  while (c < c_end) {
+    const int left = c_end - c;
+    const float* go = go_r + (long)c * PHPW;
+    float* gi = gin_b + (long)c * HW;
+    if (left >= 16) {
+      bwd_batch<16>(Ay, Ax, phlo, phhi, pwlo, pwhi, G, go, gi, HW, W, g, wh, ww, PH, PW);
+      c += 16;
+    } else if (left >= 8) {
+      bwd_batch<8>(Ay, Ax, phlo, phhi, pwlo, pwhi, G, go, gi, HW, W, g, wh, ww, PH, PW);
+      c += 8;
+    } else if (left >= 4) {
+      bwd_batch<4>(Ay, Ax, phlo, phhi, pwlo, pwhi, G, go, gi, HW, W, g, wh, ww, PH, PW);
+      c += 4;
+    } else if (left >= 2) {
+      bwd_batch<2>(Ay, Ax, phlo, phhi, pwlo, pwhi, G, go, gi, HW, W, g, wh, ww, PH, PW);
+      c += 2;
+    } else {
+      bwd_batch<1>(Ay, Ax, phlo, phhi, pwlo, pwhi, G, go, gi, HW, W, g, wh, ww, PH, PW);
+      c += 1;
+    }
+  }
+}
+
+// Fallback for shapes whose separable tables do not fit LDS (huge maps / pooled sizes):
+// one lane per grad_output element scattering its samples with global atomics.
+__global__ __launch_bounds__(kThreads) void roi_align_bwd_scatter_kernel(
+    const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gin,
+    long total, int batch, int C, int H, int W, int PH, int PW, float scale,
+    int sampling_ratio) {
+  const int PHPW = PH * PW;
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (long)gridDim.x * kThreads) {
+    const int bin = (int)(i % PHPW);
+    const long rc = i / PHPW;
+    const int c = (int)(rc % C);
+    const int r = (int)(rc / C);
+    const int ph = bin / PW, pw = bin - ph * PW;
+    const RoiGeom g = make_geom(rois + (long)r * 5, scale, H, W, PH, PW, sampling_ratio, batch);
+    if (g.empty) continue;
+    float* plane = gin + ((long)g.b * C + c) * H * W;
+    const float top = gout[i];
+    for (int iy = 0; iy < g.gh; ++iy) {
+      int yl, yh;
+      float ly, hy;
+      if (!axis_sample(sample_coord(g.start_h, ph, g.bin_h, iy, g.gh), H, yl, yh, ly, hy)) continue;
+      for (int ix = 0; ix < g.gw; ++ix) {
+        int xl, xh;
+        float lx, hx;
+        if (!axis_sample(sample_coord(g.start_w, pw, g.bin_w, ix, g.gw), W, xl, xh, lx, hx)) continue;
+        atomicAdd(plane + yl * W + xl, top * (hy * hx) / g.count);
+        atomicAdd(plane + yl * W + xh, top * (hy * lx) / g.count);
+        atomicAdd(plane + yh * W + xl, top * (ly * hx) / g.count);
+        atomicAdd(plane + yh * W + xh, top * (ly * lx) / g.count);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ovis_roi_align_forward_f32(const float* input, const float* rois, float* output,
+                                          int num_rois, int batch, int channels, int height,
+                                          int width, int pooled_h, int pooled_w,
+                                          float spatial_scale, int sampling_ratio,
+                                          void* stream) {
+  if (num_rois < 0 || batch < 0 || channels < 0 || height <= 0 || width <= 0 ||
+      pooled_h <= 0 || pooled_w <= 0)
+    return OVIS_EINVAL;
+  if (num_rois == 0 || channels == 0) return OVIS_OK;  // empty output (ROIAlign_cuda.cu:278-281)
+  if (!input || !rois || !output) return OVIS_EINVAL;
+  const long n_ct = ovis_ceil_div(channels, kCPB);
+  const long blocks = n_ct * num_rois;
+  if (blocks > 0x7fffffffL) return OVIS_ERANGE;
+  hipLaunchKernelGGL(roi_align_fwd_kernel, dim3((unsigned)blocks), dim3(kThreads), 0,
+                     (hipStream_t)stream, input, rois, output, num_rois, batch, channels,
+                     height, width, pooled_h, pooled_w, spatial_scale, sampling_ratio);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}
+
+extern "C" int ovis_roi_align_backward_f32(const float* grad_output, const float* rois,
+                                           float* grad_input, int num_rois, int batch,
+                                           int channels, int height, int width, int pooled_h,
+                                           int pooled_w, float spatial_scale,
+                                           int sampling_ratio, void* stream) {
+  if (num_rois < 0 || batch < 0 || channels < 0 || height <= 0 || width <= 0 ||
+      pooled_h <= 0 || pooled_w <= 0)
+    return OVIS_EINVAL;
+  const size_t in_bytes = (size_t)batch * channels * height * width * sizeof(float);
+  if (in_bytes == 0) return OVIS_OK;
+  if (!grad_input) return OVIS_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  OVIS_HIP_TRY(hipMemsetAsync(grad_input, 0, in_bytes, s));  // at::zeros, ROIAlign_cuda.cu:316
+  if (num_rois == 0) return OVIS_OK;
+  if (!grad_output || !rois) return OVIS_EINVAL;
+  const size_t lds = sizeof(float) * ((size_t)pooled_h * height + (size_t)pooled_w * width +
+                                      2 * (size_t)(height + width) +
+                                      (size_t)kMaxBatch * pooled_h * pooled_w);
+  if (lds <= 64 * 1024) {
+    const long n_ct = ovis_ceil_div(channels, kCPB);
+    const long blocks = n_ct * num_rois;
+    if (blocks > 0x7fffffffL) return OVIS_ERANGE;
+    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, s,
+                       grad_output, rois, grad_input, num_rois, batch, channels, height, width,
+                       pooled_h, pooled_w, spatial_scale, sampling_ratio);
+  } else {
+    const long total = (long)num_rois * channels * pooled_h * pooled_w;
+    const long blocks = ovis_ceil_div(total, kThreads);
+    hipLaunchKernelGGL(roi_align_bwd_scatter_kernel,
+                       dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(kThreads), 0, s,
+                       grad_output, rois, grad_input, total, batch, channels, height, width,
+                       pooled_h, pooled_w, spatial_scale, sampling_ratio);
+  }
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}

@@ -1,0 +1,21 @@
+"""Operator API of ``maskrcnn_benchmark.layers`` (maskrcnn_benchmark/layers/__init__.py:23-46)."""
+from .batch_norm import FrozenBatchNorm2d
+from .misc import BatchNorm2d, Conv2d, ConvTranspose2d, interpolate
+from .nms import nms, nms_padded
+from .roi_align import ROIAlign, roi_align
+from .sigmoid_focal_loss import SigmoidFocalLoss
+from .smooth_l1_loss import smooth_l1_loss
+
+__all__ = [
+    "nms",
+    "nms_padded",
+    "roi_align",
+    "ROIAlign",
+    "smooth_l1_loss",
+    "Conv2d",
+    "ConvTranspose2d",
+    "interpolate",
+    "BatchNorm2d",
+    "FrozenBatchNorm2d",
+    "SigmoidFocalLoss",
+]

@@ -1,0 +1,28 @@
+"""``FrozenBatchNorm2d`` -- maskrcnn_benchmark/layers/batch_norm.py:6-31 (note: no epsilon).
+
+Same four buffers (``weight, bias, running_mean, running_var``) so reference checkpoints load
+unchanged.  ``fold()`` returns the per-channel (scale, shift) pair so a caller can fold the
+affine into the preceding convolution at load time instead of running it as a separate
+memory-bound pass."""
+import torch
+from torch import nn
+
+
+class FrozenBatchNorm2d(nn.Module):
+    def __init__(self, n):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+
+    def fold(self):
+        scale = self.weight * self.running_var.rsqrt()
+        shift = self.bias - self.running_mean * scale
+        return scale, shift
+
+    def forward(self, x):
+        scale, shift = self.fold()
+        if x.dtype != scale.dtype:
+            scale, shift = scale.to(x.dtype), shift.to(x.dtype)
+        return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)

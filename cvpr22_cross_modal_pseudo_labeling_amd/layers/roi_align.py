@@ -1,0 +1,48 @@
+"""``ROIAlign`` / ``roi_align`` -- same API as maskrcnn_benchmark/layers/roi_align.py:12-69."""
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.modules.utils import _pair
+
+from .. import _C
+from ._fp32 import float_function
+
+
+class _ROIAlign(Function):
+    @staticmethod
+    def forward(ctx, input, roi, output_size, spatial_scale, sampling_ratio):
+        ctx.save_for_backward(roi)
+        ctx.output_size = _pair(output_size)
+        ctx.spatial_scale = spatial_scale
+        ctx.sampling_ratio = sampling_ratio
+        ctx.input_shape = input.size()
+        return _C.roi_align_forward(input, roi, spatial_scale, ctx.output_size[0], ctx.output_size[1],
+                                    sampling_ratio)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        (rois,) = ctx.saved_tensors
+        bs, ch, h, w = ctx.input_shape
+        grad_input = _C.roi_align_backward(grad_output, rois, ctx.spatial_scale, ctx.output_size[0],
+                                           ctx.output_size[1], bs, ch, h, w, ctx.sampling_ratio)
+        return grad_input, None, None, None, None
+
+
+roi_align = _ROIAlign.apply
+
+
+class ROIAlign(nn.Module):
+    def __init__(self, output_size, spatial_scale, sampling_ratio):
+        super().__init__()
+        self.output_size = output_size
+        self.spatial_scale = spatial_scale
+        self.sampling_ratio = sampling_ratio
+
+    @float_function
+    def forward(self, input, rois):
+        return roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio)
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(output_size={self.output_size}, "
+                f"spatial_scale={self.spatial_scale}, sampling_ratio={self.sampling_ratio})")

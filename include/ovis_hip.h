@@ -1,0 +1,93 @@
+/*
+ * ovis_hip.h -- C ABI of libovis_hip.so, the MI355X (gfx950) native-op library behind
+ * the `maskrcnn_benchmark._C` operator surface of hbdat/cvpr22_cross_modal_pseudo_labeling.
+ *
+ * Conventions (every entry point):
+ *   - plain C linkage, raw DEVICE pointers + explicit sizes, no torch / ATen types;
+ *   - tensors are dense, contiguous, row-major (NCHW for feature maps);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     enqueued asynchronously on it, nothing here synchronises the host unless stated;
+ *   - return value: OVIS_OK (0) on success, a negative OVIS_E* code for an argument
+ *     error detected on the host, or a positive hipError_t if a HIP call failed.
+ *     Nothing throws across this boundary.
+ *
+ * Each declaration cites the reference interface (path:line under the reference repo,
+ * `mb/` = maskrcnn_benchmark/) whose behaviour it reproduces.
+ */
+#ifndef OVIS_HIP_H_
+#define OVIS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OVIS_OK 0
+#define OVIS_EINVAL (-1)    /* bad size / null pointer                     */
+#define OVIS_ENOSPC (-2)    /* caller workspace too small                  */
+#define OVIS_ERANGE (-3)    /* problem exceeds what the kernel supports    */
+
+/* Library / build identification. Returns a static NUL-terminated string such as
+ * "ovis_hip 0.1 gfx950". */
+const char* ovis_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * RoIAlign                                   mb/csrc/ROIAlign.h:11-46
+ *   forward : mb/csrc/cuda/ROIAlign_cuda.cu:65-122,257-299 (= cpu/ROIAlign_cpu.cpp:114-219)
+ *   backward: mb/csrc/cuda/ROIAlign_cuda.cu:178-254,302-346
+ * input  [batch, channels, height, width] f32
+ * rois   [num_rois, 5] f32 = (batch_index, x1, y1, x2, y2) in image pixels
+ * output [num_rois, channels, pooled_h, pooled_w] f32
+ * sampling_ratio <= 0 selects the adaptive grid ceil(roi_size / pooled_size).
+ * The forward follows the reference's operation order with FP contraction disabled, so
+ * it is bit-identical to the reference CPU kernel on finite inputs.
+ * ---------------------------------------------------------------------------------- */
+int ovis_roi_align_forward_f32(const float* input, const float* rois, float* output,
+                               int num_rois, int batch, int channels, int height,
+                               int width, int pooled_h, int pooled_w,
+                               float spatial_scale, int sampling_ratio, void* stream);
+
+/* grad_input [batch, channels, height, width] is fully overwritten (zero-filled, then
+ * accumulated into) by this call; the caller does not need to clear it. */
+int ovis_roi_align_backward_f32(const float* grad_output, const float* rois,
+                                float* grad_input, int num_rois, int batch,
+                                int channels, int height, int width, int pooled_h,
+                                int pooled_w, float spatial_scale, int sampling_ratio,
+                                void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * NMS                                        mb/csrc/nms.h:10-28, mb/csrc/cuda/nms.cu:13-131
+ * boxes [K,4] f32 xyxy (+1 pixel area convention), scores [K] f32.
+ * Greedy suppression in descending-score order (ties: lower index first) with the
+ * CUDA comparison `IoU > threshold` (nms.cu:60); set `ge_mode` != 0 for the CPU
+ * kernel's `>=` (cpu/nms_cpu.cpp:60).  Survivors are written to keep_out[0..n) as
+ * ASCENDING original indices (int64) and n to *num_keep (device int32), entirely on the
+ * device: no host round trip of the suppression mask.
+ * `workspace` is caller-provided device scratch of at least
+ * ovis_nms_workspace_bytes(K) bytes (256-byte aligned).
+ * ---------------------------------------------------------------------------------- */
+size_t ovis_nms_workspace_bytes(int num_boxes);
+int ovis_nms_f32(const float* boxes, const float* scores, int num_boxes, float threshold,
+                 int ge_mode, void* workspace, size_t workspace_bytes, int64_t* keep_out,
+                 int32_t* num_keep, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Sigmoid focal loss                         mb/csrc/SigmoidFocalLoss.h:10-41
+ *   kernels: mb/csrc/cuda/SigmoidFocalLoss_cuda.cu:21-58 (fwd), :62-101 (bwd)
+ * logits [num, num_classes] f32; targets [num] int32 (-1 ignore, 0 background,
+ * j+1 = positive for column j); losses / d_logits [num, num_classes] f32.
+ * ---------------------------------------------------------------------------------- */
+int ovis_sigmoid_focal_loss_forward_f32(const float* logits, const int32_t* targets,
+                                        float* losses, int num, int num_classes,
+                                        float gamma, float alpha, void* stream);
+int ovis_sigmoid_focal_loss_backward_f32(const float* logits, const int32_t* targets,
+                                         const float* d_losses, float* d_logits, int num,
+                                         int num_classes, float gamma, float alpha,
+                                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVIS_HIP_H_ */

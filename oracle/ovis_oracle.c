@@ -1,0 +1,230 @@
+/*
+ * ovis_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C, single-threaded CPU restatement of the reference's native hot ops.  It is the
+ * checker for the HIP kernels (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline
+ * leg); nothing in the product package may import, link or call it.
+ *
+ * Each function cites the reference source it follows (paths relative to the reference
+ * repo, maskrcnn_benchmark/csrc/...).  Pinning status (see DESIGN.md "Oracle"):
+ *   - roi_align_forward, nms       : pinned against the reference's own CPU kernels
+ *                                    (oracle/_ref build + tests/golden fixtures).
+ *   - sigmoid focal forward        : pinned against the reference's Python formula
+ *                                    layers/sigmoid_focal_loss.py:40-50 (fixtures); its
+ *                                    backward against autograd of that formula.
+ *   - roi_align_backward           : the reference has NO CPU implementation
+ *                                    (csrc/ROIAlign.h:44) and no tests -> "parity
+ *                                    unpinned" by reference vectors; pinned instead by the
+ *                                    adjoint identity <fwd(x), g> == <x, bwd(g)> in fp64.
+ *
+ * Build: `make -C oracle` -> oracle/libovis_oracle.so (gcc -O2, no -ffast-math, no FMA
+ * contraction so fp32 results follow the reference's operation order exactly).
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------ */
+/* RoIAlign. cuda/ROIAlign_cuda.cu:16-62 (bilinear_interpolate), :65-122 (forward),       */
+/* :125-175 (gradient weights), :178-254 (backward); cpu/ROIAlign_cpu.cpp:18-219.         */
+/* ------------------------------------------------------------------------------------ */
+
+#define DEFINE_ROI_ALIGN(T, SUFFIX, CEIL)                                                    \
+  static int axis_##SUFFIX(T v, int size, int* lo, int* hi, T* l, T* h) {                    \
+    if (v < (T)-1.0 || v > (T)size) return 0;                                                \
+    if (v <= 0) v = 0;                                                                       \
+    *lo = (int)v;                                                                            \
+    if (*lo >= size - 1) {                                                                   \
+      *hi = *lo = size - 1;                                                                  \
+      v = (T)*lo;                                                                            \
+    } else {                                                                                 \
+      *hi = *lo + 1;                                                                         \
+    }                                                                                        \
+    *l = v - (T)*lo;                                                                         \
+    *h = (T)1. - *l;                                                                         \
+    return 1;                                                                                \
+  }                                                                                          \
+                                                                                             \
+  void oracle_roi_align_forward_##SUFFIX(const T* in, const T* rois, T* out, int R, int N,   \
+                                         int C, int H, int W, int PH, int PW, T scale,       \
+                                         int sampling_ratio) {                               \
+    (void)N;                                                                                 \
+    for (int n = 0; n < R; ++n) {                                                            \
+      const T* roi = rois + (size_t)n * 5;                                                   \
+      int b = (int)roi[0];                                                                   \
+      T sw = roi[1] * scale, sh = roi[2] * scale, ew = roi[3] * scale, eh = roi[4] * scale;  \
+      T rw = ew - sw > (T)1. ? ew - sw : (T)1.;                                              \
+      T rh = eh - sh > (T)1. ? eh - sh : (T)1.;                                              \
+      T bh = rh / (T)PH, bw = rw / (T)PW;                                                    \
+      int gh = sampling_ratio > 0 ? sampling_ratio : (int)CEIL(rh / PH);                     \
+      int gw = sampling_ratio > 0 ? sampling_ratio : (int)CEIL(rw / PW);                     \
+      T count = (T)(gh * gw);                                                                \
+      for (int c = 0; c < C; ++c) {                                                          \
+        const T* plane = in + ((size_t)b * C + c) * H * W;                                   \
+        T* o = out + ((size_t)n * C + c) * PH * PW;                                          \
+        for (int ph = 0; ph < PH; ++ph)                                                      \
+          for (int pw = 0; pw < PW; ++pw) {                                                  \
+            T acc = 0;                                                                       \
+            for (int iy = 0; iy < gh; ++iy) {                                                \
+              T y = sh + ph * bh + (T)(iy + .5f) * bh / (T)gh;                               \
+              int yl, yh;                                                                    \
+              T ly, hy;                                                                      \
+              if (!axis_##SUFFIX(y, H, &yl, &yh, &ly, &hy)) continue;                        \
+              for (int ix = 0; ix < gw; ++ix) {                                              \
+                T x = sw + pw * bw + (T)(ix + .5f) * bw / (T)gw;                             \
+                int xl, xh;                                                                  \
+                T lx, hx;                                                                    \
+                if (!axis_##SUFFIX(x, W, &xl, &xh, &lx, &hx)) continue;                      \
+                T w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;                    \
+                acc += w1 * plane[yl * W + xl] + w2 * plane[yl * W + xh] +                   \
+                       w3 * plane[yh * W + xl] + w4 * plane[yh * W + xh];                    \
+              }                                                                              \
+            }                                                                                \
+            o[ph * PW + pw] = acc / count;                                                   \
+          }                                                                                  \
+      }                                                                                      \
+    }                                                                                        \
+  }                                                                                          \
+                                                                                             \
+  void oracle_roi_align_backward_##SUFFIX(const T* gout, const T* rois, T* gin, int R,       \
+                                          int N, int C, int H, int W, int PH, int PW,        \
+                                          T scale, int sampling_ratio) {                     \
+    memset(gin, 0, sizeof(T) * (size_t)N * C * H * W);                                       \
+    for (int n = 0; n < R; ++n) {                                                            \
+      const T* roi = rois + (size_t)n * 5;                                                   \
+      int b = (int)roi[0];                                                                   \
+      T sw = roi[1] * scale, sh = roi[2] * scale, ew = roi[3] * scale, eh = roi[4] * scale;  \
+      T rw = ew - sw > (T)1. ? ew - sw : (T)1.;                                              \
+      T rh = eh - sh > (T)1. ? eh - sh : (T)1.;                                              \
+      T bh = rh / (T)PH, bw = rw / (T)PW;                                                    \
+      int gh = sampling_ratio > 0 ? sampling_ratio : (int)CEIL(rh / PH);                     \
+      int gw = sampling_ratio > 0 ? sampling_ratio : (int)CEIL(rw / PW);                     \
+      T count = (T)(gh * gw);                                                                \
+      for (int c = 0; c < C; ++c) {                                                          \
+        T* plane = gin + ((size_t)b * C + c) * H * W;                                        \
+        const T* g = gout + ((size_t)n * C + c) * PH * PW;                                   \
+        for (int ph = 0; ph < PH; ++ph)                                                      \
+          for (int pw = 0; pw < PW; ++pw) {                                                  \
+            T top = g[ph * PW + pw];                                                         \
+            for (int iy = 0; iy < gh; ++iy) {                                                \
+              T y = sh + ph * bh + (T)(iy + .5f) * bh / (T)gh;                               \
+              int yl, yh;                                                                    \
+              T ly, hy;                                                                      \
+              if (!axis_##SUFFIX(y, H, &yl, &yh, &ly, &hy)) continue;                        \
+              for (int ix = 0; ix < gw; ++ix) {                                              \
+                T x = sw + pw * bw + (T)(ix + .5f) * bw / (T)gw;                             \
+                int xl, xh;                                                                  \
+                T lx, hx;                                                                    \
+                if (!axis_##SUFFIX(x, W, &xl, &xh, &lx, &hx)) continue;                      \
+                plane[yl * W + xl] += top * (hy * hx) / count;                               \
+                plane[yl * W + xh] += top * (hy * lx) / count;                               \
+                plane[yh * W + xl] += top * (ly * hx) / count;                               \
+                plane[yh * W + xh] += top * (ly * lx) / count;                               \
+              }                                                                              \
+            }                                                                                \
+          }                                                                                  \
+      }                                                                                      \
+    }                                                                                        \
+  }
+
+DEFINE_ROI_ALIGN(float, f32, ceilf)
+DEFINE_ROI_ALIGN(double, f64, ceil)
+
+/* ------------------------------------------------------------------------------------ */
+/* NMS. cuda/nms.cu:13-21 (devIoU), :23-67 (mask `>`), :106-130 (greedy reduce, ascending */
+/* index output); cpu/nms_cpu.cpp:37-66 (`>=`).  ge_mode selects the comparison.          */
+/* Returns the number of survivors; keep_out receives ascending original indices.         */
+/* ------------------------------------------------------------------------------------ */
+
+static void stable_order_desc(const float* s, int n, int* order) {
+  /* bottom-up merge sort on indices: descending score, ties keep the lower index first */
+  int* tmp = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  for (int i = 0; i < n; ++i) order[i] = i;
+  for (int width = 1; width < n; width *= 2) {
+    for (int lo = 0; lo < n; lo += 2 * width) {
+      int mid = lo + width < n ? lo + width : n, hi = lo + 2 * width < n ? lo + 2 * width : n;
+      int a = lo, b = mid, k = lo;
+      while (a < mid && b < hi) tmp[k++] = (s[order[b]] > s[order[a]]) ? order[b++] : order[a++];
+      while (a < mid) tmp[k++] = order[a++];
+      while (b < hi) tmp[k++] = order[b++];
+    }
+    memcpy(order, tmp, sizeof(int) * (size_t)n);
+  }
+  free(tmp);
+}
+
+int oracle_nms_f32(const float* boxes, const float* scores, int K, float thr, int ge_mode,
+                   int64_t* keep_out) {
+  if (K <= 0) return 0;
+  int* order = (int*)malloc(sizeof(int) * (size_t)K);
+  unsigned char* dead = (unsigned char*)calloc((size_t)K, 1);
+  stable_order_desc(scores, K, order);
+  for (int _i = 0; _i < K; ++_i) {
+    int i = order[_i];
+    if (dead[i]) continue;
+    const float* a = boxes + (size_t)i * 4;
+    float sa = (a[2] - a[0] + 1) * (a[3] - a[1] + 1);
+    for (int _j = _i + 1; _j < K; ++_j) {
+      int j = order[_j];
+      if (dead[j]) continue;
+      const float* b = boxes + (size_t)j * 4;
+      float left = a[0] > b[0] ? a[0] : b[0], right = a[2] < b[2] ? a[2] : b[2];
+      float top = a[1] > b[1] ? a[1] : b[1], bottom = a[3] < b[3] ? a[3] : b[3];
+      float w = right - left + 1 > 0.f ? right - left + 1 : 0.f;
+      float h = bottom - top + 1 > 0.f ? bottom - top + 1 : 0.f;
+      float inter = w * h;
+      float sb = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+      float ovr = inter / (sa + sb - inter);
+      if (ge_mode ? (ovr >= thr) : (ovr > thr)) dead[j] = 1;
+    }
+  }
+  int n = 0;
+  for (int i = 0; i < K; ++i)
+    if (!dead[i]) keep_out[n++] = i;
+  free(order);
+  free(dead);
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Sigmoid focal loss. cuda/SigmoidFocalLoss_cuda.cu:21-58 (forward), :62-101 (backward). */
+/* ------------------------------------------------------------------------------------ */
+
+void oracle_sigmoid_focal_loss_forward_f32(const float* logits, const int32_t* targets,
+                                           float* losses, int num, int C, float gamma,
+                                           float alpha) {
+  for (long i = 0; i < (long)num * C; ++i) {
+    int n = (int)(i / C), d = (int)(i % C), t = targets[n];
+    float c1 = (t == d + 1), c2 = (t >= 0 && t != d + 1);
+    float zn = 1.0f - alpha, zp = alpha, x = logits[i];
+    float p = 1.f / (1.f + expf(-x));
+    float term1 = powf(1.f - p, gamma) * logf(p > FLT_MIN ? p : FLT_MIN);
+    float pos = x >= 0;
+    float term2 = powf(p, gamma) * (-1.f * x * pos - logf(1.f + expf(x - 2.f * x * pos)));
+    float l = 0.f;
+    l += -c1 * term1 * zp;
+    l += -c2 * term2 * zn;
+    losses[i] = l;
+  }
+}
+
+void oracle_sigmoid_focal_loss_backward_f32(const float* logits, const int32_t* targets,
+                                            const float* d_losses, float* d_logits, int num,
+                                            int C, float gamma, float alpha) {
+  for (long i = 0; i < (long)num * C; ++i) {
+    int n = (int)(i / C), d = (int)(i % C), t = targets[n];
+    float c1 = (t == d + 1), c2 = (t >= 0 && t != d + 1);
+    float zn = 1.0f - alpha, zp = alpha, x = logits[i];
+    float p = 1.f / (1.f + expf(-x));
+    float term1 = powf(1.f - p, gamma) * (1.f - p - (p * gamma * logf(p > FLT_MIN ? p : FLT_MIN)));
+    float pos = x >= 0;
+    float term2 = powf(p, gamma) *
+                  ((-1.f * x * pos - logf(1.f + expf(x - 2.f * x * pos))) * (1.f - p) * gamma - p);
+    float g = 0.f;
+    g += -c1 * term1 * zp;
+    g += -c2 * term2 * zn;
+    d_logits[i] = g * d_losses[i];
+  }
+}

@@ -1,0 +1,217 @@
+"""GPU parity: HIP kernels (through the C ABI, via cvpr22_cross_modal_pseudo_labeling_amd._C) against
+the golden vectors made from the reference and against the CPU oracle on seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def C():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+
+    return _C
+
+
+def _rois(g, r, n_img, img_w, img_h, wmin, wmax):
+    b = torch.randint(0, n_img, (r, 1), generator=g).float()
+    x1 = torch.rand(r, 1, generator=g) * (img_w * 0.8)
+    y1 = torch.rand(r, 1, generator=g) * (img_h * 0.8)
+    w = torch.rand(r, 1, generator=g) * (wmax - wmin) + wmin
+    h = torch.rand(r, 1, generator=g) * (wmax - wmin) + wmin
+    return torch.cat([b, x1, y1, (x1 + w).clamp(max=img_w - 1), (y1 + h).clamp(max=img_h - 1)], 1)
+
+
+# ---------------------------------------------------------------- RoIAlign forward
+def test_roi_align_forward_golden_bit_exact(C, golden_dir):
+    z = np.load(os.path.join(golden_dir, "roi_align_forward.npz"))
+    x, rois, scale = torch.from_numpy(z["input"]).cuda(), torch.from_numpy(z["rois"]).cuda(), float(z["scale"])
+    for key, (ph, pw, sr) in {"out_sr0": (14, 14, 0), "out_sr2": (14, 14, 2), "out_7x7_sr0": (7, 7, 0)}.items():
+        got = C.roi_align_forward(x, rois, scale, ph, pw, sr).cpu()
+        assert torch.equal(got, torch.from_numpy(z[key])), key  # bit-exact vs the reference CPU kernel
+
+
+@pytest.mark.parametrize("shape", [(2, 70, 50, 84, 300, 14), (1, 33, 13, 17, 40, 7), (3, 16, 100, 168, 64, 14)])
+def test_roi_align_forward_vs_oracle(C, oracle_mod, shape):
+    n, c, h, w, r, p = shape
+    g = torch.Generator().manual_seed(n * 1000 + c)
+    x = torch.randn(n, c, h, w, generator=g)
+    rois = _rois(g, r, n, w * 16, h * 16, 4, min(w, h) * 16)
+    want = oracle_mod.roi_align_forward(x, rois, 1 / 16, p, p, 0)
+    got = C.roi_align_forward(x.cuda(), rois.cuda(), 1 / 16, p, p, 0).cpu()
+    assert torch.equal(got, want)
+
+
+def test_roi_align_forward_large_map_global_path(C, oracle_mod):
+    # 120x160 = 19200-cell window for the whole-image RoI: exceeds the LDS window budget
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 3, 120, 160, generator=g)
+    rois = torch.tensor([[0, 0.0, 0.0, 2559.0, 1919.0], [0, 100.0, 50.0, 2000.0, 1800.0], [0, 5.0, 5.0, 60.0, 70.0]])
+    want = oracle_mod.roi_align_forward(x, rois, 1 / 16, 14, 14, 0)
+    got = C.roi_align_forward(x.cuda(), rois.cuda(), 1 / 16, 14, 14, 0).cpu()
+    assert torch.equal(got, want)
+
+
+def test_roi_align_empty(C):
+    x = torch.randn(2, 4, 8, 8, device="cuda")
+    out = C.roi_align_forward(x, torch.zeros(0, 5, device="cuda"), 0.25, 7, 7, 2)
+    assert out.shape == (0, 4, 7, 7)
+    gin = C.roi_align_backward(torch.zeros(0, 4, 7, 7, device="cuda"), torch.zeros(0, 5, device="cuda"), 0.25, 7, 7,
+                               2, 4, 8, 8, 2)
+    assert gin.shape == (2, 4, 8, 8) and float(gin.abs().sum()) == 0.0
+
+
+# ---------------------------------------------------------------- RoIAlign backward
+@pytest.mark.parametrize("shape,sr", [((2, 40, 50, 84, 200, 14), 0), ((2, 8, 25, 42, 64, 14), 2),
+                                      ((1, 5, 13, 17, 30, 7), 0)])
+def test_roi_align_backward_vs_oracle(C, oracle_mod, shape, sr):
+    n, c, h, w, r, p = shape
+    g = torch.Generator().manual_seed(17 + c)
+    rois = _rois(g, r, n, w * 16, h * 16, 4, min(w, h) * 16)
+    go = torch.randn(r, c, p, p, generator=g)
+    want = oracle_mod.roi_align_backward(go.double(), rois, 1 / 16, p, p, n, c, h, w, sr, dtype=torch.float64)
+    want32 = oracle_mod.roi_align_backward(go, rois, 1 / 16, p, p, n, c, h, w, sr)
+    got = C.roi_align_backward(go.cuda(), rois.cuda(), 1 / 16, p, p, n, c, h, w, sr).cpu()
+    # fp32 sums in a different order than the reference's atomics: tolerance, stated
+    # (north_star: 1e-3 relative); the f32 oracle uses the same f32 weights -> tight.
+    assert torch.allclose(got, want32, rtol=1e-4, atol=1e-4)
+    scale = want.abs().max().item()
+    assert (got.double() - want).abs().max().item() <= 1e-3 * scale
+
+
+def test_roi_align_backward_golden_rois_adjoint(C, golden_dir):
+    z = np.load(os.path.join(golden_dir, "roi_align_forward.npz"))
+    rois, scale = torch.from_numpy(z["rois"]).cuda(), float(z["scale"])
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 8, 25, 42, generator=g).cuda()
+    go = torch.randn(rois.shape[0], 8, 14, 14, generator=g).cuda()
+    f = C.roi_align_forward(x, rois, scale, 14, 14, 0)
+    b = C.roi_align_backward(go, rois, scale, 14, 14, 2, 8, 25, 42, 0)
+    lhs = (f.double() * go.double()).sum().item()
+    rhs = (x.double() * b.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * (f.double() * go.double()).abs().sum().item()
+
+
+def test_roi_align_autograd_layer(C, oracle_mod):
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers import ROIAlign
+
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 6, 20, 30, generator=g)
+    rois = _rois(g, 25, 2, 480, 320, 8, 300)
+    layer = ROIAlign((14, 14), 1 / 16, 0)
+    xd = x.cuda().requires_grad_(True)
+    out = layer(xd, rois.cuda())
+    go = torch.randn(out.shape, generator=g)
+    out.backward(go.cuda())
+    assert torch.equal(out.detach().cpu(), oracle_mod.roi_align_forward(x, rois, 1 / 16, 14, 14, 0))
+    want = oracle_mod.roi_align_backward(go, rois, 1 / 16, 14, 14, 2, 6, 20, 30, 0)
+    assert torch.allclose(xd.grad.cpu(), want, rtol=1e-4, atol=1e-4)
+
+
+def test_roi_align_full_size_properties(C):
+    # BASELINE shape: [2,1024,50,84], R=1024. Linearity + constant-map invariance (size-independent).
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(2, 1024, 50, 84, generator=g).cuda()
+    rois = _rois(g, 1024, 2, 1333, 800, 16, 316).cuda()
+    a = C.roi_align_forward(x, rois, 1 / 16, 14, 14, 0)
+    b = C.roi_align_forward(2 * x, rois, 1 / 16, 14, 14, 0)
+    assert torch.equal(b, 2 * a)  # scaling by 2 is exact in fp32
+    ones = C.roi_align_forward(torch.ones_like(x), rois, 1 / 16, 14, 14, 0)
+    assert torch.allclose(ones, torch.ones_like(ones), atol=1e-6)  # all RoIs inside the map
+    go = torch.randn(1024, 1024, 14, 14, generator=g).cuda()
+    gi = C.roi_align_backward(go, rois, 1 / 16, 14, 14, 2, 1024, 50, 84, 0)
+    # mass conservation: each RoI bin distributes exactly its gradient (weights sum to 1)
+    assert torch.allclose(gi.double().sum(), go.double().sum(), rtol=1e-4)
+
+
+# ---------------------------------------------------------------- NMS
+@pytest.mark.parametrize("name", ["rpn_like", "dense", "tiny", "one"])
+def test_nms_golden_exact(C, golden_dir, name):
+    z = np.load(os.path.join(golden_dir, "nms.npz"))
+    boxes, scores = torch.from_numpy(z[f"{name}_boxes"]).cuda(), torch.from_numpy(z[f"{name}_scores"]).cuda()
+    keep = C.nms(boxes, scores, float(z[f"{name}_thr"]))
+    assert keep.dtype == torch.int64 and keep.is_cuda
+    assert torch.equal(keep.cpu(), torch.from_numpy(z[f"{name}_keep"]))
+
+
+@pytest.mark.parametrize("k,thr", [(6000, 0.7), (12000, 0.7), (4097, 0.5), (63, 0.3), (64, 0.3), (65, 0.3)])
+def test_nms_vs_oracle(C, oracle_mod, k, thr):
+    g = torch.Generator().manual_seed(k)
+    xy = torch.rand(k, 2, generator=g) * torch.tensor([1200.0, 720.0])
+    wh = torch.rand(k, 2, generator=g) * 200 + 8
+    boxes = torch.cat([xy, xy + wh], 1)
+    scores = torch.rand(k, generator=g)
+    want = oracle_mod.nms(boxes, scores, thr)
+    got = C.nms(boxes.cuda(), scores.cuda(), thr)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_nms_heavy_overlap_and_ties(C, oracle_mod):
+    g = torch.Generator().manual_seed(8)
+    k = 3000
+    xy = torch.rand(k, 2, generator=g) * 60 + 100   # everything overlaps: long suppression chains
+    wh = torch.rand(k, 2, generator=g) * 120 + 40
+    boxes = torch.cat([xy, xy + wh], 1)
+    scores = (torch.rand(k, generator=g) * 50).floor() / 50  # many exact score ties -> stable order
+    want = oracle_mod.nms(boxes, scores, 0.6)
+    got = C.nms(boxes.cuda(), scores.cuda(), 0.6)
+    assert torch.equal(got.cpu(), want)
+    # comparison mode: exact-tie IoU (0.5) kept by `>`, dropped by `>=`
+    b2 = torch.tensor([[0.0, 0.0, 9.0, 9.0], [0.0, 0.0, 9.0, 4.0]]).cuda()
+    s2 = torch.tensor([0.9, 0.8]).cuda()
+    assert C.nms(b2, s2, 0.5).tolist() == [0, 1]
+    keep, n = C.nms_padded(b2, s2, 0.5, ge_mode=True)
+    assert keep[: int(n)].tolist() == [0]
+
+
+def test_nms_empty_returns_cpu_like_reference(C):
+    out = C.nms(torch.zeros(0, 4, device="cuda"), torch.zeros(0, device="cuda"), 0.5)
+    assert out.numel() == 0 and out.dtype == torch.int64 and out.device.type == "cpu"
+
+
+def test_nms_idempotent_full_size(C):
+    g = torch.Generator().manual_seed(1234)
+    k = 12000
+    xy = torch.rand(k, 2, generator=g) * torch.tensor([1200.0, 720.0])
+    wh = torch.rand(k, 2, generator=g) * 200 + 8
+    boxes = torch.cat([xy, xy + wh], 1).cuda()
+    scores = torch.rand(k, generator=g).cuda()
+    keep = C.nms(boxes, scores, 0.7)
+    assert bool((keep[1:] > keep[:-1]).all())  # ascending original indices
+    again = C.nms(boxes[keep], scores[keep], 0.7)
+    assert again.numel() == keep.numel()  # survivors never suppress each other
+
+
+# ---------------------------------------------------------------- sigmoid focal loss
+def test_focal_golden(C, golden_dir):
+    z = np.load(os.path.join(golden_dir, "sigmoid_focal_loss.npz"))
+    for sfx, gamma, alpha in (("", 2.0, 0.25), ("2", 1.5, 0.4)):
+        logits, targets = torch.from_numpy(z["logits" + sfx]).cuda(), torch.from_numpy(z["targets" + sfx]).cuda()
+        d = torch.from_numpy(z["d_losses" + sfx]).cuda()
+        nc = logits.shape[1]
+        loss = C.sigmoid_focalloss_forward(logits, targets, nc, gamma, alpha).cpu().double()
+        grad = C.sigmoid_focalloss_backward(logits, targets, d, nc, gamma, alpha).cpu().double()
+        assert torch.allclose(loss, torch.from_numpy(z["loss" + sfx]), rtol=2e-5, atol=1e-7)
+        assert torch.allclose(grad, torch.from_numpy(z["grad" + sfx]), rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("num,c", [(4001, 80), (513, 7), (1, 1)])
+def test_focal_vs_oracle_and_module(C, oracle_mod, num, c):
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers import SigmoidFocalLoss
+
+    g = torch.Generator().manual_seed(num)
+    logits = torch.randn(num, c, generator=g) * 4
+    targets = torch.randint(-1, c + 1, (num,), generator=g, dtype=torch.int32)
+    want = oracle_mod.sigmoid_focal_loss_forward(logits, targets, 2.0, 0.25)
+    ld = logits.cuda().requires_grad_(True)
+    got = C.sigmoid_focalloss_forward(ld.detach(), targets.cuda(), c, 2.0, 0.25).cpu()
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-7)
+    total = SigmoidFocalLoss(2.0, 0.25)(ld, targets.cuda())
+    total.backward()
+    wgrad = oracle_mod.sigmoid_focal_loss_backward(logits, targets, torch.ones(num, c), 2.0, 0.25)
+    assert torch.allclose(ld.grad.cpu(), wgrad, rtol=1e-5, atol=1e-7)
+    assert abs(total.item() - want.double().sum().item()) <= 1e-4 * max(1.0, want.double().sum().item())

@@ -1,0 +1,107 @@
+"""Per-op micro-benchmarks on the shapes of SURVEY.md 8(d) / BASELINE.md 3: achieved GB/s (or
+TFLOP/s) of each hand-written kernel against its algorithmic byte / flop count.
+
+    python tools/bench_ops.py [--ops roi_fwd,roi_bwd,nms,focal] [--iters 20]
+Prints one JSON object per op.  Timing: HIP events on torch's current stream (the stream the
+kernels are launched on), `iters` launches after 3 warm-ups.
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cvpr22_cross_modal_pseudo_labeling_amd import _C  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+
+
+def timeit(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters  # ms
+
+
+def bench_rois(r, n_img, g, kind="uniform"):
+    b = torch.randint(0, n_img, (r, 1), generator=g).float()
+    if kind == "uniform":  # x1~U[0,1066], y1~U[0,640], w,h~U[16,316], clipped
+        x1 = torch.rand(r, 1, generator=g) * 1066
+        y1 = torch.rand(r, 1, generator=g) * 640
+        w = torch.rand(r, 1, generator=g) * 300 + 16
+        h = torch.rand(r, 1, generator=g) * 300 + 16
+    else:  # RPN-like: log-uniform areas 32^2..512^2, ratios {.5,1,2}
+        area = torch.exp(torch.rand(r, 1, generator=g) * (2 * torch.log(torch.tensor(512.0 / 32))) + 2 * torch.log(torch.tensor(32.0)))
+        ratio = torch.tensor([0.5, 1.0, 2.0])[torch.randint(0, 3, (r, 1), generator=g)]
+        w, h = torch.sqrt(area / ratio), torch.sqrt(area * ratio)
+        x1 = torch.rand(r, 1, generator=g) * (1333 - w).clamp(min=1)
+        y1 = torch.rand(r, 1, generator=g) * (800 - h).clamp(min=1)
+    return torch.cat([b, x1, y1, (x1 + w).clamp(max=1332), (y1 + h).clamp(max=799)], 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ops", default="roi_fwd,roi_bwd,nms,focal")
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
+    ops = args.ops.split(",")
+    g = torch.Generator().manual_seed(1234)
+    dev = "cuda"
+    res = []
+    if "roi_fwd" in ops or "roi_bwd" in ops:
+        n, c, h, w, r = 2, 1024, 50, 84, 1024
+        x = torch.randn(n, c, h, w, generator=g).to(dev)
+        for kind in ("uniform", "rpn_like"):
+            rois = bench_rois(r, n, g, kind).to(dev)
+            alg = 4 * r * c * 196 + 4 * n * c * h * w + 20 * r
+            if "roi_fwd" in ops:
+                ms = timeit(lambda: _C.roi_align_forward(x, rois, 1 / 16, 14, 14, 0), args.iters)
+                res.append({"op": "roi_align_forward", "rois": kind, "ms": ms, "alg_MB": alg / 1e6,
+                            "GBps": alg / ms / 1e6, "frac_hbm": alg / ms / 1e6 / HBM_PEAK_GBS})
+            if "roi_bwd" in ops:
+                go = torch.randn(r, c, 14, 14, generator=g).to(dev)
+                ms = timeit(lambda: _C.roi_align_backward(go, rois, 1 / 16, 14, 14, n, c, h, w, 0), args.iters)
+                res.append({"op": "roi_align_backward", "rois": kind, "ms": ms, "alg_MB": alg / 1e6,
+                            "GBps": alg / ms / 1e6, "frac_hbm": alg / ms / 1e6 / HBM_PEAK_GBS})
+                del go
+        del x
+    if "nms" in ops:
+        for k in (6000, 12000):
+            xy = torch.rand(k, 2, generator=g) * torch.tensor([1200.0, 720.0])
+            wh = torch.rand(k, 2, generator=g) * 200 + 8
+            boxes = torch.cat([xy, xy + wh], 1).to(dev)
+            scores = torch.rand(k, generator=g).to(dev)
+            ms = timeit(lambda: _C.nms_padded(boxes, scores, 0.7), args.iters)
+            nb = (k + 63) // 64
+            alg = 20 * k + 2 * 8 * k * nb + 8 * k
+            keep, num = _C.nms_padded(boxes, scores, 0.7)
+            res.append({"op": "nms", "K": k, "kept": int(num), "ms": ms, "alg_MB": alg / 1e6, "GBps": alg / ms / 1e6,
+                        "MIoU_per_s": k * (k - 1) / 2 / ms / 1e3})
+    if "focal" in ops:
+        m, c = 400000, 80
+        logits = (torch.randn(m, c, generator=g) * 2).to(dev)
+        targets = torch.where(torch.rand(m, generator=g) < 0.01, torch.randint(1, c + 1, (m,), generator=g),
+                              torch.zeros(m, dtype=torch.int64)).int().to(dev)
+        d = torch.rand(m, c, generator=g).to(dev)
+        ms = timeit(lambda: _C.sigmoid_focalloss_forward(logits, targets, c, 2.0, 0.25), args.iters)
+        alg = 8 * m * c + 4 * m
+        res.append({"op": "sigmoid_focal_forward", "ms": ms, "alg_MB": alg / 1e6, "GBps": alg / ms / 1e6,
+                    "frac_hbm": alg / ms / 1e6 / HBM_PEAK_GBS})
+        ms = timeit(lambda: _C.sigmoid_focalloss_backward(logits, targets, d, c, 2.0, 0.25), args.iters)
+        alg = 12 * m * c + 4 * m
+        res.append({"op": "sigmoid_focal_backward", "ms": ms, "alg_MB": alg / 1e6, "GBps": alg / ms / 1e6,
+                    "frac_hbm": alg / ms / 1e6 / HBM_PEAK_GBS})
+    for r_ in res:
+        print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r_.items()}))
+
+
+if __name__ == "__main__":
+    main()
