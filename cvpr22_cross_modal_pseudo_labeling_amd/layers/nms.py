@@ -2,5 +2,12 @@
 from .. import _C
 from ._fp32 import float_function
 
-nms = float_function(_C.nms)
-nms_padded = float_function(_C.nms_padded)
+
+@float_function
+def nms(boxes, scores, threshold):
+    return _C.nms(boxes, scores, threshold)
+
+
+@float_function
+def nms_padded(boxes, scores, threshold, ge_mode=False):
+    return _C.nms_padded(boxes, scores, threshold, ge_mode)

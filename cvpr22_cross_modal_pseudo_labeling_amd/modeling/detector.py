@@ -1,0 +1,216 @@
+"""Meta-architectures: the teacher (``GeneralizedRCNN``) and the student-teacher step
+(``STGeneralizedRCNN``) with cross-modal pseudo-labelling.
+
+Counterparts: maskrcnn_benchmark/modeling/detector/generalized_rcnn.py:16-73,
+detector/st_generalized_rcnn.py:27-88 (construction / freezing), :164-177 (``combine_embs``),
+:190-216 (``prepare_model`` / ``extract_emb``), :218-275 (``generate_pseudo_label``),
+:284-418 (``forward``), detector/detectors.py:7-16.
+
+What differs from the reference, on purpose (DESIGN.md "Deviations"):
+  * text embeddings come from a fixed matrix (``set_caption_vocab``) instead of a per-iteration BERT
+    tokenizer + embedding lookup: the vocabulary is constant, so they are computed once
+    (SURVEY 8f-3); noun embeddings of an image are rows of that matrix (``ids_cap``);
+  * per-image slicing is by image index into the feature batch (the reference indexes the list of
+    feature LEVELS with the image index and only works at 1 image / process -- SURVEY D4);
+  * the student heads run on any device the tensors live on (no ``.cuda()``), errors are not swallowed
+    by a bare ``except`` (a failure in the student pass raises instead of silently training on the
+    dummy loss);
+  * the exemplar bank is kept as an (empty) dict: ``update_exemplars`` is commented out upstream
+    (st_generalized_rcnn.py:325-326), so ``combine_embs`` reduces to row normalisation.
+"""
+import copy
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .backbone import Backbone
+from .roi_heads import CombinedROIHeads, Masker
+from .rpn import RPNModule
+from .structures import BoxList, to_image_list
+
+
+class GeneralizedRCNN(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.backbone = Backbone(cfg)
+        self.rpn = RPNModule(cfg, self.backbone.out_channels)
+        self.roi_heads = CombinedROIHeads(cfg, self.backbone.out_channels)
+
+    def set_class_embeddings(self, embs):
+        self.roi_heads["box"].predictor.set_class_embeddings(embs)
+
+    def forward(self, images, targets=None):
+        if self.training and targets is None:
+            raise ValueError("In training mode, targets should be passed")
+        images = to_image_list(images)
+        features = self.backbone(images.tensors)
+        proposals, proposal_losses = self.rpn(images, features, targets)
+        _, result, detector_losses = self.roi_heads(features, proposals, targets)
+        if self.training:
+            losses = {}
+            losses.update(detector_losses)
+            losses.update(proposal_losses)
+            return losses
+        return result
+
+
+class STGeneralizedRCNN(nn.Module):
+    LOSS_NAMES = ("loss_box_reg", "loss_classifier", "loss_mask")
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.backbone = Backbone(cfg)
+        self.rpn = RPNModule(cfg, self.backbone.out_channels)
+        self.roi_heads = CombinedROIHeads(cfg, self.backbone.out_channels, is_teacher=True)
+        self.roi_heads_student = CombinedROIHeads(cfg, self.backbone.out_channels)
+        assert cfg.MODEL.RPN.DONT_TRAIN, "the student-teacher step keeps the RPN frozen"
+        self.lambda_exemplar = nn.Parameter(torch.zeros(1), requires_grad=True)
+        self.mask_on = cfg.MODEL.MASK_ON
+        for m in (self.rpn, self.backbone, self.roi_heads):
+            for p in m.parameters():
+                p.requires_grad = False
+        self.exemplars = {}
+        self.masker = Masker(threshold=0.5, padding=1)
+        self.lambda_pseudo_label = cfg.MODEL.LAMBDA_PSEUDO_LABEL
+        self.adaptive_lamb = "N/A"
+        self.uncertainty = cfg.MODEL.UNCERTAINTY
+        self.resume = cfg.MODEL.RESUME
+        self.uncertainty_train_iter = cfg.MODEL.UNCERTAINTY_TRAIN_ITER
+        self.no_pseudo_mask = cfg.MODEL.NO_PSEUDO_MASK
+        self.reweight = cfg.MODEL.REWEIGHT
+        self.iter = 0
+        self.cap_embs = None  # [V, emb_dim] unit-norm caption-vocabulary (LVIS) embeddings
+
+    # -- text side ----------------------------------------------------------------------------------
+    def set_caption_vocab(self, embs):
+        """Embeddings of the caption vocabulary (the reference re-extracts them from BERT every
+        iteration, st_generalized_rcnn.py:190-191,202-209)."""
+        self.cap_embs = F.normalize(embs.float(), dim=-1)
+
+    def set_class_embeddings(self, embs):
+        """Seen-class matrix with the all-zero background row 0 (engine/trainer.py:85-90)."""
+        self.roi_heads["box"].predictor.set_class_embeddings(embs)
+
+    def combine_embs(self, embs):
+        # exemplar bank is empty (see module docstring) -> st_generalized_rcnn.py:165-166
+        return F.normalize(embs, dim=-1)
+
+    def prepare_model(self):
+        student, teacher = self.roi_heads_student["box"].predictor, self.roi_heads["box"].predictor
+        if student.cls_score is None or student.cls_score.shape != teacher.cls_score.shape \
+                or not torch.equal(student.cls_score, teacher.cls_score):
+            student.cls_score = teacher.cls_score
+        if self.iter == 0 and not self.resume:
+            self.roi_heads_student.load_state_dict(copy.deepcopy(self.roi_heads.state_dict()), strict=False)
+            self.iter += 1
+
+    def compute_dummy_loss(self):
+        loss = 0.0
+        for p in self.roi_heads_student.parameters():
+            loss = loss + torch.sum(p) * 0.0
+        return loss
+
+    # -- teacher: region <-> noun alignment -----------------------------------------------------------
+    @torch.no_grad()
+    def generate_pseudo_label(self, features, proposals, noun_embs, targets):
+        teacher = self.roi_heads
+        class_embs = teacher["box"].predictor.cls_score
+        teacher["box"].predictor.set_class_embeddings(features[0].new_zeros((1, teacher["box"].predictor.emb_dim)))
+        teacher.eval()
+        package_x, results, _ = teacher(features, proposals, None, bbox_only=True)
+        f_regions = package_x["bbox"].mean(dim=(2, 3))
+        cls_embs = teacher["box"].predictor.emb_pred(f_regions).split([len(p) for p in proposals])
+        pseudo_labels = []
+        for emb_img, w_cap, result_img, target_img in zip(cls_embs, noun_embs, results, targets):
+            if w_cap.shape[0] == 0:
+                pseudo_labels.append(BoxList(emb_img.new_zeros((0, 4)), result_img.size))
+                continue
+            region_scores = emb_img @ w_cap.t()  # einsum('pd,wd->pw')
+            aligned, idx = torch.max(region_scores, dim=0)
+            pl = result_img[idx]
+            pl.add_field("labels", target_img.get_field("ids_cap"))
+            pl.add_field("scores", torch.sigmoid(aligned))
+            pl.add_field("consistencies", aligned * 0.0 + 1.0)
+            pl.add_field("embs", emb_img[idx])
+            pseudo_labels.append(pl)
+        if self.mask_on:
+            _, results, _ = teacher(features, pseudo_labels, None, bbox_only=False)
+            for res, pl in zip(results, pseudo_labels):
+                masks = self.masker(res.get_field("mask"), pl)[:, 0]  # [W,H,W] bool
+                pl.add_field("masks", masks)
+        teacher["box"].predictor.set_class_embeddings(class_embs)
+        return pseudo_labels
+
+    # -- step ----------------------------------------------------------------------------------------------
+    def forward(self, images, targets=None, eps=None):
+        if self.training and targets is None:
+            raise ValueError("In training mode, targets should be passed")
+        images = to_image_list(images)
+        features = self.backbone(images.tensors)
+        student = self.roi_heads_student
+        if not self.training:
+            self.rpn.eval()
+            proposals, _ = self.rpn(images, features, None)
+            student["box"].predictor.set_class_embeddings(self.combine_embs(self.roi_heads["box"].predictor.cls_score))
+            _, result, _ = student(features, proposals, targets)
+            return result
+
+        self.prepare_model()
+        dummy_loss = self.compute_dummy_loss()
+        feat = features[0]
+
+        # ---- pseudo branch: images that come with caption nouns ------------------------------------------
+        idxs_cap = [i for i, t in enumerate(targets) if t.has_field("ids_cap") and len(t.get_field("ids_cap")) > 0]
+        loss_pseudo = {}
+        if idxs_cap:
+            self.rpn.eval()
+            proposals, _ = self.rpn(images, features, None)
+            cap_features = [feat[idxs_cap]]
+            cap_proposals = [proposals[i] for i in idxs_cap]
+            cap_targets = [targets[i] for i in idxs_cap]
+            noun_embs = [t.get_field("cap_embs") if t.has_field("cap_embs") else self.cap_embs[t.get_field("ids_cap")]
+                         for t in cap_targets]
+            pseudo_targets = self.generate_pseudo_label(cap_features, cap_proposals, noun_embs, cap_targets)
+            student["box"].predictor.set_class_embeddings(self.combine_embs(self.cap_embs))
+            _, _, loss_pseudo = student(cap_features, cap_proposals, pseudo_targets,
+                                        compute_uncertain=self.uncertainty, eps=eps)
+            for k in loss_pseudo:
+                if self.uncertainty and self.reweight:
+                    if "mask" not in k:
+                        self.adaptive_lamb = 0.01 / student["mask"].avg_uncertain.detach()
+                        loss_pseudo[k] = loss_pseudo[k] * self.adaptive_lamb
+                else:
+                    loss_pseudo[k] = loss_pseudo[k] * self.lambda_pseudo_label
+        losses = {}
+        for k in self.LOSS_NAMES:
+            v = loss_pseudo.get(k, dummy_loss)
+            if "mask" in k and self.no_pseudo_mask:
+                v = v * 0.0
+            losses[f"{k}_pseudo"] = v
+
+        # ---- seen-class branch: images with box / mask ground truth -----------------------------------------
+        idxs_gt = [i for i, t in enumerate(targets) if t.has_field("is_det") and t.get_field("is_det") == "Yes"]
+        loss_gt = {}
+        if idxs_gt:
+            self.rpn.train()
+            proposals_target, _ = self.rpn(images, features, targets, compute_loss=False)
+            gt_features = [feat[idxs_gt]]
+            gt_proposals = [proposals_target[i] for i in idxs_gt]
+            gt_targets = [targets[i] for i in idxs_gt]
+            student["box"].predictor.set_class_embeddings(self.combine_embs(self.roi_heads["box"].predictor.cls_score))
+            _, _, loss_gt = student(gt_features, gt_proposals, gt_targets, compute_uncertain=False)
+        for k in self.LOSS_NAMES:
+            losses[k] = loss_gt.get(k, dummy_loss)
+
+        self.iter += 1
+        if self.uncertainty and self.iter == self.uncertainty_train_iter and self.mask_on:
+            student["mask"].predictor.uncertain_pred.requires_grad_(False)
+        return losses
+
+
+_META_ARCHITECTURES = {"GeneralizedRCNN": GeneralizedRCNN, "STGeneralizedRCNN": STGeneralizedRCNN}
+
+
+def build_detection_model(cfg):
+    return _META_ARCHITECTURES[cfg.MODEL.META_ARCHITECTURE](cfg)

@@ -1,0 +1,459 @@
+"""RoI heads: pooler, embedding-based box head, class-agnostic C4 mask head with the uncertainty branch.
+
+Counterparts (maskrcnn_benchmark/modeling/...):
+  poolers.py:45-121                              -> ``Pooler``
+  roi_heads/box_head/roi_box_feature_extractors.py:13-46 -> ``ResNet50Conv5ROIFeatureExtractor``
+  roi_heads/box_head/roi_box_predictors.py:8-92  -> ``FastRCNNPredictor``   (region x text head)
+  roi_heads/box_head/loss.py:15-185              -> ``FastRCNNLossComputation``
+  roi_heads/box_head/inference.py:12-163         -> ``PostProcessor``
+  roi_heads/box_head/box_head.py:11-79           -> ``ROIBoxHead``
+  roi_heads/mask_head/roi_mask_predictors.py:11-65 -> ``MaskRCNNC4Predictor``
+  roi_heads/mask_head/loss.py:11-148             -> ``project_masks_on_boxes`` / ``MaskRCNNLossComputation``
+  roi_heads/mask_head/inference.py:12-66,124-205 -> ``MaskPostProcessor`` / ``Masker``
+  roi_heads/mask_head/mask_head.py:13-106        -> ``ROIMaskHead``
+  roi_heads/roi_heads.py:11-102                  -> ``CombinedROIHeads``
+
+Deviations, all stated in DESIGN.md: everything stays on the device (no ``.cpu()`` in the mask-target
+projection, no per-mask python loop there), the fg/bg class weights are built on the logits'
+device instead of a hard-coded ``.cuda()``, and the mask head handles any number of
+images per process.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..layers import Conv2d, ConvTranspose2d, ROIAlign, smooth_l1_loss
+from .backbone import ResNetHead
+from .box_coder import BoxCoder
+from .matcher import BalancedPositiveNegativeSampler, Matcher
+from .structures import BoxList, box_iou, boxlist_nms, cat_boxlist
+
+
+def _cat(tensors, dim=0):
+    return tensors[0] if len(tensors) == 1 else torch.cat(tensors, dim)
+
+
+class Pooler(nn.Module):
+    def __init__(self, output_size, scales, sampling_ratio):
+        super().__init__()
+        if len(scales) != 1:
+            raise NotImplementedError("single-level pooler only (C4)")
+        self.pooler = ROIAlign(output_size, spatial_scale=scales[0], sampling_ratio=sampling_ratio)
+        self.output_size = output_size
+
+    @staticmethod
+    def convert_to_roi_format(boxes):
+        parts = []
+        for i, b in enumerate(boxes):
+            ids = torch.full((len(b), 1), float(i), dtype=b.bbox.dtype, device=b.bbox.device)
+            parts.append(torch.cat([ids, b.bbox], dim=1))
+        return _cat(parts, 0)
+
+    def forward(self, x, boxes):
+        return self.pooler(x[0], self.convert_to_roi_format(boxes))
+
+
+class ResNet50Conv5ROIFeatureExtractor(nn.Module):
+    def __init__(self, cfg, head_cfg):
+        super().__init__()
+        res = head_cfg.POOLER_RESOLUTION
+        self.pooler = Pooler((res, res), head_cfg.POOLER_SCALES, head_cfg.POOLER_SAMPLING_RATIO)
+        self.head = ResNetHead(cfg)
+        self.out_channels = self.head.out_channels
+
+    def forward(self, x, proposals):
+        return self.head(self.pooler(x, proposals))
+
+
+# ------------------------------------------------------------------------------------------------
+# box head
+# ------------------------------------------------------------------------------------------------
+class FastRCNNPredictor(nn.Module):
+    """avgpool -> emb_pred Linear -> dot product with the class-embedding matrix; agnostic box deltas."""
+
+    def __init__(self, cfg, in_channels, is_teacher=False):
+        super().__init__()
+        bh = cfg.MODEL.ROI_BOX_HEAD
+        self.embedding_based = bh.EMBEDDING_BASED
+        if not self.embedding_based:
+            raise NotImplementedError("only the embedding-based classifier (every shipped config) is built")
+        assert cfg.MODEL.CLS_AGNOSTIC_BBOX_REG
+        self.emb_dim = bh.EMB_DIM
+        self.emb_pred = nn.Linear(in_channels, self.emb_dim)
+        nn.init.normal_(self.emb_pred.weight, mean=0, std=0.01)
+        nn.init.constant_(self.emb_pred.bias, 0)
+        self.num_classes = None
+        self.cls_score = None  # [C, emb_dim], set by set_class_embeddings after the optimizer is made
+        if bh.FREEZE_EMB_PRED:
+            self.emb_pred.weight.requires_grad = False
+            self.emb_pred.bias.requires_grad = False
+        self.bbox_pred = nn.Linear(in_channels, 2 * 4)
+        nn.init.normal_(self.bbox_pred.weight, mean=0, std=0.001)
+        nn.init.constant_(self.bbox_pred.bias, 0)
+
+    def pooled(self, x):
+        return x.mean(dim=(2, 3)) if x.dim() == 4 else x
+
+    def forward(self, x):
+        x = self.pooled(x)
+        cls_emb = self.emb_pred(x)
+        cls_logit = cls_emb @ self.cls_score.t()  # einsum('pe,ce->pc')
+        return cls_logit, self.bbox_pred(x)
+
+    def set_class_embeddings(self, embs):
+        self.num_classes = embs.shape[0]
+        self.cls_score = embs.to(self.emb_pred.weight.device)
+
+
+class FastRCNNLossComputation:
+    def __init__(self, cfg):
+        rh = cfg.MODEL.ROI_HEADS
+        self.matcher = Matcher(rh.FG_IOU_THRESHOLD, rh.BG_IOU_THRESHOLD, allow_low_quality_matches=False)
+        self.sampler = BalancedPositiveNegativeSampler(rh.BATCH_SIZE_PER_IMAGE, rh.POSITIVE_FRACTION)
+        self.box_coder = BoxCoder(weights=rh.BBOX_REG_WEIGHTS)
+        self.cls_agnostic_bbox_reg = cfg.MODEL.CLS_AGNOSTIC_BBOX_REG
+        self.bg_weight = cfg.MODEL.ROI_BOX_HEAD.LOSS_WEIGHT_BACKGROUND
+        self.generator = None  # optional torch.Generator for reproducible sampling in tests
+
+    def subsample(self, proposals, targets):
+        out = []
+        labels_all = []
+        for prop, tgt in zip(proposals, targets):
+            matched = self.matcher(box_iou(tgt.bbox, prop.bbox))
+            idx = matched.clamp(min=0)
+            labels = tgt.get_field("labels")[idx].to(torch.int64)
+            labels[matched == Matcher.BELOW_LOW_THRESHOLD] = 0
+            labels[matched == Matcher.BETWEEN_THRESHOLDS] = -1
+            reg = self.box_coder.encode(tgt.bbox[idx], prop.bbox)
+            prop.add_field("labels", labels)
+            prop.add_field("regression_targets", reg)
+            prop.add_field("matched_gt", idx)
+            labels_all.append(labels)
+        pos, neg = self.sampler(labels_all, generator=self.generator)
+        for prop, p, n in zip(proposals, pos, neg):
+            out.append(prop[torch.nonzero(p | n).squeeze(1)])
+        self._proposals = out
+        return out
+
+    def __call__(self, class_logits, box_regression):
+        proposals = self._proposals
+        labels = _cat([p.get_field("labels") for p in proposals], 0)
+        reg_targets = _cat([p.get_field("regression_targets") for p in proposals], 0)
+        pos = torch.nonzero(labels > 0).squeeze(1)
+        if self.cls_agnostic_bbox_reg:
+            map_inds = torch.tensor([4, 5, 6, 7], device=class_logits.device)
+        else:
+            map_inds = 4 * labels[pos][:, None] + torch.tensor([0, 1, 2, 3], device=class_logits.device)
+        box_loss = smooth_l1_loss(box_regression[pos[:, None], map_inds], reg_targets[pos], size_average=False,
+                                  beta=1) / labels.numel()
+        w = torch.ones(class_logits.shape[1], device=class_logits.device)
+        w[0] = self.bg_weight
+        cls_loss = (F.cross_entropy(class_logits, labels, weight=w, reduction="none") / labels.numel()).sum()
+        return cls_loss, box_loss
+
+
+class PostProcessor(nn.Module):
+    def __init__(self, cfg, is_teacher=False):
+        super().__init__()
+        rh = cfg.MODEL.ROI_HEADS
+        self.score_thresh, self.nms, self.detections_per_img = rh.SCORE_THRESH, rh.NMS, rh.DETECTIONS_PER_IMG
+        self.box_coder = BoxCoder(weights=rh.BBOX_REG_WEIGHTS)
+        self.cls_agnostic_bbox_reg = cfg.MODEL.CLS_AGNOSTIC_BBOX_REG
+        self.is_teacher = is_teacher
+
+    def forward(self, x, boxes):
+        class_logits, box_regression = x
+        class_prob = F.softmax(class_logits, -1)
+        per_img = [len(b) for b in boxes]
+        concat = _cat([b.bbox for b in boxes], 0)
+        if self.cls_agnostic_bbox_reg:
+            box_regression = box_regression[:, -4:]
+        proposals = self.box_coder.decode(box_regression.reshape(sum(per_img), -1), concat)
+        num_classes = class_prob.shape[1]
+        if self.cls_agnostic_bbox_reg:
+            proposals = proposals.repeat(1, num_classes)
+        results = []
+        for prob, prop, b in zip(class_prob.split(per_img, 0), proposals.split(per_img, 0), boxes):
+            boxlist = BoxList(prop.reshape(-1, 4), b.size)
+            boxlist.add_field("scores", prob.reshape(-1))
+            boxlist = boxlist.clip_to_image(remove_empty=False)
+            if not self.is_teacher:
+                boxlist = self.filter_results(boxlist, num_classes)
+            results.append(boxlist)
+        return results
+
+    def filter_results(self, boxlist, num_classes):  # inference.py:121-163
+        boxes = boxlist.bbox.reshape(-1, num_classes * 4)
+        scores = boxlist.get_field("scores").reshape(-1, num_classes)
+        inds_all = scores > self.score_thresh
+        result = []
+        for j in range(1, num_classes):
+            inds = inds_all[:, j].nonzero().squeeze(1)
+            if inds.numel() == 0:
+                continue
+            cls_boxes = BoxList(boxes[inds, j * 4:(j + 1) * 4], boxlist.size)
+            cls_boxes.add_field("scores", scores[inds, j])
+            cls_boxes = boxlist_nms(cls_boxes, self.nms)
+            cls_boxes.add_field("labels", torch.full((len(cls_boxes),), j, dtype=torch.int64, device=scores.device))
+            result.append(cls_boxes)
+        if not result:
+            empty = BoxList(boxes.new_zeros((0, 4)), boxlist.size)
+            empty.add_field("scores", scores.new_zeros((0,)))
+            empty.add_field("labels", torch.zeros((0,), dtype=torch.int64, device=scores.device))
+            return empty
+        result = cat_boxlist(result)
+        n = len(result)
+        if n > self.detections_per_img > 0:
+            s = result.get_field("scores")
+            thresh = torch.kthvalue(s, n - self.detections_per_img + 1).values
+            result = result[torch.nonzero(s >= thresh).squeeze(1)]
+        return result
+
+
+class ROIBoxHead(nn.Module):
+    def __init__(self, cfg, in_channels, is_teacher=False):
+        super().__init__()
+        self.feature_extractor = ResNet50Conv5ROIFeatureExtractor(cfg, cfg.MODEL.ROI_BOX_HEAD)
+        self.predictor = FastRCNNPredictor(cfg, self.feature_extractor.out_channels, is_teacher)
+        self.post_processor = PostProcessor(cfg, is_teacher)
+        self.loss_evaluator = FastRCNNLossComputation(cfg)
+        if cfg.MODEL.ROI_BOX_HEAD.FREEZE_FEATURE_EXTRACTOR:
+            for p in self.feature_extractor.parameters():
+                p.requires_grad = False
+        self.is_teacher = is_teacher
+
+    def forward(self, features, proposals, targets=None):
+        if self.training:
+            with torch.no_grad():
+                proposals = self.loss_evaluator.subsample(proposals, targets)
+        x = self.feature_extractor(features, proposals)
+        class_logits, box_regression = self.predictor(x)
+        if not self.training:
+            return x, self.post_processor((class_logits, box_regression), proposals), {}
+        loss_classifier, loss_box_reg = self.loss_evaluator(class_logits, box_regression)
+        return x, proposals, dict(loss_classifier=loss_classifier, loss_box_reg=loss_box_reg)
+
+
+# ------------------------------------------------------------------------------------------------
+# mask head
+# ------------------------------------------------------------------------------------------------
+class MaskRCNNC4Predictor(nn.Module):
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        num_classes = 2 if cfg.MODEL.CLS_AGNOSTIC_MASK else cfg.MODEL.ROI_BOX_HEAD.NUM_CLASSES
+        dim_reduced = cfg.MODEL.ROI_MASK_HEAD.CONV_LAYERS[-1]
+        self.conv5_mask = ConvTranspose2d(in_channels, dim_reduced, 2, 2, 0)
+        self.mask_fcn_logits = Conv2d(dim_reduced, num_classes, 1, 1, 0)
+        self.uncertainty = cfg.MODEL.UNCERTAINTY
+        if self.uncertainty:
+            self.uncertain_pred = Conv2d(dim_reduced, 1, 1, 1, 0)
+        for name, param in self.named_parameters():
+            if "bias" in name:
+                nn.init.constant_(param, 0)
+            elif "weight" in name:
+                nn.init.kaiming_normal_(param, mode="fan_out", nonlinearity="relu")
+        if self.uncertainty:
+            nn.init.normal_(self.uncertain_pred.weight, mean=0, std=0.001)
+            nn.init.constant_(self.uncertain_pred.bias, 1)
+
+    def forward(self, x, compute_uncertain=False, eps=None):
+        """``eps`` (standard-normal noise, [1,P,1,M,M]) can be injected for reproducible tests;
+        by default it is drawn on the device (the reference draws on the host and copies)."""
+        x_ = F.relu(self.conv5_mask(x))
+        mask_logits = self.mask_fcn_logits(x_)
+        if self.uncertainty and compute_uncertain:
+            scale = torch.exp(0.5 * self.uncertain_pred(x_.detach()))  # [P,1,M,M] std-dev
+            if self.training:
+                if eps is None:
+                    eps = torch.randn((1, *scale.shape), device=scale.device, dtype=scale.dtype)
+                mask_logits = mask_logits[None] + eps * (mask_logits * 0.0 + scale)[None]  # [1,P,2,M,M]
+            return mask_logits, scale
+        return mask_logits
+
+
+def project_masks_on_boxes(masks, gt_index, boxes, M):
+    """Device-side counterpart of mask_head/loss.py:11-42 for binary ('mask' mode) targets.
+
+    masks [G,H,W] (bool or uint8), gt_index [P] (which mask each box uses), boxes [P,4] xyxy.
+    Crop (rounded, clamped like BinaryMaskList.crop, segmentation_mask.py:117-136) and bilinear-resize
+    (F.interpolate align_corners=False semantics, :138-156) to MxM, then cast back to the mask dtype
+    (bool: any positive weight on a set pixel -> 1; uint8: truncation) and to float32."""
+    P = boxes.shape[0]
+    if P == 0:
+        return torch.empty(0, dtype=torch.float32, device=boxes.device)
+    H, W = masks.shape[-2:]
+    b = torch.round(boxes)  # python round() in the reference = half-to-even = torch.round
+    xmin = b[:, 0].clamp(0, W - 1)
+    ymin = b[:, 1].clamp(0, H - 1)
+    xmax = torch.maximum(b[:, 2].clamp(0, W), xmin + 1)
+    ymax = torch.maximum(b[:, 3].clamp(0, H), ymin + 1)
+    w, h = xmax - xmin, ymax - ymin  # crop is [ymin:ymax, xmin:xmax]
+    dst = torch.arange(M, device=boxes.device, dtype=torch.float32)
+
+    def axis(size, lo):
+        src = ((dst[None, :] + 0.5) * (size[:, None] / M) - 0.5).clamp(min=0)  # [P,M]
+        i0 = src.floor()
+        lam = src - i0
+        i0 = torch.minimum(i0, size[:, None] - 1)
+        i1 = torch.minimum(i0 + 1, size[:, None] - 1)
+        return (i0 + lo[:, None]).long(), (i1 + lo[:, None]).long(), lam
+
+    y0, y1, ly = axis(h, ymin)
+    x0, x1, lx = axis(w, xmin)
+    g = gt_index[:, None, None]
+    mf = masks
+    v00 = mf[g, y0[:, :, None], x0[:, None, :]].float()
+    v01 = mf[g, y0[:, :, None], x1[:, None, :]].float()
+    v10 = mf[g, y1[:, :, None], x0[:, None, :]].float()
+    v11 = mf[g, y1[:, :, None], x1[:, None, :]].float()
+    ly, lx = ly[:, :, None], lx[:, None, :]
+    out = (1 - ly) * ((1 - lx) * v00 + lx * v01) + ly * ((1 - lx) * v10 + lx * v11)
+    if masks.dtype == torch.bool:
+        return (out != 0).float()
+    return out.to(masks.dtype).float()
+
+
+class MaskRCNNLossComputation:
+    def __init__(self, cfg):
+        rh = cfg.MODEL.ROI_HEADS
+        self.matcher = Matcher(rh.FG_IOU_THRESHOLD, rh.BG_IOU_THRESHOLD, allow_low_quality_matches=False)
+        self.discretization_size = cfg.MODEL.ROI_MASK_HEAD.RESOLUTION
+        self.cls_agnostic_mask = cfg.MODEL.CLS_AGNOSTIC_MASK
+
+    def prepare_targets(self, proposals, targets):
+        labels, masks = [], []
+        for prop, tgt in zip(proposals, targets):
+            if len(prop) == 0:  # an image without positive proposals contributes nothing
+                labels.append(torch.zeros(0, dtype=torch.int64, device=prop.bbox.device))
+                masks.append(torch.empty(0, dtype=torch.float32, device=prop.bbox.device))
+                continue
+            matched = self.matcher(box_iou(tgt.bbox, prop.bbox))
+            idx = matched.clamp(min=0)
+            lab = tgt.get_field("labels")[idx].to(torch.int64)
+            lab[matched == Matcher.BELOW_LOW_THRESHOLD] = 0
+            pos = torch.nonzero(lab > 0).squeeze(1)
+            masks.append(project_masks_on_boxes(tgt.get_field("masks"), idx[pos], prop.bbox[pos],
+                                                self.discretization_size))
+            labels.append(lab)
+        return labels, masks
+
+    def __call__(self, proposals, mask_logits, targets):
+        repeat = 1
+        if mask_logits.dim() == 5:  # [n_samples, P, C, M, M]
+            repeat = mask_logits.shape[0]
+            mask_logits = torch.flatten(mask_logits, 0, 1)
+        labels, mask_targets = self.prepare_targets(list(proposals) * repeat, list(targets) * repeat)
+        labels = _cat(labels, 0)
+        mask_targets = _cat([m for m in mask_targets if m.numel() > 0] or mask_targets[:1], 0)
+        pos = torch.nonzero(labels > 0).squeeze(1)
+        labels_pos = labels[pos]
+        if self.cls_agnostic_mask:
+            labels_pos = labels_pos * 0 + 1
+        if mask_targets.numel() == 0:
+            return mask_logits.sum() * 0
+        self.mask_targets, self.positive_inds = mask_targets, pos
+        return F.binary_cross_entropy_with_logits(mask_logits[pos, labels_pos], mask_targets, reduction="none").mean()
+
+
+def paste_mask_in_image(mask, box, im_h, im_w, thresh=0.5, padding=1):
+    """mask [M,M] probabilities, box [4] -> bool [im_h, im_w] (mask_head/inference.py:100-160), on device."""
+    M = mask.shape[-1]
+    scale = float(M + 2 * padding) / M
+    padded = mask.new_zeros((M + 2 * padding, M + 2 * padding))
+    padded[padding:-padding, padding:-padding] = mask
+    w_half = (box[2] - box[0]) * 0.5 * scale
+    h_half = (box[3] - box[1]) * 0.5 * scale
+    x_c, y_c = (box[2] + box[0]) * 0.5, (box[3] + box[1]) * 0.5
+    bx = torch.stack((x_c - w_half, y_c - h_half, x_c + w_half, y_c + h_half)).to(torch.int32).tolist()
+    w = max(bx[2] - bx[0] + 1, 1)
+    h = max(bx[3] - bx[1] + 1, 1)
+    resized = F.interpolate(padded[None, None].float(), size=(h, w), mode="bilinear", align_corners=False)[0, 0]
+    resized = resized > thresh
+    im_mask = torch.zeros((im_h, im_w), dtype=torch.bool, device=mask.device)
+    x0, x1 = max(bx[0], 0), min(bx[2] + 1, im_w)
+    y0, y1 = max(bx[1], 0), min(bx[3] + 1, im_h)
+    if x1 > x0 and y1 > y0:
+        im_mask[y0:y1, x0:x1] = resized[(y0 - bx[1]):(y1 - bx[1]), (x0 - bx[0]):(x1 - bx[0])]
+    return im_mask
+
+
+class Masker:
+    def __init__(self, threshold=0.5, padding=1):
+        self.threshold, self.padding = threshold, padding
+
+    def __call__(self, masks, boxlist):
+        """masks [P,1,M,M], boxlist -> bool [P,1,H,W]"""
+        im_w, im_h = boxlist.size
+        res = [paste_mask_in_image(m[0], b, im_h, im_w, self.threshold, self.padding)
+               for m, b in zip(masks, boxlist.bbox)]
+        if res:
+            return torch.stack(res, 0)[:, None]
+        return masks.new_empty((0, 1, im_h, im_w), dtype=torch.bool)
+
+
+class ROIMaskHead(nn.Module):
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        self.cfg = cfg
+        self.share = cfg.MODEL.ROI_MASK_HEAD.SHARE_BOX_FEATURE_EXTRACTOR
+        self.feature_extractor = ResNet50Conv5ROIFeatureExtractor(cfg, cfg.MODEL.ROI_MASK_HEAD)
+        self.predictor = MaskRCNNC4Predictor(cfg, self.feature_extractor.out_channels)
+        self.loss_evaluator = MaskRCNNLossComputation(cfg)
+        self.cls_agnostic_mask = cfg.MODEL.CLS_AGNOSTIC_MASK
+        self.log = "N/A"
+        self.avg_uncertain = "N/A"
+
+    def forward(self, features, proposals, targets=None, compute_uncertain=False, eps=None):
+        if self.training:
+            positive_inds = [p.get_field("labels") > 0 for p in proposals]
+            proposals = [p[i] for p, i in zip(proposals, positive_inds)]
+        if self.training and self.share:
+            x = features[_cat(positive_inds, 0)]
+        else:
+            x = self.feature_extractor(features, proposals)
+        if compute_uncertain:
+            mask_logits, scale = self.predictor(x, True, eps=eps)
+            self.log, self.avg_uncertain = scale.max(), scale.mean()
+        else:
+            mask_logits = self.predictor(x)
+        if not self.training:
+            prob = mask_logits.sigmoid()
+            if self.cls_agnostic_mask:
+                prob = prob[:, 1][:, None]
+            else:
+                labels = _cat([b.get_field("labels") for b in proposals], 0)
+                prob = prob[torch.arange(prob.shape[0], device=prob.device), labels][:, None]
+            results = []
+            for p, b in zip(prob.split([len(b) for b in proposals], 0), proposals):
+                out = b.copy_with_fields(b.fields())
+                out.add_field("mask", p)
+                results.append(out)
+            return x, results, {}
+        loss_mask = self.loss_evaluator(proposals, mask_logits, targets)
+        return x, proposals, dict(loss_mask=loss_mask)
+
+
+class CombinedROIHeads(nn.ModuleDict):
+    def __init__(self, cfg, in_channels, is_teacher=False):
+        heads = [("box", ROIBoxHead(cfg, in_channels, is_teacher))]
+        if cfg.MODEL.MASK_ON:
+            heads.append(("mask", ROIMaskHead(cfg, in_channels)))
+        super().__init__(heads)
+        self.cfg = cfg
+        self.mask_on = cfg.MODEL.MASK_ON
+        if self.mask_on and cfg.MODEL.ROI_MASK_HEAD.SHARE_BOX_FEATURE_EXTRACTOR:
+            self.mask.feature_extractor = self.box.feature_extractor
+
+    def forward(self, features, proposals, targets=None, bbox_only=False, compute_uncertain=False, eps=None):
+        losses, package_x = {}, {}
+        x, detections, loss_box = self.box(features, proposals, targets)
+        package_x["bbox"] = x
+        losses.update(loss_box)
+        if self.mask_on and not bbox_only:
+            mask_features = features
+            if self.training and self.cfg.MODEL.ROI_MASK_HEAD.SHARE_BOX_FEATURE_EXTRACTOR:
+                mask_features = x
+            x, detections, loss_mask = self.mask(mask_features, detections, targets, compute_uncertain, eps=eps)
+            package_x["mask"] = x
+            losses.update(loss_mask)
+        return package_x, detections, losses

@@ -1,0 +1,193 @@
+"""Region proposal network: anchors, head, proposal selection (top-k -> decode -> clip -> NMS), loss.
+
+Counterpart of maskrcnn_benchmark/modeling/rpn/anchor_generator.py:34-128,200-290,
+rpn/rpn.py:74-197, rpn/inference.py:15-205 and rpn/loss.py:21-131 for the single-level (C4)
+case every shipped config uses.  The proposal path calls the HIP NMS through ``layers.nms``.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..layers import smooth_l1_loss
+from .box_coder import BoxCoder
+from .matcher import BalancedPositiveNegativeSampler, Matcher
+from .structures import BoxList, box_iou, boxlist_nms, cat_boxlist, remove_small_boxes
+
+
+# ---- anchors (anchor_generator.py:200-290; the classic Faster R-CNN enumeration) ------------------------
+def _whctrs(a):
+    w, h = a[2] - a[0] + 1, a[3] - a[1] + 1
+    return w, h, a[0] + 0.5 * (w - 1), a[1] + 0.5 * (h - 1)
+
+
+def _mkanchors(ws, hs, x_ctr, y_ctr):
+    ws, hs = ws[:, None], hs[:, None]
+    return np.hstack((x_ctr - 0.5 * (ws - 1), y_ctr - 0.5 * (hs - 1), x_ctr + 0.5 * (ws - 1), y_ctr + 0.5 * (hs - 1)))
+
+
+def generate_cell_anchors(stride, sizes, aspect_ratios):
+    base = np.array([1, 1, stride, stride], dtype=np.float64) - 1
+    w, h, x_ctr, y_ctr = _whctrs(base)
+    ratios = np.array(aspect_ratios, dtype=np.float64)
+    ws = np.round(np.sqrt(w * h / ratios))
+    hs = np.round(ws * ratios)
+    ratio_anchors = _mkanchors(ws, hs, x_ctr, y_ctr)
+    scales = np.array(sizes, dtype=np.float64) / stride
+    out = []
+    for a in ratio_anchors:
+        w, h, x_ctr, y_ctr = _whctrs(a)
+        out.append(_mkanchors(w * scales, h * scales, x_ctr, y_ctr))
+    return torch.from_numpy(np.vstack(out)).float()
+
+
+class AnchorGenerator(nn.Module):
+    def __init__(self, sizes, aspect_ratios, stride, straddle_thresh=0):
+        super().__init__()
+        self.stride = stride
+        self.straddle_thresh = straddle_thresh
+        self.register_buffer("cell_anchors", generate_cell_anchors(stride, sizes, aspect_ratios), persistent=False)
+        self._grid_cache = {}
+
+    def num_anchors_per_location(self):
+        return self.cell_anchors.shape[0]
+
+    def grid_anchors(self, grid_h, grid_w):
+        key = (grid_h, grid_w, self.cell_anchors.device)
+        if key not in self._grid_cache:
+            dev = self.cell_anchors.device
+            sx = torch.arange(0, grid_w * self.stride, step=self.stride, dtype=torch.float32, device=dev)
+            sy = torch.arange(0, grid_h * self.stride, step=self.stride, dtype=torch.float32, device=dev)
+            yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+            shifts = torch.stack((xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)), dim=1)
+            self._grid_cache[key] = (shifts.view(-1, 1, 4) + self.cell_anchors.view(1, -1, 4)).reshape(-1, 4)
+        return self._grid_cache[key]
+
+    def visibility(self, anchors, image_w, image_h):
+        if self.straddle_thresh < 0:
+            return torch.ones(anchors.shape[0], dtype=torch.bool, device=anchors.device)
+        t = self.straddle_thresh
+        return ((anchors[:, 0] >= -t) & (anchors[:, 1] >= -t) & (anchors[:, 2] < image_w + t)
+                & (anchors[:, 3] < image_h + t))
+
+    def forward(self, image_sizes, feature):
+        """-> list (one per image) of BoxList with a 'visibility' field."""
+        anchors = self.grid_anchors(feature.shape[-2], feature.shape[-1])
+        out = []
+        for (h, w) in image_sizes:
+            b = BoxList(anchors, (w, h))
+            b.add_field("visibility", self.visibility(anchors, w, h))
+            out.append(b)
+        return out
+
+
+class RPNHead(nn.Module):  # rpn.py:74-106
+    def __init__(self, in_channels, num_anchors):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+        self.cls_logits = nn.Conv2d(in_channels, num_anchors, kernel_size=1, stride=1)
+        self.bbox_pred = nn.Conv2d(in_channels, num_anchors * 4, kernel_size=1, stride=1)
+        for l in (self.conv, self.cls_logits, self.bbox_pred):
+            nn.init.normal_(l.weight, std=0.01)
+            nn.init.constant_(l.bias, 0)
+
+    def forward(self, feature):
+        t = F.relu(self.conv(feature))
+        return self.cls_logits(t), self.bbox_pred(t)
+
+
+def permute_and_flatten(layer, n, a, c, h, w):  # rpn/utils.py
+    return layer.view(n, -1, c, h, w).permute(0, 3, 4, 1, 2).reshape(n, -1, c)
+
+
+class RPNPostProcessor(nn.Module):  # inference.py:15-140 (single feature map)
+    def __init__(self, pre_nms_top_n, post_nms_top_n, nms_thresh, min_size, box_coder):
+        super().__init__()
+        self.pre_nms_top_n = pre_nms_top_n
+        self.post_nms_top_n = post_nms_top_n
+        self.nms_thresh = nms_thresh
+        self.min_size = min_size
+        self.box_coder = box_coder
+
+    def forward(self, anchors, objectness, box_regression, targets=None, add_gt=False):
+        n, a, h, w = objectness.shape
+        objectness = permute_and_flatten(objectness, n, a, 1, h, w).view(n, -1).sigmoid()
+        box_regression = permute_and_flatten(box_regression, n, a, 4, h, w)
+        pre_nms_top_n = min(self.pre_nms_top_n, a * h * w)
+        objectness, topk_idx = objectness.topk(pre_nms_top_n, dim=1, sorted=True)
+        batch_idx = torch.arange(n, device=objectness.device)[:, None]
+        box_regression = box_regression[batch_idx, topk_idx]
+        concat_anchors = torch.stack([b.bbox for b in anchors], 0)[batch_idx, topk_idx]
+        proposals = self.box_coder.decode(box_regression.reshape(-1, 4), concat_anchors.reshape(-1, 4)).view(n, -1, 4)
+        result = []
+        for i in range(n):
+            boxlist = BoxList(proposals[i], anchors[i].size)
+            boxlist.add_field("objectness", objectness[i])
+            boxlist = boxlist.clip_to_image(remove_empty=False)
+            boxlist = remove_small_boxes(boxlist, self.min_size)
+            boxlist = boxlist_nms(boxlist, self.nms_thresh, max_proposals=self.post_nms_top_n,
+                                  score_field="objectness")
+            if add_gt and targets is not None:  # inference.py:51-74
+                gt = BoxList(targets[i].bbox, targets[i].size)
+                gt.add_field("objectness", torch.ones(len(gt), device=gt.bbox.device))
+                boxlist = cat_boxlist((boxlist, gt))
+            result.append(boxlist)
+        return result
+
+
+class RPNLossComputation:  # loss.py:21-131
+    def __init__(self, matcher, sampler, box_coder):
+        self.matcher, self.sampler, self.box_coder = matcher, sampler, box_coder
+
+    def __call__(self, anchors, objectness, box_regression, targets):
+        labels, reg_targets = [], []
+        for anc, tgt in zip(anchors, targets):
+            matched = self.matcher(box_iou(tgt.bbox, anc.bbox))
+            lab = (matched >= 0).to(torch.float32)
+            lab[matched == Matcher.BELOW_LOW_THRESHOLD] = 0
+            lab[~anc.get_field("visibility")] = -1
+            lab[matched == Matcher.BETWEEN_THRESHOLDS] = -1
+            labels.append(lab)
+            reg_targets.append(self.box_coder.encode(tgt.bbox[matched.clamp(min=0)], anc.bbox))
+        pos, neg = self.sampler(labels)
+        pos = torch.nonzero(torch.cat(pos, 0)).squeeze(1)
+        neg = torch.nonzero(torch.cat(neg, 0)).squeeze(1)
+        sampled = torch.cat([pos, neg], 0)
+        n, a, h, w = objectness.shape
+        obj = permute_and_flatten(objectness, n, a, 1, h, w).reshape(-1)
+        reg = permute_and_flatten(box_regression, n, a, 4, h, w).reshape(-1, 4)
+        labels, reg_targets = torch.cat(labels, 0), torch.cat(reg_targets, 0)
+        box_loss = smooth_l1_loss(reg[pos], reg_targets[pos], beta=1.0 / 9, size_average=False) / sampled.numel()
+        objectness_loss = F.binary_cross_entropy_with_logits(obj[sampled], labels[sampled])
+        return objectness_loss, box_loss
+
+
+class RPNModule(nn.Module):  # rpn.py:109-197
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        r = cfg.MODEL.RPN
+        if r.USE_FPN or len(r.ANCHOR_STRIDE) != 1:
+            raise NotImplementedError("single-level RPN only (no shipped config uses FPN)")
+        self.anchor_generator = AnchorGenerator(r.ANCHOR_SIZES, r.ASPECT_RATIOS, r.ANCHOR_STRIDE[0], r.STRADDLE_THRESH)
+        self.head = RPNHead(in_channels, self.anchor_generator.num_anchors_per_location())
+        coder = BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
+        self.box_selector_train = RPNPostProcessor(r.PRE_NMS_TOP_N_TRAIN, r.POST_NMS_TOP_N_TRAIN, r.NMS_THRESH,
+                                                   r.MIN_SIZE, coder)
+        self.box_selector_test = RPNPostProcessor(r.PRE_NMS_TOP_N_TEST, r.POST_NMS_TOP_N_TEST, r.NMS_THRESH,
+                                                  r.MIN_SIZE, coder)
+        self.loss_evaluator = RPNLossComputation(
+            Matcher(r.FG_IOU_THRESHOLD, r.BG_IOU_THRESHOLD, allow_low_quality_matches=True),
+            BalancedPositiveNegativeSampler(r.BATCH_SIZE_PER_IMAGE, r.POSITIVE_FRACTION), coder)
+
+    def forward(self, images, features, targets=None, compute_loss=True):
+        feature = features[0]
+        objectness, box_regression = self.head(feature)
+        anchors = self.anchor_generator(images.image_sizes, feature)
+        if self.training:
+            with torch.no_grad():
+                boxes = self.box_selector_train(anchors, objectness, box_regression, targets, add_gt=True)
+            if not compute_loss:
+                return boxes, {}
+            lo, lb = self.loss_evaluator(anchors, objectness, box_regression, targets)
+            return boxes, {"loss_objectness": lo, "loss_rpn_box_reg": lb}
+        return self.box_selector_test(anchors, objectness, box_regression), {}
