@@ -257,16 +257,19 @@ class MaskRCNNC4Predictor(nn.Module):
             nn.init.constant_(self.uncertain_pred.bias, 1)
 
     def forward(self, x, compute_uncertain=False, eps=None):
-        """``eps`` (standard-normal noise, [1,P,1,M,M]) can be injected for reproducible tests;
-        by default it is drawn on the device (the reference draws on the host and copies)."""
+        """``eps`` (standard-normal noise, [1,P,C,M,M] -- the reference draws it with the shape of
+        ``mask_logits*0+scale``, i.e. independently per logit channel, roi_mask_predictors.py:47-53,62)
+        can be injected for reproducible tests; by default it is drawn on the device (the reference
+        draws on the host and copies)."""
         x_ = F.relu(self.conv5_mask(x))
         mask_logits = self.mask_fcn_logits(x_)
         if self.uncertainty and compute_uncertain:
             scale = torch.exp(0.5 * self.uncertain_pred(x_.detach()))  # [P,1,M,M] std-dev
             if self.training:
+                std = mask_logits * 0.0 + scale  # [P,C,M,M]
                 if eps is None:
-                    eps = torch.randn((1, *scale.shape), device=scale.device, dtype=scale.dtype)
-                mask_logits = mask_logits[None] + eps * (mask_logits * 0.0 + scale)[None]  # [1,P,2,M,M]
+                    eps = torch.randn((1, *std.shape), device=std.device, dtype=std.dtype)
+                mask_logits = mask_logits[None] + eps * std[None]  # [1,P,C,M,M]
             return mask_logits, scale
         return mask_logits
 

@@ -122,12 +122,163 @@ def gen_focal():
                         d_losses2=d2.float().numpy(), loss2=loss2.detach().numpy(), grad2=grad2.numpy())
 
 
+# --------------------------------------------------------------------------------------------------
+# Python-side components of the hot path (SURVEY.md 8a rows a6, a8, a9, a10 + RPN / anchors / paste)
+# --------------------------------------------------------------------------------------------------
+def _ns(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+def _ref_cfg(uncertainty=True):
+    return _ns(MODEL=_ns(
+        CLS_AGNOSTIC_BBOX_REG=True, CLS_AGNOSTIC_MASK=True, UNCERTAINTY=uncertainty,
+        ROI_BOX_HEAD=_ns(EMBEDDING_BASED=True, EMB_DIM=48, FREEZE_EMB_PRED=False, NUM_CLASSES=49,
+                         LOSS_WEIGHT_BACKGROUND=0.2),
+        ROI_MASK_HEAD=_ns(CONV_LAYERS=(24, 24, 24, 24), RESOLUTION=14),
+        ROI_HEADS=_ns(FG_IOU_THRESHOLD=0.5, BG_IOU_THRESHOLD=0.5)))
+
+
+def gen_heads():
+    """FastRCNNPredictor / MaskRCNNC4Predictor / losses, run through the reference's own modules."""
+    for m in ("cv2", "pycocotools", "pycocotools.mask"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    if not hasattr(np, "float"):
+        np.float = float  # numpy>=1.24 dropped the alias rpn/anchor_generator.py:227-228 still uses
+    from maskrcnn_benchmark.modeling.roi_heads.box_head.roi_box_predictors import FastRCNNPredictor
+    from maskrcnn_benchmark.modeling.roi_heads.mask_head.roi_mask_predictors import MaskRCNNC4Predictor
+    from maskrcnn_benchmark.modeling.roi_heads.box_head.loss import FastRCNNLossComputation
+    from maskrcnn_benchmark.modeling.box_coder import BoxCoder
+    from maskrcnn_benchmark.modeling.matcher import Matcher
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.boxlist_ops import boxlist_iou
+    from maskrcnn_benchmark.layers import smooth_l1_loss, FrozenBatchNorm2d
+    from maskrcnn_benchmark.modeling.rpn.anchor_generator import AnchorGenerator
+    from maskrcnn_benchmark.modeling.rpn.inference import RPNPostProcessor
+    from maskrcnn_benchmark.modeling.roi_heads.mask_head.inference import paste_mask_in_image
+    import torch.nn.functional as F
+
+    out = {}
+    g = torch.Generator().manual_seed(99)
+    cfg = _ref_cfg()
+
+    # ---- box predictor (roi_box_predictors.py:62-81) for the three class-matrix sizes of the step
+    torch.manual_seed(5)
+    pred = FastRCNNPredictor(cfg, 96, False)  # small dims keep the fixture small; the math is size-agnostic
+    with torch.no_grad():
+        pred.emb_pred.bias.normal_(0, 0.01, generator=g)
+        pred.bbox_pred.bias.normal_(0, 0.01, generator=g)
+    x = torch.randn(24, 96, 7, 7, generator=g)
+    out["pred_x"] = x.numpy()
+    for k, v in pred.state_dict().items():
+        out["pred_" + k] = v.numpy()
+    for c in (1, 49, 1203):
+        e = F.normalize(torch.randn(c, 48, generator=g), dim=-1)
+        if c > 1:
+            e[0] = 0
+        pred.set_class_embeddings(e)
+        logits, box = pred(x)
+        out[f"pred_cls{c}"], out[f"pred_logits{c}"] = e.numpy(), logits.detach().numpy()
+    out["pred_box"] = box.detach().numpy()
+
+    # ---- box loss arithmetic (box_head/loss.py:125-185); `.cuda()` is hard-coded there (SURVEY D5)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    loss_eval = FastRCNNLossComputation.__new__(FastRCNNLossComputation)
+    loss_eval.cls_agnostic_bbox_reg, loss_eval.bg_weight = True, 0.2
+    P = 40
+    labels = torch.randint(0, 49, (P,), generator=g)
+    labels[::3] = 0
+    reg_t = torch.randn(P, 4, generator=g)
+    prop = BoxList(torch.zeros(P, 4), (100, 100))
+    prop.add_field("labels", labels)
+    prop.add_field("regression_targets", reg_t)
+    loss_eval._proposals = [prop]
+    cl, br = torch.randn(P, 49, generator=g), torch.randn(P, 8, generator=g) * 0.3
+    lc, lb = loss_eval([cl], [br], None)
+    out.update(boxloss_logits=cl.numpy(), boxloss_reg=br.numpy(), boxloss_labels=labels.numpy(),
+               boxloss_targets=reg_t.numpy(), boxloss_cls=lc.numpy(), boxloss_box=lb.numpy())
+
+    # ---- mask predictor with the uncertainty branch (roi_mask_predictors.py:41-65), eps captured
+    torch.manual_seed(6)
+    mp = MaskRCNNC4Predictor(cfg, 64)
+    with torch.no_grad():
+        mp.uncertain_pred.weight.normal_(0, 0.05, generator=g)
+    xm = torch.randn(6, 64, 7, 7, generator=g) * 0.2
+    out["mask_x"] = xm.numpy()
+    for k, v in mp.state_dict().items():
+        out["maskpred_" + k] = v.numpy()
+    mp.train()
+    torch.manual_seed(1234)
+    eps = torch.randn(1, 6, 2, 14, 14)  # exactly what reparameterize() draws next: std = logits*0+scale is [P,2,M,M]
+    torch.manual_seed(1234)
+    logits5, scale = mp(xm, True)
+    out.update(mask_eps=eps.numpy(), mask_logits5=logits5.detach().numpy(), mask_scale=scale.detach().numpy())
+    mp.eval()
+    out["mask_logits_eval"] = mp(xm).detach().numpy()
+    # mask loss arithmetic (mask_head/loss.py:117-148) on channel 1 of positives
+    tgt = (torch.rand(6, 14, 14, generator=g) > 0.5).float()
+    flat = torch.flatten(logits5, 0, 1)
+    out["mask_targets"] = tgt.numpy()
+    out["mask_loss"] = F.binary_cross_entropy_with_logits(flat[torch.arange(6), torch.ones(6, dtype=torch.long)], tgt,
+                                                          reduction="none").mean().detach().numpy()
+
+    # ---- small numeric helpers
+    coder = BoxCoder(weights=(10.0, 10.0, 5.0, 5.0))
+    xy = torch.rand(30, 2, generator=g) * 300
+    ref_b = torch.cat([xy, xy + torch.rand(30, 2, generator=g) * 200 + 4], 1)
+    xy2 = xy + torch.randn(30, 2, generator=g) * 10
+    prop_b = torch.cat([xy2, xy2 + torch.rand(30, 2, generator=g) * 200 + 4], 1)
+    enc = coder.encode(ref_b, prop_b)
+    codes = torch.randn(30, 8, generator=g)
+    codes[0, 2] = 50.0  # exercises the bbox_xform_clip clamp
+    out.update(coder_ref=ref_b.numpy(), coder_prop=prop_b.numpy(), coder_enc=enc.numpy(), coder_codes=codes.numpy(),
+               coder_dec=coder.decode(codes, prop_b).numpy())
+    iou = boxlist_iou(BoxList(ref_b[:7], (600, 600)), BoxList(prop_b, (600, 600)))
+    out["iou"] = iou.numpy()
+    out["match_plain"] = Matcher(0.5, 0.5, False)(iou).numpy()
+    out["match_rpn"] = Matcher(0.7, 0.3, True)(iou).numpy()
+    a, b = torch.randn(50, 4, generator=g), torch.randn(50, 4, generator=g)
+    out.update(sl1_a=a.numpy(), sl1_b=b.numpy(), sl1_beta1_sum=smooth_l1_loss(a, b, beta=1, size_average=False).numpy(),
+               sl1_beta9_mean=smooth_l1_loss(a, b).numpy())
+    bn = FrozenBatchNorm2d(5)
+    for n_ in ("weight", "bias", "running_mean"):
+        getattr(bn, n_).copy_(torch.randn(5, generator=g))
+    bn.running_var.copy_(torch.rand(5, generator=g) + 0.5)
+    xb = torch.randn(2, 5, 3, 4, generator=g)
+    out.update(bn_x=xb.numpy(), bn_y=bn(xb).numpy(), **{"bn_" + k: v.numpy() for k, v in bn.state_dict().items()})
+
+    # ---- anchors + RPN proposal selection on one small feature map (rpn/inference.py:76-123)
+    ag = AnchorGenerator((32, 64, 128, 256, 512), (0.5, 1.0, 2.0), (16,), 0)
+    out["cell_anchors"] = list(ag.cell_anchors)[0].numpy()
+    n, A, H, W = 2, 15, 9, 12
+    feat = torch.zeros(n, 1, H, W)
+    il = _ns(image_sizes=[(H * 16, W * 16), (H * 16 - 10, W * 16 - 7)])
+    anchors = ag(il, [feat])
+    out["anchors_img1"] = anchors[1][0].bbox.numpy()
+    out["anchors_vis1"] = anchors[1][0].get_field("visibility").numpy()
+    obj = torch.randn(n, A, H, W, generator=g)
+    reg = torch.randn(n, A * 4, H, W, generator=g) * 0.2
+    pp = RPNPostProcessor(pre_nms_top_n=600, post_nms_top_n=50, nms_thresh=0.7, min_size=0)
+    res = pp.forward_for_single_feature_map([a_[0] for a_ in anchors], obj, reg)
+    out.update(rpn_obj=obj.numpy(), rpn_reg=reg.numpy())
+    for i, r in enumerate(res):
+        out[f"rpn_boxes{i}"], out[f"rpn_scores{i}"] = r.bbox.numpy(), r.get_field("objectness").numpy()
+
+    # ---- Masker paste (mask_head/inference.py:124-160)
+    m = torch.rand(14, 14, generator=g)
+    for i, box in enumerate(([10.3, 20.7, 90.2, 70.9], [-5.0, -8.0, 30.0, 25.0], [100.0, 60.0, 159.0, 119.0])):
+        out[f"paste_box{i}"] = np.array(box, dtype=np.float32)
+        out[f"paste_out{i}"] = paste_mask_in_image(m, torch.tensor(box), 120, 160).numpy()
+    out["paste_mask"] = m.numpy()
+    np.savez_compressed(os.path.join(HERE, "heads.npz"), **out)
+
+
 def main():
     torch.set_num_threads(1)
     ref_c = import_reference()
     gen_roi_align(ref_c)
     gen_nms(ref_c)
     gen_focal()
+    gen_heads()
     print("fixtures written to", HERE)
 
 

@@ -1,0 +1,219 @@
+"""CPU: host-side components of the hot path against fixtures produced by the reference's own Python
+modules (tests/golden/make_golden.py::gen_heads), plus the config surface and a tiny end-to-end step
+with the native ops routed to the oracle (tests/oracle_backend.py)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+from cvpr22_cross_modal_pseudo_labeling_amd.modeling import roi_heads as RH
+from cvpr22_cross_modal_pseudo_labeling_amd.modeling.box_coder import BoxCoder
+from cvpr22_cross_modal_pseudo_labeling_amd.modeling.matcher import Matcher
+from cvpr22_cross_modal_pseudo_labeling_amd.modeling.structures import BoxList, box_iou
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def z(golden_dir):
+    return np.load(os.path.join(golden_dir, "heads.npz"))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def small_cfg(**over):
+    cfg = get_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, "configs/coco_cap_det/student_teacher_mask_rcnn_uncertainty.yaml"))
+    cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.EMB_DIM", 48, "MODEL.ROI_MASK_HEAD.CONV_LAYERS", (24, 24, 24, 24)])
+    return cfg
+
+
+def test_box_predictor_matches_reference(z):
+    pred = RH.FastRCNNPredictor(small_cfg(), 96)
+    pred.load_state_dict({k[5:]: T(z[k]) for k in z.files if k.startswith("pred_") and k[5:] in pred.state_dict()})
+    x = T(z["pred_x"])
+    for c in (1, 49, 1203):
+        pred.set_class_embeddings(T(z[f"pred_cls{c}"]))
+        logits, box = pred(x)
+        assert logits.shape == (24, c)
+        assert torch.allclose(logits, T(z[f"pred_logits{c}"]), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(box, T(z["pred_box"]), rtol=1e-4, atol=1e-6)
+
+
+def test_box_loss_matches_reference(z):
+    ev = RH.FastRCNNLossComputation(small_cfg())
+    P = z["boxloss_labels"].shape[0]
+    prop = BoxList(torch.zeros(P, 4), (100, 100))
+    prop.add_field("labels", T(z["boxloss_labels"]))
+    prop.add_field("regression_targets", T(z["boxloss_targets"]))
+    ev._proposals = [prop]
+    lc, lb = ev(T(z["boxloss_logits"]), T(z["boxloss_reg"]))
+    assert torch.allclose(lc, T(z["boxloss_cls"]), rtol=1e-5)
+    assert torch.allclose(lb, T(z["boxloss_box"]), rtol=1e-5)
+
+
+def test_mask_predictor_and_loss_match_reference(z):
+    mp = RH.MaskRCNNC4Predictor(small_cfg(), 64)
+    mp.load_state_dict({k[9:]: T(z[k]) for k in z.files if k.startswith("maskpred_")})
+    x = T(z["mask_x"])
+    mp.train()
+    logits5, scale = mp(x, True, eps=T(z["mask_eps"]))
+    assert logits5.shape == (1, 6, 2, 14, 14) and scale.shape == (6, 1, 14, 14)
+    assert torch.allclose(scale, T(z["mask_scale"]), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(logits5, T(z["mask_logits5"]), rtol=1e-4, atol=1e-5)
+    mp.eval()
+    assert torch.allclose(mp(x), T(z["mask_logits_eval"]), rtol=1e-4, atol=1e-5)
+    flat = torch.flatten(logits5, 0, 1)
+    loss = F.binary_cross_entropy_with_logits(flat[torch.arange(6), torch.ones(6, dtype=torch.long)],
+                                              T(z["mask_targets"]), reduction="none").mean()
+    assert torch.allclose(loss, T(z["mask_loss"]), rtol=1e-5)
+
+
+def test_numeric_helpers_match_reference(z):
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers import FrozenBatchNorm2d, smooth_l1_loss
+
+    coder = BoxCoder(weights=(10.0, 10.0, 5.0, 5.0))
+    assert torch.allclose(coder.encode(T(z["coder_ref"]), T(z["coder_prop"])), T(z["coder_enc"]), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(coder.decode(T(z["coder_codes"]), T(z["coder_prop"])), T(z["coder_dec"]), rtol=1e-5, atol=1e-3)
+    iou = box_iou(T(z["coder_ref"])[:7], T(z["coder_prop"]))
+    assert torch.allclose(iou, T(z["iou"]), rtol=1e-6, atol=1e-7)
+    assert torch.equal(Matcher(0.5, 0.5, False)(T(z["iou"])), T(z["match_plain"]))
+    assert torch.equal(Matcher(0.7, 0.3, True)(T(z["iou"])), T(z["match_rpn"]))
+    a, b = T(z["sl1_a"]), T(z["sl1_b"])
+    assert torch.allclose(smooth_l1_loss(a, b, beta=1, size_average=False), T(z["sl1_beta1_sum"]))
+    assert torch.allclose(smooth_l1_loss(a, b), T(z["sl1_beta9_mean"]))
+    bn = FrozenBatchNorm2d(5)
+    bn.load_state_dict({k[3:]: T(z[k]) for k in z.files if k.startswith("bn_") and k not in ("bn_x", "bn_y")})
+    assert torch.allclose(bn(T(z["bn_x"])), T(z["bn_y"]), rtol=1e-6, atol=1e-6)
+
+
+def test_frozen_bn_fold_into_conv_is_equivalent():
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers import Conv2d, FrozenBatchNorm2d
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.backbone import ConvBN
+
+    g = torch.Generator().manual_seed(0)
+    conv, bn = Conv2d(6, 9, 3, stride=2, padding=1, bias=False), FrozenBatchNorm2d(9)
+    bn.weight.copy_(torch.randn(9, generator=g)); bn.bias.copy_(torch.randn(9, generator=g))
+    bn.running_mean.copy_(torch.randn(9, generator=g)); bn.running_var.copy_(torch.rand(9, generator=g) + 0.5)
+    x = torch.randn(2, 6, 11, 13, generator=g)
+    fused = ConvBN(conv, bn)
+    assert torch.allclose(fused(x), bn(conv(x)), rtol=1e-5, atol=1e-5)
+    fused(x).sum().backward()  # gradient reaches the (trainable) conv weight through the fold
+    gf = conv.weight.grad.clone()
+    conv.weight.grad = None
+    bn(conv(x)).sum().backward()
+    assert torch.allclose(gf, conv.weight.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_anchors_and_rpn_proposals_match_reference(z):
+    from tests.oracle_backend import oracle_ops
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling import rpn as R
+
+    ag = R.AnchorGenerator((32, 64, 128, 256, 512), (0.5, 1.0, 2.0), 16, 0)
+    assert torch.equal(ag.cell_anchors, T(z["cell_anchors"]))
+    H, W = 9, 12
+    sizes = [(H * 16, W * 16), (H * 16 - 10, W * 16 - 7)]
+    anchors = ag(sizes, torch.zeros(2, 1, H, W))
+    assert torch.equal(anchors[1].bbox, T(z["anchors_img1"]))
+    assert torch.equal(anchors[1].get_field("visibility"), T(z["anchors_vis1"]))
+    pp = R.RPNPostProcessor(600, 50, 0.7, 0, BoxCoder(weights=(1.0, 1.0, 1.0, 1.0)))
+    with oracle_ops():
+        res = pp(anchors, T(z["rpn_obj"]), T(z["rpn_reg"]))
+    for i, r in enumerate(res):
+        assert torch.allclose(r.bbox, T(z[f"rpn_boxes{i}"]), rtol=1e-5, atol=1e-4)
+        assert torch.allclose(r.get_field("objectness"), T(z[f"rpn_scores{i}"]))
+
+
+def test_paste_mask_matches_reference(z):
+    m = T(z["paste_mask"])
+    for i in range(3):
+        got = RH.paste_mask_in_image(m, T(z[f"paste_box{i}"]), 120, 160)
+        assert torch.equal(got, T(z[f"paste_out{i}"]))
+
+
+def test_project_masks_on_boxes_semantics():
+    # rectangles: an analytic case -- crop inside a filled rectangle gives all ones, outside all zeros
+    masks = torch.zeros(2, 60, 80, dtype=torch.bool)
+    masks[0, 10:40, 20:60] = True
+    boxes = torch.tensor([[25.0, 15.0, 50.0, 35.0], [0.0, 45.0, 15.0, 58.0], [10.0, 5.0, 30.0, 20.0]])
+    out = RH.project_masks_on_boxes(masks, torch.tensor([0, 0, 0]), boxes, 14)
+    assert out.shape == (3, 14, 14) and out.dtype == torch.float32
+    assert bool((out[0] == 1).all()) and bool((out[1] == 0).all())
+    # straddling box: against the straightforward crop + F.interpolate restatement of the reference steps
+    xmin, ymin, xmax, ymax = 10, 5, 30, 20
+    ref = F.interpolate(masks[0:1, ymin:ymax, xmin:xmax][None].float(), size=(14, 14), mode="bilinear",
+                        align_corners=False)[0, 0]
+    assert torch.equal(out[2], (ref != 0).float())
+    # uint8 masks truncate after interpolation (type_as); a cell whose true value is 1 can land on either
+    # side of 1.0 by one ulp depending on the interpolation kernel, so compare away from that edge
+    u8 = RH.project_masks_on_boxes(masks.to(torch.uint8), torch.tensor([0]), boxes[2:], 14)
+    safe = (ref < 0.999) | (ref == 1.0)
+    assert torch.equal(u8[0][safe], ref.to(torch.uint8).float()[safe])
+    assert bool(((u8 == 0) | (u8 == 1)).all())
+
+
+def test_config_surface():
+    cfg = get_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, "configs/coco_cap_det/student_teacher_mask_rcnn_uncertainty.yaml"))
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", "16", "MODEL.RPN.NMS_THRESH", 0.6])
+    assert cfg.MODEL.META_ARCHITECTURE == "STGeneralizedRCNN" and cfg.SOLVER.IMS_PER_BATCH == 16
+    assert cfg.SOLVER.STEPS == (20000, 50000) and cfg.MODEL.RPN.NMS_THRESH == 0.6
+    with pytest.raises(KeyError):
+        cfg.merge_from_list(["MODEL.NOT_A_KEY", 1])
+    with pytest.raises(ValueError):
+        cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", "many"])
+    cfg.freeze()
+    with pytest.raises(AttributeError):
+        cfg.SOLVER.BASE_LR = 1.0
+    assert cfg.clone().SOLVER.BASE_LR == cfg.SOLVER.BASE_LR
+
+
+@pytest.mark.parametrize("name", ["student_teacher_mask_rcnn_uncertainty", "zeroshot_mask"])
+def test_tiny_train_step_on_cpu_with_oracle_ops(name):
+    """BASELINE.json configs[0] (CPU plumbing): both meta-architectures step on CPU tensors when -- and
+    only when -- the test harness routes the native ops to the oracle."""
+    from tests.oracle_backend import oracle_ops
+    from cvpr22_cross_modal_pseudo_labeling_amd.data.synthetic import calibrate_stem_bn, make_batch, make_embeddings
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm, solver, trainer
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.detector import build_detection_model
+
+    torch.manual_seed(0)
+    cfg = get_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, f"configs/coco_cap_det/{name}.yaml"))
+    cfg.merge_from_list(["MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 300, "MODEL.RPN.PRE_NMS_TOP_N_TEST", 200,
+                         "MODEL.RPN.POST_NMS_TOP_N_TRAIN", 60, "MODEL.RPN.POST_NMS_TOP_N_TEST", 40,
+                         "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 16, "SOLVER.BASE_LR", 1e-5])
+    cfg.freeze()
+    model = build_detection_model(cfg)
+    e_vocab, e_seen = make_embeddings(n_vocab=50)
+    model.set_class_embeddings(e_seen)
+    if hasattr(model, "set_caption_vocab"):
+        model.set_caption_vocab(e_vocab)
+    images, targets = make_batch(2, height=128, width=160, num_gt=3, num_nouns=2, n_vocab=50)
+    calibrate_stem_bn(model, images)
+    model.train()
+    opt = solver.make_optimizer(cfg, model)
+    red = comm.BucketedGradReducer(model)
+    with pytest.raises(RuntimeError):  # the product ops themselves refuse CPU tensors
+        model(images, targets)
+    with oracle_ops():
+        before = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+        losses = trainer.train_step(model, opt, red, images, targets)
+    want = {"loss_classifier", "loss_box_reg", "loss_mask"}
+    if name.startswith("student"):
+        want |= {k + "_pseudo" for k in want}
+        frozen = [n for n, p in model.named_parameters() if not p.requires_grad]
+        assert any(n.startswith("backbone.") for n in frozen) and any(n.startswith("roi_heads.") for n in frozen)
+        assert all(n.startswith("roi_heads_student.") or n == "lambda_exemplar" for n in before)
+    else:
+        want |= {"loss_objectness", "loss_rpn_box_reg"}
+    assert set(losses) == want
+    assert all(bool(torch.isfinite(v)) for v in losses.values())
+    moved = [n for n, p in model.named_parameters() if p.requires_grad and not torch.equal(p.detach(), before[n])]
+    assert len(moved) > 10
