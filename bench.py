@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="student", choices=["student", "teacher"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--channels-last", action="store_true", help="experiment: run the trunk / heads in NHWC")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,6 +171,11 @@ def main():
         model.set_caption_vocab(e_vocab)
     images, targets = make_batch(IMS_PER_GPU, device=dev, seed=1234 + rank)
     calibrate_stem_bn(model, images)
+    if args.channels_last:
+        model = model.to(memory_format=torch.channels_last)
+        images = images.contiguous(memory_format=torch.channels_last)
+        _orig_fwd = _C.roi_align_forward
+        _C.roi_align_forward = lambda *a: _orig_fwd(*a).contiguous(memory_format=torch.channels_last)
     comm.broadcast_parameters(model)
     model.train()
     optimizer = solver.make_optimizer(cfg, model)

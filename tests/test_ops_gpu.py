@@ -215,3 +215,33 @@ def test_focal_vs_oracle_and_module(C, oracle_mod, num, c):
     wgrad = oracle_mod.sigmoid_focal_loss_backward(logits, targets, torch.ones(num, c), 2.0, 0.25)
     assert torch.allclose(ld.grad.cpu(), wgrad, rtol=1e-5, atol=1e-7)
     assert abs(total.item() - want.double().sum().item()) <= 1e-4 * max(1.0, want.double().sum().item())
+
+
+def test_roi_align_backward_deterministic_mode(oracle_mod):
+    """OVIS_ROI_BWD_DETERMINISTIC=1: the atomics-free plane-owner kernel -- same values (tolerance), and two runs
+    are bit-identical.  Runs in a subprocess because the switch is read once per process."""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+import oracle
+from cvpr22_cross_modal_pseudo_labeling_amd import _C
+g = torch.Generator().manual_seed(5)
+n, c, h, w, r = 2, 10, 50, 84, 300
+b = torch.randint(0, n, (r, 1), generator=g).float()
+xy = torch.rand(r, 2, generator=g) * torch.tensor([1000.0, 600.0])
+wh = torch.rand(r, 2, generator=g) * 500 + 4
+rois = torch.cat([b, xy, (xy + wh).clamp(max=1300)], 1)
+go = torch.randn(r, c, 14, 14, generator=g)
+a = _C.roi_align_backward(go.cuda(), rois.cuda(), 1 / 16, 14, 14, n, c, h, w, 0)
+b2 = _C.roi_align_backward(go.cuda(), rois.cuda(), 1 / 16, 14, 14, n, c, h, w, 0)
+want = oracle.roi_align_backward(go, rois, 1 / 16, 14, 14, n, c, h, w, 0)
+assert torch.equal(a, b2), "not reproducible"
+assert torch.allclose(a.cpu(), want, rtol=1e-4, atol=1e-4), (a.cpu() - want).abs().max()
+print("ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OVIS_ROI_BWD_DETERMINISTIC="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
