@@ -56,7 +56,8 @@ template <bool GE>
 __global__ __launch_bounds__(kTile) void nms_mask_kernel(const float4* __restrict__ boxes,
                                                          const int* __restrict__ order, int K,
                                                          int nb, float thr,
-                                                         unsigned long long* __restrict__ mask) {
+                                                         unsigned long long* __restrict__ mask,
+                                                         unsigned long long* __restrict__ diag_t) {
   const int row_blk = blockIdx.y, col_blk = blockIdx.x;
   if (row_blk > col_blk) return;
   __shared__ float4 col_boxes[kTile];
@@ -65,17 +66,29 @@ __global__ __launch_bounds__(kTile) void nms_mask_kernel(const float4* __restric
   if (col < K) col_boxes[lane] = boxes[order[col]];
   __syncthreads();
   const int row = row_blk * kTile + lane;
-  if (row >= K) return;
-  const float4 a = boxes[order[row]];
-  const int ncol = min(K - col_blk * kTile, kTile);
   unsigned long long bits = 0;
-  const int start = (row_blk == col_blk) ? lane + 1 : 0;
-  for (int j = start; j < ncol; ++j) {
-    const float v = iou_xyxy(a, col_boxes[j]);
-    const bool hit = GE ? (v >= thr) : (v > thr);
-    if (hit) bits |= 1ull << j;
+  if (row < K) {
+    const float4 a = boxes[order[row]];
+    const int ncol = min(K - col_blk * kTile, kTile);
+    const int start = (row_blk == col_blk) ? lane + 1 : 0;
+    for (int j = start; j < ncol; ++j) {
+      const float v = iou_xyxy(a, col_boxes[j]);
+      const bool hit = GE ? (v >= thr) : (v > thr);
+      if (hit) bits |= 1ull << j;
+    }
+    mask[(size_t)row * nb + col_blk] = bits;
   }
-  mask[(size_t)row * nb + col_blk] = bits;
+  if (row_blk == col_blk) {
+    // transposed diagonal tile: word c = the higher-scored boxes of this chunk that suppress box c.  The
+    // device-side reduce resolves a chunk from it with a few ballot iterations instead of a 64-step loop.
+    unsigned long long mine = 0;
+#pragma unroll 8
+    for (int c = 0; c < kTile; ++c) {
+      const unsigned long long col = __ballot((bits >> c) & 1ull);
+      if (lane == c) mine = col;
+    }
+    if (row < K) diag_t[row] = mine;
+  }
 }
 
 __global__ __launch_bounds__(kReduceThreads) void nms_reduce_kernel(
@@ -158,10 +171,133 @@ __global__ __launch_bounds__(kReduceThreads) void nms_reduce_kernel(
   if (tid == kReduceThreads - 1) *num_keep = part[tid];
 }
 
+
+// Pipelined reduce for nb <= kFastBlocks (K <= 12288: every RPN setting of the reference).
+// The chunk-b rows of the mask are needed only after chunk b is resolved, but WHICH bytes are needed does not
+// depend on the result -- so every lane streams its slice of the 64 rows of chunk b+1 into registers while
+// chunk b is being resolved, and applies the survivor mask to data that is already on chip.  Thread layout:
+// row = tid/16 (64 rows of the chunk), 16 lanes per row cover words b + l16 + 16*m.  Per chunk the critical
+// path is: barrier -> wave 0 resolves 64 boxes with scalar bit tricks -> barrier -> masked OR of registers
+// (4 rows pre-reduced in-wave with shuffles, then one 64-bit LDS atomic-or per word).
+constexpr int kFastBlocks = 192;
+constexpr int kMaxM = kFastBlocks / 16;
+
+__device__ __forceinline__ unsigned long long shfl_xor64(unsigned long long v, int m) {
+  unsigned lo = __shfl_xor((unsigned)v, m), hi = __shfl_xor((unsigned)(v >> 32), m);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(kReduceThreads) void nms_reduce_pipelined_kernel(
+    const unsigned long long* __restrict__ mask, const unsigned long long* __restrict__ diag_t,
+    const int* __restrict__ order, int K, int nb,
+    long long* __restrict__ keep_out, int* __restrict__ num_keep) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];
+  unsigned long long* removed = sm;
+  unsigned long long* keepw = sm + nb;
+  unsigned long long* obits = sm + 2 * nb;
+  int* part = (int*)(sm + 3 * nb);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = tid >> 4, l16 = tid & 15;
+  for (int i = tid; i < nb; i += kReduceThreads) { removed[i] = 0; obits[i] = 0; }
+
+  // three register buffers: chunk b is consumed while chunks b+1 and b+2 are in flight from L2 / MALL
+  unsigned long long buf0[kMaxM], buf1[kMaxM], buf2[kMaxM], dg0 = 0, dg1 = 0, dg2 = 0;
+  auto load_chunk = [&](int b, unsigned long long* dst, unsigned long long& diag) {
+    const long r = (long)b * kTile + row;
+    const unsigned long long* src = mask + r * nb;
+#pragma unroll
+    for (int m = 0; m < kMaxM; ++m) {
+      const int j = b + 1 + l16 + 16 * m;
+      dst[m] = (b < nb && r < K && j < nb) ? src[j] : 0ull;
+    }
+    if (wave == 0) {  // wave 0 additionally streams the transposed diagonal tile it resolves from
+      const long rd = (long)b * kTile + lane;
+      diag = (b < nb && rd < K) ? diag_t[rd] : 0ull;
+    }
+  };
+  auto step = [&](int b, const unsigned long long* cur, unsigned long long diag_cur) {
+    if (wave == 0) {
+      // Greedy survivors of the chunk as a fixed point: box i survives iff it is alive and no SURVIVING
+      // higher-scored box of the chunk suppresses it.  Starting from "all alive", after t rounds the first
+      // t boxes are final, so the iteration reaches the unique greedy answer in <= 64 rounds (typically 2-4);
+      // one round is a lane-local AND plus a ballot.
+      const int nvalid = min(K - b * kTile, kTile);
+      const unsigned long long valid = nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+      const unsigned long long alive = uniform64(~removed[b] & valid);
+      const bool me_alive = (alive >> lane) & 1ull;
+      unsigned long long keep = alive;
+      for (int it = 0; it <= kTile; ++it) {
+        const unsigned long long next = __ballot(me_alive && (diag_cur & keep) == 0ull);
+        if (next == keep) break;
+        keep = next;
+      }
+      if (lane == 0) keepw[b] = keep;
+    }
+    __syncthreads();
+    const unsigned long long keep = uniform64(keepw[b]);
+    const bool mine = (keep >> row) & 1ull;
+#pragma unroll
+    for (int m = 0; m < kMaxM; ++m) {
+      if (b + 1 + 16 * m >= nb) break;  // uniform
+      // 64-bit integer LDS atomics are cheap on gfx950 (~4-15 cycles per wave instruction even with the
+      // 4 rows of a wave colliding), cheaper than pre-reducing the rows with cross-lane shuffles
+      const unsigned long long v = mine ? cur[m] : 0ull;
+      const int j = b + 1 + l16 + 16 * m;
+      if (v != 0ull && j < nb) atomicOr(&removed[j], v);
+    }
+    __syncthreads();
+  };
+  load_chunk(0, buf0, dg0);
+  load_chunk(1, buf1, dg1);
+  __syncthreads();
+  for (int b = 0; b < nb; b += 3) {
+    load_chunk(b + 2, buf2, dg2);
+    step(b, buf0, dg0);
+    if (b + 1 >= nb) break;
+    load_chunk(b + 3, buf0, dg0);
+    step(b + 1, buf1, dg1);
+    if (b + 2 >= nb) break;
+    load_chunk(b + 4, buf1, dg1);
+    step(b + 2, buf2, dg2);
+  }
+
+  for (int p = tid; p < K; p += kReduceThreads) {
+    if ((keepw[p >> 6] >> (p & 63)) & 1ull) {
+      const int o = order[p];
+      atomicOr(&obits[o >> 6], 1ull << (o & 63));
+    }
+  }
+  __syncthreads();
+  const int seg = (nb + kReduceThreads - 1) / kReduceThreads;
+  const int w0 = tid * seg, w1 = min(nb, w0 + seg);
+  int cnt = 0;
+  for (int w = w0; w < w1; ++w) cnt += __popcll(obits[w]);
+  part[tid] = cnt;
+  __syncthreads();
+  for (int off = 1; off < kReduceThreads; off <<= 1) {
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int pos = part[tid] - cnt;
+  for (int w = w0; w < w1; ++w) {
+    unsigned long long bits = obits[w];
+    while (bits) {
+      const int i = __builtin_ctzll(bits);
+      bits &= bits - 1;
+      keep_out[pos++] = (long long)w * 64 + i;
+    }
+  }
+  if (tid == kReduceThreads - 1) *num_keep = part[tid];
+}
+
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct NmsLayout {
-  size_t keys_out, idx_in, order, cub_temp, cub_bytes, mask, total;
+  size_t keys_out, idx_in, order, cub_temp, cub_bytes, mask, diag_t, total;
 };
 
 int nms_layout(int K, NmsLayout* L) {
@@ -178,6 +314,7 @@ int nms_layout(int K, NmsLayout* L) {
   L->cub_temp = off; off = align256(off + cub_bytes);
   L->cub_bytes = cub_bytes;
   L->mask = off;     off = align256(off + sizeof(unsigned long long) * (size_t)K * nb);
+  L->diag_t = off;   off = align256(off + sizeof(unsigned long long) * (size_t)K);
   L->total = off;
   return OVIS_OK;
 }
@@ -214,6 +351,7 @@ extern "C" int ovis_nms_f32(const float* boxes, const float* scores, int num_box
   int* idx_in = (int*)(ws + L.idx_in);
   int* order = (int*)(ws + L.order);
   unsigned long long* mask = (unsigned long long*)(ws + L.mask);
+  unsigned long long* diag_t = (unsigned long long*)(ws + L.diag_t);
 
   hipLaunchKernelGGL(iota_kernel, dim3(ovis_ceil_div(K, 256)), dim3(256), 0, s, idx_in, K);
   OVIS_LAUNCH_CHECK();
@@ -224,14 +362,18 @@ extern "C" int ovis_nms_f32(const float* boxes, const float* scores, int num_box
   dim3 grid(nb, nb);
   if (ge_mode)
     hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(kTile), 0, s, (const float4*)boxes,
-                       order, K, nb, threshold, mask);
+                       order, K, nb, threshold, mask, diag_t);
   else
     hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(kTile), 0, s, (const float4*)boxes,
-                       order, K, nb, threshold, mask);
+                       order, K, nb, threshold, mask, diag_t);
   OVIS_LAUNCH_CHECK();
   const size_t lds = sizeof(unsigned long long) * 3 * (size_t)nb + sizeof(int) * kReduceThreads;
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(kReduceThreads), lds, s, mask, order, K,
-                     nb, (long long*)keep_out, num_keep);
+  if (nb <= kFastBlocks)
+    hipLaunchKernelGGL(nms_reduce_pipelined_kernel, dim3(1), dim3(kReduceThreads), lds, s, mask, diag_t, order, K, nb,
+                       (long long*)keep_out, num_keep);
+  else
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(kReduceThreads), lds, s, mask, order, K, nb,
+                       (long long*)keep_out, num_keep);
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
 }

@@ -138,7 +138,8 @@ def test_nms_golden_exact(C, golden_dir, name):
     assert torch.equal(keep.cpu(), torch.from_numpy(z[f"{name}_keep"]))
 
 
-@pytest.mark.parametrize("k,thr", [(6000, 0.7), (12000, 0.7), (4097, 0.5), (63, 0.3), (64, 0.3), (65, 0.3)])
+@pytest.mark.parametrize("k,thr", [(6000, 0.7), (12000, 0.7), (4097, 0.5), (63, 0.3), (64, 0.3), (65, 0.3), (12289, 0.7),
+                                   (12288, 0.6)])
 def test_nms_vs_oracle(C, oracle_mod, k, thr):
     g = torch.Generator().manual_seed(k)
     xy = torch.rand(k, 2, generator=g) * torch.tensor([1200.0, 720.0])
