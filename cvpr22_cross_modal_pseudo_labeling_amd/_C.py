@@ -117,3 +117,84 @@ def sigmoid_focalloss_backward(logits, targets, d_losses, num_classes, gamma, al
                                                      alpha, _stream())
     _lib.check(rc, "sigmoid_focalloss_backward")
     return d_logits
+
+
+# ---- cross-modal head + student losses (extensions beyond vision.cpp; include/ovis_hip.h) --------------
+def gemm_nt(a, b, bias=None):
+    """a [M,K] @ b[N,K]^T (+ bias[N]) -> [M,N] on the fp32 matrix cores.  a / b may be any 2-D strided views."""
+    if not (a.is_cuda and b.is_cuda):
+        raise RuntimeError("gemm_nt: HIP device tensors only")
+    if a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise RuntimeError("gemm_nt: float32 only")
+    m, k = a.shape
+    n, k2 = b.shape
+    if k != k2:
+        raise RuntimeError(f"gemm_nt: inner dimensions differ ({k} vs {k2})")
+    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    if m == 0 or n == 0:
+        return out
+    if k == 0:
+        return out.zero_() if bias is None else out.copy_(bias.expand(m, n))
+    if bias is not None:
+        bias = _dev(bias, "bias")
+    with torch.cuda.device(a.device):
+        rc = _L.ovis_gemm_f32(a.data_ptr(), a.stride(0), a.stride(1), b.data_ptr(), b.stride(0), b.stride(1),
+                              0 if bias is None else bias.data_ptr(), out.data_ptr(), n, m, n, k, _stream())
+    _lib.check(rc, "gemm_f32")
+    return out
+
+
+def region_noun_align(region_emb, noun_emb):
+    """-> (raw max score [W], sigmoid score [W], argmax region [W] int64)"""
+    region_emb, noun_emb = _dev(region_emb, "region_emb"), _dev(noun_emb, "noun_emb")
+    p, d = region_emb.shape
+    w = noun_emb.shape[0]
+    raw = torch.empty((w,), dtype=torch.float32, device=region_emb.device)
+    prob = torch.empty_like(raw)
+    idx = torch.empty((w,), dtype=torch.int64, device=region_emb.device)
+    if w == 0:
+        return raw, prob, idx
+    with torch.cuda.device(region_emb.device):
+        rc = _L.ovis_region_noun_align_f32(region_emb.data_ptr(), noun_emb.data_ptr(), raw.data_ptr(),
+                                           prob.data_ptr(), idx.data_ptr(), p, w, d, _stream())
+    _lib.check(rc, "region_noun_align")
+    return raw, prob, idx
+
+
+def weighted_ce_fwd_bwd(logits, labels, bg_weight, need_grad=True):
+    """-> (loss scalar tensor, dlogits or None)"""
+    logits, labels = _dev(logits, "logits"), _dev(labels, "labels", torch.int64)
+    p, c = logits.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits) if need_grad else None
+    scratch = torch.empty((max(p, 1),), dtype=torch.float32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        rc = _L.ovis_weighted_ce_fwd_bwd_f32(logits.data_ptr(), labels.data_ptr(), bg_weight, loss.data_ptr(),
+                                             0 if dlogits is None else dlogits.data_ptr(), scratch.data_ptr(), p, c,
+                                             _stream())
+    _lib.check(rc, "weighted_ce_fwd_bwd")
+    return loss[0], dlogits
+
+
+def mask_bce_stochastic_fwd_bwd(mu, sigma, eps, pos_index, targets, channel, need_grad=True):
+    """mu [P,C,M,M]; sigma [P,1,M,M] or None; eps [P,C,M,M] or None; pos_index [Pp]; targets [Pp,M,M]
+    -> (loss, dmu or None, dsigma or None)"""
+    mu = _dev(mu, "mu")
+    p, c = mu.shape[0], mu.shape[1]
+    mm = mu.shape[2] * mu.shape[3]
+    pos_index, targets = _dev(pos_index, "pos_index", torch.int64), _dev(targets, "targets")
+    sigma = None if sigma is None else _dev(sigma, "sigma")
+    eps = None if eps is None else _dev(eps, "eps")
+    npos = pos_index.numel()
+    loss = torch.empty((1,), dtype=torch.float32, device=mu.device)
+    dmu = torch.empty_like(mu) if need_grad else None
+    dsigma = torch.empty((p, 1, mu.shape[2], mu.shape[3]), dtype=torch.float32, device=mu.device) \
+        if (need_grad and sigma is not None) else None
+    scratch = torch.empty((max(npos, 1),), dtype=torch.float32, device=mu.device)
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    with torch.cuda.device(mu.device):
+        rc = _L.ovis_mask_bce_stochastic_fwd_bwd_f32(mu.data_ptr(), ptr(sigma), ptr(eps), pos_index.data_ptr(),
+                                                     targets.data_ptr(), loss.data_ptr(), ptr(dmu), ptr(dsigma),
+                                                     scratch.data_ptr(), p, npos, c, mm, channel, _stream())
+    _lib.check(rc, "mask_bce_stochastic_fwd_bwd")
+    return loss[0], dmu, dsigma

@@ -10,7 +10,7 @@ _ERRORS = {-1: "OVIS_EINVAL (bad size or null pointer)",
            -2: "OVIS_ENOSPC (workspace too small)",
            -3: "OVIS_ERANGE (problem size not supported by the kernel)"}
 
-_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_vp, _i, _f, _sz, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long
 
 # name -> (restype, argtypes); must list every symbol include/ovis_hip.h declares
 SIGNATURES = {
@@ -21,6 +21,10 @@ SIGNATURES = {
     "ovis_nms_f32": (_i, [_vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp]),
     "ovis_sigmoid_focal_loss_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "ovis_sigmoid_focal_loss_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),
+    "ovis_gemm_f32": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _i, _i, _i, _vp]),
+    "ovis_region_noun_align_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ovis_weighted_ce_fwd_bwd_f32": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp]),
+    "ovis_mask_bce_stochastic_fwd_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

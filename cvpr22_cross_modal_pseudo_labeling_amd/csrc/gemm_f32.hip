@@ -1,0 +1,150 @@
+// fp32 GEMM on the CDNA4 matrix cores for the cross-modal head (region embedding x text embedding).
+//
+// Reference semantics: maskrcnn_benchmark/modeling/roi_heads/box_head/roi_box_predictors.py:66-71 --
+//   cls_emb = emb_pred(x)                (Linear 2048 -> 768, fp32)
+//   cls_logit = einsum('pe,ce->pc', cls_emb, cls_score)
+//   bbox_pred = Linear 2048 -> 8
+// and their autograd transposes.  All are C[m,n] = sum_k A(m,k) * B(n,k) (+ bias[n]) with different operand
+// strides, so ONE kernel with strided operands serves forward (NT) and both backward products (NN, TN).
+//
+// v_mfma_f32_32x32x2_f32 is exact fp32 (one rounding per product, an fmaf chain in k order), so the result
+// differs from a cuBLAS/ATen fp32 GEMM only by summation order.  Tile: 64x64 per 256-lane workgroup, each of
+// the 4 waves owns one 32x32 accumulator (16 VGPRs); K is staged through LDS 16 at a time, k-major so the
+// per-lane MFMA operand reads (A[i=lane&31][k=lane>>5]) are bank-conflict free.
+#include "ovis_common.h"
+
+namespace {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+constexpr int BM = 64, BN = 64, BK = 16, LDP = BM + 4;
+
+// Stage a [64 x BK] operand tile into LDS as T[k][row].  `rs`/`cs` are the element strides of (row, k).
+__device__ __forceinline__ void stage_tile(float* T, const float* __restrict__ P, long rs, long cs, int row0,
+                                           int k0, int nrows, int K, bool vec_k, bool vec_r) {
+  const int t = threadIdx.x;
+  if (vec_k) {  // k contiguous (cs == 1), 16-byte aligned rows: 4 lanes x float4 cover one row's 16 k
+    const int r = t >> 2, kq = (t & 3) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < nrows && k0 + kq < K) v = *(const float4*)(P + (long)(row0 + r) * rs + (k0 + kq));
+    T[(kq + 0) * LDP + r] = v.x;
+    T[(kq + 1) * LDP + r] = v.y;
+    T[(kq + 2) * LDP + r] = v.z;
+    T[(kq + 3) * LDP + r] = v.w;
+  } else if (vec_r) {  // rows contiguous (rs == 1): 16 lanes x float4 cover the 64 rows of one k
+    const int k = t >> 4, rq = (t & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k0 + k < K && row0 + rq < nrows) v = *(const float4*)(P + (long)(k0 + k) * cs + (row0 + rq));
+    *(float4*)(T + k * LDP + rq) = v;
+  } else {  // generic strides / ragged edges
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = t + e * 256;
+      const int k = idx >> 6, r = idx & 63;
+      float v = 0.f;
+      if (row0 + r < nrows && k0 + k < K) v = P[(long)(row0 + r) * rs + (long)(k0 + k) * cs];
+      T[k * LDP + r] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long a_rs, long a_cs,
+                                                      const float* __restrict__ B, long b_rs, long b_cs,
+                                                      const float* __restrict__ bias, float* __restrict__ C,
+                                                      long c_rs, int M, int N, int K, int flags) {
+  __shared__ __attribute__((aligned(16))) float As[BK * LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDP];
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const bool a_vk = flags & 1, a_vr = flags & 2, b_vk = flags & 4, b_vr = flags & 8;
+  // full-tile vector paths need the whole 64-row / 16-k tile in range
+  const bool a_full = m0 + BM <= M, b_full = n0 + BN <= N;
+  f16v acc = {0.f};
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    const bool k_full = k0 + BK <= K;
+    stage_tile(As, A, a_rs, a_cs, m0, k0, M, K, a_vk && a_full && k_full, a_vr && a_full && k_full);
+    stage_tile(Bs, B, b_rs, b_cs, n0, k0, N, K, b_vk && b_full && k_full, b_vr && b_full && k_full);
+    __syncthreads();
+    const float* ap = As + (lane >> 5) * LDP + wm + (lane & 31);
+    const float* bp = Bs + (lane >> 5) * LDP + wn + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk * 2 * LDP], bp[kk * 2 * LDP], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int col = n0 + wn + (lane & 31);
+  if (col < N) {
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < M) C[(long)row * c_rs + col] = acc[r] + bv;
+    }
+  }
+}
+
+// Per-noun best region: scores[w] = sigmoid(max_p <emb[p], noun[w]>), index[w] = argmax_p (lowest p on ties).
+// maskrcnn_benchmark/modeling/detector/st_generalized_rcnn.py:243-262.  One workgroup per noun, one wave per
+// region at a time, lanes split the embedding dimension with 16-byte loads.
+__global__ __launch_bounds__(256) void region_noun_align_kernel(const float* __restrict__ emb,
+                                                               const float* __restrict__ nouns,
+                                                               float* __restrict__ raw, float* __restrict__ prob,
+                                                               long long* __restrict__ index, int P, int D) {
+  __shared__ float s_best[4];
+  __shared__ int s_idx[4];
+  const int w = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* nv = nouns + (long)w * D;
+  float best = -INFINITY;
+  int best_i = 0x7fffffff;
+  for (int p = wave; p < P; p += 4) {
+    const float* e = emb + (long)p * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += e[d] * nv[d];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (s > best) { best = s; best_i = p; }  // p ascends within a wave: first maximum wins
+  }
+  if (lane == 0) { s_best[wave] = best; s_idx[wave] = best_i; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k)
+      if (s_best[k] > best || (s_best[k] == best && s_idx[k] < best_i)) { best = s_best[k]; best_i = s_idx[k]; }
+    raw[w] = best;
+    prob[w] = 1.f / (1.f + expf(-best));
+    index[w] = best_i;
+  }
+}
+
+}  // namespace
+
+extern "C" int ovis_gemm_f32(const float* A, long a_row_stride, long a_k_stride, const float* B,
+                             long b_row_stride, long b_k_stride, const float* bias, float* C,
+                             long c_row_stride, int M, int N, int K, void* stream) {
+  if (M < 0 || N < 0 || K < 0) return OVIS_EINVAL;
+  if (M == 0 || N == 0) return OVIS_OK;
+  if (!A || !B || !C) return OVIS_EINVAL;
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  int flags = 0;
+  if (a_k_stride == 1 && a_row_stride % 4 == 0 && al16(A)) flags |= 1;
+  else if (a_row_stride == 1 && a_k_stride % 4 == 0 && al16(A)) flags |= 2;
+  if (b_k_stride == 1 && b_row_stride % 4 == 0 && al16(B)) flags |= 4;
+  else if (b_row_stride == 1 && b_k_stride % 4 == 0 && al16(B)) flags |= 8;
+  dim3 grid(ovis_ceil_div(N, BN), ovis_ceil_div(M, BM));
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, a_row_stride, a_k_stride, B,
+                     b_row_stride, b_k_stride, bias, C, c_row_stride, M, N, K, flags);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}
+
+extern "C" int ovis_region_noun_align_f32(const float* region_emb, const float* noun_emb, float* raw_scores,
+                                          float* sigmoid_scores, int64_t* best_region, int num_regions,
+                                          int num_nouns, int dim, void* stream) {
+  if (num_regions <= 0 || num_nouns < 0 || dim <= 0) return OVIS_EINVAL;
+  if (num_nouns == 0) return OVIS_OK;
+  if (!region_emb || !noun_emb || !raw_scores || !sigmoid_scores || !best_region) return OVIS_EINVAL;
+  hipLaunchKernelGGL(region_noun_align_kernel, dim3(num_nouns), dim3(256), 0, (hipStream_t)stream, region_emb,
+                     noun_emb, raw_scores, sigmoid_scores, (long long*)best_region, num_regions, dim);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}

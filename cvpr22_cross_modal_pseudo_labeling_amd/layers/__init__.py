@@ -1,5 +1,6 @@
 """Operator API of ``maskrcnn_benchmark.layers`` (maskrcnn_benchmark/layers/__init__.py:23-46)."""
 from .batch_norm import FrozenBatchNorm2d
+from .cross_modal import linear_mfma, stochastic_mask_bce, text_logits, weighted_cross_entropy
 from .misc import BatchNorm2d, Conv2d, ConvTranspose2d, interpolate
 from .nms import nms, nms_padded
 from .roi_align import ROIAlign, roi_align
@@ -18,4 +19,8 @@ __all__ = [
     "BatchNorm2d",
     "FrozenBatchNorm2d",
     "SigmoidFocalLoss",
+    "linear_mfma",
+    "text_logits",
+    "weighted_cross_entropy",
+    "stochastic_mask_bce",
 ]

@@ -1,0 +1,83 @@
+"""Autograd wrappers of the cross-modal head kernels (include/ovis_hip.h, csrc/gemm_f32.hip, csrc/losses.hip).
+
+* ``linear_mfma`` / ``text_logits`` -- the two products of FastRCNNPredictor.forward
+  (maskrcnn_benchmark/modeling/roi_heads/box_head/roi_box_predictors.py:66-71) on the fp32 matrix cores,
+  forward and both backward products through the same strided GEMM kernel;
+* ``weighted_cross_entropy`` -- box_head/loss.py:172-174, loss and d/dlogits in one pass;
+* ``stochastic_mask_bce`` -- roi_mask_predictors.py:41-65 + mask_head/loss.py:139-142, loss and the
+  gradients w.r.t. the mask logits and the predicted std-dev in one pass.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _C
+
+
+class _LinearMFMA(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return _C.gemm_nt(x, weight, bias)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = _C.gemm_nt(dy, weight.t()) if ctx.needs_input_grad[0] else None          # [M,N] x [K,N]^T
+        dw = _C.gemm_nt(dy.t(), x.t()) if ctx.needs_input_grad[1] else None          # [N,M] x [K,M]^T
+        db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def linear_mfma(x, weight, bias=None):
+    """y = x @ weight^T + bias with x [M,K], weight [N,K] (nn.Linear layout)."""
+    return _LinearMFMA.apply(x, weight, bias)
+
+
+def text_logits(region_emb, class_emb):
+    """einsum('pe,ce->pc'): region embeddings [P,E] against the class / vocabulary matrix [C,E]."""
+    return _LinearMFMA.apply(region_emb, class_emb, None)
+
+
+class _WeightedCE(Function):
+    @staticmethod
+    def forward(ctx, logits, labels, bg_weight):
+        loss, dlogits = _C.weighted_ce_fwd_bwd(logits, labels, bg_weight, need_grad=logits.requires_grad)
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g, None, None
+
+
+def weighted_cross_entropy(logits, labels, bg_weight):
+    """sum_p w[label_p] * CE_p / P with w[0] = bg_weight, w[c>0] = 1 (scalar)."""
+    return _WeightedCE.apply(logits, labels, bg_weight)
+
+
+class _StochasticMaskBCE(Function):
+    @staticmethod
+    def forward(ctx, mu, sigma, eps, pos_index, targets, channel):
+        need = mu.requires_grad or (sigma is not None and sigma.requires_grad)
+        loss, dmu, dsigma = _C.mask_bce_stochastic_fwd_bwd(mu, sigma, eps, pos_index, targets, channel, need_grad=need)
+        ctx.has_sigma = sigma is not None
+        ctx.save_for_backward(dmu, dsigma)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        dmu, dsigma = ctx.saved_tensors
+        return (dmu * g if dmu is not None else None, dsigma * g if (ctx.has_sigma and dsigma is not None) else None,
+                None, None, None, None)
+
+
+def stochastic_mask_bce(mu, sigma, eps, pos_index, targets, channel=1):
+    """mean BCEWithLogits(mu[pos, channel] + eps[pos, channel] * sigma[pos], targets); sigma / eps may be None."""
+    return _StochasticMaskBCE.apply(mu, sigma, eps, pos_index, targets, channel)

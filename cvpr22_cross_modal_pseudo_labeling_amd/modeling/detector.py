@@ -24,6 +24,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import _C
 from .backbone import Backbone
 from .roi_heads import CombinedROIHeads, Masker
 from .rpn import RPNModule
@@ -119,18 +120,17 @@ class STGeneralizedRCNN(nn.Module):
         teacher["box"].predictor.set_class_embeddings(features[0].new_zeros((1, teacher["box"].predictor.emb_dim)))
         teacher.eval()
         package_x, results, _ = teacher(features, proposals, None, bbox_only=True)
-        f_regions = package_x["bbox"].mean(dim=(2, 3))
-        cls_embs = teacher["box"].predictor.emb_pred(f_regions).split([len(p) for p in proposals])
+        cls_embs = teacher["box"].predictor.embed(package_x["bbox"]).split([len(p) for p in proposals])
         pseudo_labels = []
         for emb_img, w_cap, result_img, target_img in zip(cls_embs, noun_embs, results, targets):
             if w_cap.shape[0] == 0:
                 pseudo_labels.append(BoxList(emb_img.new_zeros((0, 4)), result_img.size))
                 continue
-            region_scores = emb_img @ w_cap.t()  # einsum('pd,wd->pw')
-            aligned, idx = torch.max(region_scores, dim=0)
+            # einsum('pd,wd->pw') -> max over regions -> sigmoid, without materialising the [P,W] matrix
+            aligned, prob, idx = _C.region_noun_align(emb_img, w_cap)
             pl = result_img[idx]
             pl.add_field("labels", target_img.get_field("ids_cap"))
-            pl.add_field("scores", torch.sigmoid(aligned))
+            pl.add_field("scores", prob)
             pl.add_field("consistencies", aligned * 0.0 + 1.0)
             pl.add_field("embs", emb_img[idx])
             pseudo_labels.append(pl)

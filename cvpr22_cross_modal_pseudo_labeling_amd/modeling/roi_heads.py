@@ -22,7 +22,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..layers import Conv2d, ConvTranspose2d, ROIAlign, smooth_l1_loss
+from ..layers import (Conv2d, ConvTranspose2d, ROIAlign, linear_mfma, smooth_l1_loss, stochastic_mask_bce,
+                      text_logits, weighted_cross_entropy)
 from .backbone import ResNetHead
 from .box_coder import BoxCoder
 from .matcher import BalancedPositiveNegativeSampler, Matcher
@@ -96,9 +97,17 @@ class FastRCNNPredictor(nn.Module):
 
     def forward(self, x):
         x = self.pooled(x)
-        cls_emb = self.emb_pred(x)
-        cls_logit = cls_emb @ self.cls_score.t()  # einsum('pe,ce->pc')
-        return cls_logit, self.bbox_pred(x)
+        # both Linear layers share the pooled operand: one MFMA GEMM over the concatenated [768+8, 2048] weight
+        w = torch.cat([self.emb_pred.weight, self.bbox_pred.weight], 0)
+        b = torch.cat([self.emb_pred.bias, self.bbox_pred.bias], 0)
+        y = linear_mfma(x, w, b)
+        cls_emb, bbox = y[:, : self.emb_dim], y[:, self.emb_dim:]
+        cls_logit = text_logits(cls_emb, self.cls_score)  # einsum('pe,ce->pc')
+        return cls_logit, bbox
+
+    def embed(self, x):
+        """region embeddings only (teacher alignment pass)"""
+        return linear_mfma(self.pooled(x), self.emb_pred.weight, self.emb_pred.bias)
 
     def set_class_embeddings(self, embs):
         self.num_classes = embs.shape[0]
@@ -146,9 +155,7 @@ class FastRCNNLossComputation:
             map_inds = 4 * labels[pos][:, None] + torch.tensor([0, 1, 2, 3], device=class_logits.device)
         box_loss = smooth_l1_loss(box_regression[pos[:, None], map_inds], reg_targets[pos], size_average=False,
                                   beta=1) / labels.numel()
-        w = torch.ones(class_logits.shape[1], device=class_logits.device)
-        w[0] = self.bg_weight
-        cls_loss = (F.cross_entropy(class_logits, labels, weight=w, reduction="none") / labels.numel()).sum()
+        cls_loss = weighted_cross_entropy(class_logits, labels, self.bg_weight)
         return cls_loss, box_loss
 
 
@@ -256,6 +263,13 @@ class MaskRCNNC4Predictor(nn.Module):
             nn.init.normal_(self.uncertain_pred.weight, mean=0, std=0.001)
             nn.init.constant_(self.uncertain_pred.bias, 1)
 
+    def forward_parts(self, x):
+        """-> (mask logits mu [P,C,M,M], predicted std-dev sigma [P,1,M,M]) for the fused stochastic BCE."""
+        x_ = F.relu(self.conv5_mask(x))
+        mu = self.mask_fcn_logits(x_)
+        sigma = torch.exp(0.5 * self.uncertain_pred(x_.detach())) if self.uncertainty else None
+        return mu, sigma
+
     def forward(self, x, compute_uncertain=False, eps=None):
         """``eps`` (standard-normal noise, [1,P,C,M,M] -- the reference draws it with the shape of
         ``mask_logits*0+scale``, i.e. independently per logit channel, roi_mask_predictors.py:47-53,62)
@@ -340,6 +354,21 @@ class MaskRCNNLossComputation:
             labels.append(lab)
         return labels, masks
 
+    def fused(self, proposals, mu, sigma, eps, targets):
+        """Same value as ``__call__`` on ``mu[None] + eps * sigma`` (one noise sample), through the fused HIP
+        forward+backward kernel; ``sigma`` / ``eps`` None = deterministic logits."""
+        labels, mask_targets = self.prepare_targets(list(proposals), list(targets))
+        labels = _cat(labels, 0)
+        mask_targets = _cat([m for m in mask_targets if m.numel() > 0] or mask_targets[:1], 0)
+        pos = torch.nonzero(labels > 0).squeeze(1)
+        if mask_targets.numel() == 0:
+            return mu.sum() * 0
+        if not self.cls_agnostic_mask:
+            raise NotImplementedError("fused mask loss is class-agnostic (CLS_AGNOSTIC_MASK, every shipped config)")
+        self.mask_targets, self.positive_inds = mask_targets, pos
+        e = None if eps is None else eps.reshape(mu.shape)
+        return stochastic_mask_bce(mu, sigma, e, pos, mask_targets.reshape(pos.numel(), -1), 1)
+
     def __call__(self, proposals, mask_logits, targets):
         repeat = 1
         if mask_logits.dim() == 5:  # [n_samples, P, C, M, M]
@@ -414,6 +443,19 @@ class ROIMaskHead(nn.Module):
             x = features[_cat(positive_inds, 0)]
         else:
             x = self.feature_extractor(features, proposals)
+        if self.training and self.cls_agnostic_mask:
+            # training: fused stochastic BCE (noise drawn on the device unless injected)
+            mu, sigma = self.predictor.forward_parts(x)
+            if compute_uncertain and sigma is not None:
+                self.log, self.avg_uncertain = sigma.max(), sigma.mean()
+                if eps is None:
+                    eps = torch.randn((1, *mu.shape), device=mu.device, dtype=mu.dtype)
+                else:  # injected noise (tests): a pool at least as large as the positives
+                    eps = eps[:, : mu.shape[0]].to(mu.device)
+                loss_mask = self.loss_evaluator.fused(proposals, mu, sigma, eps, targets)
+            else:
+                loss_mask = self.loss_evaluator.fused(proposals, mu, None, None, targets)
+            return x, proposals, dict(loss_mask=loss_mask)
         if compute_uncertain:
             mask_logits, scale = self.predictor(x, True, eps=eps)
             self.log, self.avg_uncertain = scale.max(), scale.mean()

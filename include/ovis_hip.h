@@ -87,6 +87,48 @@ int ovis_sigmoid_focal_loss_backward_f32(const float* logits, const int32_t* tar
                                          int num_classes, float gamma, float alpha,
                                          void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Cross-modal head: fp32 GEMM on the matrix cores
+ *   mb/modeling/roi_heads/box_head/roi_box_predictors.py:66-71 (emb_pred Linear, einsum('pe,ce->pc'),
+ *   bbox_pred Linear) and their autograd transposes.
+ * C[m,n] = sum_k A(m,k) * B(n,k) (+ bias[n]);  A(m,k) = A[m*a_row_stride + k*a_k_stride], B likewise,
+ * C row-major with row stride c_row_stride.  Exact fp32 (v_mfma_f32_32x32x2_f32): differs from a
+ * BLAS fp32 GEMM by summation order only.
+ * ---------------------------------------------------------------------------------- */
+int ovis_gemm_f32(const float* A, long a_row_stride, long a_k_stride, const float* B,
+                  long b_row_stride, long b_k_stride, const float* bias, float* C,
+                  long c_row_stride, int M, int N, int K, void* stream);
+
+/* Region <-> noun alignment of the teacher (mb/modeling/detector/st_generalized_rcnn.py:243-262):
+ * for every noun w: raw_scores[w] = max_p <region_emb[p], noun_emb[w]>, best_region[w] = argmax_p
+ * (lowest p on exact ties), sigmoid_scores[w] = sigmoid(raw).  region_emb [num_regions, dim],
+ * noun_emb [num_nouns, dim]; the [num_regions, num_nouns] score matrix is never materialised. */
+int ovis_region_noun_align_f32(const float* region_emb, const float* noun_emb, float* raw_scores,
+                               float* sigmoid_scores, int64_t* best_region, int num_regions,
+                               int num_nouns, int dim, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Student losses, forward + backward fused
+ *   weighted CE : mb/modeling/roi_heads/box_head/loss.py:172-174
+ *     loss[0] = sum_p w[label_p] * CE(logits_p, label_p) / num_rows, w[0] = bg_weight, w[c>0] = 1;
+ *     dlogits (may be NULL) receives d loss / d logits.  row_scratch: num_rows floats.
+ *   stochastic mask BCE : mb/modeling/roi_heads/mask_head/roi_mask_predictors.py:41-65,
+ *                         mb/modeling/roi_heads/mask_head/loss.py:117-148
+ *     z = mu + eps * sigma on logit channel `channel` of the positive RoIs pos_index[0..num_pos);
+ *     loss[0] = mean BCEWithLogits(z, targets); dmu [num_rois, C, pixels] and dsigma [num_rois, pixels]
+ *     (either may be NULL) are fully written (zero outside the positives).  sigma / eps may be NULL
+ *     (plain BCE).  mu [num_rois, C, pixels], sigma [num_rois, pixels], eps [num_rois, C, pixels],
+ *     targets [num_pos, pixels].  row_scratch: num_pos floats.
+ * ---------------------------------------------------------------------------------- */
+int ovis_weighted_ce_fwd_bwd_f32(const float* logits, const int64_t* labels, float bg_weight,
+                                 float* loss, float* dlogits, float* row_scratch, int num_rows,
+                                 int num_classes, void* stream);
+int ovis_mask_bce_stochastic_fwd_bwd_f32(const float* mu, const float* sigma, const float* eps,
+                                         const int64_t* pos_index, const float* targets, float* loss,
+                                         float* dmu, float* dsigma, float* row_scratch, int num_rois,
+                                         int num_pos, int num_channels, int mask_pixels, int channel,
+                                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

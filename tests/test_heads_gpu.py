@@ -1,0 +1,157 @@
+"""GPU parity of the cross-modal head kernels (MFMA GEMM, region<->noun alignment, fused losses): against
+fixtures produced by the reference's own Python modules (tests/golden/heads.npz) and against plain fp32/fp64
+torch formulas (what the reference computes these with) on seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def z(golden_dir):
+    return np.load(os.path.join(golden_dir, "heads.npz"))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_box_predictor_fixture(z):
+    from tests.test_components import small_cfg
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling import roi_heads as RH
+
+    pred = RH.FastRCNNPredictor(small_cfg(), 96).cuda()
+    pred.load_state_dict({k[5:]: T(z[k]) for k in z.files if k.startswith("pred_") and k[5:] in pred.state_dict()})
+    x = T(z["pred_x"]).cuda()
+    for c in (1, 49, 1203):
+        pred.set_class_embeddings(T(z[f"pred_cls{c}"]).cuda())
+        logits, box = pred(x)
+        assert torch.allclose(logits.cpu(), T(z[f"pred_logits{c}"]), rtol=1e-4, atol=1e-5)  # north_star: 1e-3 rel
+    assert torch.allclose(box.cpu(), T(z["pred_box"]), rtol=1e-4, atol=1e-6)
+
+
+def test_box_loss_fixture(z):
+    from tests.test_components import small_cfg
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling import roi_heads as RH
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.structures import BoxList
+
+    ev = RH.FastRCNNLossComputation(small_cfg())
+    P = z["boxloss_labels"].shape[0]
+    prop = BoxList(torch.zeros(P, 4), (100, 100))
+    prop.add_field("labels", T(z["boxloss_labels"]).cuda())
+    prop.add_field("regression_targets", T(z["boxloss_targets"]).cuda())
+    ev._proposals = [prop]
+    lc, lb = ev(T(z["boxloss_logits"]).cuda(), T(z["boxloss_reg"]).cuda())
+    assert torch.allclose(lc.cpu(), T(z["boxloss_cls"]), rtol=1e-5)
+    assert torch.allclose(lb.cpu(), T(z["boxloss_box"]), rtol=1e-5)
+
+
+def test_mask_predictor_and_fused_loss_fixture(z):
+    from tests.test_components import small_cfg
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers import stochastic_mask_bce
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling import roi_heads as RH
+
+    mp = RH.MaskRCNNC4Predictor(small_cfg(), 64).cuda()
+    mp.load_state_dict({k[9:]: T(z[k]) for k in z.files if k.startswith("maskpred_")})
+    x = T(z["mask_x"]).cuda()
+    mp.train()
+    eps = T(z["mask_eps"]).cuda()
+    logits5, scale = mp(x, True, eps=eps)
+    assert torch.allclose(logits5.cpu(), T(z["mask_logits5"]), rtol=1e-4, atol=1e-5)
+    mu, sigma = mp.forward_parts(x)
+    loss = stochastic_mask_bce(mu, sigma, eps[0], torch.arange(6, device="cuda"), T(z["mask_targets"]).cuda().reshape(6, -1), 1)
+    assert torch.allclose(loss.cpu(), T(z["mask_loss"]), rtol=1e-5)
+
+
+@pytest.mark.parametrize("m,n,k", [(512, 776, 2048), (1000, 1203, 768), (1024, 49, 768), (7, 5, 768), (65, 130, 33),
+                                   (1, 1, 1)])
+def test_gemm_and_linear_autograd_vs_torch(m, n, k):
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers import linear_mfma
+
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a, b, bias = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g), torch.randn(n, generator=g)
+    want = (a.double() @ b.double().t() + bias.double())
+    got = _C.gemm_nt(a.cuda(), b.cuda(), bias.cuda()).cpu().double()
+    tol = 2e-6 * (a.double().abs() @ b.double().abs().t() + bias.double().abs())  # fp32 round-off class bound
+    assert bool(((got - want).abs() <= tol + 1e-30).all())
+    # strided operands (the backward products) and autograd
+    ad, bd, biasd = a.cuda().requires_grad_(True), b.cuda().requires_grad_(True), bias.cuda().requires_grad_(True)
+    y = linear_mfma(ad, bd, biasd)
+    gy = torch.randn(m, n, generator=g)
+    y.backward(gy.cuda())
+    ar, br, biasr = a.double().requires_grad_(True), b.double().requires_grad_(True), bias.double().requires_grad_(True)
+    (ar @ br.t() + biasr).backward(gy.double())
+    for got_g, want_g in ((ad.grad, ar.grad), (bd.grad, br.grad), (biasd.grad, biasr.grad)):
+        scale = want_g.abs().max().item() + 1e-12
+        assert (got_g.cpu().double() - want_g).abs().max().item() <= 1e-5 * scale * max(1.0, (m + n + k) ** 0.5 / 8)
+
+
+def test_region_noun_align_vs_torch():
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn(1000, 768, generator=g) * 0.05
+    nouns = F.normalize(torch.randn(9, 768, generator=g), dim=-1)
+    raw, idx = torch.max(emb.double() @ nouns.double().t(), dim=0)
+    r, p, i = _C.region_noun_align(emb.cuda(), nouns.cuda())
+    assert torch.equal(i.cpu(), idx)  # indices exact (the fixture has no near-ties)
+    assert torch.allclose(r.cpu().double(), raw, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(p.cpu().double(), torch.sigmoid(raw), rtol=1e-5)
+    # exact ties: lowest region index wins, like torch.max
+    emb2 = torch.zeros(10, 8)
+    emb2[3, 0] = emb2[7, 0] = 2.0
+    _, _, i2 = _C.region_noun_align(emb2.cuda(), torch.eye(8)[:1].cuda())
+    assert i2.tolist() == [3]
+    r0, p0, i0 = _C.region_noun_align(emb.cuda(), torch.zeros(0, 768).cuda())
+    assert r0.numel() == 0 and i0.numel() == 0
+
+
+@pytest.mark.parametrize("p,c", [(1024, 1203), (512, 49), (3, 2), (1, 1)])
+def test_weighted_ce_vs_torch(p, c):
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers import weighted_cross_entropy
+
+    g = torch.Generator().manual_seed(p + c)
+    x = torch.randn(p, c, generator=g) * 3
+    lab = torch.randint(0, c, (p,), generator=g)
+    lab[::3] = 0
+    w = torch.ones(c, dtype=torch.float64)
+    w[0] = 0.2
+    xr = x.double().requires_grad_(True)
+    want = (F.cross_entropy(xr, lab, weight=w, reduction="none") / p).sum()
+    want.backward()
+    xd = x.cuda().requires_grad_(True)
+    got = weighted_cross_entropy(xd, lab.cuda(), 0.2)
+    (got * 1.7).backward()
+    assert abs(got.item() - want.item()) <= 1e-5 * max(abs(want.item()), 1e-3)
+    assert torch.allclose(xd.grad.cpu().double(), 1.7 * xr.grad, rtol=1e-4, atol=1e-8)
+
+
+def test_stochastic_mask_bce_vs_torch():
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers import stochastic_mask_bce
+
+    g = torch.Generator().manual_seed(11)
+    P, M = 37, 14
+    mu = torch.randn(P, 2, M, M, generator=g) * 2
+    sigma = torch.rand(P, 1, M, M, generator=g) + 0.3
+    eps = torch.randn(P, 2, M, M, generator=g)
+    pos = torch.tensor([0, 3, 4, 9, 20, 36])
+    tgt = (torch.rand(pos.numel(), M * M, generator=g) > 0.5).float()
+    mr, sr = mu.double().requires_grad_(True), sigma.double().requires_grad_(True)
+    z_ = mr + eps.double() * (mr * 0.0 + sr)
+    want = F.binary_cross_entropy_with_logits(z_[pos, 1].reshape(pos.numel(), -1), tgt.double(), reduction="none").mean()
+    want.backward()
+    md, sd = mu.cuda().requires_grad_(True), sigma.cuda().requires_grad_(True)
+    got = stochastic_mask_bce(md, sd, eps.cuda(), pos.cuda(), tgt.cuda(), 1)
+    got.backward()
+    assert abs(got.item() - want.item()) <= 1e-5 * abs(want.item())
+    assert torch.allclose(md.grad.cpu().double(), mr.grad, rtol=1e-4, atol=1e-9)
+    assert torch.allclose(sd.grad.cpu().double(), sr.grad, rtol=1e-4, atol=1e-9)
+    # deterministic variant (no sigma / eps) and the empty-positives case
+    got2 = stochastic_mask_bce(mu.cuda(), None, None, pos.cuda(), tgt.cuda(), 1)
+    want2 = F.binary_cross_entropy_with_logits(mu[pos, 1].reshape(pos.numel(), -1), tgt)
+    assert abs(got2.item() - want2.item()) <= 1e-5 * abs(want2.item())
