@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--workload", default="student", choices=["student", "teacher"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true", help="experiment: run the trunk / heads in NHWC")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen exhaustive find)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -146,6 +147,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.miopen_find:
+        torch.backends.cudnn.benchmark = True
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
