@@ -198,3 +198,154 @@ def mask_bce_stochastic_fwd_bwd(mu, sigma, eps, pos_index, targets, channel, nee
                                                      scratch.data_ptr(), p, npos, c, mm, channel, _stream())
     _lib.check(rc, "mask_bce_stochastic_fwd_bwd")
     return loss[0], dmu, dsigma
+
+
+# ---- deformable convolution (csrc/deform_conv.h:11-190; host loops deform_conv_cuda.cu:161-694) ---------
+def _gemm_raw(a_ptr, a_rs, a_ks, b_ptr, b_rs, b_ks, c_ptr, c_rs, m, n, k, bias_ptr=0, bias_per_row=0, alpha=1.0,
+              accumulate=0):
+    rc = _L.ovis_gemm_ex_f32(a_ptr, a_rs, a_ks, b_ptr, b_rs, b_ks, bias_ptr, bias_per_row, alpha, accumulate, c_ptr,
+                             c_rs, m, n, k, _stream())
+    _lib.check(rc, "gemm_ex_f32")
+
+
+def _dcn_dims(input, weight, kH, kW, dH, dW, padH, padW, dilH, dilW):
+    b, cin, h, w = input.shape
+    ho = (h + 2 * padH - (dilH * (kH - 1) + 1)) // dH + 1
+    wo = (w + 2 * padW - (dilW * (kW - 1) + 1)) // dW + 1
+    if ho <= 0 or wo <= 0:
+        raise RuntimeError(f"deform_conv: output size is too small ({ho}x{wo})")
+    return b, cin, h, w, ho, wo
+
+
+def _dcn_check(input, weight, offset, mask, kH, kW, group, dg, ho, wo):
+    b, cin = input.shape[0], input.shape[1]
+    if weight.dim() != 4 or weight.shape[2] != kH or weight.shape[3] != kW:
+        raise RuntimeError("deform_conv: kernel size does not match the weight")
+    if cin % group or weight.shape[0] % group or weight.shape[1] != cin // group or cin % dg:
+        raise RuntimeError("deform_conv: channels are not divisible by group / deformable_group")
+    if tuple(offset.shape) != (b, dg * 2 * kH * kW, ho, wo):
+        raise RuntimeError(f"deform_conv: invalid offset shape {tuple(offset.shape)}")
+    if mask is not None and tuple(mask.shape) != (b, dg * kH * kW, ho, wo):
+        raise RuntimeError(f"deform_conv: invalid mask shape {tuple(mask.shape)}")
+
+
+def _dcn_forward(input, weight, bias, offset, mask, output, kH, kW, dH, dW, padH, padW, dilH, dilW, group, dg, step):
+    input, weight, offset = _dev(input, "input"), _dev(weight, "weight"), _dev(offset, "offset")
+    mask = None if mask is None else _dev(mask, "mask")
+    b, cin, h, w, ho, wo = _dcn_dims(input, weight, kH, kW, dH, dW, padH, padW, dilH, dilW)
+    _dcn_check(input, weight, offset, mask, kH, kW, group, dg, ho, wo)
+    cout = weight.shape[0]
+    if tuple(output.shape) != (b, cout, ho, wo) or not output.is_contiguous():
+        raise RuntimeError("deform_conv: output must be a contiguous [B, C_out, H_out, W_out] tensor")
+    K, plane = kH * kW, ho * wo
+    cin_g, cout_g = cin // group, cout // group
+    step = max(1, min(step, b))
+    col = torch.empty((cin * K, step, plane), dtype=torch.float32, device=input.device)
+    with torch.cuda.device(input.device):
+        for s0 in range(0, b, step):
+            nb = min(step, b - s0)
+            rc = _L.ovis_deform_im2col_f32(input[s0].data_ptr(), offset[s0].data_ptr(),
+                                           0 if mask is None else mask[s0].data_ptr(), col.data_ptr(), nb, cin, h, w,
+                                           kH, kW, padH, padW, dH, dW, dilH, dilW, dg, _stream())
+            _lib.check(rc, "deform_im2col")
+            for i in range(nb):
+                for g in range(group):
+                    _gemm_raw(weight[g * cout_g].data_ptr(), cin_g * K, 1,
+                              col.data_ptr() + 4 * ((g * cin_g * K) * nb * plane + i * plane), 1, nb * plane,
+                              output[s0 + i, g * cout_g].data_ptr(), plane, cout_g, plane, cin_g * K,
+                              0 if bias is None else bias[g * cout_g:].data_ptr(), 1)
+    return 1
+
+
+def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW, padH, dilationW,
+                        dilationH, group, deformable_group, im2col_step):
+    """Writes ``output`` in place; ``columns`` / ``ones`` are accepted for signature compatibility (the reference
+    re-allocates them internally as well, deform_conv_cuda.cu:207-214).  Note W-before-H argument order."""
+    return _dcn_forward(input, weight, None, offset, None, output, kH, kW, dH, dW, padH, padW, dilationH, dilationW,
+                        group, deformable_group, im2col_step)
+
+
+def _dcn_backward(input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask, grad_weight, scale,
+                  kH, kW, dH, dW, padH, padW, dilH, dilW, group, dg, step):
+    input, weight, offset = _dev(input, "input"), _dev(weight, "weight"), _dev(offset, "offset")
+    grad_output = _dev(grad_output, "grad_output")
+    mask = None if mask is None else _dev(mask, "mask")
+    b, cin, h, w, ho, wo = _dcn_dims(input, weight, kH, kW, dH, dW, padH, padW, dilH, dilW)
+    _dcn_check(input, weight, offset, mask, kH, kW, group, dg, ho, wo)
+    cout = weight.shape[0]
+    K, plane = kH * kW, ho * wo
+    cin_g, cout_g = cin // group, cout // group
+    step = max(1, min(step, b))
+    for t in (grad_input, grad_offset, grad_mask, grad_weight):
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("deform_conv backward: gradient buffers must be contiguous")
+    col = torch.empty((cin * K, step, plane), dtype=torch.float32, device=input.device)
+    with torch.cuda.device(input.device):
+        for s0 in range(0, b, step):
+            nb = min(step, b - s0)
+            if grad_input is not None or grad_offset is not None:
+                # columns = W^T . grad_output  (per image, per group)
+                for i in range(nb):
+                    for g in range(group):
+                        _gemm_raw(weight[g * cout_g].data_ptr(), 1, cin_g * K,
+                                  grad_output[s0 + i, g * cout_g].data_ptr(), 1, plane,
+                                  col.data_ptr() + 4 * ((g * cin_g * K) * nb * plane + i * plane), nb * plane,
+                                  cin_g * K, plane, cout_g)
+                if grad_offset is not None:
+                    rc = _L.ovis_deform_col2im_coord_f32(
+                        col.data_ptr(), input[s0].data_ptr(), offset[s0].data_ptr(),
+                        0 if mask is None else mask[s0].data_ptr(), grad_offset[s0].data_ptr(),
+                        0 if grad_mask is None else grad_mask[s0].data_ptr(), nb, cin, h, w, kH, kW, padH, padW, dH,
+                        dW, dilH, dilW, dg, _stream())
+                    _lib.check(rc, "deform_col2im_coord")
+                if grad_input is not None:
+                    rc = _L.ovis_deform_col2im_f32(col.data_ptr(), offset[s0].data_ptr(),
+                                                   0 if mask is None else mask[s0].data_ptr(),
+                                                   grad_input[s0].data_ptr(), nb, cin, h, w, kH, kW, padH, padW, dH, dW,
+                                                   dilH, dilW, dg, _stream())
+                    _lib.check(rc, "deform_col2im")
+            if grad_weight is not None:
+                rc = _L.ovis_deform_im2col_f32(input[s0].data_ptr(), offset[s0].data_ptr(),
+                                               0 if mask is None else mask[s0].data_ptr(), col.data_ptr(), nb, cin, h,
+                                               w, kH, kW, padH, padW, dH, dW, dilH, dilW, dg, _stream())
+                _lib.check(rc, "deform_im2col")
+                for i in range(nb):
+                    for g in range(group):
+                        _gemm_raw(grad_output[s0 + i, g * cout_g].data_ptr(), plane, 1,
+                                  col.data_ptr() + 4 * ((g * cin_g * K) * nb * plane + i * plane), nb * plane, 1,
+                                  grad_weight[g * cout_g].data_ptr(), cin_g * K, cout_g, cin_g * K, plane,
+                                  alpha=scale, accumulate=1)
+
+
+def deform_conv_backward_input(input, offset, gradOutput, gradInput, gradOffset, weight, columns, kW, kH, dW, dH, padW,
+                               padH, dilationW, dilationH, group, deformable_group, im2col_step):
+    """gradInput is accumulated into (callers pass zeros, dcn/deform_conv_func.py:85-86); gradOffset is overwritten."""
+    _dcn_backward(input, weight, offset, None, gradOutput, gradInput, gradOffset, None, None, 1.0, kH, kW, dH, dW, padH,
+                  padW, dilationH, dilationW, group, deformable_group, im2col_step)
+    return 1
+
+
+def deform_conv_backward_parameters(input, offset, gradOutput, gradWeight, columns, ones, kW, kH, dW, dH, padW, padH,
+                                    dilationW, dilationH, group, deformable_group, scale, im2col_step):
+    """gradWeight += scale * d(loss)/d(weight)."""
+    _dcn_backward(input, gradWeight, offset, None, gradOutput, None, None, None, gradWeight, float(scale), kH, kW, dH,
+                  dW, padH, padW, dilationH, dilationW, group, deformable_group, im2col_step)
+    return 1
+
+
+def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, output, columns, kernel_h, kernel_w, stride_h,
+                                  stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group, with_bias):
+    _dcn_forward(input, weight, _dev(bias, "bias") if with_bias else None, offset, mask, output, kernel_h, kernel_w,
+                 stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group, 8)
+
+
+def modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, columns, grad_input, grad_weight, grad_bias,
+                                   grad_offset, grad_mask, grad_output, kernel_h, kernel_w, stride_h, stride_w, pad_h,
+                                   pad_w, dilation_h, dilation_w, group, deformable_group, with_bias):
+    """grad_input / grad_weight / grad_bias are accumulated into (callers pass zeros); grad_offset / grad_mask are
+    overwritten (deform_conv_cuda.cu:580-694)."""
+    _dcn_backward(input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask, grad_weight, 1.0,
+                  kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group,
+                  8)
+    if with_bias:
+        grad_bias += grad_output.sum(dim=(0, 2, 3))

@@ -22,6 +22,10 @@ SIGNATURES = {
     "ovis_sigmoid_focal_loss_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "ovis_sigmoid_focal_loss_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "ovis_gemm_f32": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _i, _i, _i, _vp]),
+    "ovis_gemm_ex_f32": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _i, _f, _i, _vp, _l, _i, _i, _i, _vp]),
+    "ovis_deform_im2col_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
+    "ovis_deform_col2im_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
+    "ovis_deform_col2im_coord_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
     "ovis_region_noun_align_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ovis_weighted_ce_fwd_bwd_f32": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp]),
     "ovis_mask_bce_stochastic_fwd_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

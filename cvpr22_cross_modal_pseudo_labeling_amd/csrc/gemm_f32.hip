@@ -50,7 +50,7 @@ __device__ __forceinline__ void stage_tile(float* T, const float* __restrict__ P
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long a_rs, long a_cs,
                                                       const float* __restrict__ B, long b_rs, long b_cs,
                                                       const float* __restrict__ bias, float* __restrict__ C,
-                                                      long c_rs, int M, int N, int K, int flags) {
+                                                      long c_rs, int M, int N, int K, int flags, float alpha) {
   __shared__ __attribute__((aligned(16))) float As[BK * LDP];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDP];
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -73,13 +73,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     __syncthreads();
   }
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  // epilogue: C = alpha * acc (+ C if flags&16) + bias[col] (or bias[row] if flags&32)
   const int col = n0 + wn + (lane & 31);
+  const bool accumulate = flags & 16, row_bias = flags & 32;
   if (col < N) {
-    const float bv = bias ? bias[col] : 0.f;
+    const float bv = (bias && !row_bias) ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < M) C[(long)row * c_rs + col] = acc[r] + bv;
+      if (row < M) {
+        float v = alpha * acc[r] + bv;
+        if (bias && row_bias) v += bias[row];
+        float* dst = C + (long)row * c_rs + col;
+        *dst = accumulate ? *dst + v : v;
+      }
     }
   }
 }
@@ -118,9 +125,10 @@ __global__ __launch_bounds__(256) void region_noun_align_kernel(const float* __r
 
 }  // namespace
 
-extern "C" int ovis_gemm_f32(const float* A, long a_row_stride, long a_k_stride, const float* B,
-                             long b_row_stride, long b_k_stride, const float* bias, float* C,
-                             long c_row_stride, int M, int N, int K, void* stream) {
+extern "C" int ovis_gemm_ex_f32(const float* A, long a_row_stride, long a_k_stride, const float* B,
+                                long b_row_stride, long b_k_stride, const float* bias, int bias_per_row,
+                                float alpha, int accumulate, float* C, long c_row_stride, int M, int N, int K,
+                                void* stream) {
   if (M < 0 || N < 0 || K < 0) return OVIS_EINVAL;
   if (M == 0 || N == 0) return OVIS_OK;
   if (!A || !B || !C) return OVIS_EINVAL;
@@ -130,11 +138,20 @@ extern "C" int ovis_gemm_f32(const float* A, long a_row_stride, long a_k_stride,
   else if (a_row_stride == 1 && a_k_stride % 4 == 0 && al16(A)) flags |= 2;
   if (b_k_stride == 1 && b_row_stride % 4 == 0 && al16(B)) flags |= 4;
   else if (b_row_stride == 1 && b_k_stride % 4 == 0 && al16(B)) flags |= 8;
+  if (accumulate) flags |= 16;
+  if (bias_per_row) flags |= 32;
   dim3 grid(ovis_ceil_div(N, BN), ovis_ceil_div(M, BM));
   hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, a_row_stride, a_k_stride, B,
-                     b_row_stride, b_k_stride, bias, C, c_row_stride, M, N, K, flags);
+                     b_row_stride, b_k_stride, bias, C, c_row_stride, M, N, K, flags, alpha);
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
+}
+
+extern "C" int ovis_gemm_f32(const float* A, long a_row_stride, long a_k_stride, const float* B,
+                             long b_row_stride, long b_k_stride, const float* bias, float* C,
+                             long c_row_stride, int M, int N, int K, void* stream) {
+  return ovis_gemm_ex_f32(A, a_row_stride, a_k_stride, B, b_row_stride, b_k_stride, bias, 0, 1.f, 0, C,
+                          c_row_stride, M, N, K, stream);
 }
 
 extern "C" int ovis_region_noun_align_f32(const float* region_emb, const float* noun_emb, float* raw_scores,

@@ -1,7 +1,8 @@
 """Operator API of ``maskrcnn_benchmark.layers`` (maskrcnn_benchmark/layers/__init__.py:23-46)."""
 from .batch_norm import FrozenBatchNorm2d
 from .cross_modal import linear_mfma, stochastic_mask_bce, text_logits, weighted_cross_entropy
-from .misc import BatchNorm2d, Conv2d, ConvTranspose2d, interpolate
+from .dcn import DeformConv, ModulatedDeformConv, ModulatedDeformConvPack, deform_conv, modulated_deform_conv
+from .misc import BatchNorm2d, Conv2d, ConvTranspose2d, DFConv2d, interpolate
 from .nms import nms, nms_padded
 from .roi_align import ROIAlign, roi_align
 from .sigmoid_focal_loss import SigmoidFocalLoss
@@ -19,6 +20,12 @@ __all__ = [
     "BatchNorm2d",
     "FrozenBatchNorm2d",
     "SigmoidFocalLoss",
+    "DFConv2d",
+    "deform_conv",
+    "modulated_deform_conv",
+    "DeformConv",
+    "ModulatedDeformConv",
+    "ModulatedDeformConvPack",
     "linear_mfma",
     "text_logits",
     "weighted_cross_entropy",

@@ -24,3 +24,45 @@ class BatchNorm2d(nn.BatchNorm2d):
 
 def interpolate(input, size=None, scale_factor=None, mode="nearest", align_corners=None):
     return torch.nn.functional.interpolate(input, size, scale_factor, mode, align_corners)
+
+
+class DFConv2d(nn.Module):
+    """Deformable convolutional layer: an ordinary conv predicts the offsets (+ sigmoid masks for v2) that drive
+    ``DeformConv`` / ``ModulatedDeformConv`` (maskrcnn_benchmark/layers/misc.py:114-203)."""
+
+    def __init__(self, in_channels, out_channels, with_modulated_dcn=True, kernel_size=3, stride=1, groups=1,
+                 dilation=1, deformable_groups=1, bias=False):
+        super().__init__()
+        from .dcn import DeformConv, ModulatedDeformConv
+
+        if isinstance(kernel_size, (list, tuple)):
+            assert isinstance(stride, (list, tuple)) and isinstance(dilation, (list, tuple))
+            assert len(kernel_size) == 2 and len(stride) == 2 and len(dilation) == 2
+            padding = (dilation[0] * (kernel_size[0] - 1) // 2, dilation[1] * (kernel_size[1] - 1) // 2)
+            base = kernel_size[0] * kernel_size[1]
+        else:
+            padding = dilation * (kernel_size - 1) // 2
+            base = kernel_size * kernel_size
+        self.offset_base_channels = base
+        offset_channels = base * (3 if with_modulated_dcn else 2)
+        conv_block = ModulatedDeformConv if with_modulated_dcn else DeformConv
+        self.offset = Conv2d(in_channels, deformable_groups * offset_channels, kernel_size=kernel_size, stride=stride,
+                             padding=padding, groups=1, dilation=dilation)
+        nn.init.kaiming_uniform_(self.offset.weight, a=1)
+        nn.init.constant_(self.offset.bias, 0.0)
+        self.conv = conv_block(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                               dilation=dilation, groups=groups, deformable_groups=deformable_groups, bias=bias)
+        self.with_modulated_dcn = with_modulated_dcn
+        self.kernel_size, self.stride, self.padding, self.dilation = kernel_size, stride, padding, dilation
+
+    def forward(self, x):
+        if x.numel() == 0:
+            k, s, p, d = (v if isinstance(v, (list, tuple)) else (v, v)
+                          for v in (self.kernel_size, self.stride, self.padding, self.dilation))
+            hw = [(i + 2 * pp - (dd * (kk - 1) + 1)) // ss + 1 for i, pp, dd, kk, ss in zip(x.shape[-2:], p, d, k, s)]
+            return x.new_empty([x.shape[0], self.conv.weight.shape[0]] + hw)
+        if not self.with_modulated_dcn:
+            return self.conv(x, self.offset(x))
+        offset_mask = self.offset(x)
+        n = self.offset_base_channels  # the reference hard-codes 18 / 9 (3x3 kernels, one deformable group)
+        return self.conv(x, offset_mask[:, : 2 * n], offset_mask[:, -n:].sigmoid())

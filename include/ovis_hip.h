@@ -99,6 +99,13 @@ int ovis_gemm_f32(const float* A, long a_row_stride, long a_k_stride, const floa
                   long b_row_stride, long b_k_stride, const float* bias, float* C,
                   long c_row_stride, int M, int N, int K, void* stream);
 
+/* General form: C = alpha * A.B^T (+ C when accumulate != 0) + bias, bias indexed by column n or, when
+ * bias_per_row != 0, by row m (convolution bias in the deformable-conv products). */
+int ovis_gemm_ex_f32(const float* A, long a_row_stride, long a_k_stride, const float* B,
+                     long b_row_stride, long b_k_stride, const float* bias, int bias_per_row,
+                     float alpha, int accumulate, float* C, long c_row_stride, int M, int N, int K,
+                     void* stream);
+
 /* Region <-> noun alignment of the teacher (mb/modeling/detector/st_generalized_rcnn.py:243-262):
  * for every noun w: raw_scores[w] = max_p <region_emb[p], noun_emb[w]>, best_region[w] = argmax_p
  * (lowest p on exact ties), sigmoid_scores[w] = sigmoid(raw).  region_emb [num_regions, dim],
@@ -128,6 +135,31 @@ int ovis_mask_bce_stochastic_fwd_bwd_f32(const float* mu, const float* sigma, co
                                          float* dmu, float* dsigma, float* row_scratch, int num_rois,
                                          int num_pos, int num_channels, int mask_pixels, int channel,
                                          void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Deformable convolution v1 / v2 building blocks      mb/csrc/deform_conv.h:11-190
+ *   kernels: mb/csrc/cuda/deform_conv_kernel_cuda.cu:198-250 (im2col), :287-342 (col2im),
+ *            :381-443 (col2im_coord), modulated variants :578-774; host loops deform_conv_cuda.cu:161-694
+ * columns [channels*kernel_h*kernel_w, num_images, H_out, W_out]; input [num_images, channels, H, W];
+ * offset [num_images, deformable_group*2*kernel_h*kernel_w, H_out, W_out];
+ * mask   [num_images, deformable_group*kernel_h*kernel_w, H_out, W_out] or NULL (v1).
+ * col2im ACCUMULATES into grad_input (caller zero-fills, as the reference does); col2im_coord overwrites
+ * grad_offset (and grad_mask when non-NULL).  The surrounding GEMMs are ovis_gemm_ex_f32 on this layout.
+ * ---------------------------------------------------------------------------------- */
+int ovis_deform_im2col_f32(const float* input, const float* offset, const float* mask, float* columns,
+                           int num_images, int channels, int height, int width, int kernel_h,
+                           int kernel_w, int pad_h, int pad_w, int stride_h, int stride_w,
+                           int dilation_h, int dilation_w, int deformable_group, void* stream);
+int ovis_deform_col2im_f32(const float* columns, const float* offset, const float* mask,
+                           float* grad_input, int num_images, int channels, int height, int width,
+                           int kernel_h, int kernel_w, int pad_h, int pad_w, int stride_h,
+                           int stride_w, int dilation_h, int dilation_w, int deformable_group,
+                           void* stream);
+int ovis_deform_col2im_coord_f32(const float* columns, const float* input, const float* offset,
+                                 const float* mask, float* grad_offset, float* grad_mask,
+                                 int num_images, int channels, int height, int width, int kernel_h,
+                                 int kernel_w, int pad_h, int pad_w, int stride_h, int stride_w,
+                                 int dilation_h, int dilation_w, int deformable_group, void* stream);
 
 #ifdef __cplusplus
 }

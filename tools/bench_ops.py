@@ -49,7 +49,7 @@ def bench_rois(r, n_img, g, kind="uniform"):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--ops", default="roi_fwd,roi_bwd,nms,focal")
+    ap.add_argument("--ops", default="roi_fwd,roi_bwd,nms,focal,gemm,dcn")
     ap.add_argument("--iters", type=int, default=20)
     args = ap.parse_args()
     ops = args.ops.split(",")
@@ -99,6 +99,22 @@ def main():
         alg = 12 * m * c + 4 * m
         res.append({"op": "sigmoid_focal_backward", "ms": ms, "alg_MB": alg / 1e6, "GBps": alg / ms / 1e6,
                     "frac_hbm": alg / ms / 1e6 / HBM_PEAK_GBS})
+    if "gemm" in ops:
+        for (m, n, k, what) in ((1024, 776, 2048, "emb_pred+bbox_pred fwd"), (1024, 1203, 768, "text logits LVIS"),
+                                (2000, 776, 2048, "teacher pass"), (1024, 49, 768, "text logits COCO")):
+            a, b = torch.randn(m, k, generator=g).to(dev), torch.randn(n, k, generator=g).to(dev)
+            ms = timeit(lambda: _C.gemm_nt(a, b), args.iters)
+            res.append({"op": "gemm_f32_mfma", "shape": f"{m}x{n}x{k}", "what": what, "ms": ms,
+                        "TFLOPs": 2.0 * m * n * k / ms / 1e9, "frac_fp32_mfma_peak": 2.0 * m * n * k / ms / 1e9 / 157.3})
+    if "dcn" in ops:
+        from cvpr22_cross_modal_pseudo_labeling_amd.layers import deform_conv
+        x = torch.randn(2, 512, 100, 168, generator=g).to(dev)
+        w = (torch.randn(512, 512, 3, 3, generator=g) * 0.02).to(dev)
+        off = (torch.randn(2, 18, 100, 168, generator=g) * 2).to(dev)
+        ms = timeit(lambda: deform_conv(x, off, w, 1, 1, 1, 1, 1, 2), max(3, args.iters // 4))
+        fl = 2.0 * 512 * 512 * 9 * 2 * 100 * 168
+        res.append({"op": "deform_conv_forward", "shape": "[2,512,100,168] 3x3 -> 512", "ms": ms, "TFLOPs": fl / ms / 1e9,
+                    "frac_fp32_mfma_peak": fl / ms / 1e9 / 157.3, "col_MB": 4 * 512 * 9 * 2 * 100 * 168 / 1e6})
     for r_ in res:
         print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r_.items()}))
 
