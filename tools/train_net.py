@@ -1,0 +1,83 @@
+"""Training entry point with the reference's command line (tools/train_net.py:162-234):
+
+    python -m torch.distributed.run --nproc-per-node N tools/train_net.py --config-file CFG [--skip-test] KEY VALUE ...
+
+One process per GPU (RCCL via torch.distributed, env:// rendezvous), config = defaults <- yaml <- trailing overrides,
+frozen before use.  There is no dataset / checkpoint access in this build, so the data stream is the synthetic
+COCO-shaped generator (cvpr22_cross_modal_pseudo_labeling_amd/data/synthetic.py); evaluation, checkpointing and
+TensorBoard are outside the hot-path scope.
+"""
+import argparse
+import logging
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults  # noqa: E402
+from cvpr22_cross_modal_pseudo_labeling_amd.data.synthetic import calibrate_stem_bn, make_batch, make_embeddings  # noqa: E402
+from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm, solver, trainer  # noqa: E402
+from cvpr22_cross_modal_pseudo_labeling_amd.modeling.detector import build_detection_model  # noqa: E402
+
+
+def train(cfg, local_rank, distributed, max_iter, ims_per_gpu):
+    device = torch.device(cfg.MODEL.DEVICE, local_rank) if cfg.MODEL.DEVICE == "cuda" else torch.device(cfg.MODEL.DEVICE)
+    model = build_detection_model(cfg).to(device)
+    e_vocab, e_seen = make_embeddings(cfg.MODEL.ROI_BOX_HEAD.EMB_DIM, device=device)
+    model.set_class_embeddings(e_seen)  # engine/trainer.py:85-90
+    if hasattr(model, "set_caption_vocab"):
+        model.set_caption_vocab(e_vocab)
+    optimizer = solver.make_optimizer(cfg, model)
+    scheduler = solver.make_lr_scheduler(cfg, optimizer)
+    if distributed:
+        comm.broadcast_parameters(model)
+
+    def stream():
+        it = 0
+        while True:
+            yield make_batch(ims_per_gpu, device=device, seed=1234 + 1000 * it + comm.get_rank())
+            it += 1
+
+    data = stream()
+    images, _ = make_batch(1, device=device, seed=7)
+    calibrate_stem_bn(model, images)
+    return trainer.do_train(cfg, model, data, optimizer, scheduler, max_iter)
+
+
+def main():
+    parser = argparse.ArgumentParser(description="MI355X-native detection training (synthetic data)")
+    parser.add_argument("--config-file", default="", metavar="FILE", help="path to config file")
+    parser.add_argument("--local_rank", type=int, default=int(os.environ.get("LOCAL_RANK", 0)))
+    parser.add_argument("--skip-test", dest="skip_test", action="store_true", help="accepted for compatibility")
+    parser.add_argument("--max-iter", type=int, default=None, help="override SOLVER.MAX_ITER for a short run")
+    parser.add_argument("opts", default=None, nargs=argparse.REMAINDER, help="KEY VALUE overrides")
+    args = parser.parse_args()
+
+    num_gpus = int(os.environ.get("WORLD_SIZE", 1))
+    distributed = num_gpus > 1
+    cfg = get_defaults()
+    if args.config_file:
+        cfg.merge_from_file(args.config_file)
+    cfg.merge_from_list(args.opts or [])
+    cfg.freeze()
+    if cfg.MODEL.DEVICE == "cuda":
+        torch.cuda.set_device(args.local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl" if cfg.MODEL.DEVICE == "cuda" else "gloo", init_method="env://")
+        comm.synchronize()
+    logging.basicConfig(level=logging.INFO if comm.get_rank() == 0 else logging.WARNING,
+                        format="%(asctime)s %(name)s %(levelname)s: %(message)s")
+    logging.getLogger("ovis.trainer").info("Using %d GPUs\n%s", num_gpus, args)
+    ims_per_gpu = max(cfg.SOLVER.IMS_PER_BATCH // num_gpus, 1)
+    train(cfg, args.local_rank, distributed, args.max_iter or cfg.SOLVER.MAX_ITER, ims_per_gpu)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
