@@ -52,9 +52,13 @@ def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, b
     if gin.numel() == 0:
         return gin
     with torch.cuda.device(grad.device):
-        rc = _L.ovis_roi_align_backward_f32(grad.data_ptr(), rois.data_ptr(), gin.data_ptr(), r, batch_size,
-                                            channels, height, width, pooled_height, pooled_width,
-                                            spatial_scale, sampling_ratio, _stream())
+        # plane-owner MFMA kernel when the H x W plane fits LDS (needs a per-call table workspace); the
+        # library falls back to the window-gather + atomic kernel for larger maps
+        nbytes = _L.ovis_roi_align_backward_workspace_bytes(r, batch_size, height, width)
+        ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=grad.device)
+        rc = _L.ovis_roi_align_backward_ws_f32(grad.data_ptr(), rois.data_ptr(), gin.data_ptr(), r, batch_size,
+                                               channels, height, width, pooled_height, pooled_width,
+                                               spatial_scale, sampling_ratio, ws.data_ptr(), nbytes, _stream())
     _lib.check(rc, "roi_align_backward")
     return gin
 

@@ -22,103 +22,15 @@
 #include <stdlib.h>
 
 #include "ovis_common.h"
+#include "roi_geom.h"
 
 namespace {
+using namespace ovis_roi;
 
 constexpr int kThreads = 256;
 constexpr int kCPB = 32;            // channels per block (forward and backward)
 constexpr int kMaxBatch = 16;       // channels staged per LDS batch
 constexpr int kFwdLdsFloats = 4352; // 17 KB window budget (>= 50*84 C4 map for 1 channel)
-
-struct RoiGeom {
-  int b;
-  float start_w, start_h, bin_w, bin_h;
-  int gh, gw;
-  float count;
-  // When the sampling grid is a power of two per axis (every RoI up to 448 px at 14x14 / scale 1/16),
-  // x / g == x * (1/g) and acc / count == acc * (1/count) EXACTLY, so the IEEE divisions of the reference
-  // formula (10+ VALU each) can be replaced by multiplies without changing a single bit.
-  bool pow2;
-  float inv_gh, inv_gw, inv_count;
-  int wy0, wy1, wx0, wx1;  // inclusive feature-map window touched by valid samples
-  bool empty;
-};
-
-// One axis of the reference's bilinear set-up (ROIAlign_cuda.cu:22-50): returns false for a
-// coordinate outside [-1, size]; otherwise low/high cell and the two lerp weights.
-__device__ __forceinline__ bool axis_sample(float v, int size, int& lo, int& hi, float& l,
-                                            float& h) {
-  if (v < -1.0f || v > (float)size) return false;
-  if (v <= 0.f) v = 0.f;
-  lo = (int)v;
-  if (lo >= size - 1) {
-    hi = lo = size - 1;
-    v = (float)lo;
-  } else {
-    hi = lo + 1;
-  }
-  l = v - (float)lo;
-  h = 1.f - l;
-  return true;
-}
-
-__device__ __forceinline__ int axis_low(float v, int size) {
-  if (v <= 0.f) return 0;
-  int lo = (int)v;
-  return lo >= size - 1 ? size - 1 : lo;
-}
-
-__device__ __forceinline__ float sample_coord(float start, int p, float bin, int i, int g) {
-  // ROIAlign_cuda.cu:109,112: start + p*bin + (i + .5f)*bin / g
-  return start + (float)p * bin + ((float)i + .5f) * bin / (float)g;
-}
-
-template <bool FAST>
-__device__ __forceinline__ float sample_coord_t(float start, int p, float bin, int i, int g, float inv_g) {
-  const float t = ((float)i + .5f) * bin;
-  return start + (float)p * bin + (FAST ? t * inv_g : t / (float)g);
-}
-
-__device__ __forceinline__ RoiGeom make_geom(const float* __restrict__ roi, float scale, int H,
-                                             int W, int PH, int PW, int sampling_ratio,
-                                             int batch) {
-  RoiGeom g;
-  g.b = (int)roi[0];
-  g.start_w = roi[1] * scale;
-  g.start_h = roi[2] * scale;
-  float end_w = roi[3] * scale;
-  float end_h = roi[4] * scale;
-  float roi_w = fmaxf(end_w - g.start_w, 1.f);
-  float roi_h = fmaxf(end_h - g.start_h, 1.f);
-  g.bin_h = roi_h / (float)PH;
-  g.bin_w = roi_w / (float)PW;
-  g.gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_h / (float)PH);
-  g.gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_w / (float)PW);
-  g.count = (float)(g.gh * g.gw);
-  g.pow2 = g.gh > 0 && g.gw > 0 && (g.gh & (g.gh - 1)) == 0 && (g.gw & (g.gw - 1)) == 0 && g.gh <= 1024 &&
-           g.gw <= 1024;
-  g.inv_gh = 1.f / (float)g.gh;
-  g.inv_gw = 1.f / (float)g.gw;
-  g.inv_count = 1.f / g.count;
-  // Sample coordinates are monotone in (p, i), so the first / last sample bound them all.
-  float y_first = sample_coord(g.start_h, 0, g.bin_h, 0, g.gh);
-  float y_last = sample_coord(g.start_h, PH - 1, g.bin_h, g.gh - 1, g.gh);
-  float x_first = sample_coord(g.start_w, 0, g.bin_w, 0, g.gw);
-  float x_last = sample_coord(g.start_w, PW - 1, g.bin_w, g.gw - 1, g.gw);
-  bool finite = isfinite(y_first) && isfinite(y_last) && isfinite(x_first) && isfinite(x_last);
-  g.empty = !finite || g.b < 0 || g.b >= batch || g.gh <= 0 || g.gw <= 0 ||
-            y_last < -1.f || y_first > (float)H || x_last < -1.f || x_first > (float)W;
-  if (!g.empty) {
-    g.wy0 = axis_low(fmaxf(y_first, -1.f), H);
-    g.wx0 = axis_low(fmaxf(x_first, -1.f), W);
-    g.wy1 = min(axis_low(fminf(y_last, (float)H), H) + 1, H - 1);
-    g.wx1 = min(axis_low(fminf(x_last, (float)W), W) + 1, W - 1);
-  } else {
-    g.wy0 = g.wx0 = 0;
-    g.wy1 = g.wx1 = -1;
-  }
-  return g;
-}
 
 // ---------------------------------------------------------------------------------------
 // Forward
@@ -451,208 +363,6 @@ __global__ __launch_bounds__(kThreads) void roi_align_bwd_kernel(
 }
 
 
-// ---------------------------------------------------------------------------------------
-// Backward, plane-owner form (the fast path for C4-sized maps): no atomics anywhere.
-//
-// Two measured facts about gfx950 shape this kernel (tools/microbench/lds_atomic_bench.hip, PMC in profiles/):
-//   * device-scope fp32 atomics execute at the memory side (the 8 XCD L2s are not coherent): the
-//     one-atomic-per-window-cell kernel above spends 69 % of its wave cycles waiting on them;
-//   * ds_add_f32 costs ~190 LDS cycles per wave instruction (ds_add_u32: 4, ds_read_b32: 2.4), so
-//     accumulating into an LDS plane with float atomics is ~50x worse than plain read-modify-write.
-// So ownership is exclusive instead: a 4-wave workgroup owns image n / 4 consecutive channels, wave w owns
-// the whole H x W gradient plane of channel c0+w in LDS and is the only writer of it.  The workgroup walks
-// the image's RoIs IN ORDER (results are bit-reproducible run to run): waves 0 / 1 build the separable
-// row / column weight tables Ay, Ax of the RoI (plain stores: every table entry has one writer) and the
-// bin ranges touching each window row / column, all waves park their channel's 14x14 grad_output tile in
-// LDS (the next RoI's tile is already in flight from HBM), one barrier, then every wave evaluates
-// Ay^T * G * Ax for its channel -- the bins touching a cell are gathered in 3x3 chunks whose 15 LDS reads
-// are all independent -- and adds the window into its plane with plain LDS read-modify-write.  At the end
-// the planes go to HBM with coalesced stores: no zero-fill pass, no global atomic, HBM traffic equals
-// the algorithmic bytes (grad_output once + grad_input once).
-// ---------------------------------------------------------------------------------------
-constexpr int kBwdWaves = 4;
-constexpr int kBwdThreads = kBwdWaves * 64;
-constexpr int kBwdCP = kBwdWaves;  // channels per workgroup (one per wave)
-constexpr int kTab = 20;           // window tile extent (cells) of the separable tables
-constexpr int kChunk = 3;
-constexpr int kRowsPerBin = 6;     // a bin's samples touch at most grid+1 rows; grids up to 5 take the fast path
-
-__host__ __device__ constexpr int bwd_table_floats(int PH, int PW) {
-  return (PH + kChunk) * kTab + (PW + kChunk) * kTab + 4 * kTab;  // Ay | Ax | phlo phhi pwlo pwhi
-}
-__host__ __device__ constexpr int bwd_gtile_floats(int PH, int PW) { return PH * PW + kChunk * PW + kChunk + 1; }
-__host__ __device__ constexpr size_t bwd_plane_lds_bytes(int H, int W, int PH, int PW) {
-  return sizeof(float) * ((size_t)kBwdCP * H * W + 2 * (size_t)bwd_table_floats(PH, PW) +
-                          (size_t)kBwdWaves * bwd_gtile_floats(PH, PW));
-}
-
-// Build one axis of the separable tables for the window tile [t0, t0+tn): lane p < P owns table row p.
-template <int P>
-__device__ __forceinline__ void bwd_build_axis(float* A, int* lo_arr, int* hi_arr, int lane, float start,
-                                               float bin, int grid, bool adaptive, int size, int t0, int tn) {
-  for (int i = lane; i < (P + kChunk) * kTab; i += 64) A[i] = 0.f;
-  __builtin_amdgcn_wave_barrier();
-  if (lane < P) {
-    // adaptive grids space a bin's samples <= 1 cell apart, so they touch at most grid+1 consecutive rows
-    if (adaptive && grid < kRowsPerBin) {
-      float acc[kRowsPerBin];
-#pragma unroll
-      for (int k = 0; k < kRowsPerBin; ++k) acc[k] = 0.f;
-      int base = 0x7fffffff;
-      for (int i = 0; i < grid; ++i) {
-        int l, h;
-        float wl, wh;
-        if (!axis_sample(sample_coord(start, lane, bin, i, grid), size, l, h, wl, wh)) continue;
-        if (base == 0x7fffffff) base = l;
-#pragma unroll
-        for (int k = 0; k < kRowsPerBin; ++k)
-          acc[k] += (l - base == k ? wh : 0.f) + (h - base == k ? wl : 0.f);
-      }
-      if (base != 0x7fffffff) {
-#pragma unroll
-        for (int k = 0; k < kRowsPerBin; ++k) {
-          const int rel = base + k - t0;
-          if (rel >= 0 && rel < tn && acc[k] != 0.f) A[lane * kTab + rel] = acc[k];
-        }
-      }
-    } else {  // huge sampling grids: serial read-modify-write on the lane's own table row
-      for (int i = 0; i < grid; ++i) {
-        int l, h;
-        float wl, wh;
-        if (!axis_sample(sample_coord(start, lane, bin, i, grid), size, l, h, wl, wh)) continue;
-        l -= t0; h -= t0;
-        if (l >= 0 && l < tn) A[lane * kTab + l] += wh;
-        if (h >= 0 && h < tn) A[lane * kTab + h] += wl;
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (lane < kTab) {  // bins [lo, hi] with a non-zero weight on tile row `lane`
-    int lo = 0x7fffffff, hi = -1;
-    if (lane < tn) {
-#pragma unroll
-      for (int p = 0; p < P; ++p)
-        if (A[p * kTab + lane] != 0.f) { lo = min(lo, p); hi = p; }
-    }
-    lo_arr[lane] = lo;
-    hi_arr[lane] = hi;
-  }
-}
-
-template <int PH, int PW>
-__global__ __launch_bounds__(kBwdThreads) void roi_align_bwd_plane_kernel(
-    const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gin, int R,
-    int batch, int C, int H, int W, float scale, int sampling_ratio) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int PHPW = PH * PW;
-  constexpr int kGRegs = (PHPW + 63) / 64;
-  constexpr int TF = bwd_table_floats(PH, PW);
-  constexpr int GF = bwd_gtile_floats(PH, PW);
-  const int HW = H * W;
-  const int n_ct = (C + kBwdCP - 1) / kBwdCP;
-  const int n = blockIdx.x / n_ct;
-  const int c0 = (blockIdx.x - n * n_ct) * kBwdCP;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ch = c0 + wave;
-  const bool live = ch < C;  // a partial channel tile: the wave still takes part in the barriers
-
-  float* plane = smem + wave * HW;                      // this wave's channel plane
-  float* tabs = smem + kBwdCP * HW;                     // [2][TF] double-buffered tables
-  float* G = tabs + 2 * TF + wave * GF;                 // this wave's grad_output tile (+ finite pad)
-
-  for (int i = threadIdx.x; i < kBwdCP * HW + 2 * TF + kBwdWaves * GF; i += kBwdThreads) smem[i] = 0.f;
-  __syncthreads();
-
-  float greg[kGRegs];
-  auto issue_loads = [&](int r) {
-    const float* src = gout + ((long)r * C + ch) * PHPW;
-#pragma unroll
-    for (int k = 0; k < kGRegs; ++k) {
-      const int i = k * 64 + lane;
-      greg[k] = (live && i < PHPW) ? src[i] : 0.f;
-    }
-  };
-
-  int buf = 0;
-  bool have = false;  // greg holds the tile of the RoI about to be processed
-  for (int rb = 0; rb < R; rb += 64) {
-    // which of the next 64 RoIs belong to image n (identical in every wave -> same order everywhere)
-    const int rr = rb + lane;
-    const bool mine = rr < R && (int)rois[(long)rr * 5] == n;
-    unsigned long long todo = __ballot(mine);
-    while (todo) {
-      const int r = rb + __builtin_ctzll(todo);
-      todo &= todo - 1;
-      if (!have) issue_loads(r);
-      // park this RoI's tile in LDS; the tile of the NEXT RoI of this 64-group starts streaming now
-#pragma unroll
-      for (int k = 0; k < kGRegs; ++k) {
-        const int i = k * 64 + lane;
-        if (i < PHPW) G[i] = greg[k];
-      }
-      have = false;
-      if (todo) { issue_loads(rb + __builtin_ctzll(todo)); have = true; }
-
-      const RoiGeom g = make_geom(rois + (long)r * 5, scale, H, W, PH, PW, sampling_ratio, batch);
-      if (g.empty) continue;  // uniform across the workgroup
-      for (int sy = g.wy0; sy <= g.wy1; sy += kTab) {
-        const int th = min(kTab, g.wy1 - sy + 1);
-        for (int sx = g.wx0; sx <= g.wx1; sx += kTab) {
-          const int tw = min(kTab, g.wx1 - sx + 1);
-          float* Ay = tabs + buf * TF;
-          float* Ax = Ay + (PH + kChunk) * kTab;
-          int* phlo = (int*)(Ax + (PW + kChunk) * kTab);
-          int* phhi = phlo + kTab;
-          int* pwlo = phhi + kTab;
-          int* pwhi = pwlo + kTab;
-          if (wave == 0) bwd_build_axis<PH>(Ay, phlo, phhi, lane, g.start_h, g.bin_h, g.gh, sampling_ratio <= 0, H, sy, th);
-          if (wave == 1) bwd_build_axis<PW>(Ax, pwlo, pwhi, lane, g.start_w, g.bin_w, g.gw, sampling_ratio <= 0, W, sx, tw);
-          __syncthreads();
-          buf ^= 1;  // the next tile's tables go to the other buffer: one barrier per tile is enough
-          if (!live) continue;
-          const int tarea = th * tw;
-          const float inv_tw = 1.f / (float)tw;
-          for (int idx = lane; idx < tarea; idx += 64) {
-            const int y = (int)(((float)idx + 0.5f) * inv_tw);
-            const int x = idx - y * tw;
-            const int p0 = phlo[y], p1 = phhi[y], q0 = pwlo[x], q1 = pwhi[x];
-            if (p1 < p0 || q1 < q0) continue;
-            float s = 0.f;
-            for (int pc = p0; pc <= p1; pc += kChunk) {
-              const float* ayp = Ay + pc * kTab + y;  // rows past p1 are zero for this cell / zero pad rows
-              float ay[kChunk];
-#pragma unroll
-              for (int a = 0; a < kChunk; ++a) ay[a] = ayp[a * kTab];
-              for (int qc = q0; qc <= q1; qc += kChunk) {
-                const float* axp = Ax + qc * kTab + x;
-                const float* gp = G + pc * PW + qc;
-                float ax[kChunk], gv[kChunk][kChunk];
-#pragma unroll
-                for (int b = 0; b < kChunk; ++b) ax[b] = axp[b * kTab];
-#pragma unroll
-                for (int a = 0; a < kChunk; ++a)
-#pragma unroll
-                  for (int b = 0; b < kChunk; ++b) gv[a][b] = gp[a * PW + b];
-#pragma unroll
-                for (int a = 0; a < kChunk; ++a)
-#pragma unroll
-                  for (int b = 0; b < kChunk; ++b) s += (ay[a] * ax[b]) * gv[a][b];
-              }
-            }
-            plane[(sy + y) * W + (sx + x)] += s / g.count;
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (live) {
-    float* dst = gin + ((long)n * C + ch) * HW;
-    for (int i = lane; i < HW; i += 64) dst[i] = plane[i];
-  }
-}
-
 // Fallback for shapes whose separable tables do not fit LDS (huge maps / pooled sizes):
 // one lane per grad_output element scattering its samples with global atomics.
 __global__ __launch_bounds__(kThreads) void roi_align_bwd_scatter_kernel(
@@ -710,6 +420,13 @@ extern "C" int ovis_roi_align_forward_f32(const float* input, const float* rois,
   return OVIS_OK;
 }
 
+// roi_align_bwd_plane.hip
+int ovis_roi_align_backward_plane_launch(const float* grad_output, const float* rois, float* grad_input,
+                                         int num_rois, int batch, int channels, int height, int width,
+                                         int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                                         void* workspace, size_t workspace_bytes, hipStream_t s);
+extern "C" int ovis_roi_align_backward_plane_supported(int height, int width, int pooled_h, int pooled_w);
+
 extern "C" int ovis_roi_align_backward_f32(const float* grad_output, const float* rois,
                                            float* grad_input, int num_rois, int batch,
                                            int channels, int height, int width, int pooled_h,
@@ -722,38 +439,6 @@ extern "C" int ovis_roi_align_backward_f32(const float* grad_output, const float
   if (in_bytes == 0) return OVIS_OK;
   if (!grad_input) return OVIS_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  // plane-owner fast path: one workgroup per (image, 4 channels) keeps that gradient plane in LDS
-  const bool plane_shape = (pooled_h == 14 && pooled_w == 14) || (pooled_h == 7 && pooled_w == 7);
-  const size_t plane_lds = bwd_plane_lds_bytes(height, width, pooled_h, pooled_w);
-  // OVIS_ROI_BWD_DETERMINISTIC=1 selects the atomics-free plane-owner kernel: bit-reproducible run to run,
-  // HBM traffic == algorithmic bytes, but (round 1) ~2x slower than the window-gather + global-atomic kernel.
-  static const bool deterministic = [] {
-    const char* e = getenv("OVIS_ROI_BWD_DETERMINISTIC");
-    return e && e[0] == '1';
-  }();
-  if (deterministic && num_rois > 0 && plane_shape && plane_lds <= 160 * 1024) {
-    if (!grad_output || !rois) return OVIS_EINVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_align_bwd_plane_kernel<14, 14>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_align_bwd_plane_kernel<7, 7>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
-    }
-    const long blocks = (long)batch * ovis_ceil_div(channels, kBwdCP);
-    if (blocks > 0x7fffffffL) return OVIS_ERANGE;
-    if (pooled_h == 14)
-      hipLaunchKernelGGL((roi_align_bwd_plane_kernel<14, 14>), dim3((unsigned)blocks), dim3(kBwdThreads),
-                         plane_lds, s, grad_output, rois, grad_input, num_rois, batch, channels, height, width,
-                         spatial_scale, sampling_ratio);
-    else
-      hipLaunchKernelGGL((roi_align_bwd_plane_kernel<7, 7>), dim3((unsigned)blocks), dim3(kBwdThreads),
-                         plane_lds, s, grad_output, rois, grad_input, num_rois, batch, channels, height, width,
-                         spatial_scale, sampling_ratio);
-    OVIS_LAUNCH_CHECK();
-    return OVIS_OK;
-  }
   OVIS_HIP_TRY(hipMemsetAsync(grad_input, 0, in_bytes, s));  // at::zeros, ROIAlign_cuda.cu:316
   if (num_rois == 0) return OVIS_OK;
   if (!grad_output || !rois) return OVIS_EINVAL;
@@ -777,4 +462,22 @@ extern "C" int ovis_roi_align_backward_f32(const float* grad_output, const float
   }
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
+}
+
+extern "C" int ovis_roi_align_backward_ws_f32(const float* grad_output, const float* rois, float* grad_input,
+                                              int num_rois, int batch, int channels, int height, int width,
+                                              int pooled_h, int pooled_w, float spatial_scale,
+                                              int sampling_ratio, void* workspace, size_t workspace_bytes,
+                                              void* stream) {
+  if (num_rois < 0 || batch < 0 || channels < 0 || height <= 0 || width <= 0 || pooled_h <= 0 || pooled_w <= 0)
+    return OVIS_EINVAL;
+  if ((size_t)batch * channels == 0) return OVIS_OK;
+  if (num_rois > 0 && ovis_roi_align_backward_plane_supported(height, width, pooled_h, pooled_w)) {
+    if (!grad_output || !rois || !grad_input) return OVIS_EINVAL;
+    return ovis_roi_align_backward_plane_launch(grad_output, rois, grad_input, num_rois, batch, channels, height,
+                                                width, pooled_h, pooled_w, spatial_scale, sampling_ratio,
+                                                workspace, workspace_bytes, (hipStream_t)stream);
+  }
+  return ovis_roi_align_backward_f32(grad_output, rois, grad_input, num_rois, batch, channels, height, width,
+                                     pooled_h, pooled_w, spatial_scale, sampling_ratio, stream);
 }

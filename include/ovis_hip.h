@@ -57,6 +57,24 @@ int ovis_roi_align_backward_f32(const float* grad_output, const float* rois,
                                 int pooled_w, float spatial_scale, int sampling_ratio,
                                 void* stream);
 
+/* Workspace form of the backward (the fast path).  When
+ * ovis_roi_align_backward_plane_supported(height, width, pooled_h, pooled_w) is non-zero
+ * (pooled sizes <= 16 and an H x W f32 plane of at most 40 KB, e.g. the 50 x 84 C4 map) the
+ * gradient is computed by the plane-owner matrix-core kernel: one wave owns one
+ * (image, channel) plane in LDS, no atomics, no zero-fill pass, bit-reproducible run to
+ * run, HBM traffic == grad_output once + grad_input once.  `workspace` is device scratch of
+ * at least ovis_roi_align_backward_workspace_bytes(num_rois, batch, height, width) bytes,
+ * 256-byte aligned (per-RoI separable weight tables + per-image RoI lists, rebuilt by every
+ * call).  Unsupported shapes take the same path as ovis_roi_align_backward_f32 and ignore
+ * the workspace.  Replaces ROIAlign_backward_cuda, mb/csrc/cuda/ROIAlign_cuda.cu:302-346. */
+size_t ovis_roi_align_backward_workspace_bytes(int num_rois, int batch, int height, int width);
+int ovis_roi_align_backward_plane_supported(int height, int width, int pooled_h, int pooled_w);
+int ovis_roi_align_backward_ws_f32(const float* grad_output, const float* rois,
+                                   float* grad_input, int num_rois, int batch, int channels,
+                                   int height, int width, int pooled_h, int pooled_w,
+                                   float spatial_scale, int sampling_ratio, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * NMS                                        mb/csrc/nms.h:10-28, mb/csrc/cuda/nms.cu:13-131
  * boxes [K,4] f32 xyxy (+1 pixel area convention), scores [K] f32.

@@ -218,31 +218,48 @@ def test_focal_vs_oracle_and_module(C, oracle_mod, num, c):
     assert abs(total.item() - want.double().sum().item()) <= 1e-4 * max(1.0, want.double().sum().item())
 
 
-def test_roi_align_backward_deterministic_mode(oracle_mod):
-    """OVIS_ROI_BWD_DETERMINISTIC=1: the atomics-free plane-owner kernel -- same values (tolerance), and two runs
-    are bit-identical.  Runs in a subprocess because the switch is read once per process."""
-    import subprocess
-    import sys
+def test_roi_align_backward_plane_kernel_reproducible(C, oracle_mod):
+    """The plane-owner matrix-core kernel (default for maps whose plane fits LDS) issues no atomics: two runs are
+    bit-identical; RoIs up to 500 px exercise multi-block windows (several 16-cell blocks per axis)."""
+    g = torch.Generator().manual_seed(5)
+    n, c, h, w, r = 2, 10, 50, 84, 300
+    b = torch.randint(0, n, (r, 1), generator=g).float()
+    xy = torch.rand(r, 2, generator=g) * torch.tensor([1000.0, 600.0])
+    wh = torch.rand(r, 2, generator=g) * 500 + 4
+    rois = torch.cat([b, xy, (xy + wh).clamp(max=1300)], 1)
+    go = torch.randn(r, c, 14, 14, generator=g)
+    a = C.roi_align_backward(go.cuda(), rois.cuda(), 1 / 16, 14, 14, n, c, h, w, 0)
+    b2 = C.roi_align_backward(go.cuda(), rois.cuda(), 1 / 16, 14, 14, n, c, h, w, 0)
+    want = oracle_mod.roi_align_backward(go, rois, 1 / 16, 14, 14, n, c, h, w, 0)
+    assert torch.equal(a, b2), "not reproducible"
+    assert torch.allclose(a.cpu(), want, rtol=1e-4, atol=1e-4), (a.cpu() - want).abs().max()
 
-    code = r'''
-import sys, torch
-sys.path.insert(0, %r)
-import oracle
-from cvpr22_cross_modal_pseudo_labeling_amd import _C
-g = torch.Generator().manual_seed(5)
-n, c, h, w, r = 2, 10, 50, 84, 300
-b = torch.randint(0, n, (r, 1), generator=g).float()
-xy = torch.rand(r, 2, generator=g) * torch.tensor([1000.0, 600.0])
-wh = torch.rand(r, 2, generator=g) * 500 + 4
-rois = torch.cat([b, xy, (xy + wh).clamp(max=1300)], 1)
-go = torch.randn(r, c, 14, 14, generator=g)
-a = _C.roi_align_backward(go.cuda(), rois.cuda(), 1 / 16, 14, 14, n, c, h, w, 0)
-b2 = _C.roi_align_backward(go.cuda(), rois.cuda(), 1 / 16, 14, 14, n, c, h, w, 0)
-want = oracle.roi_align_backward(go, rois, 1 / 16, 14, 14, n, c, h, w, 0)
-assert torch.equal(a, b2), "not reproducible"
-assert torch.allclose(a.cpu(), want, rtol=1e-4, atol=1e-4), (a.cpu() - want).abs().max()
-print("ok")
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, OVIS_ROI_BWD_DETERMINISTIC="1")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+def test_roi_align_backward_edge_rois(C, oracle_mod):
+    """Degenerate / clipped / out-of-map RoIs, odd pooled width, fixed sampling grids."""
+    rois = torch.tensor([[0, -50.0, -40.0, 30.0, 20.0],       # hangs over the top-left corner
+                         [1, 600.0, 300.0, 600.0, 300.0],      # zero size -> clamped to one cell
+                         [0, 650.0, 380.0, 2000.0, 900.0],     # runs past the bottom-right corner
+                         [1, 5000.0, 5000.0, 5100.0, 5100.0],  # entirely outside: contributes nothing
+                         [0, 0.0, 0.0, 671.0, 399.0],          # the whole map
+                         [1, 100.3, 50.7, 101.9, 52.2]])       # sub-cell RoI: all bins in one or two cells
+    g = torch.Generator().manual_seed(11)
+    for (p, sr) in [(14, 0), (7, 0), (7, 3), (14, 1)]:
+        go = torch.randn(rois.shape[0], 3, p, p, generator=g)
+        want = oracle_mod.roi_align_backward(go, rois, 1 / 16, p, p, 2, 3, 25, 42, sr)
+        got = C.roi_align_backward(go.cuda(), rois.cuda(), 1 / 16, p, p, 2, 3, 25, 42, sr).cpu()
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-4), (p, sr, (got - want).abs().max())
+
+
+def test_roi_align_backward_large_map_fallback(C, oracle_mod):
+    """A plane larger than the LDS budget (120 x 100 f32 = 48 KB) takes the window-gather + atomic kernel."""
+    from cvpr22_cross_modal_pseudo_labeling_amd import _lib
+    L = _lib.load()
+    assert L.ovis_roi_align_backward_plane_supported(50, 84, 14, 14) == 1
+    assert L.ovis_roi_align_backward_plane_supported(120, 100, 14, 14) == 0
+    g = torch.Generator().manual_seed(3)
+    rois = _rois(g, 40, 1, 1600, 1900, 8, 600)
+    go = torch.randn(40, 4, 14, 14, generator=g)
+    want = oracle_mod.roi_align_backward(go, rois, 1 / 16, 14, 14, 1, 4, 120, 100, 0)
+    got = C.roi_align_backward(go.cuda(), rois.cuda(), 1 / 16, 14, 14, 1, 4, 120, 100, 0).cpu()
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-4)
