@@ -474,9 +474,11 @@ extern "C" int ovis_roi_align_backward_ws_f32(const float* grad_output, const fl
   if ((size_t)batch * channels == 0) return OVIS_OK;
   if (num_rois > 0 && ovis_roi_align_backward_plane_supported(height, width, pooled_h, pooled_w)) {
     if (!grad_output || !rois || !grad_input) return OVIS_EINVAL;
-    return ovis_roi_align_backward_plane_launch(grad_output, rois, grad_input, num_rois, batch, channels, height,
-                                                width, pooled_h, pooled_w, spatial_scale, sampling_ratio,
-                                                workspace, workspace_bytes, (hipStream_t)stream);
+    const int rc = ovis_roi_align_backward_plane_launch(grad_output, rois, grad_input, num_rois, batch, channels,
+                                                        height, width, pooled_h, pooled_w, spatial_scale,
+                                                        sampling_ratio, workspace, workspace_bytes,
+                                                        (hipStream_t)stream);
+    if (rc != -100) return rc;  // -100: offsets would not fit 32 bits -> atomic path below
   }
   return ovis_roi_align_backward_f32(grad_output, rois, grad_input, num_rois, batch, channels, height, width,
                                      pooled_h, pooled_w, spatial_scale, sampling_ratio, stream);
