@@ -40,9 +40,12 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 constexpr int kT = 16;        // window block edge == MFMA tile edge
-constexpr int kDepth = 10;    // items in flight per wave (G tile + table blocks): ~63 KB of G per CU covers ~2 us of HBM latency
+constexpr int kRI = 4;         // items per round (one barrier per round)
+constexpr int kGDepth = 8;    // G tiles in flight per wave = two rounds (8 waves x 8 x 784 B = 50 KB per CU)
+constexpr int kRing = 3;      // table ring depth in rounds: consumed | landed | in flight
+constexpr int kRoundBytes = 2 * kRI * 1024;  // 4 tx blocks + 4 ty blocks
+constexpr int kListPad = 4 * kGDepth;        // zero-contribution items after the last real one
 constexpr int kPlanThreads = 1024;
-constexpr int kMinLds = 20 * 1024;  // 160 KB / 8: pins residency at 8 single-wave workgroups per CU
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   f2 v = {a, b};
@@ -103,7 +106,7 @@ __device__ __forceinline__ float axis_weight(float start, float bin, int grid, i
 //                            last group repeats bins of the previous one);
 //   ty[r * NYB + yb][lane] = A operand of stage 2 (same packing): lane (row q, s) holds Ay[i = 4s+e][oy+q] / count.
 // ---------------------------------------------------------------------------------------------------
-__host__ __device__ inline long list_stride(int R, int NXB, int NYB) { return (long)R * NXB * NYB + 2 * kDepth + 2; }
+__host__ __device__ inline long list_stride(int R, int NXB, int NYB) { return (long)R * NXB * NYB + kListPad + kGDepth; }
 
 __device__ __forceinline__ int block_origin(int w0, int blk, int size) {
   return max(min(w0 + blk * kT, size - kT), 0);
@@ -161,8 +164,8 @@ __global__ __launch_bounds__(kPlanThreads) void roi_bwd_plan_kernel(
       __syncthreads();
     }
     // pad to a whole number of ring rounds plus the prefetch run-ahead with items that add exact zeros
-    const int padded = (base + kDepth - 1) / kDepth * kDepth;
-    for (int i = base + threadIdx.x; i < padded + kDepth + 1; i += kPlanThreads)
+    const int padded = (base + kGDepth - 1) / kGDepth * kGDepth;
+    for (int i = base + threadIdx.x; i < padded + kListPad; i += kPlanThreads)
       my[i] = (u4){0u, 0u, (unsigned)(R * NXB) * 1024u, (unsigned)(R * NYB) * 1024u};
     if (threadIdx.x == 0) counts[n] = padded;
     return;
@@ -199,89 +202,130 @@ __global__ __launch_bounds__(kPlanThreads) void roi_bwd_plan_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Main kernel: one wave == one workgroup == one (image, channel) plane.
-// The per-item code is straight-line: exactly three 16-byte loads per item (G slice, tx block, ty block), issued
-// kDepth items ahead into a register ring, item scalars by s_load one step further ahead, footprint added
-// unconditionally (FIT: map >= 16 x 16).
+// Main kernel: one workgroup of NW waves owns NW consecutive channels of image n; wave w keeps the whole H x W
+// gradient plane of channel c0 + w in LDS and is its only writer.
 //
-// The ring loads are inline asm so that hipcc does not count them: left to itself it waits vmcnt(0) before every
-// item (its loop-carried bookkeeping gives up on a ring this deep) and the prefetch is drained each time.  Rules
-// followed (guide 5.7 form ii): destinations are "+v" (refilled in place, never copied), every consumer sits
-// below a wait statement naming the registers it reads, loads are issued in item order so the counted wait
-// vmcnt(3 * kDepth - 3) retires exactly the oldest item, sched_barrier pins the statement order.  Addresses are
-// SGPR base (kernel pointer + the item's byte offset, SALU) + a per-lane 32-bit VGPR offset that never changes.
+// What bounds this kernel is the CU's vector-memory path (64 B/clk): with every wave fetching its own copy of the
+// 2 KB of table blocks per item, 3 KB per (item, channel) went through it and the kernel sat at ~0.30 ms with
+// the HBM stream (0.16 ms alone) waiting behind table traffic.  So the table blocks -- identical for all
+// channels -- are brought in ONCE per workgroup by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip) into a
+// ring of three rounds of four items and read back with ds_read_b128; only the 784-byte G tile per (item,
+// channel) still goes through the vector path.
+//
+// Per wave, per round r (items 4r .. 4r+3):
+//   DMA the wave's share (8 / NW blocks) of round r+2's tables           -> ring slot (r+2) % 3
+//   per item k: [plane reads of item k-1]  wait G(k)  ds_read tx, ty  stage 1 (3 MFMA)
+//               [plane adds + writes of item k-1]  stage 2 (3 MFMA)  refill the G slot with item k+8
+//   wait until the wave's DMAs for round r+1 have landed; s_barrier
+// All vector loads of a wave complete in issue order, and the order is the same every round, so the waits are
+// counted: when G(k) is needed, 7 younger G loads and the DMAs of two round starts are behind it
+// (vmcnt(7 + 2P), P = 8 / NW); at the round end the DMAs for round r+1 have 8 G loads and P DMAs behind them
+// (vmcnt(8 + P)) -- which are exactly the loads that would have been waited for anyway, so the deep G prefetch
+// is never drained.  The loads are inline asm so that hipcc does not count them itself (left to itself it
+// waits vmcnt(0) per item); rules followed (guide 5.7 form ii): G destinations are "+v", refilled in place,
+// every consumer sits below a wait statement naming the register, sched_barrier pins statement order; the
+// DMA statements save / restore M0 inside one statement.
 // ---------------------------------------------------------------------------------------------------
 #define OVIS_GLOAD4(dst, voff, sbase) \
   asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory")
-#define OVIS_WAIT3(N, a, b, c) \
-  asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "i"(N) : "memory")
+#define OVIS_WAIT1(N, a) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "i"(N) : "memory")
 
-template <bool FIT>
-__global__ __launch_bounds__(64) void roi_bwd_mfma_kernel(
+__device__ __forceinline__ void lds_dma16(const void* gsrc_lane, unsigned lds_dst_wave) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc_lane), "s"(lds_dst_wave)
+      : "memory");
+}
+
+template <int NW, bool FIT>
+__global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
     const float* __restrict__ gout, const u4* __restrict__ list, const int* __restrict__ counts,
     const u4* __restrict__ tx, const u4* __restrict__ ty, float* __restrict__ gin, int R, int batch,
-    int C, int H, int W, int PH, int PW, int NXB, int NYB) {
-  extern __shared__ __attribute__((aligned(16))) float plane[];
-  const int lane = threadIdx.x;
-  const int n = blockIdx.x % batch;  // neighbouring workgroups alternate images: a CU's 8 planes mix them
-  const int c = blockIdx.x / batch;
+    int C, int H, int W, int PH, int PW, int NXB, int NYB, unsigned plane_stride) {
+  // no static LDS in this kernel: the dynamic segment starts at LDS address 0, which the DMA destinations rely on
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int P = 2 * kRI / NW;  // table blocks each wave DMAs per round
+  static_assert(2 * kRI % NW == 0 && kGDepth == 2 * kRI, "round geometry");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = blockIdx.x % batch;
+  const int c_raw = (blockIdx.x / batch) * NW + wave;
+  const bool live = c_raw < C;          // a partial channel group: the wave still loads, DMAs and meets barriers
+  const int c = live ? c_raw : C - 1;
   const int HW = H * W;
   const int PHPW = PH * PW;
+  float* plane = (float*)(smem + (size_t)wave * plane_stride);
+  const unsigned ring_base = NW * plane_stride;
   for (int i = lane; i < HW; i += 64) plane[i] = 0.f;
 
-  const int cnt = counts[n];  // padded to a multiple of kDepth by the plan kernel
-  float* dst = gin + ((long)n * C + c) * HW;
-  {
-    const u4* my = list + (long)n * list_stride(R, NXB, NYB);
-    const int q = lane & 15, s = lane >> 4;
-    // Lane's slice of a G tile: row q, four columns starting at min(4s, PW - 4) -- the last k-group is pulled back
-    // so that no lane reads past its row (the plan kernel zeroes the duplicated k-slots in tx).  Rows q >= PH re-read
-    // row PH - 1: finite values that meet zero ty entries (i >= PH).
-    const unsigned g_lane = (unsigned)(min(q, PH - 1) * PW + min(4 * s, PW - 4)) * 4u;
-    const unsigned t_lane = (unsigned)lane * 16u;
-    const char* gbase = (const char*)(gout + (long)c * PHPW);
-    const char* txb = (const char*)tx;
-    const char* tyb = (const char*)ty;
-    const unsigned lane_cell = (unsigned)(4 * s * W + q) * 4u;  // byte offset of the lane's first footprint cell
+  const int cnt = counts[n];  // padded to a multiple of kGDepth by the plan kernel
+  const u4* my = list + (long)n * list_stride(R, NXB, NYB);
+  const int q = lane & 15, s = lane >> 4;
+  // Lane's slice of a G tile: row q, four columns starting at min(4s, PW - 4) -- the last k-group is pulled back
+  // so that no lane reads past its row (the plan kernel zeroes the duplicated k-slots in tx).  Rows q >= PH re-read
+  // row PH - 1: finite values that meet zero ty entries (i >= PH).
+  const unsigned g_lane = (unsigned)(min(q, PH - 1) * PW + min(4 * s, PW - 4)) * 4u;
+  const char* gbase = (const char*)(gout + (long)c * PHPW);
+  const char* txl = (const char*)tx + lane * 16;
+  const char* tyl = (const char*)ty + lane * 16;
+  const unsigned lane_cell = (unsigned)(4 * s * W + q) * 4u;  // byte offset of the lane's first footprint cell
 
-    f4 rg[kDepth];     // lane's 4 grad_output values G[i = min(q, PH-1)][j = min(4s, PW-4) + e] of the item in slot d
-    u4 rbx[kDepth];    // its column block of tx
-    u4 ray[kDepth];    // its row block of ty
-    unsigned org[kDepth];  // its footprint origin (LDS byte offset)
+  // this wave's DMA duty for round `rr` into ring slot `slot`: blocks b = wave*P .. wave*P+P-1 of the round's 8,
+  // block b = {tx, ty}[b >> 2] of item rr*4 + (b & 3); lands at ring_base + slot*kRoundBytes + b*1024
+  auto dma_round = [&](int rr, unsigned slot) {
 #pragma unroll
-    for (int d = 0; d < kDepth; ++d) {
-      rg[d] = (f4){0.f, 0.f, 0.f, 0.f};
-      rbx[d] = ray[d] = (u4){0u, 0u, 0u, 0u};
+    for (int p = 0; p < P; ++p) {
+      const int b = wave * P + p;
+      const u4 e = my[rr * kRI + (b & 3)];
+      const char* src = (b >> 2) ? tyl + e.w : txl + e.z;
+      lds_dma16(src, ring_base + slot * kRoundBytes + (unsigned)b * 1024u);
     }
-#define OVIS_FETCH(d, e)                         \
-  do {                                           \
-    const char* pg_ = gbase + (e).x;             \
-    const char* pb_ = txb + (e).z;               \
-    const char* pa_ = tyb + (e).w;               \
-    OVIS_GLOAD4(rg[d], g_lane, pg_);             \
-    OVIS_GLOAD4(rbx[d], t_lane, pb_);            \
-    OVIS_GLOAD4(ray[d], t_lane, pa_);            \
-    org[d] = (e).y;                              \
+  };
+
+  f4 rg[kGDepth];         // lane's 4 grad_output values G[i = min(q, PH-1)][j = min(4s, PW-4) + e] of the item in slot d
+  unsigned org[kGDepth];  // its footprint origin (LDS byte offset inside the plane)
+#pragma unroll
+  for (int d = 0; d < kGDepth; ++d) rg[d] = (f4){0.f, 0.f, 0.f, 0.f};
+#define OVIS_FETCH(d, e)                       \
+  do {                                         \
+    const char* pg_ = gbase + (e).x;           \
+    OVIS_GLOAD4(rg[d], g_lane, pg_);           \
+    org[d] = (e).y;                            \
   } while (0)
 
+  // prologue, in the steady-state issue order: DMA(0) G(0..3) DMA(1) G(4..7)
+  dma_round(0, 0);
 #pragma unroll
-    for (int d = 0; d < kDepth; ++d) {
-      const u4 e = my[d];
-      OVIS_FETCH(d, e);
-    }
-    u4 epre = my[kDepth];  // entry of the item to prefetch next
-
-    // Software pipeline: the footprint of item k-1 is folded into the plane while item k runs through the matrix
-    // pipe -- its four plane reads are issued before the wait on item k's loads, the adds + writes sit between
-    // the two MFMA stages of item k.  Starts with a zero footprint at cell 0 (adds 0.0f, FIT) / nothing (masked).
-    f4 w_prev = {0.f, 0.f, 0.f, 0.f};
-    unsigned cell_prev = lane_cell;
-    bool on_prev = false;  // masked form only: does the lane own a column of the previous footprint
-
-    // cnt is a multiple of kDepth and the list runs kDepth + 1 entries past it (zero-contribution padding items)
-    for (int k0 = 0; k0 < cnt; k0 += kDepth) {
+  for (int d = 0; d < kRI; ++d) { const u4 e = my[d]; OVIS_FETCH(d, e); }
+  dma_round(1, 1);
 #pragma unroll
-      for (int d = 0; d < kDepth; ++d) {
+  for (int d = kRI; d < kGDepth; ++d) { const u4 e = my[d]; OVIS_FETCH(d, e); }
+  u4 epre = my[kGDepth];  // entry of the item to prefetch next
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(kGDepth + P) : "memory");  // round 0's tables landed
+  __builtin_amdgcn_sched_barrier(0);
+
+  // Software pipeline: the footprint of item k-1 is folded into the plane while item k runs through the matrix
+  // pipe.  Starts with a zero footprint at cell 0 (adds 0.0f, FIT) / nothing (masked).
+  f4 w_prev = {0.f, 0.f, 0.f, 0.f};
+  unsigned cell_prev = lane_cell;
+  bool on_prev = false;  // masked form only: does the lane own a column of the previous footprint
+  unsigned slot = 0;     // ring slot of the round being consumed
+
+  // cnt is a multiple of kGDepth; the list runs kListPad zero-contribution items past it
+  for (int k0 = 0; k0 < cnt; k0 += kGDepth) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      {
+        const unsigned slot2 = slot + 2 >= kRing ? slot + 2 - kRing : slot + 2;
+        dma_round(k0 / kRI + half + 2, slot2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const char* tab = smem + ring_base + slot * kRoundBytes + lane * 16;
+#pragma unroll
+      for (int i = 0; i < kRI; ++i) {
+        const int d = half * kRI + i;
         const int k = k0 + d;
         const unsigned cell = org[d] + lane_cell;
         float* pp = (float*)((char*)plane + cell_prev);
@@ -289,12 +333,14 @@ __global__ __launch_bounds__(64) void roi_bwd_mfma_kernel(
         if (FIT) {
           v0 = pp[0]; v1 = pp[W]; v2 = pp[2 * W]; v3 = pp[3 * W];
         }
+        const u4 bx = *(const u4*)(tab + i * 1024);
+        const u4 ay = *(const u4*)(tab + (kRI + i) * 1024);
         __builtin_amdgcn_sched_barrier(0);
-        OVIS_WAIT3(3 * kDepth - 3, rg[d], rbx[d], ray[d]);  // the oldest item's three loads have landed
+        OVIS_WAIT1(kGDepth - 1 + 2 * P, rg[d]);  // G(k) has landed
         __builtin_amdgcn_sched_barrier(0);
         // stage 1: T[i][x] = sum_j G[i][j] Ax[j][x]
         const u4 a1 = split_bf16(rg[d]);
-        const f4 t = mfma3(a1, rbx[d], (f4){0.f, 0.f, 0.f, 0.f});
+        const f4 t = mfma3(a1, bx, (f4){0.f, 0.f, 0.f, 0.f});
         // previous item's footprint (its reads were issued above, their latency is behind stage 1 by now)
         if (FIT) {
           pp[0] = v0 + w_prev.x;
@@ -311,37 +357,46 @@ __global__ __launch_bounds__(64) void roi_bwd_mfma_kernel(
         // stage 2: dW[y][x] = sum_i Ay[i][y] T[i][x]; T's accumulator layout (col = lane & 15, row = 4s + e) is
         // the B-operand layout, so it only needs the hi/lo split
         const u4 b2 = split_bf16(t);
-        w_prev = mfma3(ray[d], b2, (f4){0.f, 0.f, 0.f, 0.f});
+        w_prev = mfma3(ay, b2, (f4){0.f, 0.f, 0.f, 0.f});
         cell_prev = cell;
         if (!FIT) on_prev = (int)(org[d] >> 2) % W + q < W;
-        // slot d is dead from here: refill it in place, kDepth items ahead (always three loads)
+        // G slot d is dead from here: refill it in place, kGDepth items ahead
         __builtin_amdgcn_sched_barrier(0);
         OVIS_FETCH(d, epre);
         __builtin_amdgcn_sched_barrier(0);
-        epre = my[k + kDepth + 1];
+        epre = my[k + kGDepth + 1];
       }
+      // the wave's DMAs for the next round have landed (nothing younger than G(k+1) is forced); all waves have
+      // finished reading this round's slot once they pass the barrier
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(kGDepth + P) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      slot = slot + 1 >= kRing ? 0 : slot + 1;
     }
-    {  // drain the pipeline: the last item's footprint
-      float* pp = (float*)((char*)plane + cell_prev);
-      if (FIT) {
-        pp[0] += w_prev.x;
-        pp[W] += w_prev.y;
-        pp[2 * W] += w_prev.z;
-        pp[3 * W] += w_prev.w;
-      } else if (on_prev) {
-        const int y = (int)(cell_prev >> 2) / W;
-        if (y + 0 < H) pp[0] += w_prev.x;
-        if (y + 1 < H) pp[W] += w_prev.y;
-        if (y + 2 < H) pp[2 * W] += w_prev.z;
-        if (y + 3 < H) pp[3 * W] += w_prev.w;
-      }
-    }
-    // the prefetches past the end still target the ring registers: retire them before anything reuses them
-#pragma unroll
-    for (int d = 0; d < kDepth; ++d) OVIS_WAIT3(0, rg[d], rbx[d], ray[d]);
-#undef OVIS_FETCH
   }
-  for (int i = lane; i < HW; i += 64) dst[i] = plane[i];
+  {  // drain the pipeline: the last item's footprint
+    float* pp = (float*)((char*)plane + cell_prev);
+    if (FIT) {
+      pp[0] += w_prev.x;
+      pp[W] += w_prev.y;
+      pp[2 * W] += w_prev.z;
+      pp[3 * W] += w_prev.w;
+    } else if (on_prev) {
+      const int y = (int)(cell_prev >> 2) / W;
+      if (y + 0 < H) pp[0] += w_prev.x;
+      if (y + 1 < H) pp[W] += w_prev.y;
+      if (y + 2 < H) pp[2 * W] += w_prev.z;
+      if (y + 3 < H) pp[3 * W] += w_prev.w;
+    }
+  }
+  // the prefetches past the end still target the G registers / the ring: retire them before anything is reused
+#pragma unroll
+  for (int d = 0; d < kGDepth; ++d) OVIS_WAIT1(0, rg[d]);
+#undef OVIS_FETCH
+  if (live) {
+    float* dst = gin + ((long)n * C + c) * HW;
+    for (int i = lane; i < HW; i += 64) dst[i] = plane[i];
+  }
 }
 
 }  // namespace
@@ -357,10 +412,20 @@ extern "C" size_t ovis_roi_align_backward_workspace_bytes(int num_rois, int batc
          align_up((size_t)batch * sizeof(int), 256) + ((size_t)num_rois * (nxb + nyb) + 2) * 64 * sizeof(u4);
 }
 
+// Waves (= channels) per workgroup for an H x W plane: all planes of the group plus the table ring must fit the
+// CU's 160 KB of LDS.  0 = the plane is too large for this kernel.
+static int plane_waves(int height, int width) {
+  const size_t stride = align_up((size_t)height * width * sizeof(float), 16);
+  const size_t room = 160 * 1024 - (size_t)kRing * kRoundBytes;
+  if (8 * stride <= room) return 8;
+  if (4 * stride <= room) return 4;
+  return 0;
+}
+
 // Whether the plane-owner kernel covers this shape (otherwise the caller falls back to the atomic kernels).
 extern "C" int ovis_roi_align_backward_plane_supported(int height, int width, int pooled_h, int pooled_w) {
   return pooled_h >= 1 && pooled_w >= 4 && pooled_h <= kT && pooled_w <= kT && height < 65536 && width < 32768 &&
-         (size_t)height * width * sizeof(float) <= 40 * 1024;
+         plane_waves(height, width) != 0;
 }
 
 int ovis_roi_align_backward_plane_launch(const float* grad_output, const float* rois, float* grad_input,
@@ -384,22 +449,35 @@ int ovis_roi_align_backward_plane_launch(const float* grad_output, const float* 
   u4* tx = (u4*)w;
   u4* ty = tx + ((size_t)num_rois * NXB + 1) * 64;
 
+  const int nw = plane_waves(height, width);
+  const unsigned stride = (unsigned)align_up((size_t)height * width * sizeof(float), 16);
+  const size_t lds = (size_t)nw * stride + (size_t)kRing * kRoundBytes;
   const long plan_blocks = (long)batch + ovis_ceil_div(num_rois, kPlanThreads / 64);
-  const long blocks = (long)batch * channels;
+  const long blocks = (long)batch * ovis_ceil_div(channels, nw);
   if (plan_blocks > 0x7fffffffL || blocks > 0x7fffffffL) return OVIS_ERANGE;
   hipLaunchKernelGGL(roi_bwd_plan_kernel, dim3((unsigned)plan_blocks), dim3(kPlanThreads), 0, s, rois, num_rois,
                      batch, channels, height, width, pooled_h, pooled_w, spatial_scale, sampling_ratio, list, counts, tx, ty,
                      NXB, NYB);
   OVIS_LAUNCH_CHECK();
-  size_t lds = align_up((size_t)height * width * sizeof(float), 16);
-  if (lds < (size_t)kMinLds) lds = kMinLds;
-  if (height >= kT && width >= kT)
-    hipLaunchKernelGGL(roi_bwd_mfma_kernel<true>, dim3((unsigned)blocks), dim3(64), lds, s, grad_output, list, counts,
-                       tx, ty, grad_input, num_rois, batch, channels, height, width, pooled_h, pooled_w, NXB, NYB);
-  else
-    hipLaunchKernelGGL(roi_bwd_mfma_kernel<false>, dim3((unsigned)blocks), dim3(64), lds, s, grad_output, list,
-                       counts, tx, ty, grad_input, num_rois, batch, channels, height, width, pooled_h, pooled_w, NXB,
-                       NYB);
+  static bool attr_set = false;
+  if (!attr_set) {
+    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const bool fit = height >= kT && width >= kT;
+#define OVIS_BWD_LAUNCH(NW_, FIT_)                                                                                  \
+  hipLaunchKernelGGL((roi_bwd_mfma_kernel<NW_, FIT_>), dim3((unsigned)blocks), dim3(NW_ * 64), lds, s, grad_output, \
+                     list, counts, tx, ty, grad_input, num_rois, batch, channels, height, width, pooled_h, pooled_w, \
+                     NXB, NYB, stride)
+  if (nw == 8) {
+    if (fit) OVIS_BWD_LAUNCH(8, true); else OVIS_BWD_LAUNCH(8, false);
+  } else {
+    if (fit) OVIS_BWD_LAUNCH(4, true); else OVIS_BWD_LAUNCH(4, false);
+  }
+#undef OVIS_BWD_LAUNCH
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
 }
