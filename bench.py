@@ -70,6 +70,7 @@ class OpTimer:
             return 20 * k + 2 * 8 * k * nb + 8 * k
 
         self._wrap("roi_align_forward", roi_fwd_bytes)
+        self._wrap("roi_align_forward_mfma", roi_fwd_bytes)
         self._wrap("roi_align_backward", roi_bwd_bytes)
         self._wrap("nms_padded", nms_bytes)
 

@@ -16,6 +16,9 @@ _vp, _i, _f, _sz, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_s
 SIGNATURES = {
     "ovis_version": (ctypes.c_char_p, []),
     "ovis_roi_align_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "ovis_roi_align_forward_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ovis_roi_align_forward_mfma_supported": (_i, [_i, _i, _i, _i]),
+    "ovis_roi_align_forward_ws_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "ovis_roi_align_backward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "ovis_roi_align_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ovis_roi_align_backward_plane_supported": (_i, [_i, _i, _i, _i]),

@@ -420,6 +420,13 @@ extern "C" int ovis_roi_align_forward_f32(const float* input, const float* rois,
   return OVIS_OK;
 }
 
+// roi_align_fwd_mfma.hip
+int ovis_roi_align_forward_mfma_launch(const float* input, const float* rois, float* output, int num_rois, int batch,
+                                       int channels, int height, int width, int pooled_h, int pooled_w,
+                                       float spatial_scale, int sampling_ratio, void* workspace,
+                                       size_t workspace_bytes, hipStream_t s);
+extern "C" int ovis_roi_align_forward_mfma_supported(int height, int width, int pooled_h, int pooled_w);
+
 // roi_align_bwd_plane.hip
 int ovis_roi_align_backward_plane_launch(const float* grad_output, const float* rois, float* grad_input,
                                          int num_rois, int batch, int channels, int height, int width,
@@ -482,4 +489,20 @@ extern "C" int ovis_roi_align_backward_ws_f32(const float* grad_output, const fl
   }
   return ovis_roi_align_backward_f32(grad_output, rois, grad_input, num_rois, batch, channels, height, width,
                                      pooled_h, pooled_w, spatial_scale, sampling_ratio, stream);
+}
+
+extern "C" int ovis_roi_align_forward_ws_f32(const float* input, const float* rois, float* output, int num_rois,
+                                             int batch, int channels, int height, int width, int pooled_h,
+                                             int pooled_w, float spatial_scale, int sampling_ratio, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+  if (num_rois < 0 || batch < 0 || channels < 0 || height <= 0 || width <= 0 || pooled_h <= 0 || pooled_w <= 0)
+    return OVIS_EINVAL;
+  if (num_rois == 0 || channels == 0) return OVIS_OK;
+  if (!input || !rois || !output) return OVIS_EINVAL;
+  if (ovis_roi_align_forward_mfma_supported(height, width, pooled_h, pooled_w))
+    return ovis_roi_align_forward_mfma_launch(input, rois, output, num_rois, batch, channels, height, width, pooled_h,
+                                              pooled_w, spatial_scale, sampling_ratio, workspace, workspace_bytes,
+                                              (hipStream_t)stream);
+  return ovis_roi_align_forward_f32(input, rois, output, num_rois, batch, channels, height, width, pooled_h, pooled_w,
+                                    spatial_scale, sampling_ratio, stream);
 }

@@ -27,66 +27,17 @@
 // previous kernels did through LDS / global atomics is two dense 16x16x16 products on the otherwise
 // idle matrix pipe.
 #include "ovis_common.h"
-#include "roi_geom.h"
+#include "roi_mfma.h"
 
 namespace {
 using namespace ovis_roi;
 
-typedef short s4 __attribute__((ext_vector_type(4)));
-typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef unsigned u4 __attribute__((ext_vector_type(4)));
-typedef unsigned u2 __attribute__((ext_vector_type(2)));
-
-constexpr int kT = 16;        // window block edge == MFMA tile edge
 constexpr int kRI = 4;         // items per round (one barrier per round)
 constexpr int kGDepth = 8;    // G tiles in flight per wave = two rounds (8 waves x 8 x 784 B = 50 KB per CU)
 constexpr int kRing = 3;      // table ring depth in rounds: consumed | landed | in flight
 constexpr int kRoundBytes = 2 * kRI * 1024;  // 4 tx blocks + 4 ty blocks
 constexpr int kListPad = 4 * kGDepth;        // zero-contribution items after the last real one
 constexpr int kPlanThreads = 1024;
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-  f2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));  // v_cvt_pk_bf16_f32 (RNE)
-}
-
-// v -> bf16 hi (returned .x,.y) and bf16 lo of the exact remainder (.z,.w); element e of the 4-vector
-// sits in half (e & 1) of word (e >> 1), which is the k-order of an MFMA 16x16x16 operand.
-__device__ __forceinline__ u4 split_bf16(f4 v) {
-  const unsigned h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
-  const float r0 = v.x - __uint_as_float(h01 << 16), r1 = v.y - __uint_as_float(h01 & 0xffff0000u);
-  const float r2 = v.z - __uint_as_float(h23 << 16), r3 = v.w - __uint_as_float(h23 & 0xffff0000u);
-  return (u4){h01, h23, pack_bf16(r0, r1), pack_bf16(r2, r3)};
-}
-
-__device__ __forceinline__ s4 as_s4(unsigned a, unsigned b) {
-  u2 u = {a, b};
-  return __builtin_bit_cast(s4, u);
-}
-
-// D += (Ahi + Alo) . (Bhi + Blo) without the lo.lo term
-__device__ __forceinline__ f4 mfma3(u4 a, u4 b, f4 acc) {
-  const s4 ah = as_s4(a.x, a.y), al = as_s4(a.z, a.w), bh = as_s4(b.x, b.y), bl = as_s4(b.z, b.w);
-  acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, acc, 0, 0, 0);
-  return acc;
-}
-
-// Summed weight the samples of bin `p` put on feature cell `cell` along one axis (the reference's
-// bilinear_interpolate_gradient set-up, ROIAlign_cuda.cu:125-175, reduced to one axis).
-__device__ __forceinline__ float axis_weight(float start, float bin, int grid, int p, int size, int cell) {
-  float acc = 0.f;
-  for (int i = 0; i < grid; ++i) {
-    int lo, hi;
-    float l, h;
-    if (!axis_sample(sample_coord(start, p, bin, i, grid), size, lo, hi, l, h)) continue;
-    acc += (lo == cell ? h : 0.f) + (hi == cell ? l : 0.f);
-  }
-  return acc;
-}
 
 // ---------------------------------------------------------------------------------------------------
 // Plan kernel.
@@ -107,10 +58,6 @@ __device__ __forceinline__ float axis_weight(float start, float bin, int grid, i
 //   ty[r * NYB + yb][lane] = A operand of stage 2 (same packing): lane (row q, s) holds Ay[i = 4s+e][oy+q] / count.
 // ---------------------------------------------------------------------------------------------------
 __host__ __device__ inline long list_stride(int R, int NXB, int NYB) { return (long)R * NXB * NYB + kListPad + kGDepth; }
-
-__device__ __forceinline__ int block_origin(int w0, int blk, int size) {
-  return max(min(w0 + blk * kT, size - kT), 0);
-}
 
 __global__ __launch_bounds__(kPlanThreads) void roi_bwd_plan_kernel(
     const float* __restrict__ rois, int R, int batch, int C, int H, int W, int PH, int PW, float scale,

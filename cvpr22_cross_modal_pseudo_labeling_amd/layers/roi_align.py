@@ -10,14 +10,14 @@ from ._fp32 import float_function
 
 class _ROIAlign(Function):
     @staticmethod
-    def forward(ctx, input, roi, output_size, spatial_scale, sampling_ratio):
+    def forward(ctx, input, roi, output_size, spatial_scale, sampling_ratio, matrix_core=False):
         ctx.save_for_backward(roi)
         ctx.output_size = _pair(output_size)
         ctx.spatial_scale = spatial_scale
         ctx.sampling_ratio = sampling_ratio
         ctx.input_shape = input.size()
-        return _C.roi_align_forward(input, roi, spatial_scale, ctx.output_size[0], ctx.output_size[1],
-                                    sampling_ratio)
+        fwd = _C.roi_align_forward_mfma if matrix_core else _C.roi_align_forward
+        return fwd(input, roi, spatial_scale, ctx.output_size[0], ctx.output_size[1], sampling_ratio)
 
     @staticmethod
     @once_differentiable
@@ -26,22 +26,25 @@ class _ROIAlign(Function):
         bs, ch, h, w = ctx.input_shape
         grad_input = _C.roi_align_backward(grad_output, rois, ctx.spatial_scale, ctx.output_size[0],
                                            ctx.output_size[1], bs, ch, h, w, ctx.sampling_ratio)
-        return grad_input, None, None, None, None
+        return grad_input, None, None, None, None, None
 
 
 roi_align = _ROIAlign.apply
 
 
 class ROIAlign(nn.Module):
-    def __init__(self, output_size, spatial_scale, sampling_ratio):
+    def __init__(self, output_size, spatial_scale, sampling_ratio, matrix_core=False):
+        """``matrix_core`` (extension, default off = the reference's bit-exact forward): pool on the bf16 matrix
+        pipe (``_C.roi_align_forward_mfma``); the backward is the matrix-core plane-owner kernel either way."""
         super().__init__()
         self.output_size = output_size
         self.spatial_scale = spatial_scale
         self.sampling_ratio = sampling_ratio
+        self.matrix_core = matrix_core
 
     @float_function
     def forward(self, input, rois):
-        return roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio)
+        return roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.matrix_core)
 
     def __repr__(self):
         return (f"{self.__class__.__name__}(output_size={self.output_size}, "

@@ -49,6 +49,24 @@ int ovis_roi_align_forward_f32(const float* input, const float* rois, float* out
                                int width, int pooled_h, int pooled_w,
                                float spatial_scale, int sampling_ratio, void* stream);
 
+/* Workspace form of the forward (the fast path).  When
+ * ovis_roi_align_forward_mfma_supported(height, width, pooled_h, pooled_w) is non-zero (map
+ * at least 16 x 16, pooled sizes at most 16 x 16) the pooled tile of every (RoI, channel)
+ * is computed as two 16 x 16 x 16 products on the bf16 matrix pipe with the operands split
+ * into bf16 hi + lo parts: same values as the reference up to ~1e-5 relative to sum |w x|
+ * (NOT bit-identical; ovis_roi_align_forward_f32 stays the bit-exact kernel).  `workspace`:
+ * at least ovis_roi_align_forward_workspace_bytes(num_rois, height, width) bytes of device
+ * scratch, 256-byte aligned (per-RoI weight tables, rebuilt by every call).  Unsupported
+ * shapes run the exact kernel and ignore the workspace.
+ * Replaces ROIAlign_forward_cuda, mb/csrc/cuda/ROIAlign_cuda.cu:257-299. */
+size_t ovis_roi_align_forward_workspace_bytes(int num_rois, int height, int width);
+int ovis_roi_align_forward_mfma_supported(int height, int width, int pooled_h, int pooled_w);
+int ovis_roi_align_forward_ws_f32(const float* input, const float* rois, float* output,
+                                  int num_rois, int batch, int channels, int height, int width,
+                                  int pooled_h, int pooled_w, float spatial_scale,
+                                  int sampling_ratio, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+
 /* grad_input [batch, channels, height, width] is fully overwritten (zero-filled, then
  * accumulated into) by this call; the caller does not need to clear it. */
 int ovis_roi_align_backward_f32(const float* grad_output, const float* rois,

@@ -52,10 +52,11 @@ def _mask_bce(mu, sigma, eps, pos_index, targets, channel, need_grad=True):
 
 @contextlib.contextmanager
 def oracle_ops():
-    saved = {k: getattr(_C, k) for k in ("roi_align_forward", "roi_align_backward", "nms", "nms_padded",
+    saved = {k: getattr(_C, k) for k in ("roi_align_forward", "roi_align_forward_mfma", "roi_align_backward", "nms", "nms_padded",
                                          "sigmoid_focalloss_forward", "sigmoid_focalloss_backward", "gemm_nt",
                                          "region_noun_align", "weighted_ce_fwd_bwd", "mask_bce_stochastic_fwd_bwd")}
     _C.roi_align_forward = lambda x, r, s, ph, pw, sr: oracle.roi_align_forward(x, r, s, ph, pw, sr)
+    _C.roi_align_forward_mfma = _C.roi_align_forward
     _C.roi_align_backward = lambda g, r, s, ph, pw, n, c, h, w, sr: oracle.roi_align_backward(g, r, s, ph, pw, n, c, h, w, sr)
     _C.nms = lambda d, s, t: oracle.nms(d, s, t)
     _C.nms_padded = _nms_padded

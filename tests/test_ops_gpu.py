@@ -35,6 +35,20 @@ def test_roi_align_forward_golden_bit_exact(C, golden_dir):
         assert torch.equal(got, torch.from_numpy(z[key])), key  # bit-exact vs the reference CPU kernel
 
 
+def _close_to_pooled(got, want, x_absmax):
+    """Tolerance of the matrix-core forward: operands are split into bf16 hi + lo (16 mantissa bits) and the lo.lo
+    product is dropped, so a pooled value is off by at most ~2^-15 of sum |w x| <= max |x| (weights sum to 1)."""
+    return (got - want).abs().max().item() <= 4e-5 * x_absmax
+
+
+def test_roi_align_forward_golden_matrix_core(C, golden_dir):
+    z = np.load(os.path.join(golden_dir, "roi_align_forward.npz"))
+    x, rois, scale = torch.from_numpy(z["input"]).cuda(), torch.from_numpy(z["rois"]).cuda(), float(z["scale"])
+    for key, (ph, pw, sr) in {"out_sr0": (14, 14, 0), "out_sr2": (14, 14, 2), "out_7x7_sr0": (7, 7, 0)}.items():
+        got = C.roi_align_forward_mfma(x, rois, scale, ph, pw, sr).cpu()
+        assert _close_to_pooled(got, torch.from_numpy(z[key]), x.abs().max().item()), key
+
+
 @pytest.mark.parametrize("shape", [(2, 70, 50, 84, 300, 14), (1, 33, 13, 17, 40, 7), (3, 16, 100, 168, 64, 14)])
 def test_roi_align_forward_vs_oracle(C, oracle_mod, shape):
     n, c, h, w, r, p = shape
@@ -44,6 +58,22 @@ def test_roi_align_forward_vs_oracle(C, oracle_mod, shape):
     want = oracle_mod.roi_align_forward(x, rois, 1 / 16, p, p, 0)
     got = C.roi_align_forward(x.cuda(), rois.cuda(), 1 / 16, p, p, 0).cpu()
     assert torch.equal(got, want)
+    fast = C.roi_align_forward_mfma(x.cuda(), rois.cuda(), 1 / 16, p, p, 0).cpu()  # 13x17 map: falls back to exact
+    assert _close_to_pooled(fast, want, x.abs().max().item())
+
+
+def test_roi_align_forward_matrix_core_edge_rois(C, oracle_mod):
+    """Degenerate / clipped / out-of-map / multi-block RoIs and fixed sampling grids through the matrix-core path."""
+    rois = torch.tensor([[0, -50.0, -40.0, 30.0, 20.0], [1, 600.0, 300.0, 600.0, 300.0],
+                         [0, 650.0, 380.0, 2000.0, 900.0], [1, 5000.0, 5000.0, 5100.0, 5100.0],
+                         [0, 0.0, 0.0, 671.0, 399.0], [1, 100.3, 50.7, 101.9, 52.2], [0, 3.0, 200.0, 660.0, 230.0]])
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 70, 25, 42, generator=g)  # 70 channels: a full 64-channel slab + a partial one
+    for (p, sr) in [(14, 0), (7, 0), (7, 3), (14, 1)]:
+        want = oracle_mod.roi_align_forward(x, rois, 1 / 16, p, p, sr)
+        got = C.roi_align_forward_mfma(x.cuda(), rois.cuda(), 1 / 16, p, p, sr).cpu()
+        assert _close_to_pooled(got, want, x.abs().max().item()), (p, sr, (got - want).abs().max())
+    assert float(got[3].abs().max()) == 0.0  # the out-of-map RoI pools to exact zeros
 
 
 def test_roi_align_forward_large_map_global_path(C, oracle_mod):
@@ -54,11 +84,14 @@ def test_roi_align_forward_large_map_global_path(C, oracle_mod):
     want = oracle_mod.roi_align_forward(x, rois, 1 / 16, 14, 14, 0)
     got = C.roi_align_forward(x.cuda(), rois.cuda(), 1 / 16, 14, 14, 0).cpu()
     assert torch.equal(got, want)
+    fast = C.roi_align_forward_mfma(x.cuda(), rois.cuda(), 1 / 16, 14, 14, 0).cpu()  # 8 x 10 blocks: the generic block loop
+    assert _close_to_pooled(fast, want, x.abs().max().item())
 
 
 def test_roi_align_empty(C):
     x = torch.randn(2, 4, 8, 8, device="cuda")
     out = C.roi_align_forward(x, torch.zeros(0, 5, device="cuda"), 0.25, 7, 7, 2)
+    assert C.roi_align_forward_mfma(x, torch.zeros(0, 5, device="cuda"), 0.25, 7, 7, 2).shape == (0, 4, 7, 7)
     assert out.shape == (0, 4, 7, 7)
     gin = C.roi_align_backward(torch.zeros(0, 4, 7, 7, device="cuda"), torch.zeros(0, 5, device="cuda"), 0.25, 7, 7,
                                2, 4, 8, 8, 2)
@@ -89,7 +122,7 @@ def test_roi_align_backward_golden_rois_adjoint(C, golden_dir):
     g = torch.Generator().manual_seed(9)
     x = torch.randn(2, 8, 25, 42, generator=g).cuda()
     go = torch.randn(rois.shape[0], 8, 14, 14, generator=g).cuda()
-    f = C.roi_align_forward(x, rois, scale, 14, 14, 0)
+    f = C.roi_align_forward_mfma(x, rois, scale, 14, 14, 0)
     b = C.roi_align_backward(go, rois, scale, 14, 14, 2, 8, 25, 42, 0)
     lhs = (f.double() * go.double()).sum().item()
     rhs = (x.double() * b.double()).sum().item()
@@ -107,7 +140,10 @@ def test_roi_align_autograd_layer(C, oracle_mod):
     out = layer(xd, rois.cuda())
     go = torch.randn(out.shape, generator=g)
     out.backward(go.cuda())
-    assert torch.equal(out.detach().cpu(), oracle_mod.roi_align_forward(x, rois, 1 / 16, 14, 14, 0))
+    want_f = oracle_mod.roi_align_forward(x, rois, 1 / 16, 14, 14, 0)
+    assert torch.equal(out.detach().cpu(), want_f)  # the layer's default forward is the bit-exact kernel
+    fast = ROIAlign((14, 14), 1 / 16, 0, matrix_core=True)(x.cuda(), rois.cuda())
+    assert _close_to_pooled(fast.cpu(), want_f, x.abs().max().item())
     want = oracle_mod.roi_align_backward(go, rois, 1 / 16, 14, 14, 2, 6, 20, 30, 0)
     assert torch.allclose(xd.grad.cpu(), want, rtol=1e-4, atol=1e-4)
 
@@ -117,10 +153,10 @@ def test_roi_align_full_size_properties(C):
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(2, 1024, 50, 84, generator=g).cuda()
     rois = _rois(g, 1024, 2, 1333, 800, 16, 316).cuda()
-    a = C.roi_align_forward(x, rois, 1 / 16, 14, 14, 0)
-    b = C.roi_align_forward(2 * x, rois, 1 / 16, 14, 14, 0)
-    assert torch.equal(b, 2 * a)  # scaling by 2 is exact in fp32
-    ones = C.roi_align_forward(torch.ones_like(x), rois, 1 / 16, 14, 14, 0)
+    a = C.roi_align_forward_mfma(x, rois, 1 / 16, 14, 14, 0)
+    b = C.roi_align_forward_mfma(2 * x, rois, 1 / 16, 14, 14, 0)
+    assert torch.equal(b, 2 * a)  # scaling by 2 is exact in fp32 and in the bf16 hi/lo split
+    ones = C.roi_align_forward_mfma(torch.ones_like(x), rois, 1 / 16, 14, 14, 0)
     assert torch.allclose(ones, torch.ones_like(ones), atol=1e-6)  # all RoIs inside the map
     go = torch.randn(1024, 1024, 14, 14, generator=g).cuda()
     gi = C.roi_align_backward(go, rois, 1 / 16, 14, 14, 2, 1024, 50, 84, 0)

@@ -63,6 +63,9 @@ def main():
             rois = bench_rois(r, n, g, kind).to(dev)
             alg = 4 * r * c * 196 + 4 * n * c * h * w + 20 * r
             if "roi_fwd" in ops:
+                ms = timeit(lambda: _C.roi_align_forward_mfma(x, rois, 1 / 16, 14, 14, 0), args.iters)
+                res.append({"op": "roi_align_forward_mfma", "rois": kind, "ms": ms, "alg_MB": alg / 1e6,
+                            "GBps": alg / ms / 1e6, "frac_hbm": alg / ms / 1e6 / HBM_PEAK_GBS})
                 ms = timeit(lambda: _C.roi_align_forward(x, rois, 1 / 16, 14, 14, 0), args.iters)
                 res.append({"op": "roi_align_forward", "rois": kind, "ms": ms, "alg_MB": alg / 1e6,
                             "GBps": alg / ms / 1e6, "frac_hbm": alg / ms / 1e6 / HBM_PEAK_GBS})
