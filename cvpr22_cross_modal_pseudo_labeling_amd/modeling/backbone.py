@@ -10,6 +10,8 @@ pass after every convolution (layers/batch_norm.py:19-31).  Here each conv+Froze
 MIOpen call with the affine folded into the weights (``w * scale``) and bias (``shift``); the fold
 is a weight-sized op, differentiable w.r.t. the conv weight, and cached for frozen modules.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -72,6 +74,7 @@ class Bottleneck(nn.Module):
         self._f2 = [ConvBN(self.conv2, self.bn2)]
         self._f3 = [ConvBN(self.conv3, self.bn3)]
         self._fd = [ConvBN(self.downsample[0], self.downsample[1])] if self.downsample is not None else None
+        self.conv3x3_nchw = True
 
     def forward(self, x):
         out = F.relu_(self._f1[0](x))
@@ -80,6 +83,52 @@ class Bottleneck(nn.Module):
         identity = self._fd[0](x) if self._fd is not None else x
         out += identity
         return F.relu_(out)
+
+    def nhwc_supported(self):
+        c1, c2, c3 = self.conv1, self.conv2, self.conv3
+        return (c1.kernel_size == (1, 1) and c3.kernel_size == (1, 1) and c1.groups == 1 and c3.groups == 1
+                and c1.padding == (0, 0) and c3.padding == (0, 0) and c3.stride == (1, 1))
+
+    def forward_nhwc(self, x):
+        """Same block on an NHWC tensor ``x`` [R, H, W, C] (contiguous).  The 1x1 convolutions -- 53 % of the
+        res5 FLOPs -- become ONE row-major GEMM over all R*H*W positions each ([R*H*W, Cin] x [Cin, Cout], bias
+        = the folded FrozenBN shift) instead of R batched [Cout, Cin] x [Cin, 49] products behind layout
+        transposes; a stride-2 1x1 (STRIDE_IN_1X1) first drops the rows it never reads.  The 3x3 runs on the
+        channels_last view of the same memory.  Values equal ``forward`` up to fp32 summation order."""
+        r, h, w, c = x.shape
+        sy, sx = self.conv1.stride
+        xs = x[:, ::sy, ::sx, :].contiguous() if (sy, sx) != (1, 1) else x
+        hs, ws = xs.shape[1], xs.shape[2]
+        x2d = xs.view(-1, c)
+        w1, b1 = self._f1[0].folded()
+        out = torch.addmm(b1, x2d, w1.view(w1.shape[0], -1).t()).relu_()
+        w2, b2 = self._f2[0].folded()
+        c2 = self.conv2
+        if self.conv3x3_nchw:
+            # MIOpen's NCHW fp32 Winograd is the fastest 3x3 it has for these shapes (its NHWC pick at R = 2000 is a
+            # 50 TFLOP/s grouped-conv kernel): two 0.1 ms layout copies around it are cheaper than that
+            out = F.conv2d(out.view(r, hs, ws, -1).permute(0, 3, 1, 2).contiguous(), w2, b2, c2.stride, c2.padding,
+                           c2.dilation, c2.groups)
+            out = out.permute(0, 2, 3, 1).contiguous()
+        else:
+            out = F.conv2d(out.view(r, hs, ws, -1).permute(0, 3, 1, 2),
+                           w2.contiguous(memory_format=torch.channels_last), b2, c2.stride, c2.padding, c2.dilation,
+                           c2.groups)
+            out = out.permute(0, 2, 3, 1)
+            if not out.is_contiguous():
+                out = out.contiguous()
+        ho, wo = out.shape[1], out.shape[2]
+        out = out.relu_().view(-1, out.shape[3])
+        w3, b3 = self._f3[0].folded()
+        out = torch.addmm(b3, out, w3.view(w3.shape[0], -1).t())
+        if self._fd is not None:
+            wd, bd = self._fd[0].folded()
+            dy, dx = self.downsample[0].stride
+            xd = x2d if (dy, dx) == (sy, sx) else x[:, ::dy, ::dx, :].contiguous().view(-1, c)
+            out += torch.addmm(bd, xd, wd.view(wd.shape[0], -1).t())
+        else:
+            out += x.view(-1, c)
+        return out.relu_().view(r, ho, wo, -1)
 
 
 class Stem(nn.Module):
@@ -169,6 +218,15 @@ class ResNetHead(nn.Module):
         self.layer4 = _make_stage(out_channels // 2, r.NUM_GROUPS * r.WIDTH_PER_GROUP * factor, out_channels, 3,
                                   r.NUM_GROUPS, r.STRIDE_IN_1X1, first_stride=2, dilation=r.RES5_DILATION)
         self.out_channels = out_channels
+        self.nhwc = os.environ.get("OVIS_RES5_NCHW", "0") != "1"
 
     def forward(self, x):
+        """x [R, C, 14, 14] -> [R, 2048, 7, 7].  On the GPU the stage runs in NHWC with GEMM 1x1s
+        (``Bottleneck.forward_nhwc``) and returns the channels_last view of the result; ``OVIS_RES5_NCHW=1``
+        keeps the plain per-layer convolution path (also taken for grouped / exotic configurations)."""
+        if x.is_cuda and self.nhwc and all(b.nhwc_supported() for b in self.layer4):
+            y = x.permute(0, 2, 3, 1)  # the first block's stride-2 slice makes this the only NCHW -> NHWC copy
+            for b in self.layer4:
+                y = b.forward_nhwc(y)
+            return y.permute(0, 3, 1, 2)
         return self.layer4(x)
