@@ -145,6 +145,23 @@ def sigmoid_focalloss_backward(logits, targets, d_losses, num_classes, gamma, al
 
 
 # ---- cross-modal head + student losses (extensions beyond vision.cpp; include/ovis_hip.h) --------------
+def split_bf16x3(x, mode):
+    """x [rows, cols] f32 (row-strided view ok) -> [rows, 3*cols] bf16, rows = [hi|hi|lo] (mode 0) / [hi|lo|hi]
+    (mode 1).  See include/ovis_hip.h."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2:
+        raise RuntimeError("split_bf16x3: 2-D float32 HIP tensor expected")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    rows, cols = x.shape
+    out = torch.empty((rows, 3 * cols), dtype=torch.bfloat16, device=x.device)
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(x.device):
+        rc = _L.ovis_split_bf16x3_f32(x.data_ptr(), x.stride(0), out.data_ptr(), rows, cols, mode, _stream())
+    _lib.check(rc, "split_bf16x3")
+    return out
+
+
 def gemm_nt(a, b, bias=None):
     """a [M,K] @ b[N,K]^T (+ bias[N]) -> [M,N] on the fp32 matrix cores.  a / b may be any 2-D strided views."""
     if not (a.is_cuda and b.is_cuda):

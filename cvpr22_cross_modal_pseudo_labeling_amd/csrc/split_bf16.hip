@@ -1,0 +1,63 @@
+// fp32 -> bf16 hi/lo operand split for fp32-accurate GEMMs on the bf16 matrix pipe (gfx950).
+//
+// x = hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi).  A product of two split operands keeps
+// hi.hi + hi.lo + lo.hi (relative error ~4e-6 in practice, cf. 1.7e-6 for a plain fp32 GEMM) and runs three
+// bf16 MFMA passes instead of one fp32 pass that is 16x slower.  To feed ONE plain bf16 GEMM, the three
+// products are concatenated along K:
+//     left  operand rows:  [ hi | hi | lo ]      (mode 0)
+//     right operand rows:  [ hi | lo | hi ]      (mode 1)
+// so that  sum_k' L[m,k'] R[n,k']  over the 3K columns is exactly the three-term product.  Used by the res5
+// 1x1 convolutions (modeling/backbone.py), which are [R*49, Cin] x [Cout, Cin]^T GEMMs in NHWC.
+//
+// HBM-bound byte kernel: 4 B read + 6 B written per element, 16-byte loads / 8-byte stores, grid-stride.
+#include "ovis_common.h"
+
+namespace {
+typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  f2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ src, long src_rs,
+                                                          unsigned short* __restrict__ dst, long rows, int cols) {
+  const int qcols = cols >> 2;  // float4 groups per row
+  const long total = rows * qcols;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / qcols;
+    const int c = (int)(i - r * qcols) * 4;
+    const float4 v = *(const float4*)(src + r * src_rs + c);
+    const unsigned h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
+    const unsigned l01 = pack_bf16(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+    const unsigned l23 = pack_bf16(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+    unsigned short* d = dst + r * 3L * cols + c;
+    const uint2 hi = make_uint2(h01, h23), lo = make_uint2(l01, l23);
+    *(uint2*)d = hi;
+    *(uint2*)(d + cols) = MODE == 0 ? hi : lo;
+    *(uint2*)(d + 2 * cols) = MODE == 0 ? lo : hi;
+  }
+}
+}  // namespace
+
+extern "C" int ovis_split_bf16x3_f32(const float* src, long src_row_stride, void* dst_bf16, long rows, int cols,
+                                     int mode, void* stream) {
+  if (rows < 0 || cols < 0 || (mode != 0 && mode != 1)) return OVIS_EINVAL;
+  if (rows == 0 || cols == 0) return OVIS_OK;
+  if (!src || !dst_bf16) return OVIS_EINVAL;
+  if (cols % 4 != 0 || src_row_stride % 4 != 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst_bf16 & 7))
+    return OVIS_ERANGE;  // the caller falls back to the fp32 GEMM
+  const long total = rows * (cols / 4);
+  const long blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 8L * OVIS_NUM_CU ? blocks : 8L * OVIS_NUM_CU);
+  if (mode == 0)
+    hipLaunchKernelGGL(split_bf16x3_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, src_row_stride,
+                       (unsigned short*)dst_bf16, rows, cols);
+  else
+    hipLaunchKernelGGL(split_bf16x3_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, src_row_stride,
+                       (unsigned short*)dst_bf16, rows, cols);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}

@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..layers import Conv2d, FrozenBatchNorm2d
+from ..layers import Conv2d, FrozenBatchNorm2d, split_linear
 
 
 class ConvBN(nn.Module):
@@ -75,6 +75,7 @@ class Bottleneck(nn.Module):
         self._f3 = [ConvBN(self.conv3, self.bn3)]
         self._fd = [ConvBN(self.downsample[0], self.downsample[1])] if self.downsample is not None else None
         self.conv3x3_nchw = True
+        self.split_gemm = os.environ.get("OVIS_RES5_FP32_GEMM", "0") != "1"
 
     def forward(self, x):
         out = F.relu_(self._f1[0](x))
@@ -93,15 +94,36 @@ class Bottleneck(nn.Module):
         """Same block on an NHWC tensor ``x`` [R, H, W, C] (contiguous).  The 1x1 convolutions -- 53 % of the
         res5 FLOPs -- become ONE row-major GEMM over all R*H*W positions each ([R*H*W, Cin] x [Cin, Cout], bias
         = the folded FrozenBN shift) instead of R batched [Cout, Cin] x [Cin, 49] products behind layout
-        transposes; a stride-2 1x1 (STRIDE_IN_1X1) first drops the rows it never reads.  The 3x3 runs on the
-        channels_last view of the same memory.  Values equal ``forward`` up to fp32 summation order."""
+        transposes; a stride-2 1x1 (STRIDE_IN_1X1) first drops the rows it never reads.  By default the GEMMs run as
+        bf16 hi/lo split products on the bf16 matrix pipe (~4e-6 relative error, ``OVIS_RES5_FP32_GEMM=1`` selects
+        the fp32 GEMM); the 3x3 goes through MIOpen.  Values equal ``forward`` up to that error."""
         r, h, w, c = x.shape
         sy, sx = self.conv1.stride
         xs = x[:, ::sy, ::sx, :].contiguous() if (sy, sx) != (1, 1) else x
         hs, ws = xs.shape[1], xs.shape[2]
         x2d = xs.view(-1, c)
         w1, b1 = self._f1[0].folded()
-        out = torch.addmm(b1, x2d, w1.view(w1.shape[0], -1).t()).relu_()
+        w1 = w1.view(w1.shape[0], -1)
+        idn = None
+        if self._fd is not None:
+            wd, bd = self._fd[0].folded()
+            wd = wd.view(wd.shape[0], -1)
+            dy, dx = self.downsample[0].stride
+            xd = x2d if (dy, dx) == (sy, sx) else x[:, ::dy, ::dx, :].contiguous().view(-1, c)
+        if self.split_gemm:
+            # fp32-accurate GEMMs on the bf16 matrix pipe (layers/cross_modal.py::split_linear); conv1 and the
+            # projection shortcut read the same rows, so they share one operand split
+            if self._fd is not None and xd is x2d:
+                out, idn = split_linear(x2d, w1, b1, wd, bd)
+            else:
+                (out,) = split_linear(x2d, w1, b1)
+                if self._fd is not None:
+                    (idn,) = split_linear(xd, wd, bd)
+            out = out.relu_()
+        else:
+            out = torch.addmm(b1, x2d, w1.t()).relu_()
+            if self._fd is not None:
+                idn = torch.addmm(bd, xd, wd.t())
         w2, b2 = self._f2[0].folded()
         c2 = self.conv2
         if self.conv3x3_nchw:
@@ -120,14 +142,12 @@ class Bottleneck(nn.Module):
         ho, wo = out.shape[1], out.shape[2]
         out = out.relu_().view(-1, out.shape[3])
         w3, b3 = self._f3[0].folded()
-        out = torch.addmm(b3, out, w3.view(w3.shape[0], -1).t())
-        if self._fd is not None:
-            wd, bd = self._fd[0].folded()
-            dy, dx = self.downsample[0].stride
-            xd = x2d if (dy, dx) == (sy, sx) else x[:, ::dy, ::dx, :].contiguous().view(-1, c)
-            out += torch.addmm(bd, xd, wd.view(wd.shape[0], -1).t())
+        w3 = w3.view(w3.shape[0], -1)
+        if self.split_gemm:
+            (out,) = split_linear(out, w3, b3)
         else:
-            out += x.view(-1, c)
+            out = torch.addmm(b3, out, w3.t())
+        out += idn if idn is not None else x.view(-1, c)
         return out.relu_().view(r, ho, wo, -1)
 
 

@@ -124,6 +124,19 @@ int ovis_sigmoid_focal_loss_backward_f32(const float* logits, const int32_t* tar
                                          void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * bf16 hi/lo operand split for fp32-accurate GEMMs on the bf16 matrix pipe ("next" row f-1:
+ * the res5 1x1 convolutions, mb/modeling/backbone/resnet.py:239-344, as NHWC GEMMs).
+ * src [rows, cols] f32 (row stride in elements) -> dst [rows, 3*cols] bf16 with row layout
+ * [hi | hi | lo] (mode 0, left operand) or [hi | lo | hi] (mode 1, right operand), hi =
+ * bf16(x), lo = bf16(x - hi): a plain bf16 GEMM over the 3*cols columns of a mode-0 and a
+ * mode-1 operand is the three-term product hi.hi + hi.lo + lo.hi (~4e-6 relative error).
+ * cols and the row stride must be multiples of 4, src 16-byte and dst 8-byte aligned
+ * (else OVIS_ERANGE: use the fp32 GEMM).
+ * ---------------------------------------------------------------------------------- */
+int ovis_split_bf16x3_f32(const float* src, long src_row_stride, void* dst_bf16, long rows,
+                          int cols, int mode, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Cross-modal head: fp32 GEMM on the matrix cores
  *   mb/modeling/roi_heads/box_head/roi_box_predictors.py:66-71 (emb_pred Linear, einsum('pe,ce->pc'),
  *   bbox_pred Linear) and their autograd transposes.

@@ -26,10 +26,13 @@ print("max |diff| / max |y|:", ((ya - yb).abs().max() / ya.abs().max()).item(), 
 head.zero_grad(); run(False, True); ga = [p.grad.clone() for p in head.parameters() if p.grad is not None]
 head.zero_grad(); run(True, True); gb = [p.grad.clone() for p in head.parameters() if p.grad is not None]
 print("grad rel diff:", max(((a - b).abs().max() / a.abs().max()).item() for a, b in zip(ga, gb)))
-for nhwc, c33 in ((False, True), (True, False), (True, True)):
+for b in head.layer4:
+    b.split_gemm = False
+for nhwc, c33, sg in ((False, True, False), (True, True, False), (True, True, True)):
     for b in head.layer4:
         b.conv3x3_nchw = c33
+        b.split_gemm = sg
     with torch.no_grad():
         f = t(lambda: run(nhwc, False))
     fb = t(lambda: run(nhwc, True))
-    print(f"nhwc={nhwc} conv3x3_nchw={c33}: fwd {f:.2f} ms  fwd+bwd {fb:.2f} ms  (R={R})")
+    print(f"nhwc={nhwc} conv3x3_nchw={c33} split_gemm={sg}: fwd {f:.2f} ms  fwd+bwd {fb:.2f} ms  (R={R})")
