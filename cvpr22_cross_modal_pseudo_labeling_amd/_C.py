@@ -162,6 +162,22 @@ def split_bf16x3(x, mode):
     return out
 
 
+def bias_act_(y, bias=None, residual=None, relu=True):
+    """In place: y[rows, cols] = act(y + bias[col] (+ residual)); contiguous f32, cols % 4 == 0."""
+    if not (y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.is_contiguous()):
+        raise RuntimeError("bias_act_: contiguous 2-D float32 HIP tensor expected")
+    if residual is not None and not (residual.is_contiguous() and residual.shape == y.shape):
+        raise RuntimeError("bias_act_: residual must be contiguous with y's shape")
+    if y.numel() == 0:
+        return y
+    with torch.cuda.device(y.device):
+        rc = _L.ovis_bias_act_f32(y.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                  0 if residual is None else residual.data_ptr(), y.shape[0], y.shape[1],
+                                  int(bool(relu)), _stream())
+    _lib.check(rc, "bias_act")
+    return y
+
+
 def gemm_nt(a, b, bias=None):
     """a [M,K] @ b[N,K]^T (+ bias[N]) -> [M,N] on the fp32 matrix cores.  a / b may be any 2-D strided views."""
     if not (a.is_cuda and b.is_cuda):

@@ -61,3 +61,52 @@ extern "C" int ovis_split_bf16x3_f32(const float* src, long src_row_stride, void
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Fused GEMM epilogue for the NHWC res5 head: y = act(y + bias[col] (+ residual)) in place, one pass
+// (the separate bias add, residual add and ReLU of the reference's Bottleneck.forward, resnet.py:323-344,
+// are 3 read-modify-write passes over a [R*49, C] tensor).  16-byte accesses, grid-stride.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                      const float* __restrict__ res, long rows, int cols) {
+  const int qcols = cols >> 2;
+  const long total = rows * qcols;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % qcols) * 4;
+    float4 v = ((float4*)y)[i];
+    if (bias) {
+      const float4 b = *(const float4*)(bias + c);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (RES) {
+      const float4 r = ((const float4*)res)[i];
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (RELU) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    ((float4*)y)[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int ovis_bias_act_f32(float* y, const float* bias, const float* residual, long rows, int cols, int relu,
+                                 void* stream) {
+  if (rows < 0 || cols < 0) return OVIS_EINVAL;
+  if (rows == 0 || cols == 0) return OVIS_OK;
+  if (!y) return OVIS_EINVAL;
+  if (cols % 4 != 0 || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)residual & 15)) return OVIS_ERANGE;
+  const long total = rows * (cols / 4);
+  const long blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 8L * OVIS_NUM_CU ? blocks : 8L * OVIS_NUM_CU);
+  hipStream_t s = (hipStream_t)stream;
+#define OVIS_BA(RES_, RELU_) \
+  hipLaunchKernelGGL((bias_act_kernel<RES_, RELU_>), dim3(grid), dim3(256), 0, s, y, bias, residual, rows, cols)
+  if (residual) { if (relu) OVIS_BA(true, true); else OVIS_BA(true, false); }
+  else { if (relu) OVIS_BA(false, true); else OVIS_BA(false, false); }
+#undef OVIS_BA
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}

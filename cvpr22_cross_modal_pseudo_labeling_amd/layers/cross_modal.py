@@ -52,7 +52,10 @@ class _SplitLinearMulti(Function):
         for w, b in zip(params[0::2], params[1::2]):
             y = torch.mm(xs, _C.split_bf16x3(w, 1).t(), out_dtype=torch.float32)
             if b is not None:
-                y += b
+                if y.shape[1] % 4 == 0:
+                    _C.bias_act_(y, b.contiguous(), None, relu=False)
+                else:
+                    y += b
             outs.append(y)
         ctx.save_for_backward(xs, *ws)
         ctx.has_bias = [b is not None for b in params[1::2]]
@@ -82,6 +85,33 @@ class _SplitLinearMulti(Function):
             db = dy.sum(0) if (ctx.has_bias[i] and ctx.needs_input_grad[2 + 2 * i]) else None
             grads += [dw, db]
         return (dx, *grads)
+
+
+class _BiasActInplace(Function):
+    """y <- relu(y + bias (+ residual)) in one pass over y (csrc/split_bf16.hip::bias_act_kernel); the backward is the
+    ReLU gate on the saved output, shared by y and the residual."""
+
+    @staticmethod
+    def forward(ctx, y, bias, residual):
+        _C.bias_act_(y, bias, residual, relu=True)
+        ctx.mark_dirty(y)
+        ctx.save_for_backward(y)
+        ctx.has = (bias is not None, residual is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        gi = torch.ops.aten.threshold_backward(g, out, 0.0)
+        db = gi.sum(0) if (ctx.has[0] and ctx.needs_input_grad[1]) else None
+        return gi, db, (gi if ctx.has[1] else None)
+
+
+def bias_relu_(y, bias=None, residual=None):
+    """In place on the contiguous [rows, cols] f32 tensor y: relu(y + bias[col] (+ residual)).  y must be a tensor
+    autograd allows to be modified in place (the fresh output of a GEMM)."""
+    return _BiasActInplace.apply(y, bias, residual)
 
 
 def split_linear(x, *weights_and_biases):

@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..layers import Conv2d, FrozenBatchNorm2d, split_linear
+from ..layers import Conv2d, FrozenBatchNorm2d, bias_relu_, split_linear
 
 
 class ConvBN(nn.Module):
@@ -74,7 +74,7 @@ class Bottleneck(nn.Module):
         self._f2 = [ConvBN(self.conv2, self.bn2)]
         self._f3 = [ConvBN(self.conv3, self.bn3)]
         self._fd = [ConvBN(self.downsample[0], self.downsample[1])] if self.downsample is not None else None
-        self.conv3x3_nchw = True
+        self.conv3x3_nchw = None  # None = by autograd mode (see forward_nhwc)
         self.split_gemm = os.environ.get("OVIS_RES5_FP32_GEMM", "0") != "1"
 
     def forward(self, x):
@@ -102,53 +102,54 @@ class Bottleneck(nn.Module):
         xs = x[:, ::sy, ::sx, :].contiguous() if (sy, sx) != (1, 1) else x
         hs, ws = xs.shape[1], xs.shape[2]
         x2d = xs.view(-1, c)
+        # raw products (no bias): bf16 hi/lo split GEMMs on the bf16 matrix pipe (layers/cross_modal.py::split_linear)
+        # or fp32 GEMMs; every bias / shortcut add / ReLU below is ONE fused in-place pass (bias_relu_)
+        if self.split_gemm:
+            def products(a, *ws):
+                return split_linear(a, *[t for w_ in ws for t in (w_, None)])
+        else:
+            def products(a, *ws):
+                return tuple(torch.mm(a, w_.t()) for w_ in ws)
         w1, b1 = self._f1[0].folded()
         w1 = w1.view(w1.shape[0], -1)
-        idn = None
+        idn, bd = None, None
         if self._fd is not None:
             wd, bd = self._fd[0].folded()
             wd = wd.view(wd.shape[0], -1)
             dy, dx = self.downsample[0].stride
-            xd = x2d if (dy, dx) == (sy, sx) else x[:, ::dy, ::dx, :].contiguous().view(-1, c)
-        if self.split_gemm:
-            # fp32-accurate GEMMs on the bf16 matrix pipe (layers/cross_modal.py::split_linear); conv1 and the
-            # projection shortcut read the same rows, so they share one operand split
-            if self._fd is not None and xd is x2d:
-                out, idn = split_linear(x2d, w1, b1, wd, bd)
+            if (dy, dx) == (sy, sx):  # conv1 and the projection shortcut read the same rows: one operand split
+                out, idn = products(x2d, w1, wd)
             else:
-                (out,) = split_linear(x2d, w1, b1)
-                if self._fd is not None:
-                    (idn,) = split_linear(xd, wd, bd)
-            out = out.relu_()
+                (out,) = products(x2d, w1)
+                (idn,) = products(x[:, ::dy, ::dx, :].contiguous().view(-1, c), wd)
         else:
-            out = torch.addmm(b1, x2d, w1.t()).relu_()
-            if self._fd is not None:
-                idn = torch.addmm(bd, xd, wd.t())
+            (out,) = products(x2d, w1)
+        out = bias_relu_(out, b1)
         w2, b2 = self._f2[0].folded()
         c2 = self.conv2
-        if self.conv3x3_nchw:
-            # MIOpen's NCHW fp32 Winograd is the fastest 3x3 it has for these shapes (its NHWC pick at R = 2000 is a
-            # 50 TFLOP/s grouped-conv kernel): two 0.1 ms layout copies around it are cheaper than that
-            out = F.conv2d(out.view(r, hs, ws, -1).permute(0, 3, 1, 2).contiguous(), w2, b2, c2.stride, c2.padding,
+        nchw = self.conv3x3_nchw
+        if nchw is None:
+            # MIOpen's NCHW fp32 Winograd is its fastest 3x3 forward for these shapes (the NHWC pick at R = 2000 is a
+            # 50 TFLOP/s grouped-conv kernel), worth two 0.1 ms layout copies around it; under autograd MIOpen runs
+            # NHWC implicit-GEMM kernels for all three directions, so the tensor stays channels_last
+            nchw = not (torch.is_grad_enabled() and (out.requires_grad or w2.requires_grad))
+        if nchw:
+            out = F.conv2d(out.view(r, hs, ws, -1).permute(0, 3, 1, 2).contiguous(), w2, None, c2.stride, c2.padding,
                            c2.dilation, c2.groups)
             out = out.permute(0, 2, 3, 1).contiguous()
         else:
             out = F.conv2d(out.view(r, hs, ws, -1).permute(0, 3, 1, 2),
-                           w2.contiguous(memory_format=torch.channels_last), b2, c2.stride, c2.padding, c2.dilation,
+                           w2.contiguous(memory_format=torch.channels_last), None, c2.stride, c2.padding, c2.dilation,
                            c2.groups)
             out = out.permute(0, 2, 3, 1)
             if not out.is_contiguous():
                 out = out.contiguous()
         ho, wo = out.shape[1], out.shape[2]
-        out = out.relu_().view(-1, out.shape[3])
+        out = bias_relu_(out.view(-1, out.shape[3]), b2)
         w3, b3 = self._f3[0].folded()
-        w3 = w3.view(w3.shape[0], -1)
-        if self.split_gemm:
-            (out,) = split_linear(out, w3, b3)
-        else:
-            out = torch.addmm(b3, out, w3.t())
-        out += idn if idn is not None else x.view(-1, c)
-        return out.relu_().view(r, ho, wo, -1)
+        (out,) = products(out, w3.view(w3.shape[0], -1))
+        out = bias_relu_(out, b3 if bd is None else b3 + bd, idn if idn is not None else x.view(-1, c))
+        return out.view(r, ho, wo, -1)
 
 
 class Stem(nn.Module):

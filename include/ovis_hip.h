@@ -136,6 +136,13 @@ int ovis_sigmoid_focal_loss_backward_f32(const float* logits, const int32_t* tar
 int ovis_split_bf16x3_f32(const float* src, long src_row_stride, void* dst_bf16, long rows,
                           int cols, int mode, void* stream);
 
+/* Fused GEMM epilogue of the NHWC res5 head: y[rows, cols] = act(y + bias[col] (+ residual)) in
+ * place, act = ReLU when `relu` != 0 (Bottleneck.forward, mb/modeling/backbone/resnet.py:323-344:
+ * FrozenBN shift, shortcut add and ReLU in one pass).  bias / residual may be NULL; cols % 4 == 0
+ * and 16-byte aligned pointers (else OVIS_ERANGE). */
+int ovis_bias_act_f32(float* y, const float* bias, const float* residual, long rows, int cols,
+                      int relu, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Cross-modal head: fp32 GEMM on the matrix cores
  *   mb/modeling/roi_heads/box_head/roi_box_predictors.py:66-71 (emb_pred Linear, einsum('pe,ce->pc'),
