@@ -162,6 +162,21 @@ def split_bf16x3(x, mode):
     return out
 
 
+def im2col_split_bf16x3(x, kh, kw, flip=False):
+    """x [R, H, W, C] f32 contiguous (NHWC) -> [R*H*W, 3*kh*kw*C] bf16 rows [hi taps | hi taps | lo taps]
+    (stride 1, zero "same" padding; flip = taps in reverse order).  See include/ovis_hip.h."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        raise RuntimeError("im2col_split_bf16x3: contiguous [R,H,W,C] float32 HIP tensor expected")
+    r, h, w, c = x.shape
+    out = torch.empty((r * h * w, 3 * kh * kw * c), dtype=torch.bfloat16, device=x.device)
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(x.device):
+        rc = _L.ovis_im2col_split_bf16x3_f32(x.data_ptr(), out.data_ptr(), r, h, w, c, kh, kw, int(bool(flip)), _stream())
+    _lib.check(rc, "im2col_split_bf16x3")
+    return out
+
+
 def bias_act_(y, bias=None, residual=None, relu=True):
     """In place: y[rows, cols] = act(y + bias[col] (+ residual)); contiguous f32, cols % 4 == 0."""
     if not (y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.is_contiguous()):

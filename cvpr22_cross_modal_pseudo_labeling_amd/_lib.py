@@ -28,6 +28,7 @@ SIGNATURES = {
     "ovis_sigmoid_focal_loss_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "ovis_sigmoid_focal_loss_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "ovis_split_bf16x3_f32": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),
+    "ovis_im2col_split_bf16x3_f32": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "ovis_bias_act_f32": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "ovis_gemm_f32": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _i, _i, _i, _vp]),
     "ovis_gemm_ex_f32": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _i, _f, _i, _vp, _l, _i, _i, _i, _vp]),

@@ -110,3 +110,62 @@ extern "C" int ovis_bias_act_f32(float* y, const float* bias, const float* resid
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Split + im2col for 3x3 (any odd KH x KW, stride 1, "same" zero padding) convolutions on NHWC tensors, so
+// that the convolution and both of its gradients become plain bf16 GEMMs with fp32 accumulation:
+//   src [R, H, W, C] f32  ->  dst [R*H*W, 3 * T*C] bf16,  T = KH*KW taps, row m = (r, y, x):
+//       [ hi(tap 0) .. hi(tap T-1) | hi(tap 0) .. hi(tap T-1) | lo(tap 0) .. lo(tap T-1) ]
+//   tap t = (ky, kx) reads pixel (y + ky - KH/2, x + kx - KW/2), zeros outside the map; with `flip` the taps
+//   are taken in reverse order (the data-gradient convolution uses the 180-degree rotated kernel).
+// Against a mode-1 split of the weight matrix [Cout, T*C] this is the three-term product of split_bf16x3.
+// HBM-bound: every source element is read 9x from L2 and written 3 x T times as bf16 (27 x 2 B).
+// ---------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void im2col_split_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                          long pixels, int H, int W, int C, int KH, int KW, int flip) {
+  const int qc = C >> 2;
+  const int T = KH * KW;
+  const long total = pixels * T * qc;
+  const long TC = (long)T * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % qc) * 4;
+    const long mt = i / qc;
+    const int t = (int)(mt % T);
+    const long m = mt / T;
+    const int x = (int)(m % W);
+    const int y = (int)((m / W) % H);
+    const int ts = flip ? T - 1 - t : t;
+    const int yy = y + ts / KW - KH / 2, xx = x + ts % KW - KW / 2;
+    uint2 hi = make_uint2(0u, 0u), lo = make_uint2(0u, 0u);
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+      const float4 v = *(const float4*)(src + ((m - x - (long)y * W) + (long)yy * W + xx) * C + c);
+      const unsigned h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
+      hi = make_uint2(h01, h23);
+      lo = make_uint2(pack_bf16(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u)),
+                      pack_bf16(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u)));
+    }
+    unsigned short* d = dst + m * 3 * TC + (long)t * C + c;
+    *(uint2*)d = hi;
+    *(uint2*)(d + TC) = hi;
+    *(uint2*)(d + 2 * TC) = lo;
+  }
+}
+}  // namespace
+
+extern "C" int ovis_im2col_split_bf16x3_f32(const float* src, void* dst_bf16, long num, int height, int width,
+                                            int channels, int kh, int kw, int flip, void* stream) {
+  if (num < 0 || height <= 0 || width <= 0 || channels < 0 || kh <= 0 || kw <= 0 || !(kh & 1) || !(kw & 1))
+    return OVIS_EINVAL;
+  if (num == 0 || channels == 0) return OVIS_OK;
+  if (!src || !dst_bf16) return OVIS_EINVAL;
+  if (channels % 4 != 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst_bf16 & 7)) return OVIS_ERANGE;
+  const long pixels = num * height * width;
+  const long total = pixels * kh * kw * (channels / 4);
+  const long blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 16L * OVIS_NUM_CU ? blocks : 16L * OVIS_NUM_CU);
+  hipLaunchKernelGGL(im2col_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src,
+                     (unsigned short*)dst_bf16, pixels, height, width, channels, kh, kw, flip);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}

@@ -87,6 +87,56 @@ class _SplitLinearMulti(Function):
         return (dx, *grads)
 
 
+class _SplitConvSame(Function):
+    """y[R,H,W,N] = conv(x[R,H,W,C], w[N,C,KH,KW]), stride 1, zero "same" padding, NHWC, as bf16 hi/lo split GEMMs:
+    the split + im2col kernel (csrc/split_bf16.hip) lays every pixel's KH*KW neighbourhood out as one row
+    [hi taps | hi taps | lo taps], so the convolution is ONE bf16 GEMM with fp32 accumulation over 3*KH*KW*C, the data
+    gradient the same thing on dY with the rotated kernel, and the weight gradient three M-contracting GEMMs of dY^T
+    against the saved rows.  ~2x MIOpen's fp32 implicit-GEMM kernels on the res5 3x3 (which sit at ~115 TFLOP/s of
+    the 157 TFLOP/s fp32 matrix peak), relative error ~4e-6."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        r, h, wd, c = x.shape
+        n, _, kh, kw = w.shape
+        rows = _C.im2col_split_bf16x3(x, kh, kw)                                    # [M, 3*T*C]
+        wm = w.permute(0, 2, 3, 1).reshape(n, kh * kw * c)                           # [N, T*C], tap-major like rows
+        y = torch.mm(rows, _C.split_bf16x3(wm, 1).t(), out_dtype=torch.float32)
+        ctx.save_for_backward(rows, w)
+        ctx.shape = (r, h, wd, c, n, kh, kw)
+        return y  # [R*H*W, N]: no view is created inside the Function, so callers may finish it in place
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        rows, w = ctx.saved_tensors
+        r, h, wd, c, n, kh, kw = ctx.shape
+        t = kh * kw
+        dy = dy.contiguous().view(r, h, wd, n)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # dX[p, c] = sum_{tap, n} dY[p - tap, n] W[n, c, tap]: the same im2col on dY with the taps reversed
+            wt = w.permute(1, 2, 3, 0).reshape(c, t * n)                             # [C, T*N]
+            dx = torch.mm(_C.im2col_split_bf16x3(dy, kh, kw, flip=True), _C.split_bf16x3(wt, 1).t(),
+                          out_dtype=torch.float32).view(r, h, wd, c)
+        if ctx.needs_input_grad[1]:
+            dys = _C.split_bf16x3(dy.view(-1, n), 0)                                 # [M, 3N] = [hi | hi | lo]
+            dy_hi, dy_lo = dys[:, :n], dys[:, 2 * n:]
+            x_hi, x_lo = rows[:, : t * c], rows[:, 2 * t * c:]
+            dwm = torch.mm(dy_hi.t(), x_hi, out_dtype=torch.float32)                 # [N, T*C], M-contraction
+            dwm += torch.mm(dy_hi.t(), x_lo, out_dtype=torch.float32)
+            dwm += torch.mm(dy_lo.t(), x_hi, out_dtype=torch.float32)
+            dw = dwm.view(n, kh, kw, c).permute(0, 3, 1, 2)
+        return dx, dw
+
+
+def split_conv_same(x, w):
+    """NHWC stride-1 "same" convolution (odd kernel, groups = 1, dilation 1) of x [R,H,W,C] as bf16 hi/lo split
+    GEMMs; returns the fp32 result as the [R*H*W, N] matrix (view it as [R,H,W,N]); bias / activation are left to
+    ``bias_relu_``."""
+    return _SplitConvSame.apply(x, w)
+
+
 class _BiasActInplace(Function):
     """y <- relu(y + bias (+ residual)) in one pass over y (csrc/split_bf16.hip::bias_act_kernel); the backward is the
     ReLU gate on the saved output, shared by y and the residual."""

@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..layers import Conv2d, FrozenBatchNorm2d, bias_relu_, split_linear
+from ..layers import Conv2d, FrozenBatchNorm2d, bias_relu_, split_conv_same, split_linear
 
 
 class ConvBN(nn.Module):
@@ -76,6 +76,7 @@ class Bottleneck(nn.Module):
         self._fd = [ConvBN(self.downsample[0], self.downsample[1])] if self.downsample is not None else None
         self.conv3x3_nchw = None  # None = by autograd mode (see forward_nhwc)
         self.split_gemm = os.environ.get("OVIS_RES5_FP32_GEMM", "0") != "1"
+        self.split_conv = self.split_gemm and os.environ.get("OVIS_RES5_MIOPEN_3X3", "0") != "1"
 
     def forward(self, x):
         out = F.relu_(self._f1[0](x))
@@ -127,25 +128,33 @@ class Bottleneck(nn.Module):
         out = bias_relu_(out, b1)
         w2, b2 = self._f2[0].folded()
         c2 = self.conv2
-        nchw = self.conv3x3_nchw
-        if nchw is None:
-            # MIOpen's NCHW fp32 Winograd is its fastest 3x3 forward for these shapes (the NHWC pick at R = 2000 is a
-            # 50 TFLOP/s grouped-conv kernel), worth two 0.1 ms layout copies around it; under autograd MIOpen runs
-            # NHWC implicit-GEMM kernels for all three directions, so the tensor stays channels_last
-            nchw = not (torch.is_grad_enabled() and (out.requires_grad or w2.requires_grad))
-        if nchw:
-            out = F.conv2d(out.view(r, hs, ws, -1).permute(0, 3, 1, 2).contiguous(), w2, None, c2.stride, c2.padding,
-                           c2.dilation, c2.groups)
-            out = out.permute(0, 2, 3, 1).contiguous()
+        if (self.split_conv and c2.stride == (1, 1) and c2.dilation == (1, 1) and c2.groups == 1
+                and c2.kernel_size[0] % 2 == 1 and c2.kernel_size[1] % 2 == 1
+                and c2.padding == (c2.kernel_size[0] // 2, c2.kernel_size[1] // 2)):
+            # the 3x3 as a bf16 hi/lo split GEMM over its im2col rows (layers/cross_modal.py::split_conv_same)
+            out = split_conv_same(out.view(r, hs, ws, -1), w2)  # [r*hs*ws, Cout]
+            ho, wo = hs, ws
         else:
-            out = F.conv2d(out.view(r, hs, ws, -1).permute(0, 3, 1, 2),
-                           w2.contiguous(memory_format=torch.channels_last), None, c2.stride, c2.padding, c2.dilation,
-                           c2.groups)
-            out = out.permute(0, 2, 3, 1)
-            if not out.is_contiguous():
-                out = out.contiguous()
-        ho, wo = out.shape[1], out.shape[2]
-        out = bias_relu_(out.view(-1, out.shape[3]), b2)
+            nchw = self.conv3x3_nchw
+            if nchw is None:
+                # MIOpen's NCHW fp32 Winograd is its fastest 3x3 forward for these shapes (the NHWC pick at R = 2000
+                # is a 50 TFLOP/s grouped-conv kernel), worth two 0.1 ms layout copies around it; under autograd
+                # MIOpen runs NHWC implicit-GEMM kernels for all three directions: the tensor stays channels_last
+                nchw = not (torch.is_grad_enabled() and (out.requires_grad or w2.requires_grad))
+            if nchw:
+                out = F.conv2d(out.view(r, hs, ws, -1).permute(0, 3, 1, 2).contiguous(), w2, None, c2.stride,
+                               c2.padding, c2.dilation, c2.groups)
+                out = out.permute(0, 2, 3, 1).contiguous()
+            else:
+                out = F.conv2d(out.view(r, hs, ws, -1).permute(0, 3, 1, 2),
+                               w2.contiguous(memory_format=torch.channels_last), None, c2.stride, c2.padding,
+                               c2.dilation, c2.groups)
+                out = out.permute(0, 2, 3, 1)
+                if not out.is_contiguous():
+                    out = out.contiguous()
+            ho, wo = out.shape[1], out.shape[2]
+            out = out.view(-1, out.shape[3])
+        out = bias_relu_(out, b2)
         w3, b3 = self._f3[0].folded()
         (out,) = products(out, w3.view(w3.shape[0], -1))
         out = bias_relu_(out, b3 if bd is None else b3 + bd, idn if idn is not None else x.view(-1, c))

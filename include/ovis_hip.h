@@ -136,6 +136,16 @@ int ovis_sigmoid_focal_loss_backward_f32(const float* logits, const int32_t* tar
 int ovis_split_bf16x3_f32(const float* src, long src_row_stride, void* dst_bf16, long rows,
                           int cols, int mode, void* stream);
 
+/* Split + im2col of an NHWC tensor for odd-sized stride-1 "same" convolutions as bf16 GEMMs:
+ * src [num, height, width, channels] f32 -> dst [num*height*width, 3*T*channels] bf16 with
+ * T = kh*kw taps and row layout [hi(tap 0..T-1) | hi(tap 0..T-1) | lo(tap 0..T-1)]; tap
+ * (ky, kx) reads pixel (y + ky - kh/2, x + kx - kw/2), zeros outside the map; flip != 0
+ * takes the taps in reverse order (180-degree rotated kernel of the data gradient).
+ * A bf16 GEMM of dst against the mode-1 split of the [Cout, T*channels] weight matrix is the
+ * convolution (res5 conv2, mb/modeling/backbone/resnet.py:288-300).  channels % 4 == 0. */
+int ovis_im2col_split_bf16x3_f32(const float* src, void* dst_bf16, long num, int height,
+                                 int width, int channels, int kh, int kw, int flip, void* stream);
+
 /* Fused GEMM epilogue of the NHWC res5 head: y[rows, cols] = act(y + bias[col] (+ residual)) in
  * place, act = ReLU when `relu` != 0 (Bottleneck.forward, mb/modeling/backbone/resnet.py:323-344:
  * FrozenBN shift, shortcut add and ReLU in one pass).  bias / residual may be NULL; cols % 4 == 0

@@ -205,6 +205,45 @@ def test_split_linear_vs_fp64(m, k, ns):
     assert ((x.grad.double() - dx_ref).abs() <= dx_bound).all()
 
 
+@pytest.mark.parametrize("r,h,w,c,n,k", [(9, 7, 7, 64, 32, 3), (3, 5, 6, 8, 12, 3), (2, 4, 4, 16, 8, 5), (4, 7, 7, 32, 16, 1)])
+def test_split_conv_same_vs_fp64(r, h, w, c, n, k):
+    """Stride-1 "same" convolution, its data gradient and weight gradient as split GEMMs over im2col rows, against
+    fp64 conv2d; tolerance 2e-5 of the |x| * |w| convolution (the split bound)."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers import split_conv_same
+
+    g = torch.Generator().manual_seed(r * 100 + c)
+    x = torch.randn(r, h, w, c, generator=g).cuda().requires_grad_(True)
+    wt = (torch.randn(n, c, k, k, generator=g) / (c * k * k) ** 0.5).cuda().requires_grad_(True)
+    y = split_conv_same(x, wt).view(r, h, w, n)
+    gy = torch.randn(r, h, w, n, generator=g).cuda()
+    (y * gy).sum().backward()
+    xd = x.detach().double().permute(0, 3, 1, 2).requires_grad_(True)
+    wd = wt.detach().double().requires_grad_(True)
+    ref = F.conv2d(xd, wd, padding=k // 2)
+    (ref * gy.double().permute(0, 3, 1, 2)).sum().backward()
+    bound = 2e-5 * F.conv2d(xd.detach().abs(), wd.detach().abs(), padding=k // 2) + 1e-6
+    assert ((y.detach().double().permute(0, 3, 1, 2) - ref.detach()).abs() <= bound).all()
+    assert (x.grad.double().permute(0, 3, 1, 2) - xd.grad).abs().max() <= 2e-5 * xd.grad.abs().max() * 8
+    assert (wt.grad.double() - wd.grad).abs().max() <= 2e-5 * wd.grad.abs().max() * 8
+
+
+def test_im2col_split_layout():
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 3, 4, 8, generator=g).cuda()
+    for flip in (False, True):
+        rows = _C.im2col_split_bf16x3(x, 3, 3, flip=flip)
+        assert rows.shape == (24, 3 * 9 * 8)
+        hi = x.to(torch.bfloat16)
+        pad = F.pad(hi.permute(0, 3, 1, 2), (1, 1, 1, 1)).permute(0, 2, 3, 1)  # [2, 5, 6, 8]
+        for t in range(9):
+            ts = 8 - t if flip else t
+            want = pad[:, ts // 3: ts // 3 + 3, ts % 3: ts % 3 + 4, :].reshape(24, 8)
+            assert torch.equal(rows[:, t * 8:(t + 1) * 8], want)
+            assert torch.equal(rows[:, 72 + t * 8: 72 + (t + 1) * 8], want)
+
+
 def test_res5_head_nhwc_paths_match_conv_path():
     """ResNetHead: the NHWC / GEMM path (fp32 GEMMs and bf16 hi/lo split GEMMs, 3x3 through either layout) against the
     plain per-layer convolution path on the same weights."""
@@ -221,10 +260,10 @@ def test_res5_head_nhwc_paths_match_conv_path():
             m.bias.uniform_(-0.2, 0.2)
     x = torch.randn(24, 1024, 14, 14, device="cuda")
 
-    def run(nhwc, split, c33):
+    def run(nhwc, split, c33, sconv=False):
         head.nhwc = nhwc
         for b in head.layer4:
-            b.split_gemm, b.conv3x3_nchw = split, c33
+            b.split_gemm, b.conv3x3_nchw, b.split_conv = split, c33, sconv
         xx = x.clone().requires_grad_(True)
         y = head(xx)
         head.zero_grad()
@@ -232,7 +271,7 @@ def test_res5_head_nhwc_paths_match_conv_path():
         return y.detach(), xx.grad, head.layer4[0].conv1.weight.grad.clone(), head.layer4[2].conv3.weight.grad.clone()
 
     ref = run(False, False, True)
-    for cfg_ in ((True, False, True), (True, False, False), (True, True, True)):
+    for cfg_ in ((True, False, True), (True, False, False), (True, True, True), (True, True, None, True)):
         got = run(*cfg_)
         assert got[0].shape == ref[0].shape
         assert (got[0] - ref[0]).abs().max().item() <= 2e-4 * ref[0].abs().max().item(), cfg_

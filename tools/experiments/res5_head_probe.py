@@ -28,6 +28,7 @@ head.zero_grad(); run(True, True); gb = [p.grad.clone() for p in head.parameters
 print("grad rel diff:", max(((a - b).abs().max() / a.abs().max()).item() for a, b in zip(ga, gb)))
 for b in head.layer4:
     b.split_gemm = False
+    b.split_conv = False
 for nhwc, c33, sg in ((False, True, False), (True, True, False), (True, True, True), (True, None, True)):
     for b in head.layer4:
         b.conv3x3_nchw = c33
@@ -35,4 +36,12 @@ for nhwc, c33, sg in ((False, True, False), (True, True, False), (True, True, Tr
     with torch.no_grad():
         f = t(lambda: run(nhwc, False))
     fb = t(lambda: run(nhwc, True))
-    print(f"nhwc={nhwc} conv3x3_nchw={c33} split_gemm={sg}: fwd {f:.2f} ms  fwd+bwd {fb:.2f} ms  (R={R})")
+    print(f"nhwc={nhwc} conv3x3_nchw={c33} split_gemm={sg} split_conv={head.layer4[0].split_conv}: fwd {f:.2f} ms  fwd+bwd {fb:.2f} ms  (R={R})")
+
+for b in head.layer4:
+    b.split_conv = True
+with torch.no_grad():
+    yc = run(True, False)
+    f = t(lambda: run(True, False))
+fb = t(lambda: run(True, True))
+print("split conv: max |diff| / max |y|:", ((ya - yc).abs().max() / ya.abs().max()).item(), f"fwd {f:.2f} ms  fwd+bwd {fb:.2f} ms")
