@@ -69,10 +69,22 @@ class OpTimer:
             nb = (k + 63) // 64
             return 20 * k + 2 * 8 * k * nb + 8 * k
 
+        def split_bytes(x, mode):
+            return 10 * x.numel()  # 4 B read + 3 x 2 B written per element
+
+        def im2col_bytes(x, kh, kw, flip=False):
+            return (4 + 6 * kh * kw) * x.numel()  # source once + [hi | hi | lo] for every tap
+
+        def bias_act_bytes(y, bias=None, residual=None, relu=True):
+            return (8 + (4 if residual is not None else 0)) * y.numel()
+
         self._wrap("roi_align_forward", roi_fwd_bytes)
         self._wrap("roi_align_forward_mfma", roi_fwd_bytes)
         self._wrap("roi_align_backward", roi_bwd_bytes)
         self._wrap("nms_padded", nms_bytes)
+        self._wrap("split_bf16x3", split_bytes)
+        self._wrap("im2col_split_bf16x3", im2col_bytes)
+        self._wrap("bias_act_", bias_act_bytes)
 
     def summary(self):
         out = {}
@@ -109,21 +121,26 @@ def cpu_baseline(workload):
         roi_counts, nms_counts = [512], [12000]
     torch.set_num_threads(1)  # the reference kernels are single-threaded (cpu/ROIAlign_cpu.cpp:133)
     t0 = time.perf_counter()
-    for r in roi_counts:
-        rr = rois(r)
-        if ref is not None:
-            ref.roi_align_forward(feat, rr, 1 / 16, 14, 14, 0)
-        else:
-            oracle.roi_align_forward(feat, rr, 1 / 16, 14, 14, 0)
-    for k in nms_counts:
-        b, s = boxes(k)
-        if ref is not None:
-            ref.nms(b, s, 0.7)
-        else:
-            oracle.nms(b, s, 0.7)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "images/sec", "cores": 1, "kind": "reference" if ref is not None else "port",
-            "sample": (f"native ops of ONE image of the {workload} step only (RoIAlign fwd R={roi_counts} on [1,1024,50,84], "
+    images = 0
+    while True:  # whole images until >= 10 s of CPU work (bounded sample, 10-30 s)
+        for r in roi_counts:
+            rr = rois(r)
+            if ref is not None:
+                ref.roi_align_forward(feat, rr, 1 / 16, 14, 14, 0)
+            else:
+                oracle.roi_align_forward(feat, rr, 1 / 16, 14, 14, 0)
+        for k in nms_counts:
+            b, s = boxes(k)
+            if ref is not None:
+                ref.nms(b, s, 0.7)
+            else:
+                oracle.nms(b, s, 0.7)
+        images += 1
+        dt = time.perf_counter() - t0
+        if dt >= 10.0 or images >= 64:
+            break
+    return {"value": images / dt, "unit": "images/sec", "cores": 1, "kind": "reference" if ref is not None else "port",
+            "sample": (f"native ops of {images} images of the {workload} step only (per image: RoIAlign fwd R={roi_counts} on [1,1024,50,84], "
                        f"NMS K={nms_counts}, thr .7) with the reference's single-threaded CPU kernels; convolutions, heads "
                        "and backward excluded because the reference cannot train on CPU (ROIAlign.h:44) -- an UPPER bound "
                        f"on CPU images/sec; {dt:.1f} s of CPU work"),
