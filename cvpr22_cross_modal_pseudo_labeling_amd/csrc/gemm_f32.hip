@@ -92,35 +92,60 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 }
 
 // Per-noun best region: scores[w] = sigmoid(max_p <emb[p], noun[w]>), index[w] = argmax_p (lowest p on ties).
-// maskrcnn_benchmark/modeling/detector/st_generalized_rcnn.py:243-262.  One workgroup per noun, one wave per
-// region at a time, lanes split the embedding dimension with 16-byte loads.
-__global__ __launch_bounds__(256) void region_noun_align_kernel(const float* __restrict__ emb,
-                                                               const float* __restrict__ nouns,
-                                                               float* __restrict__ raw, float* __restrict__ prob,
-                                                               long long* __restrict__ index, int P, int D) {
-  __shared__ float s_best[4];
-  __shared__ int s_idx[4];
+// maskrcnn_benchmark/modeling/detector/st_generalized_rcnn.py:243-262.  Grid = (noun, chunk of 64 regions): each
+// wave walks 16 regions with the embedding dimension split over its lanes (16-byte loads), the workgroup's best
+// (score, region) goes into the noun's 64-bit key with one atomicMax -- key = order-preserving score bits << 32 |
+// ~region, so the maximum key is the maximum score and, among equal scores, the lowest region -- and a second
+// tiny kernel unpacks the keys.  (The first version ran ONE workgroup per noun: 5 workgroups on 256 CUs, 0.9 ms.)
+constexpr int kAlignChunk = 64;
+
+__device__ __forceinline__ unsigned ordered_bits(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void region_noun_partial_kernel(const float* __restrict__ emb,
+                                                                 const float* __restrict__ nouns,
+                                                                 unsigned long long* __restrict__ keys, int P, int D) {
+  __shared__ unsigned long long s_key[4];
   const int w = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p0 = blockIdx.y * kAlignChunk;
   const float* nv = nouns + (long)w * D;
-  float best = -INFINITY;
-  int best_i = 0x7fffffff;
-  for (int p = wave; p < P; p += 4) {
+  unsigned long long best = 0ull;
+  for (int p = p0 + wave; p < min(p0 + kAlignChunk, P); p += 4) {
     const float* e = emb + (long)p * D;
     float s = 0.f;
-    for (int d = lane; d < D; d += 64) s += e[d] * nv[d];
+    if ((D & 3) == 0) {
+      for (int d = lane * 4; d < D; d += 256) {
+        const float4 a = *(const float4*)(e + d), b = *(const float4*)(nv + d);
+        s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+      }
+    } else {
+      for (int d = lane; d < D; d += 64) s += e[d] * nv[d];
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (s > best) { best = s; best_i = p; }  // p ascends within a wave: first maximum wins
+    const unsigned long long key = ((unsigned long long)ordered_bits(s) << 32) | (unsigned)(~p);
+    best = key > best ? key : best;
   }
-  if (lane == 0) { s_best[wave] = best; s_idx[wave] = best_i; }
+  if (lane == 0) s_key[wave] = best;
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int k = 1; k < 4; ++k)
-      if (s_best[k] > best || (s_best[k] == best && s_idx[k] < best_i)) { best = s_best[k]; best_i = s_idx[k]; }
-    raw[w] = best;
-    prob[w] = 1.f / (1.f + expf(-best));
-    index[w] = best_i;
+    for (int k = 1; k < 4; ++k) best = s_key[k] > best ? s_key[k] : best;
+    if (best) atomicMax(keys + w, best);
   }
+}
+
+__global__ void region_noun_finalize_kernel(const unsigned long long* __restrict__ keys, float* __restrict__ raw,
+                                            float* __restrict__ prob, long long* __restrict__ index, int num_nouns) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= num_nouns) return;
+  const unsigned long long key = keys[w];
+  const unsigned ob = (unsigned)(key >> 32);
+  const float best = __uint_as_float((ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob);
+  raw[w] = best;
+  prob[w] = 1.f / (1.f + expf(-best));
+  index[w] = (long long)(unsigned)(~(unsigned)key);  // written last: `keys` aliases `index`
 }
 
 }  // namespace
@@ -160,8 +185,15 @@ extern "C" int ovis_region_noun_align_f32(const float* region_emb, const float* 
   if (num_regions <= 0 || num_nouns < 0 || dim <= 0) return OVIS_EINVAL;
   if (num_nouns == 0) return OVIS_OK;
   if (!region_emb || !noun_emb || !raw_scores || !sigmoid_scores || !best_region) return OVIS_EINVAL;
-  hipLaunchKernelGGL(region_noun_align_kernel, dim3(num_nouns), dim3(256), 0, (hipStream_t)stream, region_emb,
-                     noun_emb, raw_scores, sigmoid_scores, (long long*)best_region, num_regions, dim);
+  // the int64 index output doubles as the 64-bit key array of the partial kernel
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long* keys = (unsigned long long*)best_region;
+  OVIS_HIP_TRY(hipMemsetAsync(keys, 0, sizeof(unsigned long long) * num_nouns, s));
+  hipLaunchKernelGGL(region_noun_partial_kernel, dim3(num_nouns, ovis_ceil_div(num_regions, kAlignChunk)), dim3(256),
+                     0, s, region_emb, noun_emb, keys, num_regions, dim);
+  OVIS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(region_noun_finalize_kernel, dim3(ovis_ceil_div(num_nouns, 64)), dim3(64), 0, s, keys,
+                     raw_scores, sigmoid_scores, (long long*)best_region, num_nouns);
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
 }
