@@ -9,8 +9,9 @@
 //
 // v_mfma_f32_32x32x2_f32 is exact fp32 (one rounding per product, an fmaf chain in k order), so the result
 // differs from a cuBLAS/ATen fp32 GEMM only by summation order.  Tile: 64x64 per 256-lane workgroup, each of
-// the 4 waves owns one 32x32 accumulator (16 VGPRs); K is staged through LDS 16 at a time, k-major so the
-// per-lane MFMA operand reads (A[i=lane&31][k=lane>>5]) are bank-conflict free.
+// the 4 waves owns one 32x32 accumulator (16 VGPRs); K is staged through a double-buffered LDS tile 16 at a time
+// (registers -> LDS, the next tile's global loads in flight during the MFMAs, one barrier per step), k-major so
+// the per-lane MFMA operand reads (A[i=lane&31][k=lane>>5]) are bank-conflict free.
 #include "ovis_common.h"
 
 namespace {
@@ -18,31 +19,50 @@ namespace {
 typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int BM = 64, BN = 64, BK = 16, LDP = BM + 4;
 
-// Stage a [64 x BK] operand tile into LDS as T[k][row].  `rs`/`cs` are the element strides of (row, k).
-__device__ __forceinline__ void stage_tile(float* T, const float* __restrict__ P, long rs, long cs, int row0,
-                                           int k0, int nrows, int K, bool vec_k, bool vec_r) {
+// A [64 x BK] operand tile travels global -> registers -> LDS (as T[k][row]) in two steps so that the loads of
+// tile k+1 are in flight while the matrix cores work on tile k.  `rs`/`cs` are the element strides of (row, k).
+// mode 0: k contiguous (cs == 1), 16-byte aligned rows: 4 lanes x float4 cover one row's 16 k
+// mode 1: rows contiguous (rs == 1): 16 lanes x float4 cover the 64 rows of one k
+// mode 2: generic strides / ragged edges, element-wise with bounds checks
+__device__ __forceinline__ float4 load_tile(const float* __restrict__ P, long rs, long cs, int row0, int k0, int nrows,
+                                            int K, int mode) {
   const int t = threadIdx.x;
-  if (vec_k) {  // k contiguous (cs == 1), 16-byte aligned rows: 4 lanes x float4 cover one row's 16 k
+  if (mode == 0) {
     const int r = t >> 2, kq = (t & 3) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row0 + r < nrows && k0 + kq < K) v = *(const float4*)(P + (long)(row0 + r) * rs + (k0 + kq));
+    return *(const float4*)(P + (long)(row0 + r) * rs + (k0 + kq));
+  }
+  if (mode == 1) {
+    const int k = t >> 4, rq = (t & 15) * 4;
+    return *(const float4*)(P + (long)(k0 + k) * cs + (row0 + rq));
+  }
+  float4 v;
+  float* pv = (float*)&v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = t + e * 256;
+    const int k = idx >> 6, r = idx & 63;
+    pv[e] = (row0 + r < nrows && k0 + k < K) ? P[(long)(row0 + r) * rs + (long)(k0 + k) * cs] : 0.f;
+  }
+  return v;
+}
+
+__device__ __forceinline__ void store_tile(float* T, float4 v, int mode) {
+  const int t = threadIdx.x;
+  if (mode == 0) {
+    const int r = t >> 2, kq = (t & 3) * 4;
     T[(kq + 0) * LDP + r] = v.x;
     T[(kq + 1) * LDP + r] = v.y;
     T[(kq + 2) * LDP + r] = v.z;
     T[(kq + 3) * LDP + r] = v.w;
-  } else if (vec_r) {  // rows contiguous (rs == 1): 16 lanes x float4 cover the 64 rows of one k
+  } else if (mode == 1) {
     const int k = t >> 4, rq = (t & 15) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k0 + k < K && row0 + rq < nrows) v = *(const float4*)(P + (long)(k0 + k) * cs + (row0 + rq));
     *(float4*)(T + k * LDP + rq) = v;
-  } else {  // generic strides / ragged edges
+  } else {
+    const float* pv = (const float*)&v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int idx = t + e * 256;
-      const int k = idx >> 6, r = idx & 63;
-      float v = 0.f;
-      if (row0 + r < nrows && k0 + k < K) v = P[(long)(row0 + r) * rs + (long)(k0 + k) * cs];
-      T[k * LDP + r] = v;
+      T[(idx >> 6) * LDP + (idx & 63)] = pv[e];
     }
   }
 }
@@ -51,26 +71,34 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                       const float* __restrict__ B, long b_rs, long b_cs,
                                                       const float* __restrict__ bias, float* __restrict__ C,
                                                       long c_rs, int M, int N, int K, int flags, float alpha) {
-  __shared__ __attribute__((aligned(16))) float As[BK * LDP];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDP];
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDP];
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  const bool a_vk = flags & 1, a_vr = flags & 2, b_vk = flags & 4, b_vr = flags & 8;
-  // full-tile vector paths need the whole 64-row / 16-k tile in range
+  // full-tile vector paths need the whole 64-row tile in range (and every k-step full: checked per step)
   const bool a_full = m0 + BM <= M, b_full = n0 + BN <= N;
+  const int a_vec = !a_full ? 2 : (flags & 1) ? 0 : (flags & 2) ? 1 : 2;
+  const int b_vec = !b_full ? 2 : (flags & 4) ? 0 : (flags & 8) ? 1 : 2;
+  auto mode_at = [&](int vec, int k0) { return k0 + BK <= K ? vec : 2; };
   f16v acc = {0.f};
+  float4 ra = load_tile(A, a_rs, a_cs, m0, 0, M, K, mode_at(a_vec, 0));
+  float4 rb = load_tile(B, b_rs, b_cs, n0, 0, N, K, mode_at(b_vec, 0));
+  int buf = 0;
   for (int k0 = 0; k0 < K; k0 += BK) {
-    const bool k_full = k0 + BK <= K;
-    stage_tile(As, A, a_rs, a_cs, m0, k0, M, K, a_vk && a_full && k_full, a_vr && a_full && k_full);
-    stage_tile(Bs, B, b_rs, b_cs, n0, k0, N, K, b_vk && b_full && k_full, b_vr && b_full && k_full);
-    __syncthreads();
-    const float* ap = As + (lane >> 5) * LDP + wm + (lane & 31);
-    const float* bp = Bs + (lane >> 5) * LDP + wn + (lane & 31);
+    store_tile(As[buf], ra, mode_at(a_vec, k0));
+    store_tile(Bs[buf], rb, mode_at(b_vec, k0));
+    __syncthreads();  // one barrier per k-step: the other buffer was last read before the previous barrier
+    if (k0 + BK < K) {  // next tile's loads fly while this tile is in the matrix pipe
+      ra = load_tile(A, a_rs, a_cs, m0, k0 + BK, M, K, mode_at(a_vec, k0 + BK));
+      rb = load_tile(B, b_rs, b_cs, n0, k0 + BK, N, K, mode_at(b_vec, k0 + BK));
+    }
+    const float* ap = As[buf] + (lane >> 5) * LDP + wm + (lane & 31);
+    const float* bp = Bs[buf] + (lane >> 5) * LDP + wn + (lane & 31);
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk * 2 * LDP], bp[kk * 2 * LDP], acc, 0, 0, 0);
-    __syncthreads();
+    buf ^= 1;
   }
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   // epilogue: C = alpha * acc (+ C if flags&16) + bias[col] (or bias[row] if flags&32)
