@@ -37,7 +37,7 @@ constexpr int kGDepth = 8;    // G tiles in flight per wave = two rounds (8 wave
 constexpr int kRing = 3;      // table ring depth in rounds: consumed | landed | in flight
 constexpr int kRoundBytes = 2 * kRI * 1024;  // 4 tx blocks + 4 ty blocks
 constexpr int kListPad = 4 * kGDepth;        // zero-contribution items after the last real one
-constexpr int kPlanThreads = 1024;
+constexpr int kPlanThreads = 256;
 
 // ---------------------------------------------------------------------------------------------------
 // Plan kernel.
@@ -186,11 +186,14 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc_lane, unsigned lds_ds
       : "memory");
 }
 
-template <int NW, bool FIT>
+template <int NW, bool FIT, int WC>
 __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
     const float* __restrict__ gout, const u4* __restrict__ list, const int* __restrict__ counts,
     const u4* __restrict__ tx, const u4* __restrict__ ty, float* __restrict__ gin, int R, int batch,
-    int C, int H, int W, int PH, int PW, int NXB, int NYB, unsigned plane_stride) {
+    int C, int H, int W_rt, int PH, int PW, int NXB, int NYB, unsigned plane_stride) {
+  // WC != 0: the map width is a compile-time constant, so the four plane rows of a footprint are immediate offsets
+  // (ds_read2_b32 / ds_write2_b32 pairs, no address VALU); WC == 0: any width
+  const int W = WC ? WC : W_rt;
   // no static LDS in this kernel: the dynamic segment starts at LDS address 0, which the DMA destinations rely on
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int P = 2 * kRI / NW;  // table blocks each wave DMAs per round
@@ -408,21 +411,24 @@ int ovis_roi_align_backward_plane_launch(const float* grad_output, const float* 
   OVIS_LAUNCH_CHECK();
   static bool attr_set = false;
   if (!attr_set) {
-    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<8, true, 84>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<8, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<8, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<4, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<4, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const bool fit = height >= kT && width >= kT;
-#define OVIS_BWD_LAUNCH(NW_, FIT_)                                                                                  \
-  hipLaunchKernelGGL((roi_bwd_mfma_kernel<NW_, FIT_>), dim3((unsigned)blocks), dim3(NW_ * 64), lds, s, grad_output, \
-                     list, counts, tx, ty, grad_input, num_rois, batch, channels, height, width, pooled_h, pooled_w, \
+#define OVIS_BWD_LAUNCH(NW_, FIT_, WC_)                                                                                  \
+  hipLaunchKernelGGL((roi_bwd_mfma_kernel<NW_, FIT_, WC_>), dim3((unsigned)blocks), dim3(NW_ * 64), lds, s, grad_output, \
+                     list, counts, tx, ty, grad_input, num_rois, batch, channels, height, width, pooled_h, pooled_w,      \
                      NXB, NYB, stride)
   if (nw == 8) {
-    if (fit) OVIS_BWD_LAUNCH(8, true); else OVIS_BWD_LAUNCH(8, false);
+    if (fit && width == 84) OVIS_BWD_LAUNCH(8, true, 84);  // the C4 map of an 800 x 1333 batch
+    else if (fit) OVIS_BWD_LAUNCH(8, true, 0);
+    else OVIS_BWD_LAUNCH(8, false, 0);
   } else {
-    if (fit) OVIS_BWD_LAUNCH(4, true); else OVIS_BWD_LAUNCH(4, false);
+    if (fit) OVIS_BWD_LAUNCH(4, true, 0); else OVIS_BWD_LAUNCH(4, false, 0);
   }
 #undef OVIS_BWD_LAUNCH
   OVIS_LAUNCH_CHECK();
