@@ -122,14 +122,15 @@ extern "C" int ovis_bias_act_f32(float* y, const float* bias, const float* resid
 // HBM-bound: every source element is read 9x from L2 and written 3 x T times as bf16 (27 x 2 B).
 // ---------------------------------------------------------------------------------------------------
 namespace {
+template <int V>  // channels per thread: 8 (16-byte stores) when channels % 8 == 0, else 4
 __global__ __launch_bounds__(256) void im2col_split_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
                                                           long pixels, int H, int W, int C, int KH, int KW, int flip) {
-  const int qc = C >> 2;
+  const int qc = C / V;
   const int T = KH * KW;
   const long total = pixels * T * qc;
   const long TC = (long)T * C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % qc) * 4;
+    const int c = (int)(i % qc) * V;
     const long mt = i / qc;
     const int t = (int)(mt % T);
     const long m = mt / T;
@@ -137,18 +138,33 @@ __global__ __launch_bounds__(256) void im2col_split_kernel(const float* __restri
     const int y = (int)((m / W) % H);
     const int ts = flip ? T - 1 - t : t;
     const int yy = y + ts / KW - KH / 2, xx = x + ts % KW - KW / 2;
-    uint2 hi = make_uint2(0u, 0u), lo = make_uint2(0u, 0u);
+    unsigned hi[V / 2], lo[V / 2];
+#pragma unroll
+    for (int k = 0; k < V / 2; ++k) hi[k] = lo[k] = 0u;
     if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-      const float4 v = *(const float4*)(src + ((m - x - (long)y * W) + (long)yy * W + xx) * C + c);
-      const unsigned h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
-      hi = make_uint2(h01, h23);
-      lo = make_uint2(pack_bf16(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u)),
-                      pack_bf16(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u)));
+      const float* p = src + ((m - x - (long)y * W) + (long)yy * W + xx) * C + c;
+#pragma unroll
+      for (int k = 0; k < V / 4; ++k) {
+        const float4 v = *(const float4*)(p + 4 * k);
+        const unsigned h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
+        hi[2 * k] = h01;
+        hi[2 * k + 1] = h23;
+        lo[2 * k] = pack_bf16(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+        lo[2 * k + 1] = pack_bf16(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+      }
     }
     unsigned short* d = dst + m * 3 * TC + (long)t * C + c;
-    *(uint2*)d = hi;
-    *(uint2*)(d + TC) = hi;
-    *(uint2*)(d + 2 * TC) = lo;
+    if (V == 8) {
+      const uint4 h = make_uint4(hi[0], hi[1], hi[2], hi[3]), l = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+      *(uint4*)d = h;
+      *(uint4*)(d + TC) = h;
+      *(uint4*)(d + 2 * TC) = l;
+    } else {
+      const uint2 h = make_uint2(hi[0], hi[1]), l = make_uint2(lo[0], lo[1]);
+      *(uint2*)d = h;
+      *(uint2*)(d + TC) = h;
+      *(uint2*)(d + 2 * TC) = l;
+    }
   }
 }
 }  // namespace
@@ -161,11 +177,16 @@ extern "C" int ovis_im2col_split_bf16x3_f32(const float* src, void* dst_bf16, lo
   if (!src || !dst_bf16) return OVIS_EINVAL;
   if (channels % 4 != 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst_bf16 & 7)) return OVIS_ERANGE;
   const long pixels = num * height * width;
-  const long total = pixels * kh * kw * (channels / 4);
+  const bool wide = channels % 8 == 0 && ((uintptr_t)dst_bf16 & 15) == 0;
+  const long total = pixels * kh * kw * (channels / (wide ? 8 : 4));
   const long blocks = (total + 255) / 256;
   const unsigned grid = (unsigned)(blocks < 16L * OVIS_NUM_CU ? blocks : 16L * OVIS_NUM_CU);
-  hipLaunchKernelGGL(im2col_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src,
-                     (unsigned short*)dst_bf16, pixels, height, width, channels, kh, kw, flip);
+  if (wide)
+    hipLaunchKernelGGL(im2col_split_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src,
+                       (unsigned short*)dst_bf16, pixels, height, width, channels, kh, kw, flip);
+  else
+    hipLaunchKernelGGL(im2col_split_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src,
+                       (unsigned short*)dst_bf16, pixels, height, width, channels, kh, kw, flip);
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
 }
