@@ -70,7 +70,11 @@ __device__ __forceinline__ void store_tile(float* T, float4 v, int mode) {
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long a_rs, long a_cs,
                                                       const float* __restrict__ B, long b_rs, long b_cs,
                                                       const float* __restrict__ bias, float* __restrict__ C,
-                                                      long c_rs, int M, int N, int K, int flags, float alpha) {
+                                                      long c_rs, int M, int N, int K, int flags, float alpha,
+                                                      int k_chunk) {
+  // split-K: slice z of the grid contracts k in [z * k_chunk, min(K, (z + 1) * k_chunk)) and adds its partial tile
+  // into C with fp32 atomics (C pre-zeroed by the launcher; bias from slice 0).  Small GEMMs of the head fill
+  // fewer than one workgroup per CU otherwise, and with one wave per SIMD nothing hides the LDS / barrier stalls.
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDP];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDP];
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -80,16 +84,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   const bool a_full = m0 + BM <= M, b_full = n0 + BN <= N;
   const int a_vec = !a_full ? 2 : (flags & 1) ? 0 : (flags & 2) ? 1 : 2;
   const int b_vec = !b_full ? 2 : (flags & 4) ? 0 : (flags & 8) ? 1 : 2;
+  const int k_begin = blockIdx.z * k_chunk;
+  const int k_end = min(K, k_begin + k_chunk);
   auto mode_at = [&](int vec, int k0) { return k0 + BK <= K ? vec : 2; };
   f16v acc = {0.f};
-  float4 ra = load_tile(A, a_rs, a_cs, m0, 0, M, K, mode_at(a_vec, 0));
-  float4 rb = load_tile(B, b_rs, b_cs, n0, 0, N, K, mode_at(b_vec, 0));
+  float4 ra = load_tile(A, a_rs, a_cs, m0, k_begin, M, K, mode_at(a_vec, k_begin));
+  float4 rb = load_tile(B, b_rs, b_cs, n0, k_begin, N, K, mode_at(b_vec, k_begin));
   int buf = 0;
-  for (int k0 = 0; k0 < K; k0 += BK) {
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
     store_tile(As[buf], ra, mode_at(a_vec, k0));
     store_tile(Bs[buf], rb, mode_at(b_vec, k0));
     __syncthreads();  // one barrier per k-step: the other buffer was last read before the previous barrier
-    if (k0 + BK < K) {  // next tile's loads fly while this tile is in the matrix pipe
+    if (k0 + BK < k_end) {  // next tile's loads fly while this tile is in the matrix pipe
       ra = load_tile(A, a_rs, a_cs, m0, k0 + BK, M, K, mode_at(a_vec, k0 + BK));
       rb = load_tile(B, b_rs, b_cs, n0, k0 + BK, N, K, mode_at(b_vec, k0 + BK));
     }
@@ -103,7 +109,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   // epilogue: C = alpha * acc (+ C if flags&16) + bias[col] (or bias[row] if flags&32)
   const int col = n0 + wn + (lane & 31);
-  const bool accumulate = flags & 16, row_bias = flags & 32;
+  const bool accumulate = flags & 16, row_bias = flags & 32, split = flags & 64;
+  if (split && blockIdx.z != 0) bias = nullptr;
   if (col < N) {
     const float bv = (bias && !row_bias) ? bias[col] : 0.f;
 #pragma unroll
@@ -113,7 +120,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         float v = alpha * acc[r] + bv;
         if (bias && row_bias) v += bias[row];
         float* dst = C + (long)row * c_rs + col;
-        *dst = accumulate ? *dst + v : v;
+        if (split) atomicAdd(dst, v);
+        else *dst = accumulate ? *dst + v : v;
       }
     }
   }
@@ -193,9 +201,29 @@ extern "C" int ovis_gemm_ex_f32(const float* A, long a_row_stride, long a_k_stri
   else if (b_row_stride == 1 && b_k_stride % 4 == 0 && al16(B)) flags |= 8;
   if (accumulate) flags |= 16;
   if (bias_per_row) flags |= 32;
-  dim3 grid(ovis_ceil_div(N, BN), ovis_ceil_div(M, BM));
+  const int tiles = ovis_ceil_div(N, BN) * ovis_ceil_div(M, BM);
+  // split K until ~3 workgroups per CU are resident (12 waves / CU), keeping >= 8 k-steps per slice
+  int slices = 1;
+  if (c_row_stride >= N) {
+    while (slices < 8 && tiles * slices < 3 * OVIS_NUM_CU && K / (slices * 2) >= 8 * BK) slices *= 2;
+  }
+  int k_chunk = K;
+  if (slices > 1) {
+    k_chunk = ovis_ceil_div(ovis_ceil_div(K, slices), BK) * BK;
+    slices = ovis_ceil_div(K, k_chunk);
+  }
+  if (slices > 1) {
+    flags |= 64;
+    if (!accumulate) {  // partial tiles are added atomically: start from zeros
+      if (c_row_stride == N)
+        OVIS_HIP_TRY(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, (hipStream_t)stream));
+      else
+        OVIS_HIP_TRY(hipMemset2DAsync(C, sizeof(float) * c_row_stride, 0, sizeof(float) * N, M, (hipStream_t)stream));
+    }
+  }
+  dim3 grid(ovis_ceil_div(N, BN), ovis_ceil_div(M, BM), slices);
   hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, a_row_stride, a_k_stride, B,
-                     b_row_stride, b_k_stride, bias, C, c_row_stride, M, N, K, flags, alpha);
+                     b_row_stride, b_k_stride, bias, C, c_row_stride, M, N, K, flags, alpha, k_chunk);
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
 }
