@@ -132,7 +132,7 @@ class Bottleneck(nn.Module):
                 and c2.kernel_size[0] % 2 == 1 and c2.kernel_size[1] % 2 == 1
                 and c2.padding == (c2.kernel_size[0] // 2, c2.kernel_size[1] // 2)):
             # the 3x3 as a bf16 hi/lo split GEMM over its im2col rows (layers/cross_modal.py::split_conv_same)
-            out = split_conv_same(out.view(r, hs, ws, -1), w2)  # [r*hs*ws, Cout]
+            out = split_conv_same(out.view(r, hs, ws, out.shape[-1]), w2)  # [r*hs*ws, Cout]
             ho, wo = hs, ws
         else:
             nchw = self.conv3x3_nchw
@@ -142,11 +142,11 @@ class Bottleneck(nn.Module):
                 # MIOpen runs NHWC implicit-GEMM kernels for all three directions: the tensor stays channels_last
                 nchw = not (torch.is_grad_enabled() and (out.requires_grad or w2.requires_grad))
             if nchw:
-                out = F.conv2d(out.view(r, hs, ws, -1).permute(0, 3, 1, 2).contiguous(), w2, None, c2.stride,
+                out = F.conv2d(out.view(r, hs, ws, out.shape[-1]).permute(0, 3, 1, 2).contiguous(), w2, None, c2.stride,
                                c2.padding, c2.dilation, c2.groups)
                 out = out.permute(0, 2, 3, 1).contiguous()
             else:
-                out = F.conv2d(out.view(r, hs, ws, -1).permute(0, 3, 1, 2),
+                out = F.conv2d(out.view(r, hs, ws, out.shape[-1]).permute(0, 3, 1, 2),
                                w2.contiguous(memory_format=torch.channels_last), None, c2.stride, c2.padding,
                                c2.dilation, c2.groups)
                 out = out.permute(0, 2, 3, 1)
@@ -158,7 +158,7 @@ class Bottleneck(nn.Module):
         w3, b3 = self._f3[0].folded()
         (out,) = products(out, w3.view(w3.shape[0], -1))
         out = bias_relu_(out, b3 if bd is None else b3 + bd, idn if idn is not None else x.view(-1, c))
-        return out.view(r, ho, wo, -1)
+        return out.view(r, ho, wo, out.shape[-1])
 
 
 class Stem(nn.Module):

@@ -279,3 +279,23 @@ def test_res5_head_nhwc_paths_match_conv_path():
         # by O(1) -- compare in the L2 norm
         for a, b in zip(got[1:], ref[1:]):
             assert (a - b).norm().item() <= 5e-3 * b.norm().item(), cfg_  # fp32 NHWC alone: up to 1.1e-3
+
+
+def test_res5_head_nhwc_empty_and_single_roi():
+    """R = 0 (an image without positives) and R = 1 go through the split-GEMM path without special cases."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.backbone import ResNetHead
+
+    cfg = get_defaults()
+    cfg.freeze()
+    torch.manual_seed(0)
+    head = ResNetHead(cfg).cuda()
+    y0 = head(torch.zeros(0, 1024, 14, 14, device="cuda", requires_grad=True))
+    assert y0.shape == (0, 2048, 7, 7)
+    y0.sum().backward()
+    x1 = torch.randn(1, 1024, 14, 14, device="cuda")
+    head.nhwc = False
+    ref = head(x1)
+    head.nhwc = True
+    got = head(x1)
+    assert (got - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
