@@ -78,8 +78,13 @@ class OpTimer:
         def bias_act_bytes(y, bias=None, residual=None, relu=True):
             return (8 + (4 if residual is not None else 0)) * y.numel()
 
+        def roi_fwd_strided_bytes(inp, rois, scale, ph, pw, sr, bs):
+            n, c, h, w = inp.shape
+            return 4 * rois.shape[0] * c * (-(-ph // bs)) * (-(-pw // bs)) + 4 * n * c * h * w + 20 * rois.shape[0]
+
         self._wrap("roi_align_forward", roi_fwd_bytes)
         self._wrap("roi_align_forward_mfma", roi_fwd_bytes)
+        self._wrap("roi_align_forward_strided_nhwc", roi_fwd_strided_bytes)
         self._wrap("roi_align_backward", roi_bwd_bytes)
         self._wrap("nms_padded", nms_bytes)
         self._wrap("split_bf16x3", split_bytes)

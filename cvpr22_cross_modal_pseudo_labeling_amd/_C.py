@@ -65,6 +65,26 @@ def roi_align_forward_mfma(input, rois, spatial_scale, pooled_height, pooled_wid
     return _roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio, False)
 
 
+def roi_align_forward_strided_nhwc(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio, bin_stride):
+    """Extension: bins (bin_stride*i, bin_stride*j) only, as [R, ceil(PH/s), ceil(PW/s), C] (NHWC); bit-identical to
+    ``roi_align_forward(...)[:, :, ::s, ::s].permute(0, 2, 3, 1)``."""
+    input, rois = _dev(input, "input"), _dev(rois, "rois")
+    if rois.dim() != 2 or rois.size(1) != 5 or input.dim() != 4:
+        raise RuntimeError("roi_align_forward_strided_nhwc: expected input [N,C,H,W] and rois [R,5]")
+    n, c, h, w = input.shape
+    r = rois.size(0)
+    oh, ow = -(-pooled_height // bin_stride), -(-pooled_width // bin_stride)
+    out = torch.empty((r, oh, ow, c), dtype=input.dtype, device=input.device)
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(input.device):
+        rc = _L.ovis_roi_align_forward_strided_nhwc_f32(input.data_ptr(), rois.data_ptr(), out.data_ptr(), r, n, c, h,
+                                                        w, pooled_height, pooled_width, bin_stride, spatial_scale,
+                                                        sampling_ratio, _stream())
+    _lib.check(rc, "roi_align_forward_strided_nhwc")
+    return out
+
+
 def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels, height,
                        width, sampling_ratio):
     grad, rois = _dev(grad, "grad"), _dev(rois, "rois")

@@ -236,6 +236,170 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// Forward fused with the consumer's stride: the res5 head's first 1x1 convolution (and its projection
+// shortcut) has stride 2 (STRIDE_IN_1X1, resnet.py:155-204,258-275), so three quarters of the 14x14 pooled
+// bins are never read.  This variant pools only bins (bs*i, bs*j) and writes them as [R, OH, OW, C] (NHWC),
+// the layout the head's GEMMs want: a quarter of the output bytes, no strided slice / layout copy afterwards.
+// Per-bin arithmetic is the bit-exact kernel's, so out[r, i, j, c] == roi_align_forward(...)[r, c, bs*i, bs*j].
+// Work item = (output bin, 4-channel group): every lane pools one float4 and stores 16 contiguous bytes.
+// ---------------------------------------------------------------------------------------
+template <int NCS, bool FAST>
+__device__ __forceinline__ void fwd_pool4_strided(const f4* win4, int rs, const RoiGeom& g, int H, int W, int bs,
+                                                  int OH, int OW, float* __restrict__ out_rc, int C) {
+  constexpr int NG = NCS / 4;
+  constexpr int SG = kFwdLdsFloats / NCS;
+  const int items = OH * OW * NG;
+  for (int item = threadIdx.x; item < items; item += kThreads) {
+    const int k = item % NG, obin = item / NG;
+    const int oh = obin / OW;
+    const int ph = oh * bs, pw = (obin - oh * OW) * bs;
+    const f4* base = win4 + k * SG;
+    f4 acc = (f4)(0.f);
+    for (int iy = 0; iy < g.gh; ++iy) {
+      const float y = sample_coord_t<FAST>(g.start_h, ph, g.bin_h, iy, g.gh, g.inv_gh);
+      int yl, yh;
+      float ly, hy;
+      if (!axis_sample(y, H, yl, yh, ly, hy)) continue;
+      const int ryl = (yl - g.wy0) * rs, ryh = (yh - g.wy0) * rs;
+      for (int ix = 0; ix < g.gw; ++ix) {
+        const float x = sample_coord_t<FAST>(g.start_w, pw, g.bin_w, ix, g.gw, g.inv_gw);
+        int xl, xh;
+        float lx, hx;
+        if (!axis_sample(x, W, xl, xh, lx, hx)) continue;
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        acc += w1 * base[ryl + (xl - g.wx0)] + w2 * base[ryl + (xh - g.wx0)] + w3 * base[ryh + (xl - g.wx0)] +
+               w4 * base[ryh + (xh - g.wx0)];
+      }
+    }
+    const f4 o = FAST ? acc * g.inv_count : acc / g.count;
+    *(f4*)(out_rc + (long)obin * C + 4 * k) = o;
+  }
+}
+
+// Scalar-layout fallback (windows too large for four interleaved channels; `src` may be the global plane).
+template <int NCS>
+__device__ __forceinline__ void fwd_pool_strided(const float* src, int cs, int rs, int oy, int ox, const RoiGeom& g,
+                                                 int H, int W, int bs, int OH, int OW, float* __restrict__ out_rc,
+                                                 int C) {
+  for (int obin = threadIdx.x; obin < OH * OW; obin += kThreads) {
+    const int oh = obin / OW;
+    const int ph = oh * bs, pw = (obin - oh * OW) * bs;
+    float acc[NCS];
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) acc[c] = 0.f;
+    for (int iy = 0; iy < g.gh; ++iy) {
+      int yl, yh;
+      float ly, hy;
+      if (!axis_sample(sample_coord(g.start_h, ph, g.bin_h, iy, g.gh), H, yl, yh, ly, hy)) continue;
+      const int ryl = (yl - oy) * rs, ryh = (yh - oy) * rs;
+      for (int ix = 0; ix < g.gw; ++ix) {
+        int xl, xh;
+        float lx, hx;
+        if (!axis_sample(sample_coord(g.start_w, pw, g.bin_w, ix, g.gw), W, xl, xh, lx, hx)) continue;
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        const int o1 = ryl + (xl - ox), o2 = ryl + (xh - ox), o3 = ryh + (xl - ox), o4 = ryh + (xh - ox);
+#pragma unroll
+        for (int c = 0; c < NCS; ++c) {
+          const float* p = src + c * cs;
+          acc[c] += w1 * p[o1] + w2 * p[o2] + w3 * p[o3] + w4 * p[o4];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) out_rc[(long)obin * C + c] = acc[c] / g.count;
+  }
+}
+
+template <int NCS>
+__device__ __forceinline__ void stage_window4(float* win, const float* __restrict__ plane_c0, int HW, int W,
+                                              const RoiGeom& g, int wh, int ww) {
+  constexpr int NG = NCS / 4;
+  constexpr int SG = kFwdLdsFloats / NCS;
+  f4* win4 = (f4*)win;
+  const int warea = wh * ww;
+  const float inv_ww = 1.f / (float)ww;
+  for (int idx = threadIdx.x; idx < warea; idx += kThreads) {
+    const int y = (int)(((float)idx + 0.5f) * inv_ww);
+    const int x = idx - y * ww;
+    const int off = (g.wy0 + y) * W + (g.wx0 + x);
+    float v[NCS];
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) v[c] = (plane_c0 + (long)c * HW)[off];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      f4 t;
+      t.x = v[4 * k]; t.y = v[4 * k + 1]; t.z = v[4 * k + 2]; t.w = v[4 * k + 3];
+      win4[k * SG + idx] = t;
+    }
+  }
+}
+
+template <int NCS>
+__device__ __forceinline__ void strided_batch4(float* win, const float* __restrict__ plane, int HW, int H, int W,
+                                               const RoiGeom& g, int wh, int ww, int bs, int OH, int OW,
+                                               float* __restrict__ out_rc, int C) {
+  stage_window4<NCS>(win, plane, HW, W, g, wh, ww);
+  __syncthreads();
+  if (g.pow2)
+    fwd_pool4_strided<NCS, true>((const f4*)win, ww, g, H, W, bs, OH, OW, out_rc, C);
+  else
+    fwd_pool4_strided<NCS, false>((const f4*)win, ww, g, H, W, bs, OH, OW, out_rc, C);
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_strided_nhwc_kernel(
+    const float* __restrict__ in, const float* __restrict__ rois, float* __restrict__ out, int R, int batch, int C,
+    int H, int W, int PH, int PW, int bs, int OH, int OW, float scale, int sampling_ratio) {
+  __shared__ __attribute__((aligned(16))) float win[kFwdLdsFloats];
+  const int r = blockIdx.x % R;
+  const int ct = blockIdx.x / R;
+  const int c_begin = ct * kCPB;
+  const int c_end = min(C, c_begin + kCPB);
+  const int HW = H * W;
+  const RoiGeom g = make_geom(rois + (long)r * 5, scale, H, W, PH, PW, sampling_ratio, batch);
+  float* out_r = out + (long)r * OH * OW * C;
+  if (g.empty) {
+    for (int i = threadIdx.x; i < OH * OW * (c_end - c_begin); i += kThreads)
+      out_r[(long)(i / (c_end - c_begin)) * C + c_begin + i % (c_end - c_begin)] = 0.f;
+    return;
+  }
+  const int wh = g.wy1 - g.wy0 + 1, ww = g.wx1 - g.wx0 + 1;
+  const int warea = wh * ww;
+  const int cs_max = min(kMaxBatch, kFwdLdsFloats / warea);
+  const float* img = in + (long)g.b * C * HW;
+  const bool vec_ok = (C & 3) == 0;  // float4 stores need 16-byte aligned channel groups
+  int c = c_begin;
+  while (c < c_end) {
+    const int left = c_end - c;
+    const float* plane = img + (long)c * HW;
+    float* o = out_r + c;
+    const int n = min(left, cs_max);
+    if (n >= 16 && vec_ok) {
+      strided_batch4<16>(win, plane, HW, H, W, g, wh, ww, bs, OH, OW, o, C);
+      c += 16;
+    } else if (n >= 8 && vec_ok) {
+      strided_batch4<8>(win, plane, HW, H, W, g, wh, ww, bs, OH, OW, o, C);
+      c += 8;
+    } else if (n >= 4 && vec_ok) {
+      strided_batch4<4>(win, plane, HW, H, W, g, wh, ww, bs, OH, OW, o, C);
+      c += 4;
+    } else if (n >= 1) {  // one channel through LDS in the plain layout
+      for (int idx = threadIdx.x; idx < warea; idx += kThreads) {
+        const int y = idx / ww, x = idx - (idx / ww) * ww;
+        win[idx] = plane[(g.wy0 + y) * W + (g.wx0 + x)];
+      }
+      __syncthreads();
+      fwd_pool_strided<1>(win, warea, ww, g.wy0, g.wx0, g, H, W, bs, OH, OW, o, C);
+      __syncthreads();
+      c += 1;
+    } else {  // window larger than the LDS budget: gather from global
+      fwd_pool_strided<1>(plane, HW, W, 0, 0, g, H, W, bs, OH, OW, o, C);
+      c += 1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Backward
 //
 // Bilinear average pooling is separable: out = Ay * win * Ax^T with Ay[ph][y] the summed row
@@ -505,4 +669,23 @@ extern "C" int ovis_roi_align_forward_ws_f32(const float* input, const float* ro
                                               (hipStream_t)stream);
   return ovis_roi_align_forward_f32(input, rois, output, num_rois, batch, channels, height, width, pooled_h, pooled_w,
                                     spatial_scale, sampling_ratio, stream);
+}
+
+extern "C" int ovis_roi_align_forward_strided_nhwc_f32(const float* input, const float* rois, float* output,
+                                                       int num_rois, int batch, int channels, int height, int width,
+                                                       int pooled_h, int pooled_w, int bin_stride,
+                                                       float spatial_scale, int sampling_ratio, void* stream) {
+  if (num_rois < 0 || batch < 0 || channels < 0 || height <= 0 || width <= 0 || pooled_h <= 0 || pooled_w <= 0 ||
+      bin_stride <= 0)
+    return OVIS_EINVAL;
+  if (num_rois == 0 || channels == 0) return OVIS_OK;
+  if (!input || !rois || !output) return OVIS_EINVAL;
+  const int oh = (pooled_h + bin_stride - 1) / bin_stride, ow = (pooled_w + bin_stride - 1) / bin_stride;
+  const long blocks = (long)ovis_ceil_div(channels, kCPB) * num_rois;
+  if (blocks > 0x7fffffffL) return OVIS_ERANGE;
+  hipLaunchKernelGGL(roi_align_fwd_strided_nhwc_kernel, dim3((unsigned)blocks), dim3(kThreads), 0,
+                     (hipStream_t)stream, input, rois, output, num_rois, batch, channels, height, width, pooled_h,
+                     pooled_w, bin_stride, oh, ow, spatial_scale, sampling_ratio);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
 }

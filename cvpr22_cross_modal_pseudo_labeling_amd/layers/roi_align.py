@@ -32,6 +32,39 @@ class _ROIAlign(Function):
 roi_align = _ROIAlign.apply
 
 
+class _ROIAlignStridedNHWC(Function):
+    """RoIAlign fused with the stride of the layer that consumes it: only bins (s*i, s*j), NHWC output
+    [R, ceil(PH/s), ceil(PW/s), C] (``_C.roi_align_forward_strided_nhwc``).  Backward: the gradient of the
+    skipped bins is zero, so it is scattered into a zero [R, C, PH, PW] tile and handed to ``roi_align_backward``."""
+
+    @staticmethod
+    def forward(ctx, input, roi, output_size, spatial_scale, sampling_ratio, bin_stride):
+        ctx.save_for_backward(roi)
+        ctx.output_size = _pair(output_size)
+        ctx.spatial_scale = spatial_scale
+        ctx.sampling_ratio = sampling_ratio
+        ctx.bin_stride = bin_stride
+        ctx.input_shape = input.size()
+        return _C.roi_align_forward_strided_nhwc(input, roi, spatial_scale, ctx.output_size[0], ctx.output_size[1],
+                                                 sampling_ratio, bin_stride)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        (rois,) = ctx.saved_tensors
+        bs, ch, h, w = ctx.input_shape
+        ph, pw = ctx.output_size
+        s = ctx.bin_stride
+        full = grad_output.new_zeros((grad_output.shape[0], ch, ph, pw))
+        full[:, :, ::s, ::s] = grad_output.permute(0, 3, 1, 2)
+        grad_input = _C.roi_align_backward(full, rois, ctx.spatial_scale, ph, pw, bs, ch, h, w, ctx.sampling_ratio)
+        return grad_input, None, None, None, None, None
+
+
+def roi_align_strided_nhwc(input, rois, output_size, spatial_scale, sampling_ratio, bin_stride):
+    return _ROIAlignStridedNHWC.apply(input, rois, output_size, spatial_scale, sampling_ratio, bin_stride)
+
+
 class ROIAlign(nn.Module):
     def __init__(self, output_size, spatial_scale, sampling_ratio, matrix_core=False):
         """``matrix_core`` (extension, default off = the reference's bit-exact forward): pool on the bf16 matrix
@@ -45,6 +78,12 @@ class ROIAlign(nn.Module):
     @float_function
     def forward(self, input, rois):
         return roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.matrix_core)
+
+    @float_function
+    def forward_strided_nhwc(self, input, rois, bin_stride):
+        """Extension for a consumer that reads every ``bin_stride``-th bin in NHWC (the res5 head)."""
+        return roi_align_strided_nhwc(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio,
+                                      bin_stride)
 
     def __repr__(self):
         return (f"{self.__class__.__name__}(output_size={self.output_size}, "

@@ -91,8 +91,9 @@ class Bottleneck(nn.Module):
         return (c1.kernel_size == (1, 1) and c3.kernel_size == (1, 1) and c1.groups == 1 and c3.groups == 1
                 and c1.padding == (0, 0) and c3.padding == (0, 0) and c3.stride == (1, 1))
 
-    def forward_nhwc(self, x):
-        """Same block on an NHWC tensor ``x`` [R, H, W, C] (contiguous).  The 1x1 convolutions -- 53 % of the
+    def forward_nhwc(self, x, prestrided=False):
+        """Same block on an NHWC tensor ``x`` [R, H, W, C] (contiguous); ``prestrided``: x already holds only the
+        positions conv1 / the shortcut read (the pooler applied their common stride).  The 1x1 convolutions -- 53 % of the
         res5 FLOPs -- become ONE row-major GEMM over all R*H*W positions each ([R*H*W, Cin] x [Cin, Cout], bias
         = the folded FrozenBN shift) instead of R batched [Cout, Cin] x [Cin, 49] products behind layout
         transposes; a stride-2 1x1 (STRIDE_IN_1X1) first drops the rows it never reads.  By default the GEMMs run as
@@ -100,7 +101,11 @@ class Bottleneck(nn.Module):
         the fp32 GEMM); the 3x3 goes through MIOpen.  Values equal ``forward`` up to that error."""
         r, h, w, c = x.shape
         sy, sx = self.conv1.stride
-        xs = x[:, ::sy, ::sx, :].contiguous() if (sy, sx) != (1, 1) else x
+        if prestrided:
+            assert self._fd is None or self.downsample[0].stride == (sy, sx)
+            xs = x
+        else:
+            xs = x[:, ::sy, ::sx, :].contiguous() if (sy, sx) != (1, 1) else x
         hs, ws = xs.shape[1], xs.shape[2]
         x2d = xs.view(-1, c)
         # raw products (no bias): bf16 hi/lo split GEMMs on the bf16 matrix pipe (layers/cross_modal.py::split_linear)
@@ -118,7 +123,7 @@ class Bottleneck(nn.Module):
             wd, bd = self._fd[0].folded()
             wd = wd.view(wd.shape[0], -1)
             dy, dx = self.downsample[0].stride
-            if (dy, dx) == (sy, sx):  # conv1 and the projection shortcut read the same rows: one operand split
+            if prestrided or (dy, dx) == (sy, sx):  # conv1 and the projection shortcut read the same rows
                 out, idn = products(x2d, w1, wd)
             else:
                 (out,) = products(x2d, w1)
@@ -249,6 +254,7 @@ class ResNetHead(nn.Module):
                                   r.NUM_GROUPS, r.STRIDE_IN_1X1, first_stride=2, dilation=r.RES5_DILATION)
         self.out_channels = out_channels
         self.nhwc = os.environ.get("OVIS_RES5_NCHW", "0") != "1"
+        self.fuse_pooler = os.environ.get("OVIS_RES5_UNFUSED_POOLER", "0") != "1"
 
     def forward(self, x):
         """x [R, C, 14, 14] -> [R, 2048, 7, 7].  On the GPU the stage runs in NHWC with GEMM 1x1s
@@ -260,3 +266,18 @@ class ResNetHead(nn.Module):
                 y = b.forward_nhwc(y)
             return y.permute(0, 3, 1, 2)
         return self.layer4(x)
+
+    def pooler_stride(self):
+        """Stride the pooler may apply itself (``ROIAlign.forward_strided_nhwc``): the common stride of the first
+        block's conv1 and projection shortcut when the NHWC path is on, else 0."""
+        b0 = self.layer4[0]
+        s = b0.conv1.stride
+        ok = (self.nhwc and self.fuse_pooler and all(b.nhwc_supported() for b in self.layer4) and s[0] == s[1] and s[0] > 1
+              and (b0.downsample is None or b0.downsample[0].stride == s))
+        return s[0] if ok else 0
+
+    def forward_pooled_nhwc(self, y):
+        """y [R, 7, 7, C]: the pooled bins conv1 reads, NHWC (from ``forward_strided_nhwc``) -> [R, 2048, 7, 7] view."""
+        for i, b in enumerate(self.layer4):
+            y = b.forward_nhwc(y, prestrided=(i == 0))
+        return y.permute(0, 3, 1, 2)

@@ -53,6 +53,9 @@ class Pooler(nn.Module):
     def forward(self, x, boxes):
         return self.pooler(x[0], self.convert_to_roi_format(boxes))
 
+    def forward_strided_nhwc(self, x, boxes, bin_stride):
+        return self.pooler.forward_strided_nhwc(x[0], self.convert_to_roi_format(boxes), bin_stride)
+
 
 class ResNet50Conv5ROIFeatureExtractor(nn.Module):
     def __init__(self, cfg, head_cfg):
@@ -63,6 +66,9 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
         self.out_channels = self.head.out_channels
 
     def forward(self, x, proposals):
+        s = self.head.pooler_stride() if x[0].is_cuda else 0
+        if s:  # the head's first 1x1 has stride s: pool only the bins it reads, straight into NHWC
+            return self.head.forward_pooled_nhwc(self.pooler.forward_strided_nhwc(x, proposals, s))
         return self.head(self.pooler(x, proposals))
 
 

@@ -67,6 +67,17 @@ int ovis_roi_align_forward_ws_f32(const float* input, const float* rois, float* 
                                   int sampling_ratio, void* workspace, size_t workspace_bytes,
                                   void* stream);
 
+/* Forward fused with the consumer's stride (extension): pools only bins (bin_stride*i,
+ * bin_stride*j) and writes output [num_rois, ceil(pooled_h/bin_stride),
+ * ceil(pooled_w/bin_stride), channels] (NHWC).  The res5 head's first 1x1 convolution has
+ * stride 2 (mb/modeling/backbone/resnet.py:258-275, STRIDE_IN_1X1), so it never reads the other
+ * three quarters of the 14x14 tile.  Per-bin arithmetic is ovis_roi_align_forward_f32's:
+ * out[r,i,j,c] is bit-identical to that kernel's [r,c,bin_stride*i,bin_stride*j]. */
+int ovis_roi_align_forward_strided_nhwc_f32(const float* input, const float* rois, float* output,
+                                            int num_rois, int batch, int channels, int height,
+                                            int width, int pooled_h, int pooled_w, int bin_stride,
+                                            float spatial_scale, int sampling_ratio, void* stream);
+
 /* grad_input [batch, channels, height, width] is fully overwritten (zero-filled, then
  * accumulated into) by this call; the caller does not need to clear it. */
 int ovis_roi_align_backward_f32(const float* grad_output, const float* rois,

@@ -76,6 +76,37 @@ def test_roi_align_forward_matrix_core_edge_rois(C, oracle_mod):
     assert float(got[3].abs().max()) == 0.0  # the out-of-map RoI pools to exact zeros
 
 
+def test_roi_align_forward_strided_nhwc_bit_exact(C, golden_dir):
+    """The pooler fused with the consumer's stride: bins (2i, 2j) only, NHWC -- bit-identical to the same bins of the
+    bit-exact forward (all staging paths: 16/8/4-channel LDS batches, one-channel LDS, global gather; 70 channels =
+    two full 32-channel tiles + a partial one), and its backward equals the zero-scattered full backward."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers import ROIAlign
+
+    z = np.load(os.path.join(golden_dir, "roi_align_forward.npz"))
+    x, rois, scale = torch.from_numpy(z["input"]).cuda(), torch.from_numpy(z["rois"]).cuda(), float(z["scale"])
+    for (ph, sr, s) in [(14, 0, 2), (14, 2, 2), (7, 0, 2), (14, 0, 3)]:
+        full = C.roi_align_forward(x, rois, scale, ph, ph, sr)
+        got = C.roi_align_forward_strided_nhwc(x, rois, scale, ph, ph, sr, s)
+        assert torch.equal(got, full[:, :, ::s, ::s].permute(0, 2, 3, 1)), (ph, sr, s)
+    g = torch.Generator().manual_seed(8)
+    xb = torch.randn(2, 70, 50, 84, generator=g).cuda()
+    rb = torch.cat([_rois(g, 40, 2, 1333, 800, 8, 900), torch.tensor([[0, 0.0, 0.0, 1332.0, 799.0]])]).cuda()
+    full = C.roi_align_forward(xb, rb, 1 / 16, 14, 14, 0)
+    assert torch.equal(C.roi_align_forward_strided_nhwc(xb, rb, 1 / 16, 14, 14, 0, 2), full[:, :, ::2, ::2].permute(0, 2, 3, 1))
+    big = torch.randn(1, 5, 120, 160, generator=g).cuda()  # whole-map RoI: 19200-cell window -> global gather path
+    rbig = torch.tensor([[0, 0.0, 0.0, 2559.0, 1919.0], [0, 30.0, 40.0, 900.0, 700.0]]).cuda()
+    assert torch.equal(C.roi_align_forward_strided_nhwc(big, rbig, 1 / 16, 14, 14, 0, 2),
+                       C.roi_align_forward(big, rbig, 1 / 16, 14, 14, 0)[:, :, ::2, ::2].permute(0, 2, 3, 1))
+    # autograd: same gradient as slicing the full layer's output
+    layer = ROIAlign((14, 14), 1 / 16, 0)
+    xa = xb[:, :6].clone().requires_grad_(True)
+    xc = xb[:, :6].clone().requires_grad_(True)
+    go = torch.randn(rb.shape[0], 7, 7, 6, generator=g).cuda()
+    (layer.forward_strided_nhwc(xa, rb, 2) * go).sum().backward()
+    (layer(xc, rb)[:, :, ::2, ::2].permute(0, 2, 3, 1) * go).sum().backward()
+    assert torch.equal(xa.grad, xc.grad)
+
+
 def test_roi_align_forward_large_map_global_path(C, oracle_mod):
     # 120x160 = 19200-cell window for the whole-image RoI: exceeds the LDS window budget
     g = torch.Generator().manual_seed(3)

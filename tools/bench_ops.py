@@ -69,6 +69,11 @@ def main():
                 ms = timeit(lambda: _C.roi_align_forward(x, rois, 1 / 16, 14, 14, 0), args.iters)
                 res.append({"op": "roi_align_forward", "rois": kind, "ms": ms, "alg_MB": alg / 1e6,
                             "GBps": alg / ms / 1e6, "frac_hbm": alg / ms / 1e6 / HBM_PEAK_GBS})
+            if "roi_fwd" in ops:
+                ms = timeit(lambda: _C.roi_align_forward_strided_nhwc(x, rois, 1 / 16, 14, 14, 0, 2), args.iters)
+                alg_s = 4 * r * c * 49 + 4 * n * c * h * w + 20 * r
+                res.append({"op": "roi_align_forward_strided_nhwc(s=2)", "rois": kind, "ms": ms, "alg_MB": alg_s / 1e6,
+                            "GBps": alg_s / ms / 1e6, "frac_hbm": alg_s / ms / 1e6 / HBM_PEAK_GBS})
             if "roi_bwd" in ops:
                 go = torch.randn(r, c, 14, 14, generator=g).to(dev)
                 ms = timeit(lambda: _C.roi_align_backward(go, rois, 1 / 16, 14, 14, n, c, h, w, 0), args.iters)
