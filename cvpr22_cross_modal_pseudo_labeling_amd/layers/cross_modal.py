@@ -67,7 +67,6 @@ class _SplitLinearMulti(Function):
     def backward(ctx, *dys):
         xs, *ws = ctx.saved_tensors
         k = ctx.k
-        x_hi, x_lo = xs[:, :k], xs[:, 2 * k:]
         dx = None
         grads = []
         for i, (dy, w) in enumerate(zip(dys, ws)):
@@ -78,10 +77,11 @@ class _SplitLinearMulti(Function):
                 dx = d if dx is None else dx.add_(d)
             dw = None
             if ctx.needs_input_grad[1 + 2 * i]:
-                dy_hi, dy_lo = dys_[:, :n], dys_[:, 2 * n:]
-                dw = torch.mm(dy_hi.t(), x_hi, out_dtype=torch.float32)                       # dY^T X, M-contraction
-                dw += torch.mm(dy_hi.t(), x_lo, out_dtype=torch.float32)
-                dw += torch.mm(dy_lo.t(), x_hi, out_dtype=torch.float32)
+                # dY^T X by M-contraction as ONE GEMM: columns N..3N of dys_ are [dY_hi | dY_lo], columns K..3K of the
+                # saved operand are [X_hi | X_lo], so [dY_hi | dY_lo]^T [X_hi | X_lo] holds all four hi/lo products
+                # as quadrants (the lo.lo one comes for free and is kept)
+                q = torch.mm(dys_[:, n:].t(), xs[:, k:], out_dtype=torch.float32)             # [2N, 2K]
+                dw = (q[:n, :k] + q[:n, k:]) + (q[n:, :k] + q[n:, k:])
             db = dy.sum(0) if (ctx.has_bias[i] and ctx.needs_input_grad[2 + 2 * i]) else None
             grads += [dw, db]
         return (dx, *grads)
@@ -121,11 +121,10 @@ class _SplitConvSame(Function):
                           out_dtype=torch.float32).view(r, h, wd, c)
         if ctx.needs_input_grad[1]:
             dys = _C.split_bf16x3(dy.view(-1, n), 0)                                 # [M, 3N] = [hi | hi | lo]
-            dy_hi, dy_lo = dys[:, :n], dys[:, 2 * n:]
-            x_hi, x_lo = rows[:, : t * c], rows[:, 2 * t * c:]
-            dwm = torch.mm(dy_hi.t(), x_hi, out_dtype=torch.float32)                 # [N, T*C], M-contraction
-            dwm += torch.mm(dy_hi.t(), x_lo, out_dtype=torch.float32)
-            dwm += torch.mm(dy_lo.t(), x_hi, out_dtype=torch.float32)
+            tc = t * c
+            # one M-contracting GEMM for all four hi/lo products: [dY_hi | dY_lo]^T [rows_hi | rows_lo] -> quadrants
+            q = torch.mm(dys[:, n:].t(), rows[:, tc:], out_dtype=torch.float32)      # [2N, 2*T*C]
+            dwm = (q[:n, :tc] + q[:n, tc:]) + (q[n:, :tc] + q[n:, tc:])
             dw = dwm.view(n, kh, kw, c).permute(0, 3, 1, 2)
         return dx, dw
 
