@@ -119,51 +119,60 @@ extern "C" int ovis_bias_act_f32(float* y, const float* bias, const float* resid
 //   tap t = (ky, kx) reads pixel (y + ky - KH/2, x + kx - KW/2), zeros outside the map; with `flip` the taps
 //   are taken in reverse order (the data-gradient convolution uses the 180-degree rotated kernel).
 // Against a mode-1 split of the weight matrix [Cout, T*C] this is the three-term product of split_bf16x3.
-// HBM-bound: every source element is read 9x from L2 and written 3 x T times as bf16 (27 x 2 B).
+// HBM-bound: every source element is read once and written 3 x T times as bf16 (27 x 2 B for a 3x3).
 // ---------------------------------------------------------------------------------------------------
 namespace {
+// Scatter form: a thread owns (source pixel, V channels), reads them ONCE, splits them once and writes the result
+// into the T rows whose neighbourhood contains that pixel (row of pixel p - offset(t), tap t); the taps of its own
+// row that fall outside the map are zero-filled by the same thread.  HBM traffic = source once + rows once (the
+// gather form re-read every source element T times and fetched 3.3x the source from beyond L2).
 template <int V>  // channels per thread: 8 (16-byte stores) when channels % 8 == 0, else 4
 __global__ __launch_bounds__(256) void im2col_split_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
                                                           long pixels, int H, int W, int C, int KH, int KW, int flip) {
   const int qc = C / V;
   const int T = KH * KW;
-  const long total = pixels * T * qc;
+  const long total = pixels * qc;
   const long TC = (long)T * C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % qc) * V;
-    const long mt = i / qc;
-    const int t = (int)(mt % T);
-    const long m = mt / T;
+    const long m = i / qc;
     const int x = (int)(m % W);
     const int y = (int)((m / W) % H);
-    const int ts = flip ? T - 1 - t : t;
-    const int yy = y + ts / KW - KH / 2, xx = x + ts % KW - KW / 2;
     unsigned hi[V / 2], lo[V / 2];
+    const float* p = src + m * C + c;
 #pragma unroll
-    for (int k = 0; k < V / 2; ++k) hi[k] = lo[k] = 0u;
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-      const float* p = src + ((m - x - (long)y * W) + (long)yy * W + xx) * C + c;
-#pragma unroll
-      for (int k = 0; k < V / 4; ++k) {
-        const float4 v = *(const float4*)(p + 4 * k);
-        const unsigned h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
-        hi[2 * k] = h01;
-        hi[2 * k + 1] = h23;
-        lo[2 * k] = pack_bf16(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
-        lo[2 * k + 1] = pack_bf16(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
-      }
+    for (int k = 0; k < V / 4; ++k) {
+      const float4 v = *(const float4*)(p + 4 * k);
+      const unsigned h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
+      hi[2 * k] = h01;
+      hi[2 * k + 1] = h23;
+      lo[2 * k] = pack_bf16(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+      lo[2 * k + 1] = pack_bf16(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
     }
-    unsigned short* d = dst + m * 3 * TC + (long)t * C + c;
-    if (V == 8) {
-      const uint4 h = make_uint4(hi[0], hi[1], hi[2], hi[3]), l = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-      *(uint4*)d = h;
-      *(uint4*)(d + TC) = h;
-      *(uint4*)(d + 2 * TC) = l;
-    } else {
-      const uint2 h = make_uint2(hi[0], hi[1]), l = make_uint2(lo[0], lo[1]);
-      *(uint2*)d = h;
-      *(uint2*)(d + TC) = h;
-      *(uint2*)(d + 2 * TC) = l;
+    for (int t = 0; t < T; ++t) {
+      const int ts = flip ? T - 1 - t : t;
+      const int dy = ts / KW - KH / 2, dx = ts % KW - KW / 2;  // row (y', x') reads pixel (y' + dy, x' + dx) at tap t
+      unsigned short* own = dst + m * 3 * TC + (long)t * C + c;
+      if (y + dy < 0 || y + dy >= H || x + dx < 0 || x + dx >= W) {  // this row's tap t is outside the map: zeros
+        if (V == 8) {
+          const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+          *(uint4*)own = z; *(uint4*)(own + TC) = z; *(uint4*)(own + 2 * TC) = z;
+        } else {
+          const uint2 z = make_uint2(0u, 0u);
+          *(uint2*)own = z; *(uint2*)(own + TC) = z; *(uint2*)(own + 2 * TC) = z;
+        }
+      }
+      const int yr = y - dy, xr = x - dx;  // the row whose tap t is this pixel
+      if (yr >= 0 && yr < H && xr >= 0 && xr < W) {
+        unsigned short* d = dst + (m - (long)dy * W - dx) * 3 * TC + (long)t * C + c;
+        if (V == 8) {
+          const uint4 h = make_uint4(hi[0], hi[1], hi[2], hi[3]), l = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+          *(uint4*)d = h; *(uint4*)(d + TC) = h; *(uint4*)(d + 2 * TC) = l;
+        } else {
+          const uint2 h = make_uint2(hi[0], hi[1]), l = make_uint2(lo[0], lo[1]);
+          *(uint2*)d = h; *(uint2*)(d + TC) = h; *(uint2*)(d + 2 * TC) = l;
+        }
+      }
     }
   }
 }
@@ -178,7 +187,7 @@ extern "C" int ovis_im2col_split_bf16x3_f32(const float* src, void* dst_bf16, lo
   if (channels % 4 != 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst_bf16 & 7)) return OVIS_ERANGE;
   const long pixels = num * height * width;
   const bool wide = channels % 8 == 0 && ((uintptr_t)dst_bf16 & 15) == 0;
-  const long total = pixels * kh * kw * (channels / (wide ? 8 : 4));
+  const long total = pixels * (channels / (wide ? 8 : 4));
   const long blocks = (total + 255) / 256;
   const unsigned grid = (unsigned)(blocks < 16L * OVIS_NUM_CU ? blocks : 16L * OVIS_NUM_CU);
   if (wide)

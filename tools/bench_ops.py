@@ -49,7 +49,7 @@ def bench_rois(r, n_img, g, kind="uniform"):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--ops", default="roi_fwd,roi_bwd,nms,focal,gemm,dcn")
+    ap.add_argument("--ops", default="roi_fwd,roi_bwd,nms,focal,gemm,dcn,res5")
     ap.add_argument("--iters", type=int, default=20)
     args = ap.parse_args()
     ops = args.ops.split(",")
@@ -81,6 +81,24 @@ def main():
                             "GBps": alg / ms / 1e6, "frac_hbm": alg / ms / 1e6 / HBM_PEAK_GBS})
                 del go
         del x
+    if "res5" in ops:  # byte kernels of the NHWC res5 head at the student pass's shapes (R = 1024 -> M = 50176 rows)
+        m = 1024 * 49
+        for cols in (512, 1024, 2048):
+            xm = torch.randn(m, cols, generator=g).to(dev)
+            ms = timeit(lambda: _C.split_bf16x3(xm, 0), args.iters)
+            res.append({"op": "split_bf16x3", "shape": f"{m}x{cols}", "ms": ms, "alg_MB": 10 * xm.numel() / 1e6,
+                        "GBps": 10 * xm.numel() / ms / 1e6, "frac_hbm": 10 * xm.numel() / ms / 1e6 / HBM_PEAK_GBS})
+            ym = torch.randn(m, cols, generator=g).to(dev)
+            bm = torch.randn(cols, generator=g).to(dev)
+            ms = timeit(lambda: _C.bias_act_(ym, bm, xm, True), args.iters)
+            res.append({"op": "bias_act(+shortcut)", "shape": f"{m}x{cols}", "ms": ms, "alg_MB": 12 * xm.numel() / 1e6,
+                        "GBps": 12 * xm.numel() / ms / 1e6, "frac_hbm": 12 * xm.numel() / ms / 1e6 / HBM_PEAK_GBS})
+            del xm, ym
+        xi = torch.randn(1024, 7, 7, 512, generator=g).to(dev)
+        ms = timeit(lambda: _C.im2col_split_bf16x3(xi, 3, 3), args.iters)
+        res.append({"op": "im2col_split_bf16x3", "shape": "[1024,7,7,512] 3x3", "ms": ms, "alg_MB": 58 * xi.numel() / 1e6,
+                    "GBps": 58 * xi.numel() / ms / 1e6, "frac_hbm": 58 * xi.numel() / ms / 1e6 / HBM_PEAK_GBS})
+        del xi
     if "nms" in ops:
         for k in (6000, 12000):
             xy = torch.rand(k, 2, generator=g) * torch.tensor([1200.0, 720.0])
