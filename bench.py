@@ -155,10 +155,11 @@ def cpu_baseline(workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="student", choices=["student", "teacher"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="plain sequential step (no side-stream overlap)")
     ap.add_argument("--channels-last", action="store_true", help="experiment: run the trunk / heads in NHWC")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen exhaustive find)")
     args = ap.parse_args()
@@ -215,15 +216,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Student-teacher workload: two-stream software pipeline (engine/trainer.py::PipelinedTrainer) -- the frozen half
+    # (trunk, RPN, teacher pseudo-labelling) of step k+1 overlaps the student backward of step k.  Every timed step
+    # still executes one frozen half and one student half; the synthetic batch is the same resident tensor each step.
+    pipe = trainer.PipelinedTrainer(model, optimizer, reducer, scheduler)
+    if args.no_pipeline:
+        pipe.enabled = False
+    nxt = (images, targets)
     for _ in range(args.warmup):
-        trainer.train_step(model, optimizer, reducer, images, targets, scheduler)
+        pipe.step(images, targets, nxt)
     sync()
     timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss_dict = trainer.train_step(model, optimizer, reducer, images, targets, scheduler)
+        loss_dict = pipe.step(images, targets, nxt)
     sync()
     elapsed = time.perf_counter() - t0
+    pipe.drain()
     timer.enabled = False
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)

@@ -26,6 +26,114 @@ def train_step(model, optimizer, reducer, images, targets, scheduler=None):
     return loss_dict
 
 
+def _record_stream(obj, stream):
+    """Tell the caching allocator that every tensor reachable from ``obj`` is (also) used on ``stream``."""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream)
+    elif hasattr(obj, "bbox") and hasattr(obj, "extra_fields"):  # BoxList
+        _record_stream(obj.bbox, stream)
+        _record_stream(obj.extra_fields, stream)
+
+
+class PipelinedTrainer:
+    """Student-teacher step, software-pipelined across iterations on two HIP streams.
+
+    Trunk, RPN and teacher heads are frozen in the student-teacher configuration, so features, proposals and pseudo
+    labels of batch i+1 (``model.forward_frozen``) do not depend on the optimizer step of batch i.  That half is
+    host-bound (hundreds of small kernels between host syncs: NMS counts, ``nonzero`` ...) while the student half
+    is GPU-bound (res5 GEMMs, backward), and run back to back each leaves the other resource idle (14 % of the
+    wall time in the un-pipelined step).  Here the frozen half of the NEXT batch is enqueued on a side stream
+    right after the backward of the current batch has been enqueued on the main stream: its host syncs only wait
+    for the side stream, and its small kernels fill the gaps of the main stream instead of waiting behind them.
+    Results are those of the plain step (same modules, same weights); only the order in which independent work
+    reaches the GPU changes.  Models without a frozen half (teacher training) fall back to ``train_step``."""
+
+    def __init__(self, model, optimizer, reducer, scheduler=None, threaded=True):
+        self.model, self.optimizer, self.reducer, self.scheduler = model, optimizer, reducer, scheduler
+        self.enabled = hasattr(model, "forward_frozen") and torch.cuda.is_available()
+        self.side = torch.cuda.Stream() if self.enabled else None
+        self.pending = None  # (key, frozen outputs, event recorded on the side stream)
+        # threaded: the frozen half of the next batch is ISSUED by a worker thread concurrently with the student half
+        # (both halves are host-bound between their own host syncs, which release the GIL), not after it
+        self.threaded = threaded
+        self.worker = None
+        self.worker_error = None
+
+    def _frozen_on_side(self, images, targets, after_event, device):
+        try:
+            torch.cuda.set_device(device)
+            with torch.cuda.stream(self.side):
+                if after_event is not None:
+                    self.side.wait_event(after_event)
+                frozen = self.model.forward_frozen(images, targets)
+                done = torch.cuda.Event()
+                done.record(self.side)
+            self.pending = ((id(images), id(targets)), frozen, done)
+        except BaseException as e:  # re-raised on the training thread
+            self.worker_error = e
+
+    def _launch_frozen(self, images, targets, after_event=None, threaded=False):
+        device = torch.cuda.current_device()
+        if threaded:
+            import threading
+            self.worker = threading.Thread(target=self._frozen_on_side, args=(images, targets, after_event, device))
+            self.worker.start()
+        else:
+            self._frozen_on_side(images, targets, after_event, device)
+            self._check_worker()
+
+    def _check_worker(self):
+        if self.worker is not None:
+            self.worker.join()
+            self.worker = None
+        if self.worker_error is not None:
+            e, self.worker_error = self.worker_error, None
+            raise e
+
+    def step(self, images, targets, next_batch=None):
+        """One optimisation step on (images, targets); ``next_batch`` = the (images, targets) of the following call
+        (already resident on the device), whose frozen half is started before this call returns."""
+        if not self.enabled:
+            return train_step(self.model, self.optimizer, self.reducer, images, targets, self.scheduler)
+        main = torch.cuda.current_stream()
+        inputs_ready = torch.cuda.Event()
+        inputs_ready.record(main)  # uploads of this and the next batch precede this point on the main stream
+        self._check_worker()
+        if self.pending is None or self.pending[0] != (id(images), id(targets)):
+            self._launch_frozen(images, targets, inputs_ready)  # cold start / unexpected batch: no overlap
+        _, frozen, done = self.pending
+        self.pending = None
+        main.wait_event(done)
+        _record_stream(frozen, main)
+        if next_batch is not None and self.threaded:
+            self._launch_frozen(next_batch[0], next_batch[1], inputs_ready, threaded=True)
+        self.reducer.zero_grad()
+        loss_dict = self.model.forward_student(frozen, targets)
+        losses = sum(loss for loss in loss_dict.values())
+        losses.backward()
+        self.reducer.finish()
+        self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        if next_batch is not None and not self.threaded:
+            # the GPU now has the whole backward queued: overlap the next frozen half with it
+            self._launch_frozen(next_batch[0], next_batch[1], inputs_ready)
+        return loss_dict
+
+    def drain(self):
+        self._check_worker()
+        if self.pending is not None:
+            self.pending[2].synchronize()
+            self.pending = None
+
+
 def do_train(cfg, model, data_iter, optimizer, scheduler, max_iter, start_iter=0, log_period=None, logger=None):
     logger = logger or logging.getLogger("ovis.trainer")
     log_period = log_period or cfg.SOLVER.LOG_PERIOD

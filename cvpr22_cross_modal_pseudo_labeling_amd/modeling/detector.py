@@ -92,16 +92,21 @@ class STGeneralizedRCNN(nn.Module):
     def set_class_embeddings(self, embs):
         """Seen-class matrix with the all-zero background row 0 (engine/trainer.py:85-90)."""
         self.roi_heads["box"].predictor.set_class_embeddings(embs)
+        # own reference: generate_pseudo_label swaps the teacher predictor's matrix for a dummy while it runs, and the
+        # frozen half may be running on another thread (engine/trainer.py::PipelinedTrainer)
+        self._seen_cls = self.roi_heads["box"].predictor.cls_score
 
     def combine_embs(self, embs):
         # exemplar bank is empty (see module docstring) -> st_generalized_rcnn.py:165-166
         return F.normalize(embs, dim=-1)
 
     def prepare_model(self):
-        student, teacher = self.roi_heads_student["box"].predictor, self.roi_heads["box"].predictor
-        if student.cls_score is None or student.cls_score.shape != teacher.cls_score.shape \
-                or not torch.equal(student.cls_score, teacher.cls_score):
-            student.cls_score = teacher.cls_score
+        student = self.roi_heads_student["box"].predictor
+        seen = getattr(self, "_seen_cls", None)
+        if seen is None:
+            seen = self.roi_heads["box"].predictor.cls_score
+        if student.cls_score is None:  # every pass sets the matrix it needs; this only covers first use
+            student.cls_score = seen
         if self.iter == 0 and not self.resume:
             self.roi_heads_student.load_state_dict(copy.deepcopy(self.roi_heads.state_dict()), strict=False)
             self.iter += 1
@@ -156,13 +161,22 @@ class STGeneralizedRCNN(nn.Module):
             _, result, _ = student(features, proposals, targets)
             return result
 
-        self.prepare_model()
-        dummy_loss = self.compute_dummy_loss()
-        feat = features[0]
+        frozen = self.forward_frozen(images, targets, features=features)
+        return self.forward_student(frozen, targets, eps=eps)
 
-        # ---- pseudo branch: images that come with caption nouns ------------------------------------------
+    @torch.no_grad()
+    def forward_frozen(self, images, targets, features=None):
+        """Everything of the training step that only uses FROZEN modules (trunk, RPN, teacher heads; __init__ turns
+        their gradients off): features, proposals of both branches and the teacher's pseudo labels.  It does not
+        depend on the student's weights, so ``engine.trainer.PipelinedTrainer`` runs it for batch i+1 on a side
+        stream while the student forward / backward of batch i occupies the main stream."""
+        images = to_image_list(images)
+        if features is None:
+            features = self.backbone(images.tensors)
+        feat = features[0]
+        out = {"feat": feat}
         idxs_cap = [i for i, t in enumerate(targets) if t.has_field("ids_cap") and len(t.get_field("ids_cap")) > 0]
-        loss_pseudo = {}
+        out["idxs_cap"] = idxs_cap
         if idxs_cap:
             self.rpn.eval()
             proposals, _ = self.rpn(images, features, None)
@@ -171,9 +185,29 @@ class STGeneralizedRCNN(nn.Module):
             cap_targets = [targets[i] for i in idxs_cap]
             noun_embs = [t.get_field("cap_embs") if t.has_field("cap_embs") else self.cap_embs[t.get_field("ids_cap")]
                          for t in cap_targets]
-            pseudo_targets = self.generate_pseudo_label(cap_features, cap_proposals, noun_embs, cap_targets)
+            out["cap_features"] = cap_features
+            out["cap_proposals"] = cap_proposals
+            out["pseudo_targets"] = self.generate_pseudo_label(cap_features, cap_proposals, noun_embs, cap_targets)
+        idxs_gt = [i for i, t in enumerate(targets) if t.has_field("is_det") and t.get_field("is_det") == "Yes"]
+        out["idxs_gt"] = idxs_gt
+        if idxs_gt:
+            self.rpn.train()
+            proposals_target, _ = self.rpn(images, features, targets, compute_loss=False)
+            out["gt_features"] = [feat[idxs_gt]]
+            out["gt_proposals"] = [proposals_target[i] for i in idxs_gt]
+        return out
+
+    def forward_student(self, frozen, targets, eps=None):
+        """The trainable half of the step: both student passes and their losses on the outputs of ``forward_frozen``."""
+        student = self.roi_heads_student
+        self.prepare_model()
+        dummy_loss = self.compute_dummy_loss()
+
+        # ---- pseudo branch: images that come with caption nouns ------------------------------------------
+        loss_pseudo = {}
+        if frozen["idxs_cap"]:
             student["box"].predictor.set_class_embeddings(self.combine_embs(self.cap_embs))
-            _, _, loss_pseudo = student(cap_features, cap_proposals, pseudo_targets,
+            _, _, loss_pseudo = student(frozen["cap_features"], frozen["cap_proposals"], frozen["pseudo_targets"],
                                         compute_uncertain=self.uncertainty, eps=eps)
             for k in loss_pseudo:
                 if self.uncertainty and self.reweight:
@@ -190,16 +224,11 @@ class STGeneralizedRCNN(nn.Module):
             losses[f"{k}_pseudo"] = v
 
         # ---- seen-class branch: images with box / mask ground truth -----------------------------------------
-        idxs_gt = [i for i, t in enumerate(targets) if t.has_field("is_det") and t.get_field("is_det") == "Yes"]
         loss_gt = {}
-        if idxs_gt:
-            self.rpn.train()
-            proposals_target, _ = self.rpn(images, features, targets, compute_loss=False)
-            gt_features = [feat[idxs_gt]]
-            gt_proposals = [proposals_target[i] for i in idxs_gt]
-            gt_targets = [targets[i] for i in idxs_gt]
-            student["box"].predictor.set_class_embeddings(self.combine_embs(self.roi_heads["box"].predictor.cls_score))
-            _, _, loss_gt = student(gt_features, gt_proposals, gt_targets, compute_uncertain=False)
+        if frozen["idxs_gt"]:
+            gt_targets = [targets[i] for i in frozen["idxs_gt"]]
+            student["box"].predictor.set_class_embeddings(self.combine_embs(self._seen_cls))
+            _, _, loss_gt = student(frozen["gt_features"], frozen["gt_proposals"], gt_targets, compute_uncertain=False)
         for k in self.LOSS_NAMES:
             losses[k] = loss_gt.get(k, dummy_loss)
 
