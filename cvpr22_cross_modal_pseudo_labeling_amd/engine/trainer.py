@@ -139,15 +139,30 @@ def do_train(cfg, model, data_iter, optimizer, scheduler, max_iter, start_iter=0
     log_period = log_period or cfg.SOLVER.LOG_PERIOD
     model.train()
     reducer = comm.BucketedGradReducer(model)
+    pipe = PipelinedTrainer(model, optimizer, reducer, scheduler)  # plain train_step for models without a frozen half
     start = time.time()
     last = start
     history = []
+
+    def fetch():
+        try:
+            return next(data_iter)
+        except StopIteration:
+            return None
+
+    batch = fetch()
     for iteration in range(start_iter, max_iter):
-        images, targets = next(data_iter)
+        if batch is None:
+            break
+        images, targets = batch
+        nxt = fetch() if iteration + 1 < max_iter else None  # one batch of look-ahead feeds the side-stream half
         if any(len(t) < 1 for t in targets):  # trainer.py:96-98
             logger.error("iteration %d skipped: an image has no targets", iteration + 1)
+            batch = nxt
             continue
-        loss_dict = train_step(model, optimizer, reducer, images, targets, scheduler)
+        ok_next = nxt is not None and not any(len(t) < 1 for t in nxt[1])
+        loss_dict = pipe.step(images, targets, nxt if ok_next else None)
+        batch = nxt
         if (iteration + 1) % log_period == 0 or iteration + 1 == max_iter:
             reduced = comm.reduce_loss_dict(loss_dict)  # the only host sync of the loop
             if comm.get_rank() == 0:
@@ -158,6 +173,7 @@ def do_train(cfg, model, data_iter, optimizer, scheduler, max_iter, start_iter=0
                             "  ".join(f"{k} {v:.4f}" for k, v in vals.items()), optimizer.param_groups[0]["lr"],
                             (now - last) / log_period)
                 last = now
+    pipe.drain()
     reducer.remove()
     total = time.time() - start
     logger.info("Total training time: %.1f s (%.4f s / it)", total, total / max(max_iter - start_iter, 1))
