@@ -217,6 +217,7 @@ class ResNetC4(nn.Module):
             self.stages.append(name)
             in_channels = out_channels
         self.out_channels = in_channels
+        self.nhwc = os.environ.get("OVIS_TRUNK_NCHW", "0") != "1"
         self._freeze(cfg.MODEL.BACKBONE.FREEZE_CONV_BODY_AT)
 
     def _freeze(self, freeze_at):
@@ -227,6 +228,17 @@ class ResNetC4(nn.Module):
 
     def forward(self, x):
         x = self.stem(x)
+        blocks = [b for name in self.stages for b in getattr(self, name)]
+        if (x.is_cuda and self.nhwc and not any(p.requires_grad for p in self.parameters())
+                and all(b.nhwc_supported() for b in blocks)):
+            # fully frozen trunk (student-teacher configuration): layer1-3 in NHWC with the split-GEMM bottlenecks of
+            # the res5 head (1x1 = row-major GEMM, 3x3 = GEMM over split-im2col rows); one layout copy in (64
+            # channels) and one out (the C4 map, 34 MB).  With trainable stages (teacher training) MIOpen's
+            # backward kernels at these large spatial sizes are faster than the im2col route: 55 vs 69 ms per step.
+            y = x.permute(0, 2, 3, 1).contiguous()
+            for b in blocks:
+                y = b.forward_nhwc(y)
+            return [y.permute(0, 3, 1, 2).contiguous()]
         for name in self.stages:
             x = getattr(self, name)(x)
         return [x]
