@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="student", choices=["student", "teacher"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--burn-seconds", type=float, default=3.0, help="GPU clock warm-up before the warm-up steps")
     ap.add_argument("--no-pipeline", action="store_true", help="plain sequential step (no side-stream overlap)")
     ap.add_argument("--channels-last", action="store_true", help="experiment: run the trunk / heads in NHWC")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen exhaustive find)")
@@ -219,6 +220,15 @@ def main():
     # Student-teacher workload: two-stream software pipeline (engine/trainer.py::PipelinedTrainer) -- the frozen half
     # (trunk, RPN, teacher pseudo-labelling) of step k+1 overlaps the student backward of step k.  Every timed step
     # still executes one frozen half and one student half; the synthetic batch is the same resident tensor each step.
+    # Device warm-up (not a training step): a fresh, idle GPU takes a few seconds of load to reach its sustained clocks,
+    # and the first process on a box measured 12-20 % slower without it.
+    burn = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    t_burn = time.perf_counter()
+    while time.perf_counter() - t_burn < args.burn_seconds:
+        for _ in range(20):
+            burn @ burn
+        torch.cuda.synchronize()
+    del burn
     pipe = trainer.PipelinedTrainer(model, optimizer, reducer, scheduler)
     if args.no_pipeline:
         pipe.enabled = False
