@@ -236,13 +236,30 @@ def main():
     for _ in range(args.warmup):
         pipe.step(images, targets, nxt)
     sync()
-    timer.enabled = True
+    overlapped = pipe.enabled
+    timer.enabled = not overlapped  # sequential workloads: per-kernel HIP-event timing live in the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss_dict = pipe.step(images, targets, nxt)
     sync()
     elapsed = time.perf_counter() - t0
     pipe.drain()
+    timer.enabled = False
+    replay_steps = 0
+    if overlapped:
+        # In the pipelined step two streams share the GPU, so an event pair around one kernel also spans kernels of the
+        # other stream.  The per-kernel roofline figures therefore come from a sequential replay of the same step
+        # right after the timed region (same launches, one stream); `value` is the pipelined, timed region only.
+        replay_steps = max(3, args.steps // 4)
+        pipe.enabled = False
+        for _ in range(2):  # settle the caching allocator on the single-stream allocation pattern first
+            pipe.step(images, targets, nxt)
+        sync()
+        timer.enabled = True
+        for _ in range(replay_steps):
+            pipe.step(images, targets, nxt)
+        sync()
+        timer.enabled = False
     timer.enabled = False
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -272,9 +289,12 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{name}.yaml R-50-C4, {IMS_PER_GPU} img/GPU 3x800x1333, fwd+bwd+allreduce+SGD",
-                       "global_batch": global_batch, "parallelism": f"dp{world}", "losses_finite": finite},
+                       "global_batch": global_batch, "parallelism": f"dp{world}", "losses_finite": finite,
+                       "pipelined": bool(overlapped)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": k["achieved_GBps"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": k["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None},
+                         "unit": "GB/s", "frac": k["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None,
+                         "measured_in": (f"{replay_steps} sequential replay steps after the timed region (the timed "
+                                         "steps overlap two streams)") if replay_steps else "the timed region"},
             "kernels": {n: {kk: round(vv, 3) if isinstance(vv, float) else vv for kk, vv in v.items()}
                         for n, v in kernels.items()},
         }
