@@ -197,6 +197,106 @@ def im2col_split_bf16x3(x, kh, kw, flip=False):
     return out
 
 
+def split_pair(x):
+    """x [rows, cols] f32 (row-strided view ok, cols % 32 == 0) -> pair layout [rows, 2*cols] bf16: per 32 values
+    [hi(32) | lo(32)].  See include/ovis_hip.h."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2:
+        raise RuntimeError("split_pair: 2-D float32 HIP tensor expected")
+    if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
+        x = x.contiguous()
+    rows, cols = x.shape
+    out = torch.empty((rows, 2 * cols), dtype=torch.bfloat16, device=x.device)
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(x.device):
+        rc = _L.ovis_split_pair_f32(x.data_ptr(), x.stride(0), out.data_ptr(), rows, cols, _stream())
+    _lib.check(rc, "split_pair")
+    return out
+
+
+def gate_split_pair(dy, gate=None, want_f32=False):
+    """g = dy * (y > 0) in pair layout (and as fp32 when ``want_f32``); gate = y as fp32 [rows, cols] or as its pair
+    form [rows, 2*cols] bf16 (contiguous), None = plain split.  Returns (g_pair, g_f32 or None)."""
+    if not (dy.is_cuda and dy.dtype == torch.float32 and dy.dim() == 2):
+        raise RuntimeError("gate_split_pair: 2-D float32 HIP tensor expected")
+    if dy.stride(1) != 1 or dy.stride(0) % 4 or dy.data_ptr() % 16:
+        dy = dy.contiguous()
+    rows, cols = dy.shape
+    is_pair = 0
+    if gate is not None:
+        is_pair = int(gate.dtype == torch.bfloat16)
+        if not (gate.is_cuda and gate.is_contiguous() and gate.shape == (rows, cols * (2 if is_pair else 1))
+                and gate.dtype in (torch.bfloat16, torch.float32)):
+            raise RuntimeError("gate_split_pair: gate must be the contiguous fp32 or pair form of the forward output")
+    out = torch.empty((rows, 2 * cols), dtype=torch.bfloat16, device=dy.device)
+    g32 = torch.empty((rows, cols), dtype=torch.float32, device=dy.device) if want_f32 else None
+    if out.numel() == 0:
+        return out, g32
+    with torch.cuda.device(dy.device):
+        rc = _L.ovis_gate_split_pair_f32(dy.data_ptr(), dy.stride(0), 0 if gate is None else gate.data_ptr(), is_pair,
+                                         out.data_ptr(), 0 if g32 is None else g32.data_ptr(), rows, cols, _stream())
+    _lib.check(rc, "gate_split_pair")
+    return out, g32
+
+
+def im2col_pair(xp, h, w, kh, kw):
+    """xp [R*h*w, 2*C] pair rows of an NHWC tensor -> [R*h*w, 2*kh*kw*C] pair rows (tap-major, zero rows outside
+    the map): the M-contracting operand of a 3x3 weight gradient."""
+    if not (xp.is_cuda and xp.dtype == torch.bfloat16 and xp.dim() == 2 and xp.is_contiguous()):
+        raise RuntimeError("im2col_pair: contiguous 2-D bfloat16 HIP tensor (pair layout) expected")
+    m, c2 = xp.shape
+    if m % (h * w):
+        raise RuntimeError("im2col_pair: rows must be a multiple of h*w")
+    out = torch.empty((m, kh * kw * c2), dtype=torch.bfloat16, device=xp.device)
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(xp.device):
+        rc = _L.ovis_im2col_pair(xp.data_ptr(), out.data_ptr(), m // (h * w), h, w, c2 // 2, kh, kw, _stream())
+    _lib.check(rc, "im2col_pair")
+    return out
+
+
+def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f32=True, out_pair=False, conv=None,
+                    tile_m=0):
+    """act(A @ B^T + bias + residual) with A [M, 2*ch] / B [N, 2*K] in pair layout (``split_pair``); fp32-accurate
+    three-term bf16 hi/lo product on the matrix cores (csrc/split_gemm.hip).  conv = (h, w, kh, kw, flip): A is an
+    NHWC tensor [M/(h*w), h, w, ch] and B holds [N, kh*kw*ch] tap-major weights -- stride-1 "same" convolution as an
+    implicit GEMM.  Returns (C f32 [M, N] or None, C in pair layout [M, 2*N] or None)."""
+    for t, name in ((a_pair, "a_pair"), (b_pair, "b_pair")):
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1):
+            raise RuntimeError(f"split_gemm_pair: {name} must be a 2-D bfloat16 HIP tensor in pair layout")
+    m, ch = a_pair.shape[0], a_pair.shape[1] // 2
+    n, k = b_pair.shape[0], b_pair.shape[1] // 2
+    h = w = 0
+    kh = kw = 1
+    flip = False
+    if conv is not None:
+        h, w, kh, kw, flip = conv
+        if m % (h * w):
+            raise RuntimeError("split_gemm_pair: rows must be a multiple of h*w")
+    if k != kh * kw * ch:
+        raise RuntimeError(f"split_gemm_pair: contraction mismatch (A has {ch} channels x {kh * kw} taps, B has {k})")
+    dev = a_pair.device
+    c = torch.empty((m, n), dtype=torch.float32, device=dev) if out_f32 else None
+    cp = torch.empty((m, 2 * n), dtype=torch.bfloat16, device=dev) if out_pair else None
+    if m == 0 or n == 0:
+        return c, cp
+    if bias is not None:
+        bias = _dev(bias, "bias")
+    if residual is not None and not (residual.is_cuda and residual.dtype == torch.float32 and residual.dim() == 2
+                                     and residual.stride(1) == 1 and residual.shape == (m, n)):
+        raise RuntimeError("split_gemm_pair: residual must be a float32 [M, N] HIP tensor with unit column stride")
+    with torch.cuda.device(dev):
+        rc = _L.ovis_split_gemm_pair(a_pair.data_ptr(), 2 * a_pair.stride(0), b_pair.data_ptr(), 2 * b_pair.stride(0),
+                                     0 if c is None else c.data_ptr(), n, 0 if cp is None else cp.data_ptr(), 4 * n,
+                                     0 if bias is None else bias.data_ptr(),
+                                     0 if residual is None else residual.data_ptr(),
+                                     0 if residual is None else residual.stride(0), m, n, ch, kh, kw, h, w,
+                                     int(bool(flip)), int(bool(relu)), tile_m, _stream())
+    _lib.check(rc, "split_gemm_pair")
+    return c, cp
+
+
 def bias_act_(y, bias=None, residual=None, relu=True):
     """In place: y[rows, cols] = act(y + bias[col] (+ residual)); contiguous f32, cols % 4 == 0."""
     if not (y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.is_contiguous()):

@@ -1,0 +1,454 @@
+// fp32-accurate GEMM / implicit-GEMM convolution on the bf16 matrix cores of gfx950, operands in "pair" layout.
+//
+//   C[M, N] = epilogue( sum_k A[m, k] * B[n, k] ),   A, B fp32 values carried as bf16 hi + lo
+//
+// x = hi + lo + O(2^-17 |x|), hi = bf16(x), lo = bf16(x - hi); the product keeps hi.hi + hi.lo + lo.hi, accumulated
+// in fp32 by v_mfma_f32_16x16x32_bf16 (relative error ~4e-6, cf. 1.7e-6 for an fp32 GEMM).  Unlike the K-concatenated
+// form ([hi | hi | lo] x [hi | lo | hi] through a library GEMM, split_bf16.hip) the three products share their
+// operand fragments here: per 32-deep k-step a wave reads 4 fragments kinds (A_hi, A_lo, B_hi, B_lo) from LDS and
+// issues 3 MFMAs per fragment pair, so the kernel moves 2/3 of the bytes and 4/9 of the LDS reads per MFMA of a plain
+// bf16 GEMM over 3K -- that is what lets a simple one-barrier-per-k-step structure keep the matrix cores busy.
+//
+// PAIR LAYOUT (written by split_pair_kernel / im2col_pair_kernel / this kernel's epilogue): a row of K values
+// (K % 32 == 0) is K/32 blocks of 128 bytes: [ hi(32 x bf16) | lo(32 x bf16) ].  One k-step of one row is one full
+// 128-byte line, fetched by 8 lanes of a global_load_lds_dwordx4 (no VGPR round trip).
+//
+// IMPLICIT CONVOLUTION: with T = KH*KW > 1 the A operand is an NHWC tensor [R, H, W, ch] in pair layout and
+// k = (tap, channel): row m = (r, y, x) reads pixel (y + dy, x + dx) of tap (dy, dx) ("same" zero padding, stride 1;
+// `flip` negates the offsets = the data-gradient convolution).  Rows outside the map read a 128-byte line of zeros.
+// No im2col matrix exists anywhere: the 9 shifted reads of a pixel hit L2.
+//
+// Tile: (WM x 64) x 128 per workgroup of 2*WM waves, wave tile 64 x 64 (4 x 4 MFMA tiles, 64 accumulator VGPRs),
+// two LDS stages of BM x 128 B (A) + 128 x 128 B (B); the 16-byte chunk index of a row is XOR-ed with (row >> 1) & 7
+// (applied to the SOURCE address of the LDS-DMA, so the LDS image stays lane-linear) which makes every ds_read_b128
+// of a 16-row fragment conflict-free.  Accumulators are computed transposed (D[n][m]) so that a lane owns 4
+// consecutive columns of C: 16-byte stores, float4 bias / residual reads, 8-byte pair stores.
+// Workgroups are renumbered so that each XCD owns a contiguous range of tiles (column tiles of one row tile are
+// co-resident on one L2: the A rows are fetched from HBM once).
+#include "ovis_common.h"
+
+namespace {
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ char g_zero_line[128];  // zero-initialised: the line an out-of-map tap reads
+
+struct SplitGemmArgs {
+  const char* A; long a_rs;          // pair rows of `ch` values (bytes per row = 4 * ch for a dense tensor)
+  const char* B; long b_rs;          // [N] pair rows of K = T * ch values
+  float* C; long ldc;                // fp32 result (may be null)
+  char* Cp; long cp_rs;              // pair result (may be null), bytes per row
+  const float* bias; const float* res; long ldr;
+  long M; int N; int ch; int T; int H; int W; int KH; int KW; int flip; int relu;
+};
+
+__device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  f2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));
+}
+
+template <int WM, bool CONV, int NS>
+__global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, int tiles_n, int nblocks) {
+  constexpr int BM = WM * 64, BN = 128, NW = WM * 2;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int AI = BM / 8 / NW;  // LDS-DMA instructions per wave per stage for A (8 rows each): 4
+  constexpr int BI = BN / 8 / NW;  // for B: 4 (WM = 2) or 2 (WM = 4)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // XCD-aware renumbering (bijective for any nblocks): workgroup b runs on XCD b % 8
+  int tile;
+  {
+    const int b = blockIdx.x, q = nblocks >> 3, r = nblocks & 7, xcd = b & 7, loc = b >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+  const long m0 = (long)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  // ---- per-lane load geometry (no memory reads: hipcc would wait vmcnt(0) on them inside the DMA pipeline) ----
+  const int lrow = lane >> 3;        // row within an 8-row DMA piece
+  const int lchunk = lane & 7;       // 16-byte slot within the 128-byte LDS row
+  constexpr bool conv = CONV;
+  long a_off[AI];                    // byte offset of the lane's source row (chunk swizzle included)
+  int a_yx[AI];                      // (y << 16) | x of that row, for the tap bounds test
+  int a_lds[AI];                     // wave-uniform LDS offset of the piece inside a stage
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int piece = wave * AI + i;           // 8-row piece of the A tile
+    const int row = piece * 8 + lrow;
+    int gm = (int)m0 + row;                    // M < 2^31 (checked by the launcher)
+    if (gm > (int)p.M - 1) gm = (int)p.M - 1;  // tail rows: valid memory, results never stored
+    const int chunk = lchunk ^ ((row >> 1) & 7);
+    a_off[i] = (long)gm * p.a_rs + chunk * 16;
+    a_lds[i] = piece * 1024;
+    int x = 0, y = 0;
+    if (conv) {
+      x = gm % p.W;
+      y = (gm / p.W) % p.H;
+    }
+    a_yx[i] = (y << 16) | x;
+  }
+  long b_off[BI];
+  int b_lds[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int piece = wave * BI + i;
+    const int row = piece * 8 + lrow;
+    int gn = n0 + row;
+    if (gn > p.N - 1) gn = p.N - 1;
+    const int chunk = lchunk ^ ((row >> 1) & 7);
+    b_off[i] = (long)gn * p.b_rs + chunk * 16;
+    b_lds[i] = A_BYTES + piece * 1024;
+  }
+  const char* zero_src = g_zero_line + lchunk * 16;
+
+  const int cpb = p.ch >> 5;         // 32-value blocks per tap
+  const int nk = p.T * cpb;
+  int ld_tap = 0, ld_cb = 0;         // (tap, channel block) of the next stage to load
+  int dy = 0, dx = 0;
+  auto set_tap = [&](int t) {
+    if (conv) {
+      dy = t / p.KW - p.KH / 2;
+      dx = t % p.KW - p.KW / 2;
+      if (p.flip) { dy = -dy; dx = -dx; }
+    }
+  };
+  set_tap(0);
+
+  auto issue = [&](int stage, int kb) {
+    char* base = smem + stage * STAGE;
+    const long a_shift = conv ? ((long)dy * p.W + dx) * p.a_rs + (long)ld_cb * 128 : (long)kb * 128;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const char* src = p.A + a_off[i] + a_shift;
+      if (conv) {
+        const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xffff) + dx;
+        if ((unsigned)y >= (unsigned)p.H || (unsigned)x >= (unsigned)p.W) src = zero_src;
+      }
+      glds16(src, base + a_lds[i]);
+    }
+    const long b_shift = (long)kb * 128;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) glds16(p.B + b_off[i] + b_shift, base + b_lds[i]);
+    if (++ld_cb == cpb) {
+      ld_cb = 0;
+      set_tap(++ld_tap);
+    }
+  };
+
+  // ---- fragment read addresses ----
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 15, fc = lane >> 4;
+  int a_rd[4], b_rd[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int ra = wm * 64 + f * 16 + frow;
+    a_rd[f] = ra * 128 + ((fc ^ ((ra >> 1) & 7)) << 4);
+    const int rb = wn * 64 + f * 16 + frow;
+    b_rd[f] = A_BYTES + rb * 128 + ((fc ^ ((rb >> 1) & 7)) << 4);
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // NS == 2: one __syncthreads per k-step (its fence drains this wave's DMAs: stage kb landed, stage kb-1's buffer
+  // free), the next stage in flight under the MFMAs.  NS == 3: a ring with TWO stages in flight -- the wait is a
+  // counted vmcnt that leaves the younger stage outstanding, and the barrier is a raw s_barrier (a __syncthreads
+  // would drain the DMA queue: an LDS-DMA is a pending LDS write on the VM counter).
+  issue(0, 0);
+  if (NS == 3 && nk > 1) issue(1, 1);
+  int st = 0;  // ring slot of stage kb
+  for (int kb = 0; kb < nk; ++kb) {
+    if (NS == 2) {
+      __syncthreads();
+      if (kb + 1 < nk) issue((kb + 1) & 1, kb + 1);
+    } else {
+      if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kb + 2 < nk) issue(st == 0 ? 2 : st - 1, kb + 2);
+    }
+    const char* base = smem + st * STAGE;
+    st = (st + 1 == NS) ? 0 : st + 1;
+    bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      bh[f] = *(const bf16x8*)(base + b_rd[f]);
+      ah[f] = *(const bf16x8*)(base + a_rd[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      bl[f] = *(const bf16x8*)(base + (b_rd[f] ^ 64));
+      al[f] = *(const bf16x8*)(base + (a_rd[f] ^ 64));
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[g], ah[f], acc[f][g], 0, 0, 0);
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[g], al[f], acc[f][g], 0, 0, 0);
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[g], ah[f], acc[f][g], 0, 0, 0);
+  }
+
+  // ---- epilogue: lane owns row m = .. + (lane & 15), columns n = .. + (lane >> 4) * 4 + {0..3} of each tile ----
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const long m = m0 + wm * 64 + f * 16 + frow;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + wn * 64 + g * 16 + fc * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[f][g];
+      if (p.bias) {
+        const f32x4 b = *(const f32x4*)(p.bias + n);
+        v += b;
+      }
+      if (p.res) {
+        const f32x4 r = *(const f32x4*)(p.res + m * p.ldr + n);
+        v += r;
+      }
+      if (p.relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      if (p.C) *(f32x4*)(p.C + m * p.ldc + n) = v;
+      if (p.Cp) {
+        const unsigned h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
+        const unsigned l01 = pack_bf16(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+        const unsigned l23 = pack_bf16(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+        char* d = p.Cp + m * p.cp_rs + (long)(n >> 5) * 128 + (n & 31) * 2;
+        *(uint2*)d = make_uint2(h01, h23);
+        *(uint2*)(d + 64) = make_uint2(l01, l23);
+      }
+    }
+  }
+}
+
+// fp32 [rows, cols] (row stride src_rs floats) -> pair layout [rows, cols/32 x (hi32 | lo32)] bf16; a thread owns 8
+// values: 32 B read, 16 B + 16 B written.  HBM-bound: 8 B per element.
+__global__ __launch_bounds__(256) void split_pair_kernel(const float* __restrict__ src, long src_rs,
+                                                        char* __restrict__ dst, long rows, int cols) {
+  const int oc = cols >> 3;  // 8-value groups per row
+  const long total = rows * oc;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / oc;
+    const int c = (int)(i - r * oc) * 8;
+    const float4 v0 = *(const float4*)(src + r * src_rs + c), v1 = *(const float4*)(src + r * src_rs + c + 4);
+    const unsigned h0 = pack_bf16(v0.x, v0.y), h1 = pack_bf16(v0.z, v0.w), h2 = pack_bf16(v1.x, v1.y),
+                   h3 = pack_bf16(v1.z, v1.w);
+    const unsigned l0 = pack_bf16(v0.x - __uint_as_float(h0 << 16), v0.y - __uint_as_float(h0 & 0xffff0000u));
+    const unsigned l1 = pack_bf16(v0.z - __uint_as_float(h1 << 16), v0.w - __uint_as_float(h1 & 0xffff0000u));
+    const unsigned l2 = pack_bf16(v1.x - __uint_as_float(h2 << 16), v1.y - __uint_as_float(h2 & 0xffff0000u));
+    const unsigned l3 = pack_bf16(v1.z - __uint_as_float(h3 << 16), v1.w - __uint_as_float(h3 & 0xffff0000u));
+    char* d = dst + r * 4L * cols + (long)(c >> 5) * 128 + (c & 31) * 2;
+    *(uint4*)d = make_uint4(h0, h1, h2, h3);
+    *(uint4*)(d + 64) = make_uint4(l0, l1, l2, l3);
+  }
+}
+
+// ReLU gate of a backward pass fused with the operand split of the gated gradient: g = dy * (y > 0), written in
+// pair layout (the operand of the dX / dW GEMMs) and optionally as fp32 (the shortcut branch needs it).  The gate
+// reads either the saved fp32 output y or only the hi half of its pair form (bf16 rounding keeps the sign and maps
+// no normal positive value to zero).  8 values per thread; 4 (+2 or +4) B read, 4 (+4) B written per element.
+template <bool GATE_PAIR, bool WRITE_F32>
+__global__ __launch_bounds__(256) void gate_split_pair_kernel(const float* __restrict__ dy, long dy_rs,
+                                                             const void* __restrict__ gate, char* __restrict__ dst,
+                                                             float* __restrict__ g32, long rows, int cols) {
+  const int oc = cols >> 3;
+  const long total = rows * oc;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / oc;
+    const int c = (int)(i - r * oc) * 8;
+    float v[8];
+    *(float4*)v = *(const float4*)(dy + r * dy_rs + c);
+    *(float4*)(v + 4) = *(const float4*)(dy + r * dy_rs + c + 4);
+    const long poff = r * 4L * cols + (long)(c >> 5) * 128 + (c & 31) * 2;
+    if (gate) {
+      if (GATE_PAIR) {
+        const uint4 h = *(const uint4*)((const char*)gate + poff);  // 8 bf16 hi values: positive iff 0 < bits < 0x8000
+        const unsigned w[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned a = w[k] & 0xffffu, b = w[k] >> 16;
+          if (a == 0u || a >= 0x8000u) v[2 * k] = 0.f;
+          if (b == 0u || b >= 0x8000u) v[2 * k + 1] = 0.f;
+        }
+      } else {
+        float y[8];
+        *(float4*)y = *(const float4*)((const float*)gate + r * (long)cols + c);
+        *(float4*)(y + 4) = *(const float4*)((const float*)gate + r * (long)cols + c + 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (!(y[k] > 0.f)) v[k] = 0.f;
+      }
+    }
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      h[k] = pack_bf16(v[2 * k], v[2 * k + 1]);
+      l[k] = pack_bf16(v[2 * k] - __uint_as_float(h[k] << 16), v[2 * k + 1] - __uint_as_float(h[k] & 0xffff0000u));
+    }
+    *(uint4*)(dst + poff) = make_uint4(h[0], h[1], h[2], h[3]);
+    *(uint4*)(dst + poff + 64) = make_uint4(l[0], l[1], l[2], l[3]);
+    if (WRITE_F32) {
+      *(float4*)(g32 + r * (long)cols + c) = *(float4*)v;
+      *(float4*)(g32 + r * (long)cols + c + 4) = *(float4*)(v + 4);
+    }
+  }
+}
+
+// Pair-layout im2col (only for the weight gradient of a 3x3, which contracts over the rows): src [R,H,W,C] pair
+// layout -> dst [R*H*W, T*C] pair layout, tap-major; out-of-map taps are zero rows.  Pure 16-byte copies: a thread
+// moves one 16-byte slot of one (pixel, tap).  4 B/element read (L2-served re-reads), 4*T B/element written.
+__global__ __launch_bounds__(256) void im2col_pair_kernel(const char* __restrict__ src, char* __restrict__ dst,
+                                                         long pixels, int H, int W, int C, int KH, int KW) {
+  const int slots = C >> 2;  // 16-byte slots per pixel row (4*C bytes)
+  const int T = KH * KW;
+  const long total = pixels * T * slots;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int s = (int)(i % slots);
+    const long mt = i / slots;
+    const int t = (int)(mt % T);
+    const long m = mt / T;
+    const int x = (int)(m % W), y = (int)((m / W) % H);
+    const int yy = y + t / KW - KH / 2, xx = x + t % KW - KW / 2;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+      v = *(const uint4*)(src + (m + (long)(yy - y) * W + (xx - x)) * 4L * C + s * 16L);
+    *(uint4*)(dst + (m * T + t) * 4L * C + s * 16L) = v;
+  }
+}
+}  // namespace
+
+extern "C" int ovis_split_pair_f32(const float* src, long src_row_stride, void* dst_pair, long rows, int cols,
+                                   void* stream) {
+  if (rows < 0 || cols < 0) return OVIS_EINVAL;
+  if (rows == 0 || cols == 0) return OVIS_OK;
+  if (!src || !dst_pair) return OVIS_EINVAL;
+  if (cols % 32 != 0 || src_row_stride % 4 != 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst_pair & 15))
+    return OVIS_ERANGE;
+  const long total = rows * (cols / 8);
+  const long blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 8L * OVIS_NUM_CU ? blocks : 8L * OVIS_NUM_CU);
+  hipLaunchKernelGGL(split_pair_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, src_row_stride,
+                     (char*)dst_pair, rows, cols);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}
+
+extern "C" int ovis_gate_split_pair_f32(const float* dy, long dy_row_stride, const void* gate, int gate_is_pair,
+                                        void* dst_pair, float* g_f32, long rows, int cols, void* stream) {
+  if (rows < 0 || cols < 0) return OVIS_EINVAL;
+  if (rows == 0 || cols == 0) return OVIS_OK;
+  if (!dy || !dst_pair) return OVIS_EINVAL;
+  if (cols % 32 != 0 || dy_row_stride % 4 != 0 || ((uintptr_t)dy & 15) || ((uintptr_t)dst_pair & 15) ||
+      ((uintptr_t)gate & 15) || ((uintptr_t)g_f32 & 15))
+    return OVIS_ERANGE;
+  const long total = rows * (cols / 8);
+  const long blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 8L * OVIS_NUM_CU ? blocks : 8L * OVIS_NUM_CU);
+  hipStream_t s = (hipStream_t)stream;
+#define OVIS_GS(GP_, WF_)                                                                                          \
+  hipLaunchKernelGGL((gate_split_pair_kernel<GP_, WF_>), dim3(grid), dim3(256), 0, s, dy, dy_row_stride, gate,      \
+                     (char*)dst_pair, g_f32, rows, cols)
+  if (gate_is_pair) { if (g_f32) OVIS_GS(true, true); else OVIS_GS(true, false); }
+  else { if (g_f32) OVIS_GS(false, true); else OVIS_GS(false, false); }
+#undef OVIS_GS
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}
+
+extern "C" int ovis_im2col_pair(const void* src_pair, void* dst_pair, long num, int height, int width, int channels,
+                                int kh, int kw, void* stream) {
+  if (num < 0 || height <= 0 || width <= 0 || channels < 0 || kh <= 0 || kw <= 0 || !(kh & 1) || !(kw & 1))
+    return OVIS_EINVAL;
+  if (num == 0 || channels == 0) return OVIS_OK;
+  if (!src_pair || !dst_pair) return OVIS_EINVAL;
+  if (channels % 32 != 0 || ((uintptr_t)src_pair & 15) || ((uintptr_t)dst_pair & 15)) return OVIS_ERANGE;
+  const long total = num * height * width * kh * kw * (channels / 4);
+  const long blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 16L * OVIS_NUM_CU ? blocks : 16L * OVIS_NUM_CU);
+  hipLaunchKernelGGL(im2col_pair_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char*)src_pair,
+                     (char*)dst_pair, num * height * width, height, width, channels, kh, kw);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}
+
+extern "C" int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
+                                    float* c, long ldc, void* c_pair, long c_pair_row_bytes, const float* bias,
+                                    const float* residual, long ldr, long m, int n, int channels, int taps_h,
+                                    int taps_w, int height, int width, int flip, int relu, int tile_m,
+                                    void* stream) {
+  if (m < 0 || n < 0 || channels < 0 || taps_h <= 0 || taps_w <= 0 || !(taps_h & 1) || !(taps_w & 1))
+    return OVIS_EINVAL;
+  if (m == 0 || n == 0) return OVIS_OK;
+  if (!a_pair || !b_pair || (!c && !c_pair) || channels == 0 || m > 0x7fffff00L) return OVIS_EINVAL;
+  const int T = taps_h * taps_w;
+  if (T > 1 && (height <= 0 || width <= 0 || height > 32767 || width > 32767)) return OVIS_EINVAL;
+  if (channels % 32 != 0 || n % 4 != 0 || (c_pair && n % 32 != 0) || a_row_bytes % 16 != 0 || b_row_bytes % 16 != 0 ||
+      ((uintptr_t)a_pair & 15) || ((uintptr_t)b_pair & 15) || ((uintptr_t)c & 15) || ((uintptr_t)c_pair & 15) ||
+      ((uintptr_t)bias & 15) || ((uintptr_t)residual & 15) || ldc % 4 != 0 || ldr % 4 != 0 ||
+      c_pair_row_bytes % 16 != 0)
+    return OVIS_ERANGE;
+  int stages = 2;
+  if (tile_m >= 1000) { stages = tile_m / 1000; tile_m %= 1000; }
+  if ((tile_m != 0 && tile_m != 128 && tile_m != 256) || (stages != 2 && stages != 3)) return OVIS_ERANGE;
+  SplitGemmArgs p;
+  p.A = (const char*)a_pair; p.a_rs = a_row_bytes;
+  p.B = (const char*)b_pair; p.b_rs = b_row_bytes;
+  p.C = c; p.ldc = ldc; p.Cp = (char*)c_pair; p.cp_rs = c_pair_row_bytes;
+  p.bias = bias; p.res = residual; p.ldr = ldr;
+  p.M = m; p.N = n; p.ch = channels; p.T = T; p.H = height; p.W = width; p.KH = taps_h; p.KW = taps_w;
+  p.flip = flip; p.relu = relu;
+  const int tiles_n = (n + 127) / 128;
+  hipStream_t s = (hipStream_t)stream;
+  // 256-row tiles halve the B (weight) re-reads and the LDS reads per MFMA are the same; they pay once there are
+  // enough tiles to fill the chip twice over
+  int bm = tile_m;
+  if (bm == 0) bm = ((m + 255) / 256) * tiles_n >= 2L * OVIS_NUM_CU ? 256 : 128;
+  const long tiles_m = (m + bm - 1) / bm;
+  const long nblocks = tiles_m * tiles_n;
+  if (nblocks > 0x7fffffffL) return OVIS_ERANGE;
+#define OVIS_SG_LAUNCH(WM_, CONV_, NS_)                                                                         \
+  do {                                                                                                          \
+    constexpr int lds = NS_ * (WM_ * 64 * 128 + 128 * 128);                                                     \
+    static bool attr_set = false;                                                                               \
+    if (!attr_set) {                                                                                            \
+      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<WM_, CONV_, NS_>,                         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));                       \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    hipLaunchKernelGGL((split_gemm_kernel<WM_, CONV_, NS_>), dim3((unsigned)nblocks), dim3(WM_ * 128), lds, s,  \
+                       p, tiles_n, (int)nblocks);                                                               \
+  } while (0)
+  if (bm == 256) {
+    if (stages == 3) { if (T > 1) OVIS_SG_LAUNCH(4, true, 3); else OVIS_SG_LAUNCH(4, false, 3); }
+    else { if (T > 1) OVIS_SG_LAUNCH(4, true, 2); else OVIS_SG_LAUNCH(4, false, 2); }
+  } else {
+    if (stages == 3) { if (T > 1) OVIS_SG_LAUNCH(2, true, 3); else OVIS_SG_LAUNCH(2, false, 3); }
+    else { if (T > 1) OVIS_SG_LAUNCH(2, true, 2); else OVIS_SG_LAUNCH(2, false, 2); }
+  }
+#undef OVIS_SG_LAUNCH
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}

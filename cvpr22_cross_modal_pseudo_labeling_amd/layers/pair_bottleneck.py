@@ -1,0 +1,119 @@
+"""One autograd node per ResNet bottleneck, on the pair-layout split GEMM (csrc/split_gemm.hip).
+
+Bottleneck.forward of maskrcnn_benchmark/modeling/backbone/resnet.py:323-344 (conv1 1x1 -> FrozenBN -> ReLU ->
+conv2 3x3 -> FrozenBN -> ReLU -> conv3 1x1 -> FrozenBN -> (+ shortcut) -> ReLU, FrozenBN folded into the weights) on
+NHWC rows [R*H*W, C], every convolution an fp32-accurate three-term bf16 hi/lo product on the matrix cores:
+
+* activations travel between the layers in PAIR layout only (per 32 values: 64 B hi | 64 B lo, written by the
+  producing GEMM's epilogue together with bias / shortcut / ReLU), so there is no separate bias, ReLU, shortcut-add
+  or operand-split pass, and no fp32 copy of the two inner activations at all;
+* the 3x3 is an implicit GEMM (shifted row reads, zero line outside the map): no im2col matrix in the forward or in
+  the data gradient; only the weight gradient, which contracts over the rows, materialises pair-layout im2col rows;
+* backward: the ReLU gate is fused with the split of the gated gradient (``gate_split_pair``: the gate is read from
+  the hi halves of the saved pair activations), dX products are the same kernel against transposed weights with
+  the shortcut gradient added in the epilogue, dW products are ONE M-contracting library GEMM each on the pair
+  operands ([dY_hi | dY_lo]^T [X_hi | X_lo] interleaved in 32-blocks; the four quadrants are summed).
+Saved per row: the pair forms of the input and of the two inner activations + the fp32 output.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _C
+
+
+def pair_weight(w2d):
+    """[N, K] f32 weight matrix -> pair layout [N, 2K] bf16."""
+    return _C.split_pair(w2d.contiguous())
+
+
+def conv_weight_matrix(w):
+    """[N, C, KH, KW] -> [N, KH*KW*C], tap-major like the implicit GEMM's contraction index."""
+    n, c, kh, kw = w.shape
+    return w.permute(0, 2, 3, 1).reshape(n, kh * kw * c)
+
+
+def conv_weight_matrix_t(w):
+    """[N, C, KH, KW] -> [C, KH*KW*N]: the data-gradient operand (taps are visited with negated offsets)."""
+    n, c, kh, kw = w.shape
+    return w.permute(1, 2, 3, 0).reshape(c, kh * kw * n)
+
+
+def dw_pair(gp, xp):
+    """dW[N, K] = dY^T X over the rows, both operands in pair layout ([M, 2N], [M, 2K]): one bf16 GEMM with fp32
+    accumulation gives all four hi/lo products, interleaved in 32-blocks along both axes; they are summed."""
+    n, k = gp.shape[1] // 2, xp.shape[1] // 2
+    q = torch.mm(gp.t(), xp, out_dtype=torch.float32)            # [2N, 2K]
+    return q.view(n // 32, 2, 32, k // 32, 2, 32).sum(dim=(1, 4)).reshape(n, k)
+
+
+class _BottleneckPair(Function):
+    @staticmethod
+    def forward(ctx, x, xp, geom, w1, b1, w2, b2, w3, b3, wd, want_pair, wpairs):
+        """x [M, Cin] f32 rows conv1 reads (may be None when wd is given and no input gradient is wanted), xp its pair
+        form or None; geom = (h, w) of the map the rows tile; w1/w2/w3/wd folded weights (wd None = identity
+        shortcut), b1/b2 shifts, b3 the conv3 (+ shortcut) shift; wpairs: optional cached pair weights."""
+        h, w = geom
+        if xp is None:
+            xp = _C.split_pair(x)
+        n1, n2, n3 = w1.shape[0], w2.shape[0], w3.shape[0]
+        kh, kw = w2.shape[2], w2.shape[3]
+        if wpairs is None:
+            wpairs = {"w1": pair_weight(w1.reshape(n1, -1)), "w2": pair_weight(conv_weight_matrix(w2)),
+                      "w3": pair_weight(w3.reshape(n3, -1)),
+                      "wd": pair_weight(wd.reshape(wd.shape[0], -1)) if wd is not None else None}
+        _, o1p = _C.split_gemm_pair(xp, wpairs["w1"], b1, None, True, False, True)
+        _, o2p = _C.split_gemm_pair(o1p, wpairs["w2"], b2, None, True, False, True, conv=(h, w, kh, kw, False))
+        if wd is not None:
+            res, _ = _C.split_gemm_pair(xp, wpairs["wd"])
+        else:
+            res = x
+        out, outp = _C.split_gemm_pair(o2p, wpairs["w3"], b3, res, True, True, want_pair)
+        ctx.save_for_backward(xp, o1p, o2p, out, w1, w2, w3, wd)
+        ctx.geom = (h, w, kh, kw)
+        if outp is not None:
+            ctx.mark_non_differentiable(outp)
+        return out, outp
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout, _dpair):
+        xp, o1p, o2p, out, w1, w2, w3, wd = ctx.saved_tensors
+        h, w, kh, kw = ctx.geom
+        need = ctx.needs_input_grad
+        need_x, need_w1, need_w2, need_w3, need_wd = need[0], need[3], need[5], need[7], need[9]
+        n1, n2, n3 = w1.shape[0], w2.shape[0], w3.shape[0]
+        # gate of the block's last ReLU, fused with the split; the identity shortcut also needs the gated gradient in fp32
+        g3p, g3 = _C.gate_split_pair(dout.reshape(-1, n3), out, want_f32=(wd is None and need_x))
+        dw3 = dw_pair(g3p, o2p) if need_w3 else None
+        d2, _ = _C.split_gemm_pair(g3p, pair_weight(w3.reshape(n3, -1).t()))                      # dY W3
+        g2p, _ = _C.gate_split_pair(d2, o2p)
+        del d2
+        dw2 = None
+        if need_w2:
+            rows = _C.im2col_pair(o1p, h, w, kh, kw)
+            dw2 = dw_pair(g2p, rows).view(n2, kh, kw, n1).permute(0, 3, 1, 2)
+            del rows
+        dx = dw1 = dwd = None
+        if need_x or need_w1:
+            d1, _ = _C.split_gemm_pair(g2p, pair_weight(conv_weight_matrix_t(w2)), conv=(h, w, kh, kw, True))
+            g1p, _ = _C.gate_split_pair(d1, o1p)
+            del d1
+            if need_w1:
+                dw1 = dw_pair(g1p, xp).view_as(w1)
+            if need_x:
+                if wd is not None:
+                    res, _ = _C.split_gemm_pair(g3p, pair_weight(wd.reshape(wd.shape[0], -1).t()))
+                else:
+                    res = g3
+                dx, _ = _C.split_gemm_pair(g1p, pair_weight(w1.reshape(n1, -1).t()), None, res)
+        if wd is not None and need_wd:
+            dwd = dw_pair(g3p, xp).view_as(wd)
+        if dw3 is not None:
+            dw3 = dw3.view_as(w3)
+        return dx, None, None, dw1, None, dw2, None, dw3, None, dwd, None, None
+
+
+def bottleneck_pair(x, xp, geom, w1, b1, w2, b2, w3, b3, wd=None, want_pair=False, wpairs=None):
+    """(out f32 [M, Cout], out in pair layout or None) of one bottleneck on the rows x [M, Cin] of an (h, w) map."""
+    return _BottleneckPair.apply(x, xp, geom, w1, b1, w2, b2, w3, b3, wd, want_pair, wpairs)

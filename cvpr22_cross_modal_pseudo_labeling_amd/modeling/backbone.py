@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..layers import Conv2d, FrozenBatchNorm2d, bias_relu_, split_conv_same, split_linear
+from ..layers.pair_bottleneck import bottleneck_pair, conv_weight_matrix, pair_weight
 
 
 class ConvBN(nn.Module):
@@ -77,6 +78,9 @@ class Bottleneck(nn.Module):
         self.conv3x3_nchw = None  # None = by autograd mode (see forward_nhwc)
         self.split_gemm = os.environ.get("OVIS_RES5_FP32_GEMM", "0") != "1"
         self.split_conv = self.split_gemm and os.environ.get("OVIS_RES5_MIOPEN_3X3", "0") != "1"
+        # pair-layout split GEMM with fused epilogues and implicit 3x3 (csrc/split_gemm.hip): the default NHWC route
+        self.pair_gemm = self.split_conv and os.environ.get("OVIS_RES5_PAIR", "1") != "0"
+        self._pair_cache = None
 
     def forward(self, x):
         out = F.relu_(self._f1[0](x))
@@ -91,14 +95,68 @@ class Bottleneck(nn.Module):
         return (c1.kernel_size == (1, 1) and c3.kernel_size == (1, 1) and c1.groups == 1 and c3.groups == 1
                 and c1.padding == (0, 0) and c3.padding == (0, 0) and c3.stride == (1, 1))
 
-    def forward_nhwc(self, x, prestrided=False):
+    def pair_supported(self):
+        c1, c2, c3 = self.conv1, self.conv2, self.conv3
+        d = self.downsample[0] if self.downsample is not None else None
+        return (self.nhwc_supported() and c2.stride == (1, 1) and c2.dilation == (1, 1) and c2.groups == 1
+                and c2.kernel_size[0] % 2 == 1 and c2.kernel_size[1] % 2 == 1
+                and c2.padding == (c2.kernel_size[0] // 2, c2.kernel_size[1] // 2)
+                and all(ch % 32 == 0 for ch in (c1.in_channels, c1.out_channels, c2.out_channels, c3.out_channels))
+                and (d is None or (d.kernel_size == (1, 1) and d.padding == (0, 0) and d.groups == 1
+                                   and d.stride == c1.stride))
+                and (d is not None or (c1.stride == (1, 1) and c1.in_channels == c3.out_channels)))
+
+    def _forward_pair(self, x, prestrided, xp, want_pair):
+        """The block as ONE autograd node on the pair-layout split GEMM (layers/pair_bottleneck.py): bias, shortcut,
+        ReLU and the next layer's operand split live in the GEMM epilogues, the 3x3 is an implicit GEMM."""
+        r, h, w, c = x.shape
+        sy, sx = self.conv1.stride
+        if not prestrided and (sy, sx) != (1, 1):
+            if xp is not None:
+                xp = xp.view(r, h, w, 2 * c)[:, ::sy, ::sx, :].contiguous().view(-1, 2 * c)
+            # the fp32 rows are only read by an identity shortcut or by the input gradient
+            keep = self._fd is None or (torch.is_grad_enabled() and x.requires_grad) or xp is None
+            x = x[:, ::sy, ::sx, :]
+            hs, ws = x.shape[1], x.shape[2]
+            x2d = x.contiguous().view(-1, c) if keep else None
+        else:
+            hs, ws = h, w
+            x2d = x.view(-1, c)
+        w1, b1 = self._f1[0].folded()
+        w2, b2 = self._f2[0].folded()
+        w3, b3 = self._f3[0].folded()
+        wd = bd = None
+        if self._fd is not None:
+            wd, bd = self._fd[0].folded()
+        ws_all = [t for t in (w1, w2, w3, wd) if t is not None]
+        wpairs = None
+        if not any(t.requires_grad for t in ws_all):
+            # frozen block: the pair forms of the folded weights (and the summed shift) are computed once
+            key = tuple((id(t), t._version, t.device) for t in ws_all)
+            if self._pair_cache is None or self._pair_cache[0] != key:
+                wp = {"w1": pair_weight(w1.reshape(w1.shape[0], -1)), "w2": pair_weight(conv_weight_matrix(w2)),
+                      "w3": pair_weight(w3.reshape(w3.shape[0], -1)),
+                      "wd": pair_weight(wd.reshape(wd.shape[0], -1)) if wd is not None else None}
+                self._pair_cache = (key, wp, (b3 if bd is None else b3 + bd).contiguous())
+            wpairs, b3s = self._pair_cache[1], self._pair_cache[2]
+        else:
+            b3s = b3 if bd is None else b3 + bd
+        out, outp = bottleneck_pair(x2d, xp, (hs, ws), w1, b1, w2, b2, w3, b3s, wd, want_pair, wpairs)
+        out = out.view(r, hs, ws, out.shape[-1])
+        return (out, outp) if want_pair else out
+
+    def forward_nhwc(self, x, prestrided=False, xp=None, want_pair=False):
         """Same block on an NHWC tensor ``x`` [R, H, W, C] (contiguous); ``prestrided``: x already holds only the
         positions conv1 / the shortcut read (the pooler applied their common stride).  The 1x1 convolutions -- 53 % of the
         res5 FLOPs -- become ONE row-major GEMM over all R*H*W positions each ([R*H*W, Cin] x [Cin, Cout], bias
         = the folded FrozenBN shift) instead of R batched [Cout, Cin] x [Cin, 49] products behind layout
         transposes; a stride-2 1x1 (STRIDE_IN_1X1) first drops the rows it never reads.  By default the GEMMs run as
         bf16 hi/lo split products on the bf16 matrix pipe (~4e-6 relative error, ``OVIS_RES5_FP32_GEMM=1`` selects
-        the fp32 GEMM); the 3x3 goes through MIOpen.  Values equal ``forward`` up to that error."""
+        the fp32 GEMM); the 3x3 goes through MIOpen.  Values equal ``forward`` up to that error.
+        ``xp``: the pair-layout form of x when the producer already wrote it; ``want_pair``: also return the pair
+        form of the result (or None) for the next block -- both only used by the pair-layout route."""
+        if self.pair_gemm and x.is_cuda and self.pair_supported():
+            return self._forward_pair(x, prestrided, xp, want_pair)
         r, h, w, c = x.shape
         sy, sx = self.conv1.stride
         if prestrided:
@@ -163,7 +221,8 @@ class Bottleneck(nn.Module):
         w3, b3 = self._f3[0].folded()
         (out,) = products(out, w3.view(w3.shape[0], -1))
         out = bias_relu_(out, b3 if bd is None else b3 + bd, idn if idn is not None else x.view(-1, c))
-        return out.view(r, ho, wo, out.shape[-1])
+        out = out.view(r, ho, wo, out.shape[-1])
+        return (out, None) if want_pair else out
 
 
 class Stem(nn.Module):
@@ -235,9 +294,9 @@ class ResNetC4(nn.Module):
             # the res5 head (1x1 = row-major GEMM, 3x3 = GEMM over split-im2col rows); one layout copy in (64
             # channels) and one out (the C4 map, 34 MB).  With trainable stages (teacher training) MIOpen's
             # backward kernels at these large spatial sizes are faster than the im2col route: 55 vs 69 ms per step.
-            y = x.permute(0, 2, 3, 1).contiguous()
-            for b in blocks:
-                y = b.forward_nhwc(y)
+            y, yp = x.permute(0, 2, 3, 1).contiguous(), None
+            for i, b in enumerate(blocks):
+                y, yp = b.forward_nhwc(y, xp=yp, want_pair=True) if i + 1 < len(blocks) else (b.forward_nhwc(y, xp=yp), None)
             return [y.permute(0, 3, 1, 2).contiguous()]
         for name in self.stages:
             x = getattr(self, name)(x)
@@ -273,9 +332,9 @@ class ResNetHead(nn.Module):
         (``Bottleneck.forward_nhwc``) and returns the channels_last view of the result; ``OVIS_RES5_NCHW=1``
         keeps the plain per-layer convolution path (also taken for grouped / exotic configurations)."""
         if x.is_cuda and self.nhwc and all(b.nhwc_supported() for b in self.layer4):
-            y = x.permute(0, 2, 3, 1)  # the first block's stride-2 slice makes this the only NCHW -> NHWC copy
-            for b in self.layer4:
-                y = b.forward_nhwc(y)
+            y, yp = x.permute(0, 2, 3, 1), None  # the first block's stride-2 slice makes this the only NCHW -> NHWC copy
+            for i, b in enumerate(self.layer4):
+                y, yp = b.forward_nhwc(y, xp=yp, want_pair=True) if i + 1 < len(self.layer4) else (b.forward_nhwc(y, xp=yp), None)
             return y.permute(0, 3, 1, 2)
         return self.layer4(x)
 
@@ -290,6 +349,10 @@ class ResNetHead(nn.Module):
 
     def forward_pooled_nhwc(self, y):
         """y [R, 7, 7, C]: the pooled bins conv1 reads, NHWC (from ``forward_strided_nhwc``) -> [R, 2048, 7, 7] view."""
+        yp = None
         for i, b in enumerate(self.layer4):
-            y = b.forward_nhwc(y, prestrided=(i == 0))
+            if i + 1 < len(self.layer4):
+                y, yp = b.forward_nhwc(y, prestrided=(i == 0), xp=yp, want_pair=True)
+            else:
+                y = b.forward_nhwc(y, prestrided=(i == 0), xp=yp)
         return y.permute(0, 3, 1, 2)

@@ -165,6 +165,51 @@ int ovis_bias_act_f32(float* y, const float* bias, const float* residual, long r
                       int relu, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Pair-layout split GEMM / implicit-GEMM convolution (csrc/split_gemm.hip): the res5 head and the
+ * frozen trunk (Bottleneck.forward, mb/modeling/backbone/resnet.py:323-344; ResNetHead :155-204)
+ * as fp32-accurate products on the bf16 matrix cores, with the operand split shared by the three
+ * hi/lo products inside the kernel.
+ *
+ * PAIR LAYOUT of a row of K fp32 values (K % 32 == 0): K/32 blocks of 128 bytes, each
+ * [hi(32 x bf16) | lo(32 x bf16)], hi = bf16(x), lo = bf16(x - hi); 4*K bytes per row.
+ * ---------------------------------------------------------------------------------- */
+/* src [rows, cols] f32 (row stride in elements) -> dst pair rows (4*cols bytes each, dense).
+ * cols % 32 == 0, stride % 4 == 0, 16-byte aligned pointers (else OVIS_ERANGE). */
+int ovis_split_pair_f32(const float* src, long src_row_stride, void* dst_pair, long rows,
+                        int cols, void* stream);
+
+/* Backward ReLU gate fused with the operand split: g = dy * (y > 0) -> dst_pair (pair rows, dense) and, when
+ * g_f32 != NULL, also as dense fp32.  dy [rows, cols] f32 (row stride in elements); gate = the saved forward
+ * output y, dense: its pair form (gate_is_pair != 0; only the hi halves are read) or fp32, or NULL (no gate:
+ * a plain split).  threshold_backward of mb/modeling/backbone/resnet.py:323-344's relu_ calls.  cols % 32 == 0. */
+int ovis_gate_split_pair_f32(const float* dy, long dy_row_stride, const void* gate, int gate_is_pair,
+                             void* dst_pair, float* g_f32, long rows, int cols, void* stream);
+
+/* Pair-layout im2col (the M-contracting weight gradient of a 3x3 needs the rows materialised):
+ * src NHWC [num, height, width, channels] pair rows -> dst [num*height*width, kh*kw*channels]
+ * pair rows, tap-major, zero rows for taps outside the map.  channels % 32 == 0. */
+int ovis_im2col_pair(const void* src_pair, void* dst_pair, long num, int height, int width,
+                     int channels, int kh, int kw, void* stream);
+
+/* C[m, n] = act( sum_{tap, c} A[row(m, tap), c] * B[n, tap*channels + c] + bias[n] + residual[m, n] )
+ *   a_pair : pair rows of `channels` values, a_row_bytes apart.  taps_h = taps_w = 1: a plain
+ *            [m, channels] matrix.  Otherwise an NHWC tensor [m / (height*width), height, width,
+ *            channels]; tap (ty, tx) of row (r, y, x) reads pixel (y + ty - taps_h/2, x + tx -
+ *            taps_w/2) (negated offsets when flip != 0: the data-gradient convolution), zeros
+ *            outside the map -- stride-1 "same" convolution with no im2col matrix.
+ *   b_pair : n pair rows of taps*channels values (weights [n, tap, c]), b_row_bytes apart.
+ *   c      : fp32 result, row stride ldc elements, or NULL;  c_pair: the result in pair layout
+ *            (rows c_pair_row_bytes apart; needs n % 32 == 0), or NULL -- the operand split of the
+ *            NEXT layer fused into this epilogue.  bias [n] / residual [m, n] (stride ldr) may be NULL.
+ *   tile_m : 0 = choose, 128 or 256 rows per workgroup.
+ * channels % 32 == 0, n % 4 == 0, 16-byte aligned pointers and strides (else OVIS_ERANGE). */
+int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const void* b_pair,
+                         long b_row_bytes, float* c, long ldc, void* c_pair,
+                         long c_pair_row_bytes, const float* bias, const float* residual,
+                         long ldr, long m, int n, int channels, int taps_h, int taps_w,
+                         int height, int width, int flip, int relu, int tile_m, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Cross-modal head: fp32 GEMM on the matrix cores
  *   mb/modeling/roi_heads/box_head/roi_box_predictors.py:66-71 (emb_pred Linear, einsum('pe,ce->pc'),
  *   bbox_pred Linear) and their autograd transposes.

@@ -260,10 +260,10 @@ def test_res5_head_nhwc_paths_match_conv_path():
             m.bias.uniform_(-0.2, 0.2)
     x = torch.randn(24, 1024, 14, 14, device="cuda")
 
-    def run(nhwc, split, c33, sconv=False):
+    def run(nhwc, split, c33, sconv=False, pair=False):
         head.nhwc = nhwc
         for b in head.layer4:
-            b.split_gemm, b.conv3x3_nchw, b.split_conv = split, c33, sconv
+            b.split_gemm, b.conv3x3_nchw, b.split_conv, b.pair_gemm = split, c33, sconv, pair
         xx = x.clone().requires_grad_(True)
         y = head(xx)
         head.zero_grad()
@@ -271,7 +271,8 @@ def test_res5_head_nhwc_paths_match_conv_path():
         return y.detach(), xx.grad, head.layer4[0].conv1.weight.grad.clone(), head.layer4[2].conv3.weight.grad.clone()
 
     ref = run(False, False, True)
-    for cfg_ in ((True, False, True), (True, False, False), (True, True, True), (True, True, None, True)):
+    for cfg_ in ((True, False, True), (True, False, False), (True, True, True), (True, True, None, True),
+                 (True, True, None, True, True)):  # last: pair-layout split GEMM, one autograd node per bottleneck
         got = run(*cfg_)
         assert got[0].shape == ref[0].shape
         assert (got[0] - ref[0]).abs().max().item() <= 2e-4 * ref[0].abs().max().item(), cfg_

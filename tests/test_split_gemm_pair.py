@@ -1,0 +1,158 @@
+"""GPU: pair-layout split GEMM / implicit-GEMM convolution (csrc/split_gemm.hip) and the fused bottleneck node
+(layers/pair_bottleneck.py) against fp64 references.  Tolerance: |err| <= 2e-5 * sum_k |a_k||b_k| (the three-term
+bf16 hi/lo product drops lo.lo and rounds lo to 8 bits: ~4e-6 relative per term; an fp32 GEMM sits at ~2e-6)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def _C():
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C as c
+    return c
+
+
+def _unpair(p):
+    """pair layout [rows, 2K] bf16 -> (hi, lo) [rows, K] each."""
+    rows, k2 = p.shape
+    v = p.view(rows, k2 // 64, 2, 32)
+    return v[:, :, 0, :].reshape(rows, -1), v[:, :, 1, :].reshape(rows, -1)
+
+
+def test_split_pair_layout_and_precision():
+    C = _C()
+    x = torch.randn(37, 96, device="cuda") * 3
+    p = C.split_pair(x)
+    assert p.shape == (37, 192) and p.dtype == torch.bfloat16
+    hi, lo = _unpair(p)
+    assert torch.equal(hi, x.to(torch.bfloat16))
+    assert torch.equal(lo, (x - hi.float()).to(torch.bfloat16))
+    assert ((hi.double() + lo.double()) - x.double()).abs().max().item() <= 2.0 ** -16 * x.abs().max().item()
+    # row-strided source view
+    big = torch.randn(20, 128, device="cuda")
+    assert torch.equal(C.split_pair(big[:, 32:96]), C.split_pair(big[:, 32:96].contiguous()))
+    with pytest.raises(RuntimeError):
+        C.split_pair(torch.randn(4, 40, device="cuda"))  # cols % 32 != 0
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("m,k,n,bias,res,relu", [(128, 32, 128, False, False, False), (300, 64, 64, False, False, False),
+                                                   (1000, 512, 192, True, True, True), (1813, 1024, 512, True, False, True),
+                                                   (513, 2048, 2048, False, True, False), (1, 32, 4, True, False, False)])
+def test_split_gemm_pair_vs_fp64(tile, m, k, n, bias, res, relu):
+    C = _C()
+    g = torch.Generator(device="cuda").manual_seed(m * 7 + k + n)
+    a = torch.randn(m, k, device="cuda", generator=g)
+    b = torch.randn(n, k, device="cuda", generator=g)
+    bi = torch.randn(n, device="cuda", generator=g) if bias else None
+    r = torch.randn(m, n, device="cuda", generator=g) if res else None
+    c, cp = C.split_gemm_pair(C.split_pair(a), C.split_pair(b), bi, r, relu, True, n % 32 == 0, tile_m=tile)
+    ref = a.double() @ b.double().t()
+    if bias:
+        ref += bi.double()
+    if res:
+        ref += r.double()
+    if relu:
+        ref = ref.clamp(min=0)
+    bound = a.abs().double() @ b.abs().double().t() + 1
+    assert ((c.double() - ref).abs() / bound).max().item() < TOL
+    if cp is not None:  # the fused epilogue split is bit-identical to splitting the fp32 result
+        assert torch.equal(cp, C.split_pair(c))
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("r,h,w,c,n,kh,kw,flip", [(5, 7, 7, 64, 64, 3, 3, False), (37, 7, 7, 512, 512, 3, 3, False),
+                                                    (3, 5, 9, 32, 128, 3, 3, True), (2, 13, 11, 64, 96, 3, 5, False),
+                                                    (1, 50, 84, 256, 256, 3, 3, True)])
+def test_implicit_conv_vs_fp64(tile, r, h, w, c, n, kh, kw, flip):
+    C = _C()
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers.pair_bottleneck import conv_weight_matrix
+    g = torch.Generator(device="cuda").manual_seed(r + h * 3 + w * 5 + c)
+    x = torch.randn(r, h, w, c, device="cuda", generator=g)
+    wt = torch.randn(n, c, kh, kw, device="cuda", generator=g)
+    xp = C.split_pair(x.view(-1, c))
+    wp = C.split_pair(conv_weight_matrix(wt).contiguous())
+    y, _ = C.split_gemm_pair(xp, wp, conv=(h, w, kh, kw, flip), tile_m=tile)
+    wref = wt.flip(2, 3) if flip else wt
+    pad = (kh // 2, kw // 2)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wref.double(), padding=pad).permute(0, 2, 3, 1).reshape(-1, n)
+    bound = F.conv2d(x.permute(0, 3, 1, 2).abs().double(), wref.abs().double(), padding=pad).permute(0, 2, 3, 1).reshape(-1, n) + 1
+    assert ((y.double() - ref).abs() / bound).max().item() < TOL
+    if not flip:  # the materialised pair im2col rows give the same product through the plain GEMM
+        y2, _ = C.split_gemm_pair(C.im2col_pair(xp, h, w, kh, kw), wp, tile_m=tile)
+        assert (y - y2).abs().max().item() <= 1e-5 * y.abs().max().item()
+
+
+def test_im2col_pair_layout():
+    C = _C()
+    x = torch.randn(2, 3, 4, 32, device="cuda")
+    xp = C.split_pair(x.view(-1, 32))
+    rows = C.im2col_pair(xp, 3, 4, 3, 3)
+    assert rows.shape == (24, 9 * 64)
+    padp = F.pad(xp.view(2, 3, 4, 64), (0, 0, 1, 1, 1, 1))
+    for t in range(9):
+        want = padp[:, t // 3: t // 3 + 3, t % 3: t % 3 + 4, :].reshape(24, 64)
+        assert torch.equal(rows[:, t * 64:(t + 1) * 64], want)
+
+
+def test_gate_split_pair():
+    C = _C()
+    dy = torch.randn(50, 64, device="cuda")
+    y = torch.randn(50, 64, device="cuda").clamp(min=0)
+    want = dy * (y > 0)
+    for gate in (y, C.split_pair(y)):
+        gp, g32 = C.gate_split_pair(dy, gate, want_f32=True)
+        assert torch.equal(g32, want)
+        assert torch.equal(gp, C.split_pair(want))
+    gp, g32 = C.gate_split_pair(dy)
+    assert g32 is None and torch.equal(gp, C.split_pair(dy))
+
+
+def test_dw_pair_vs_fp64():
+    C = _C()
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers.pair_bottleneck import dw_pair
+    dy = torch.randn(777, 64, device="cuda")
+    x = torch.randn(777, 96, device="cuda")
+    dw = dw_pair(C.split_pair(dy), C.split_pair(x))
+    ref = dy.double().t() @ x.double()
+    bound = dy.abs().double().t() @ x.abs().double() + 1
+    assert ((dw.double() - ref).abs() / bound).max().item() < TOL
+
+
+@pytest.mark.parametrize("proj", [True, False])
+def test_bottleneck_pair_node_vs_fp64_autograd(proj):
+    """Forward, input gradient and all weight gradients of the fused node vs an fp64 autograd bottleneck."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers.pair_bottleneck import bottleneck_pair
+    torch.manual_seed(3)
+    r, h, w = 6, 7, 7
+    cin, cb, cout = (64, 32, 128) if proj else (128, 32, 128)
+    dev = "cuda"
+    x = torch.randn(r * h * w, cin, device=dev, requires_grad=True)
+    w1 = (torch.randn(cb, cin, 1, 1, device=dev) / cin ** 0.5).requires_grad_(True)
+    w2 = (torch.randn(cb, cb, 3, 3, device=dev) / (9 * cb) ** 0.5).requires_grad_(True)
+    w3 = (torch.randn(cout, cb, 1, 1, device=dev) / cb ** 0.5).requires_grad_(True)
+    wd = (torch.randn(cout, cin, 1, 1, device=dev) / cin ** 0.5).requires_grad_(True) if proj else None
+    b1, b2, b3 = (torch.randn(n, device=dev) * 0.1 for n in (cb, cb, cout))
+    out, outp = bottleneck_pair(x, None, (h, w), w1, b1, w2, b2, w3, b3, wd, True)
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C as C
+    assert torch.equal(outp, C.split_pair(out.detach()))
+    gout = torch.randn_like(out)
+    params = [x, w1, w2, w3] + ([wd] if proj else [])
+    grads = torch.autograd.grad(out, params, gout)
+
+    xd = x.detach().double().view(r, h, w, cin).permute(0, 3, 1, 2).requires_grad_(True)
+    pd = [p.detach().double().requires_grad_(True) for p in params[1:]]
+    o = F.relu(F.conv2d(xd, pd[0], b1.double()))
+    o = F.relu(F.conv2d(o, pd[1], b2.double(), padding=1))
+    o = F.conv2d(o, pd[2], b3.double())
+    o = F.relu(o + (F.conv2d(xd, pd[3]) if proj else xd))
+    ref = o.permute(0, 2, 3, 1).reshape(-1, cout)
+    assert (out.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    rgrads = torch.autograd.grad(ref, [xd] + pd, gout.double())
+    rgrads = [rgrads[0].permute(0, 2, 3, 1).reshape(-1, cin)] + list(rgrads[1:])
+    for gname, a, b in zip(("dx", "dw1", "dw2", "dw3", "dwd"), grads, rgrads):
+        assert a.shape == b.shape, gname
+        assert (a.double() - b).norm().item() <= 1e-4 * b.norm().item(), gname
