@@ -297,6 +297,41 @@ def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f3
     return c, cp
 
 
+def split_gemm_pair_tn_supported(n, ch, conv=None):
+    if n % 128 or ch % 128:
+        return False
+    if conv is not None:
+        h, w, kh, kw = conv
+        return kh * kw <= 16 and h * w <= 8192 and kh % 2 == 1 and kw % 2 == 1
+    return True
+
+
+def split_gemm_pair_tn(g_pair, x_pair, conv=None):
+    """dW [N, taps*ch] = G^T X over the rows: G [M, 2N], X [M, 2*ch] in pair layout; conv = (h, w, kh, kw): X is an
+    NHWC tensor read shifted by every tap (the 3x3 weight gradient without im2col rows).  csrc/split_gemm.hip."""
+    for t, name in ((g_pair, "g_pair"), (x_pair, "x_pair")):
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1):
+            raise RuntimeError(f"split_gemm_pair_tn: {name} must be a 2-D bfloat16 HIP tensor in pair layout")
+    m, n, ch = g_pair.shape[0], g_pair.shape[1] // 2, x_pair.shape[1] // 2
+    if x_pair.shape[0] != m:
+        raise RuntimeError("split_gemm_pair_tn: row counts differ")
+    h = w = 0
+    kh = kw = 1
+    if conv is not None:
+        h, w, kh, kw = conv
+        if m % (h * w):
+            raise RuntimeError("split_gemm_pair_tn: rows must be a multiple of h*w")
+    if m == 0:
+        return torch.zeros((n, kh * kw * ch), dtype=torch.float32, device=g_pair.device)
+    slices = _L.ovis_split_gemm_tn_slices(m, n, ch, kh * kw)
+    slabs = torch.empty((slices, n, kh * kw * ch), dtype=torch.float32, device=g_pair.device)
+    with torch.cuda.device(g_pair.device):
+        rc = _L.ovis_split_gemm_pair_tn(g_pair.data_ptr(), 2 * g_pair.stride(0), x_pair.data_ptr(), 2 * x_pair.stride(0),
+                                        slabs.data_ptr(), slices, m, n, ch, kh, kw, h, w, _stream())
+    _lib.check(rc, "split_gemm_pair_tn")
+    return slabs[0] if slices == 1 else slabs.sum(0)
+
+
 def bias_act_(y, bias=None, residual=None, relu=True):
     """In place: y[rows, cols] = act(y + bias[col] (+ residual)); contiguous f32, cols % 4 == 0."""
     if not (y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.is_contiguous()):

@@ -54,7 +54,7 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));
 }
 
-template <int WM, bool CONV, int NS>
+template <int WM, bool CONV, int NS, int ABL = 0>
 __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, int tiles_n, int nblocks) {
   constexpr int BM = WM * 64, BN = 128, NW = WM * 2;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
   for (int kb = 0; kb < nk; ++kb) {
     if (NS == 2) {
       __syncthreads();
-      if (kb + 1 < nk) issue((kb + 1) & 1, kb + 1);
+      if (kb + 1 < nk && (ABL != 1 || kb == 0)) issue((kb + 1) & 1, kb + 1);
     } else {
       if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -192,6 +192,16 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
     for (int f = 0; f < 4; ++f) {
       bl[f] = *(const bf16x8*)(base + (b_rd[f] ^ 64));
       al[f] = *(const bf16x8*)(base + (a_rd[f] ^ 64));
+    }
+    if (ABL == 2) {  // ablation: loads + LDS reads only
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        acc[f][0] += __builtin_bit_cast(f32x4, ah[f]);
+        acc[f][1] += __builtin_bit_cast(f32x4, al[f]);
+        acc[f][2] += __builtin_bit_cast(f32x4, bh[f]);
+        acc[f][3] += __builtin_bit_cast(f32x4, bl[f]);
+      }
+      continue;
     }
 #pragma unroll
     for (int f = 0; f < 4; ++f)
@@ -240,6 +250,223 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
         *(uint2*)d = make_uint2(h01, h23);
         *(uint2*)(d + 64) = make_uint2(l01, l23);
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weight gradient: dW[n, (tap, c)] = sum_m G[m, n] * X[row(m, tap), c] -- a contraction over the ROWS of two
+// row-major pair operands, so both MFMA operands are needed k(=m)-contiguous per lane while memory is n- / c-
+// contiguous.  The tiles are staged as they lie ([32 rows][512 B], LDS-DMA) and read with the LDS transpose
+// read ds_read_b64_tr_b16: a 16-lane group fetches a 4(m) x 16(n) block (lane p: row p/4, 8 bytes at (p%4)*8) and
+// every lane receives the 4 m-values of its own column; two of them make one 16x16x32 operand.  Same three-term
+// hi/lo product, same wave tiling as the forward kernel.  The 32-byte segment index of a row is XOR-ed with
+// f(row) = ((row >> 3) & 1) << 2 | (row & 3) (on the DMA source address) so that the 8 rows a 32-lane half reads sit
+// on 8 different bank octets.  The contraction is long (M = R*49 rows) and the output small, so the rows are cut
+// into `slices` and every (tile, slice) workgroup writes its own fp32 slab; the caller sums the slabs
+// (deterministic, no atomics).  For a 3x3 the X rows are read shifted by the tap (zero line outside the map, from a
+// per-position tap mask table in LDS): no im2col rows are materialised for the weight gradient either.
+// ---------------------------------------------------------------------------------------------------
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+struct SplitGemmTnArgs {
+  const char* G; long g_rs;   // [M] pair rows of N values
+  const char* X; long x_rs;   // [M] pair rows of ch values
+  float* C;                   // [slices][N][T*ch]
+  long M; int N; int ch; int T; int H; int W; int KH; int KW; int slices; int steps_per_slice;
+};
+
+// The transpose reads are inline asm: hipcc treats the ds_read_tr builtin as possibly aliasing the in-flight LDS-DMA
+// stage and would wait vmcnt(0) before the first one of every step, i.e. serialise the next stage's loads with this
+// stage's MFMAs.  Inside asm it counts nothing, so the reads are followed by explicit lgkmcnt waits that name their
+// destination registers ("+v") -- every consumer is ordered after its wait.
+#define OVIS_TR_READ(dst, addr, off) \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define OVIS_LGKM_WAIT8(N, a, b, c, d, e, f, g, h)                                                                \
+  asm volatile("s_waitcnt lgkmcnt(%8)"                                                                             \
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h)                            \
+               : "n"(N)                                                                                            \
+               : "memory")
+
+template <bool CONV>
+__global__ __launch_bounds__(256) void split_gemm_tn_kernel(SplitGemmTnArgs p, int tiles_i, int tiles_j, int nblocks) {
+  constexpr int TILE_BYTES = 32 * 512, STAGE = 2 * TILE_BYTES, TAB = 2 * STAGE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int id;
+  {
+    const int b = blockIdx.x, q = nblocks >> 3, r = nblocks & 7, xcd = b & 7, loc = b >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int per_slice = tiles_i * tiles_j;
+  const int slice = id / per_slice;
+  const int rem = id - slice * per_slice;
+  const int tile_j = rem / tiles_i, tile_i = rem - tile_j * tiles_i;
+  const int i0 = tile_i * 128, j0 = tile_j * 128;
+  const int tap = CONV ? j0 / p.ch : 0, c0 = CONV ? j0 - tap * p.ch : j0;
+  const int HW = p.H * p.W;
+  int off_rows = 0;
+  if (CONV) {
+    // tap mask table: bit t of tab[r] = tap t of map position r = (y, x) lies inside the map
+    unsigned short* tab = (unsigned short*)(smem + TAB);
+    for (int r = threadIdx.x; r < HW; r += 256) {
+      const int y = r / p.W, x = r - y * p.W;
+      unsigned m = 0;
+      for (int t = 0; t < p.T; ++t) {
+        const int yy = y + t / p.KW - p.KH / 2, xx = x + t % p.KW - p.KW / 2;
+        if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) m |= 1u << t;
+      }
+      tab[r] = (unsigned short)m;
+    }
+    off_rows = (tap / p.KW - p.KH / 2) * p.W + (tap % p.KW - p.KW / 2);
+  }
+  const long step0 = (long)slice * p.steps_per_slice;
+  const long steps_total = (p.M + 31) >> 5;
+  long step1 = step0 + p.steps_per_slice;
+  if (step1 > steps_total) step1 = steps_total;
+  const int nk = step1 > step0 ? (int)(step1 - step0) : 0;
+
+  // ---- per-lane DMA geometry: 4 G pieces + 4 X pieces per wave per step, a piece = 2 rows x 512 B ----
+  const int prow = lane >> 5, pseg = (lane & 31) >> 1, phalf = lane & 1;
+  int rows[4];          // tile row of the lane in its 4 pieces
+  long g_off[4], x_off[4];
+  int x_r[4];           // (m mod HW) of the X row, kept incrementally
+  int m_row[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;
+    const int row = piece * 2 + prow;
+    rows[i] = row;
+    const int fr = (((row >> 3) & 1) << 2) | (row & 3);
+    const int seg = pseg ^ fr;
+    const int m = (int)(step0 << 5) + row;
+    m_row[i] = m;
+    g_off[i] = (long)m * p.g_rs + (long)i0 * 4 + seg * 32 + phalf * 16;
+    x_off[i] = ((long)m + off_rows) * p.x_rs + (long)c0 * 4 + seg * 32 + phalf * 16;
+    x_r[i] = CONV ? m % HW : 0;
+  }
+  const int inc = CONV ? 32 % HW : 0;
+  const char* zero_src = g_zero_line + (lane & 7) * 16;
+  const int Mi = (int)p.M;
+  if (CONV) __syncthreads();  // table visible
+
+  auto issue = [&](int stage) {
+    char* base = smem + stage * STAGE;
+    // the tap-mask look-ups come first: an LDS read while DMAs are in flight makes hipcc wait vmcnt(0), and right
+    // after the barrier nothing is
+    bool x_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      x_ok[i] = m_row[i] < Mi;
+      if (CONV) {
+        const unsigned short* tab = (const unsigned short*)(smem + TAB);
+        x_ok[i] = x_ok[i] && ((tab[x_r[i]] >> tap) & 1);
+        x_r[i] += inc;
+        if (x_r[i] >= HW) x_r[i] -= HW;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char* src = p.G + g_off[i];
+      if (m_row[i] >= Mi) src = zero_src;
+      glds16(src, base + (wave * 4 + i) * 1024);
+      g_off[i] += 32 * p.g_rs;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char* src = p.X + x_off[i];
+      if (!x_ok[i]) src = zero_src;
+      glds16(src, base + TILE_BYTES + (wave * 4 + i) * 1024);
+      x_off[i] += 32 * p.x_rs;
+      m_row[i] += 32;
+    }
+  };
+
+  // ---- transpose-read addresses: lane (group gq, p): row 8*gq + p/4 (+4 second half), 8 bytes at (p%4)*8 of a segment
+  const int wi = wave >> 1, wj = wave & 1;
+  const int gq = lane >> 4, pp = lane & 15;
+  const int rrow = 8 * gq + (pp >> 2);
+  const int rfr = ((gq & 1) << 2) | (pp >> 2);
+  int g_rd[4], x_rd[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int seg_g = (2 * wi + (f >> 1)) * 4 + (f & 1);
+    g_rd[f] = rrow * 512 + ((seg_g ^ rfr) << 5) + (pp & 3) * 8;
+    const int seg_x = (2 * wj + (f >> 1)) * 4 + (f & 1);
+    x_rd[f] = TILE_BYTES + rrow * 512 + ((seg_x ^ rfr) << 5) + (pp & 3) * 8;
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) issue(0);
+  for (int kb = 0; kb < nk; ++kb) {
+    __syncthreads();
+    if (kb + 1 < nk) issue((kb + 1) & 1);
+    const int so = (kb & 1) * STAGE;  // the dynamic LDS segment starts at LDS address 0 (no static LDS in this TU's kernels)
+    bf16x4 xa[4][2], xb[4][2], ga[4][2], gb[4][2];  // [fragment][hi/lo]: first / second 4 rows of the lane's 8 k values
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int ax = so + x_rd[f], ag = so + g_rd[f];
+      OVIS_TR_READ(xa[f][0], ax, 0);
+      OVIS_TR_READ(xb[f][0], ax, 2048);
+      OVIS_TR_READ(ga[f][0], ag, 0);
+      OVIS_TR_READ(gb[f][0], ag, 2048);
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int ax = so + (x_rd[f] ^ 64), ag = so + (g_rd[f] ^ 64);  // lo half = segment + 2 (XOR commutes with the swizzle)
+      OVIS_TR_READ(xa[f][1], ax, 0);
+      OVIS_TR_READ(xb[f][1], ax, 2048);
+      OVIS_TR_READ(ga[f][1], ag, 0);
+      OVIS_TR_READ(gb[f][1], ag, 2048);
+    }
+    // 32 reads are outstanding; LDS returns in order: lgkmcnt(N) = all but the youngest N have landed
+    OVIS_LGKM_WAIT8(15, xa[0][0], xb[0][0], ga[0][0], gb[0][0], xa[1][0], xb[1][0], ga[1][0], gb[1][0]);
+    OVIS_LGKM_WAIT8(15, xa[2][0], xb[2][0], ga[2][0], gb[2][0], xa[3][0], xb[3][0], ga[3][0], gb[3][0]);
+    bf16x8 gh[4], gl[4], xh[4], xl[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      xh[f] = __builtin_shufflevector(xa[f][0], xb[f][0], 0, 1, 2, 3, 4, 5, 6, 7);
+      gh[f] = __builtin_shufflevector(ga[f][0], gb[f][0], 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[g], gh[f], acc[f][g], 0, 0, 0);
+    OVIS_LGKM_WAIT8(0, xa[0][1], xb[0][1], ga[0][1], gb[0][1], xa[1][1], xb[1][1], ga[1][1], gb[1][1]);
+    OVIS_LGKM_WAIT8(0, xa[2][1], xb[2][1], ga[2][1], gb[2][1], xa[3][1], xb[3][1], ga[3][1], gb[3][1]);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      xl[f] = __builtin_shufflevector(xa[f][1], xb[f][1], 0, 1, 2, 3, 4, 5, 6, 7);
+      gl[f] = __builtin_shufflevector(ga[f][1], gb[f][1], 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[g], gl[f], acc[f][g], 0, 0, 0);
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[g], gh[f], acc[f][g], 0, 0, 0);
+  }
+
+  // D[j][i]: lane owns column i = (lane & 15) of G-block f and rows j = 4*(lane >> 4) + {0..3} of X-block g
+  const long ld = (long)p.T * p.ch;
+  float* out = p.C + (long)slice * p.N * ld;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int i = i0 + wi * 64 + f * 16 + (lane & 15);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int j = j0 + wj * 64 + g * 16 + (lane >> 4) * 4;
+      *(f32x4*)(out + (long)i * ld + j) = acc[f][g];
     }
   }
 }
@@ -394,6 +621,59 @@ extern "C" int ovis_im2col_pair(const void* src_pair, void* dst_pair, long num, 
   return OVIS_OK;
 }
 
+extern "C" int ovis_split_gemm_tn_slices(long m, int n, int channels, int taps) {
+  if (m <= 0 || n <= 0 || channels <= 0 || taps <= 0) return 1;
+  const long tiles = (long)(n / 128) * ((long)taps * channels / 128);
+  const long steps = (m + 31) / 32;
+  long s = (4L * OVIS_NUM_CU + tiles - 1) / (tiles > 0 ? tiles : 1);   // ~2 rounds of 2 workgroups per CU
+  if (s > steps / 8) s = steps / 8;                                      // at least 8 k-steps per slice
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return (int)s;
+}
+
+extern "C" int ovis_split_gemm_pair_tn(const void* g_pair, long g_row_bytes, const void* x_pair, long x_row_bytes,
+                                       float* c_slabs, int slices, long m, int n, int channels, int taps_h,
+                                       int taps_w, int height, int width, void* stream) {
+  if (m < 0 || n <= 0 || channels <= 0 || taps_h <= 0 || taps_w <= 0 || !(taps_h & 1) || !(taps_w & 1) || slices <= 0)
+    return OVIS_EINVAL;
+  if (!g_pair || !x_pair || !c_slabs || m > 0x7fffff00L) return OVIS_EINVAL;
+  const int T = taps_h * taps_w;
+  if (T > 1 && (height <= 0 || width <= 0)) return OVIS_EINVAL;
+  if (n % 128 != 0 || channels % 128 != 0 || T > 16 || (T > 1 && (long)height * width > 8192) ||
+      g_row_bytes % 16 != 0 || x_row_bytes % 16 != 0 || ((uintptr_t)g_pair & 15) || ((uintptr_t)x_pair & 15) ||
+      ((uintptr_t)c_slabs & 15))
+    return OVIS_ERANGE;
+  SplitGemmTnArgs p;
+  p.G = (const char*)g_pair; p.g_rs = g_row_bytes; p.X = (const char*)x_pair; p.x_rs = x_row_bytes;
+  p.C = c_slabs; p.M = m; p.N = n; p.ch = channels; p.T = T; p.H = height; p.W = width; p.KH = taps_h; p.KW = taps_w;
+  p.slices = slices;
+  const long steps = (m + 31) / 32;
+  p.steps_per_slice = (int)((steps + slices - 1) / slices);
+  const int tiles_i = n / 128, tiles_j = (int)((long)T * channels / 128);
+  const long nblocks = (long)tiles_i * tiles_j * slices;
+  if (nblocks > 0x7fffffffL) return OVIS_ERANGE;
+  hipStream_t s = (hipStream_t)stream;
+  const int lds = 2 * 2 * 32 * 512 + (T > 1 ? 2 * height * width : 0);
+  if (T > 1) {
+    static int lds_set = 0;
+    if (lds_set < lds) {
+      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      lds_set = lds;
+    }
+    hipLaunchKernelGGL(split_gemm_tn_kernel<true>, dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_i, tiles_j, (int)nblocks);
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(split_gemm_tn_kernel<false>, dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_i, tiles_j, (int)nblocks);
+  }
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}
+
 extern "C" int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
                                     float* c, long ldc, void* c_pair, long c_pair_row_bytes, const float* bias,
                                     const float* residual, long ldr, long m, int n, int channels, int taps_h,
@@ -410,7 +690,8 @@ extern "C" int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const 
       ((uintptr_t)bias & 15) || ((uintptr_t)residual & 15) || ldc % 4 != 0 || ldr % 4 != 0 ||
       c_pair_row_bytes % 16 != 0)
     return OVIS_ERANGE;
-  int stages = 2;
+  int stages = 2, abl = 0;
+  if (tile_m >= 10000) { abl = tile_m / 10000; tile_m %= 10000; }  // ablation probes (tools/experiments only)
   if (tile_m >= 1000) { stages = tile_m / 1000; tile_m %= 1000; }
   if ((tile_m != 0 && tile_m != 128 && tile_m != 256) || (stages != 2 && stages != 3)) return OVIS_ERANGE;
   SplitGemmArgs p;
@@ -422,14 +703,12 @@ extern "C" int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const 
   p.flip = flip; p.relu = relu;
   const int tiles_n = (n + 127) / 128;
   hipStream_t s = (hipStream_t)stream;
-  // 256-row tiles halve the B (weight) re-reads and the LDS reads per MFMA are the same; they pay once there are
-  // enough tiles to fill the chip twice over
   int bm = tile_m;
-  if (bm == 0) bm = ((m + 255) / 256) * tiles_n >= 2L * OVIS_NUM_CU ? 256 : 128;
+  if (bm == 0) bm = 128;  // two independent 4-wave workgroups per CU beat one 8-wave 256-row workgroup on every shape measured
   const long tiles_m = (m + bm - 1) / bm;
   const long nblocks = tiles_m * tiles_n;
   if (nblocks > 0x7fffffffL) return OVIS_ERANGE;
-#define OVIS_SG_LAUNCH(WM_, CONV_, NS_)                                                                         \
+ #define OVIS_SG_LAUNCH(WM_, CONV_, NS_)                                                                         \
   do {                                                                                                          \
     constexpr int lds = NS_ * (WM_ * 64 * 128 + 128 * 128);                                                     \
     static bool attr_set = false;                                                                               \
@@ -441,7 +720,16 @@ extern "C" int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const 
     hipLaunchKernelGGL((split_gemm_kernel<WM_, CONV_, NS_>), dim3((unsigned)nblocks), dim3(WM_ * 128), lds, s,  \
                        p, tiles_n, (int)nblocks);                                                               \
   } while (0)
-  if (bm == 256) {
+  if (abl) {
+    constexpr int lds = 2 * (128 * 128 + 128 * 128);
+    if (abl == 1) {
+      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      hipLaunchKernelGGL((split_gemm_kernel<2, false, 2, 1>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_n, (int)nblocks);
+    } else {
+      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      hipLaunchKernelGGL((split_gemm_kernel<2, false, 2, 2>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_n, (int)nblocks);
+    }
+  } else if (bm == 256) {
     if (stages == 3) { if (T > 1) OVIS_SG_LAUNCH(4, true, 3); else OVIS_SG_LAUNCH(4, false, 3); }
     else { if (T > 1) OVIS_SG_LAUNCH(4, true, 2); else OVIS_SG_LAUNCH(4, false, 2); }
   } else {

@@ -7,12 +7,12 @@ NHWC rows [R*H*W, C], every convolution an fp32-accurate three-term bf16 hi/lo p
 * activations travel between the layers in PAIR layout only (per 32 values: 64 B hi | 64 B lo, written by the
   producing GEMM's epilogue together with bias / shortcut / ReLU), so there is no separate bias, ReLU, shortcut-add
   or operand-split pass, and no fp32 copy of the two inner activations at all;
-* the 3x3 is an implicit GEMM (shifted row reads, zero line outside the map): no im2col matrix in the forward or in
-  the data gradient; only the weight gradient, which contracts over the rows, materialises pair-layout im2col rows;
+* the 3x3 is an implicit GEMM (shifted row reads, zero line outside the map): no im2col matrix in the forward, the
+  data gradient or the weight gradient;
 * backward: the ReLU gate is fused with the split of the gated gradient (``gate_split_pair``: the gate is read from
   the hi halves of the saved pair activations), dX products are the same kernel against transposed weights with
-  the shortcut gradient added in the epilogue, dW products are ONE M-contracting library GEMM each on the pair
-  operands ([dY_hi | dY_lo]^T [X_hi | X_lo] interleaved in 32-blocks; the four quadrants are summed).
+  the shortcut gradient added in the epilogue, dW products contract over the rows through the LDS transpose-read
+  kernel (``split_gemm_pair_tn``; the 3x3 reads its input shifted per tap, so no im2col rows exist in training either).
 Saved per row: the pair forms of the input and of the two inner activations + the fp32 output.
 """
 import torch
@@ -39,10 +39,18 @@ def conv_weight_matrix_t(w):
     return w.permute(1, 2, 3, 0).reshape(c, kh * kw * n)
 
 
-def dw_pair(gp, xp):
-    """dW[N, K] = dY^T X over the rows, both operands in pair layout ([M, 2N], [M, 2K]): one bf16 GEMM with fp32
-    accumulation gives all four hi/lo products, interleaved in 32-blocks along both axes; they are summed."""
+def dw_pair(gp, xp, conv=None):
+    """dW[N, taps*K] = dY^T X over the rows, both operands in pair layout ([M, 2N], [M, 2K]); conv = (h, w, kh, kw):
+    X is the NHWC input of a stride-1 "same" convolution and dW is tap-major [N, kh*kw*K].  The transpose-read split
+    GEMM (csrc/split_gemm.hip::split_gemm_tn_kernel: three-term product, row slices summed) when the shape allows,
+    else one library bf16 GEMM on the pair operands whose four hi/lo quadrants are summed (over pair-layout im2col
+    rows for a convolution)."""
     n, k = gp.shape[1] // 2, xp.shape[1] // 2
+    if _C.split_gemm_pair_tn_supported(n, k, conv):
+        return _C.split_gemm_pair_tn(gp, xp, conv)
+    if conv is not None:
+        xp = _C.im2col_pair(xp, *conv)
+        k = xp.shape[1] // 2
     q = torch.mm(gp.t(), xp, out_dtype=torch.float32)            # [2N, 2K]
     return q.view(n // 32, 2, 32, k // 32, 2, 32).sum(dim=(1, 4)).reshape(n, k)
 
@@ -91,9 +99,7 @@ class _BottleneckPair(Function):
         del d2
         dw2 = None
         if need_w2:
-            rows = _C.im2col_pair(o1p, h, w, kh, kw)
-            dw2 = dw_pair(g2p, rows).view(n2, kh, kw, n1).permute(0, 3, 1, 2)
-            del rows
+            dw2 = dw_pair(g2p, o1p, (h, w, kh, kw)).view(n2, kh, kw, n1).permute(0, 3, 1, 2)
         dx = dw1 = dwd = None
         if need_x or need_w1:
             d1, _ = _C.split_gemm_pair(g2p, pair_weight(conv_weight_matrix_t(w2)), conv=(h, w, kh, kw, True))

@@ -209,6 +209,16 @@ int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const void* b_pai
                          long ldr, long m, int n, int channels, int taps_h, int taps_w,
                          int height, int width, int flip, int relu, int tile_m, void* stream);
 
+/* Weight gradient on pair operands: c_slabs[s][n][tap*channels + c] = sum over the rows m of slice s of
+ * G[m, n] * X[row(m, tap), c]  (G = gated output gradient [m, n], X = the layer input [m, channels], both pair
+ * rows; taps as in ovis_split_gemm_pair, X read shifted with zeros outside the map).  The rows are cut into
+ * `slices` (ovis_split_gemm_tn_slices gives a count that fills the chip); the caller sums the slabs.
+ * n % 128 == 0, channels % 128 == 0, taps <= 16, height*width <= 8192 (else OVIS_ERANGE). */
+int ovis_split_gemm_tn_slices(long m, int n, int channels, int taps);
+int ovis_split_gemm_pair_tn(const void* g_pair, long g_row_bytes, const void* x_pair, long x_row_bytes,
+                            float* c_slabs, int slices, long m, int n, int channels, int taps_h,
+                            int taps_w, int height, int width, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Cross-modal head: fp32 GEMM on the matrix cores
  *   mb/modeling/roi_heads/box_head/roi_box_predictors.py:66-71 (emb_pred Linear, einsum('pe,ce->pc'),

@@ -122,13 +122,43 @@ def test_dw_pair_vs_fp64():
     assert ((dw.double() - ref).abs() / bound).max().item() < TOL
 
 
+@pytest.mark.parametrize("m,n,ch,conv", [(64, 128, 128, None), (1000, 128, 256, None), (49 * 37, 256, 128, (7, 7, 3, 3)),
+                                         (5 * 9 * 13, 128, 128, (9, 13, 3, 5)), (49 * 300, 512, 512, (7, 7, 3, 3)),
+                                         (31, 128, 128, None)])
+def test_split_gemm_pair_tn_vs_fp64(m, n, ch, conv):
+    """The transpose-read weight-gradient kernel (row slices + slab sum), plain and with shifted tap reads."""
+    C = _C()
+    g = torch.Generator(device="cuda").manual_seed(m + n + ch)
+    dy = torch.randn(m, n, device="cuda", generator=g)
+    x = torch.randn(m, ch, device="cuda", generator=g)
+    assert C.split_gemm_pair_tn_supported(n, ch, conv)
+    dw = C.split_gemm_pair_tn(C.split_pair(dy), C.split_pair(x), conv)
+    if conv is None:
+        cols = x.double()
+    else:
+        h, w, kh, kw = conv
+        r = m // (h * w)
+        cols = F.unfold(x.view(r, h, w, ch).permute(0, 3, 1, 2).double(), (kh, kw), padding=(kh // 2, kw // 2))
+        cols = cols.view(r, ch, kh * kw, h * w).permute(0, 3, 2, 1).reshape(m, kh * kw * ch)  # tap-major rows
+    ref = dy.double().t() @ cols
+    bound = dy.abs().double().t() @ cols.abs() + 1
+    assert ((dw.double() - ref).abs() / bound).max().item() < TOL
+    # the library route on the same operands agrees
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers.pair_bottleneck import dw_pair
+    xp = C.split_pair(x) if conv is None else C.im2col_pair(C.split_pair(x), *conv)
+    q = torch.mm(C.split_pair(dy).t(), xp, out_dtype=torch.float32)
+    k = xp.shape[1] // 2
+    lib = q.view(n // 32, 2, 32, k // 32, 2, 32).sum(dim=(1, 4)).reshape(n, k)
+    assert (dw - lib).abs().max().item() <= 1e-4 * lib.abs().max().item() + 1e-5
+
+
 @pytest.mark.parametrize("proj", [True, False])
 def test_bottleneck_pair_node_vs_fp64_autograd(proj):
     """Forward, input gradient and all weight gradients of the fused node vs an fp64 autograd bottleneck."""
     from cvpr22_cross_modal_pseudo_labeling_amd.layers.pair_bottleneck import bottleneck_pair
     torch.manual_seed(3)
     r, h, w = 6, 7, 7
-    cin, cb, cout = (64, 32, 128) if proj else (128, 32, 128)
+    cin, cb, cout = (128, 128, 256) if proj else (256, 128, 256)  # multiples of 128: the transpose-read dW kernel
     dev = "cuda"
     x = torch.randn(r * h * w, cin, device=dev, requires_grad=True)
     w1 = (torch.randn(cb, cin, 1, 1, device=dev) / cin ** 0.5).requires_grad_(True)

@@ -75,9 +75,19 @@ def bench_plain(m, k, n, tag):
     a3, b3 = _C.split_bf16x3(a, 0), _C.split_bf16x3(b, 1)
     fl = 2.0 * m * n * k
     out = []
-    for tm in (128, 3128, 256, 3256):
+    for tm in (128, 10128, 20128):
         ms = t(lambda: _C.split_gemm_pair(ap, bp, tile_m=tm))
         out.append(f"tile{tm} {ms:.3f} ms {fl / ms / 1e9:.0f} TF")
+    def padded(x, pad):
+        buf = torch.empty(x.shape[0], x.shape[1] + pad, dtype=x.dtype, device=x.device)
+        buf[:, :x.shape[1]] = x
+        return buf[:, :x.shape[1]]
+    for pad in (64, 192, 576):
+        app, bpp = padded(ap, pad), padded(bp, pad)
+        ms = t(lambda: _C.split_gemm_pair(app, bpp, tile_m=128))
+        out.append(f"pad{2 * pad}B {ms:.3f} ms {fl / ms / 1e9:.0f} TF")
+        ms = t(lambda: _C.split_gemm_pair(app, bpp, tile_m=20128))
+        out.append(f"pad{2 * pad}B-noMFMA {ms:.3f} ms")
     ms_l = t(lambda: torch.mm(a3, b3.t(), out_dtype=torch.float32))
     ms_s3 = t(lambda: _C.split_bf16x3(a, 0))
     ms_sp = t(lambda: _C.split_pair(a))
@@ -92,7 +102,7 @@ def bench_conv(r, h, w, c, n, tag):
     w3 = _C.split_bf16x3(wm, 1)
     fl = 2.0 * r * h * w * n * 9 * c
     out = []
-    for tm in (128, 3128, 256, 3256):
+    for tm in (128, 256):
         ms = t(lambda: _C.split_gemm_pair(xp, wp, conv=(h, w, 3, 3, False), tile_m=tm))
         out.append(f"tile{tm} {ms:.3f} ms {fl / ms / 1e9:.0f} TF")
     ms_i = t(lambda: _C.im2col_split_bf16x3(x, 3, 3))
@@ -102,9 +112,54 @@ def bench_conv(r, h, w, c, n, tag):
           f"({fl / (ms_i + ms_l) / 1e9:.0f} TF)")
 
 
+def check_tn(m, n, ch, conv=None):
+    g = torch.Generator(device="cuda").manual_seed(m + n + ch)
+    dy = torch.randn(m, n, device="cuda", generator=g)
+    x = torch.randn(m, ch, device="cuda", generator=g)
+    dw = _C.split_gemm_pair_tn(_C.split_pair(dy), _C.split_pair(x), conv)
+    if conv is None:
+        ref = dy.double().t() @ x.double()
+        bound = dy.abs().double().t() @ x.abs().double() + 1
+    else:
+        h, w, kh, kw = conv
+        r = m // (h * w)
+        cols = F.unfold(x.view(r, h, w, ch).permute(0, 3, 1, 2).double(), (kh, kw), padding=(kh // 2, kw // 2))  # [r, ch*T, hw]
+        cols = cols.view(r, ch, kh * kw, h * w).permute(0, 3, 2, 1).reshape(m, kh * kw * ch)                      # tap-major
+        ref = dy.double().t() @ cols
+        bound = dy.abs().double().t() @ cols.abs() + 1
+    err = ((dw.double() - ref).abs() / bound).max().item()
+    print(f"tn m={m} n={n} ch={ch} conv={conv}: err/bound {err:.2e}")
+    assert err < 2e-5
+
+
+def bench_tn(m, n, ch, conv, tag):
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers.pair_bottleneck import dw_pair
+    gp = _C.split_pair(torch.randn(m, n, device="cuda"))
+    xp = _C.split_pair(torch.randn(m, ch, device="cuda"))
+    taps = 1 if conv is None else conv[2] * conv[3]
+    fl = 2.0 * m * n * ch * taps
+    ms = t(lambda: _C.split_gemm_pair_tn(gp, xp, conv))
+    if conv is None:
+        ms_l = t(lambda: dw_pair(gp, xp))
+    else:
+        ms_l = t(lambda: dw_pair(gp, _C.im2col_pair(xp, *conv)))
+    print(f"{tag} dW m={m} n={n} ch={ch} conv={conv}: tn {ms:.3f} ms {fl / ms / 1e9:.0f} TF | hipBLASLt quadrant route {ms_l:.3f} ms {fl / ms_l / 1e9:.0f} TF")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    for tm in (128, 3128, 256, 3256):
+    check_tn(64, 128, 128)
+    check_tn(1000, 128, 256)
+    check_tn(49 * 37, 256, 128, (7, 7, 3, 3))
+    check_tn(5 * 9 * 13, 128, 128, (9, 13, 3, 5))
+    check_tn(49 * 300, 512, 512, (7, 7, 3, 3))
+    R = 1024
+    bench_tn(R * 49, 512, 1024, None, "b0 conv1")
+    bench_tn(R * 49, 2048, 1024, None, "b0 shortcut")
+    bench_tn(R * 49, 2048, 512, None, "conv3")
+    bench_tn(R * 49, 512, 2048, None, "b1 conv1")
+    bench_tn(R * 49, 512, 512, (7, 7, 3, 3), "conv2")
+    for tm in (128, 256):
         check_plain(128, 32, 128, tile_m=tm)
         check_plain(300, 64, 64, tile_m=tm)
         check_plain(1000, 512, 192, bias=True, res=True, relu=True, tile_m=tm)
