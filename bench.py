@@ -8,9 +8,10 @@ One process per GPU (RCCL), 2 images per GPU (weak scaling), fp32, inputs reside
 forward (frozen trunk + teacher pseudo-labelling + two student passes) -> backward with the bucketed
 gradient all-reduce overlapped -> SGD.  Rank 0 prints ONE JSON line with the fields the driver reads,
 plus
-  roofline     : the dominant hand-written kernel of this step (RoIAlign forward; RoIAlign backward for
-                 --workload teacher): algorithmic bytes / HIP-event time of those launches, measured live
-                 inside the timed region, against the 8 TB/s HBM peak;
+  roofline     : the hand-written kernel the step spends most time in (the pair-layout split GEMM of the res5
+                 head / frozen trunk: matrix-core bound, bf16 MFMA flops issued / HIP-event time against the
+                 2.5 PFLOP/s dense bf16 peak; a byte kernel would be priced against the 8 TB/s HBM peak),
+                 measured with HIP events on the launch stream (sequential replay when the step is pipelined);
   kernels      : the same for every native op that ran;
   cpu_baseline : the reference's own CPU kernels (oracle/_ref; falls back to the C port) on the native-op
                  work of ONE image of the same step, on the host cores (N=1, rank 0 only).
@@ -31,18 +32,25 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 IMS_PER_GPU = 2
 
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 matrix peak (the 2:1-sparsity figure is never used)
+
+
 class OpTimer:
-    """HIP-event timing of the native ops on the stream they are launched on (torch's current stream)."""
+    """HIP-event timing of the native ops on the stream they are launched on (torch's current stream).  Every op is
+    recorded with its ALGORITHMIC work: bytes for the HBM-bound byte kernels, matrix-core flops for the split GEMMs
+    (three bf16 products of 2*M*N*K flops each per fp32-accurate product; fp32-equivalent rate = a third of it)."""
 
     def __init__(self, C):
         self.C = C
-        self.records = {}   # name -> list of (start_event, end_event, algorithmic_bytes)
+        self.records = {}   # name -> list of (start_event, end_event, work)
+        self.kind = {}      # name -> "hbm" | "mfma"
         self.enabled = False
         self._orig = {}
 
-    def _wrap(self, name, bytes_fn):
+    def _wrap(self, name, work_fn, kind="hbm"):
         orig = getattr(self.C, name)
         self._orig[name] = orig
+        self.kind[name] = kind
 
         def wrapped(*args, **kwargs):
             if not self.enabled:
@@ -51,7 +59,7 @@ class OpTimer:
             a.record()
             out = orig(*args, **kwargs)
             b.record()
-            self.records.setdefault(name, []).append((a, b, bytes_fn(*args, **kwargs)))
+            self.records.setdefault(name, []).append((a, b, work_fn(*args, **kwargs)))
             return out
 
         setattr(self.C, name, wrapped)
@@ -82,6 +90,20 @@ class OpTimer:
             n, c, h, w = inp.shape
             return 4 * rois.shape[0] * c * (-(-ph // bs)) * (-(-pw // bs)) + 4 * n * c * h * w + 20 * rois.shape[0]
 
+        def split_pair_bytes(x):
+            return 8 * x.numel()  # 4 B read + hi + lo written
+
+        def gate_split_bytes(dy, gate=None, want_f32=False):
+            per = 8 + (0 if gate is None else (2 if gate.dtype == torch.bfloat16 else 4)) + (4 if want_f32 else 0)
+            return per * dy.numel()
+
+        def split_gemm_flops(a_pair, b_pair, *args, **kwargs):
+            return 6.0 * a_pair.shape[0] * b_pair.shape[0] * (b_pair.shape[1] // 2)  # 3 products x 2*M*N*K
+
+        def split_gemm_tn_flops(g_pair, x_pair, conv=None):
+            taps = 1 if conv is None else conv[2] * conv[3]
+            return 6.0 * g_pair.shape[0] * (g_pair.shape[1] // 2) * (x_pair.shape[1] // 2) * taps
+
         self._wrap("roi_align_forward", roi_fwd_bytes)
         self._wrap("roi_align_forward_mfma", roi_fwd_bytes)
         self._wrap("roi_align_forward_strided_nhwc", roi_fwd_strided_bytes)
@@ -90,14 +112,25 @@ class OpTimer:
         self._wrap("split_bf16x3", split_bytes)
         self._wrap("im2col_split_bf16x3", im2col_bytes)
         self._wrap("bias_act_", bias_act_bytes)
+        self._wrap("split_pair", split_pair_bytes)
+        self._wrap("gate_split_pair", gate_split_bytes)
+        self._wrap("split_gemm_pair", split_gemm_flops, "mfma")
+        self._wrap("split_gemm_pair_tn", split_gemm_tn_flops, "mfma")
 
     def summary(self):
         out = {}
         for name, recs in self.records.items():
             ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-            nbytes = sum(r[2] for r in recs)
-            out[name] = {"launches": len(recs), "avg_us": 1e3 * ms / len(recs), "alg_MB_per_launch": nbytes / len(recs) / 1e6,
-                         "achieved_GBps": nbytes / ms / 1e6 if ms > 0 else 0.0}
+            work = sum(r[2] for r in recs)
+            if self.kind[name] == "mfma":
+                out[name] = {"launches": len(recs), "avg_us": 1e3 * ms / len(recs), "bound": "mfma",
+                             "alg_GFLOP_per_launch": work / len(recs) / 1e9,
+                             "achieved_TFLOPs": work / ms / 1e9 if ms > 0 else 0.0,
+                             "fp32_equiv_TFLOPs": work / 3.0 / ms / 1e9 if ms > 0 else 0.0}
+            else:
+                out[name] = {"launches": len(recs), "avg_us": 1e3 * ms / len(recs), "bound": "hbm",
+                             "alg_MB_per_launch": work / len(recs) / 1e6,
+                             "achieved_GBps": work / ms / 1e6 if ms > 0 else 0.0}
         return out
 
 
@@ -269,10 +302,22 @@ def main():
 
     if rank == 0:
         kernels = timer.summary()
-        # the roofline object describes the hand-written kernel the step spends most time in (all of them are
-        # HBM-bound byte / stream kernels; every one is listed under "kernels")
+        # the roofline object describes the hand-written kernel the step spends most time in (the split GEMM:
+        # matrix-core bound; the byte kernels: HBM-bound); every native op is listed under "kernels"
         dom = max(kernels, key=lambda n: kernels[n]["launches"] * kernels[n]["avg_us"]) if kernels else "none"
-        k = kernels.get(dom, {"achieved_GBps": 0.0})
+        k = kernels.get(dom, {"bound": "hbm", "achieved_GBps": 0.0})
+        measured_in = (f"{replay_steps} sequential replay steps after the timed region (the timed steps overlap two "
+                       "streams)") if replay_steps else "the timed region"
+        if k["bound"] == "mfma":
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": k["achieved_TFLOPs"], "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": k["achieved_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                        "note": ("bf16 matrix-core flops issued: 3 hi/lo products x 2*M*N*K per fp32-accurate product "
+                                 f"({k['fp32_equiv_TFLOPs']:.0f} TFLOP/s fp32-equivalent)"),
+                        "measured_in": measured_in}
+        else:
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": k["achieved_GBps"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": k["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None,
+                        "measured_in": measured_in}
         global_batch = IMS_PER_GPU * world
         out = {
             "metric": "images/sec student-teacher train step (COCO 800x1333)" if args.workload == "student"
@@ -291,10 +336,7 @@ def main():
             "config": {"workload": f"{name}.yaml R-50-C4, {IMS_PER_GPU} img/GPU 3x800x1333, fwd+bwd+allreduce+SGD",
                        "global_batch": global_batch, "parallelism": f"dp{world}", "losses_finite": finite,
                        "pipelined": bool(overlapped)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": k["achieved_GBps"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": k["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None,
-                         "measured_in": (f"{replay_steps} sequential replay steps after the timed region (the timed "
-                                         "steps overlap two streams)") if replay_steps else "the timed region"},
+            "roofline": roofline,
             "kernels": {n: {kk: round(vv, 3) if isinstance(vv, float) else vv for kk, vv in v.items()}
                         for n, v in kernels.items()},
         }

@@ -256,6 +256,22 @@ def im2col_pair(xp, h, w, kh, kw):
     return out
 
 
+def im2col_nchw_pair(x, kh, kw, stride, pad):
+    """x [N, C, H, W] f32 contiguous -> (pair rows [N*Ho*Wo, 2*Kp] of the strided convolution's patches, k =
+    (ky*kw + kx)*C + c zero-padded to Kp % 32 == 0, (Ho, Wo)).  See include/ovis_hip.h."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        raise RuntimeError("im2col_nchw_pair: contiguous [N,C,H,W] float32 HIP tensor expected")
+    n, c, h, w = x.shape
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    kp = -(-(kh * kw * c) // 32) * 32
+    out = torch.empty((n * ho * wo, 2 * kp), dtype=torch.bfloat16, device=x.device)
+    if out.numel():
+        with torch.cuda.device(x.device):
+            rc = _L.ovis_im2col_nchw_pair_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, kh, kw, stride, pad, kp, _stream())
+        _lib.check(rc, "im2col_nchw_pair")
+    return out, (ho, wo)
+
+
 def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f32=True, out_pair=False, conv=None,
                     tile_m=0):
     """act(A @ B^T + bias + residual) with A [M, 2*ch] / B [N, 2*K] in pair layout (``split_pair``); fp32-accurate

@@ -544,6 +544,48 @@ __global__ __launch_bounds__(256) void gate_split_pair_kernel(const float* __res
   }
 }
 
+// im2col of a strided convolution on an NCHW fp32 image straight into pair rows (the 7x7 / stride-2 stem,
+// resnet.py:347-366, as a split GEMM: 3 input channels give the matrix cores nothing to do in a direct kernel):
+// row m = (n, oy, ox), k = (ky*KW + kx)*C + c, zero-padded to kp (% 32 == 0) columns.  A thread builds 8 k values of
+// one row (8 bounds-checked gathers, L1/L2-served) and writes 16 B hi + 16 B lo.
+__global__ __launch_bounds__(256) void im2col_nchw_pair_kernel(const float* __restrict__ src, char* __restrict__ dst,
+                                                              int N, int C, int H, int W, int KH, int KW, int stride,
+                                                              int pad, int Ho, int Wo, int kp) {
+  const int groups = kp >> 3;
+  const long total = (long)N * Ho * Wo * groups;
+  const int K = KH * KW * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int gidx = (int)(i % groups);
+    const long m = i / groups;
+    const int ox = (int)(m % Wo);
+    const int oy = (int)((m / Wo) % Ho);
+    const int n = (int)(m / ((long)Wo * Ho));
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = gidx * 8 + j;
+      float x = 0.f;
+      if (k < K) {
+        const int c = k % C, t = k / C;
+        const int ky = t / KW, kx = t - ky * KW;
+        const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) x = src[(((long)n * C + c) * H + iy) * W + ix];
+      }
+      v[j] = x;
+    }
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h[j] = pack_bf16(v[2 * j], v[2 * j + 1]);
+      l[j] = pack_bf16(v[2 * j] - __uint_as_float(h[j] << 16), v[2 * j + 1] - __uint_as_float(h[j] & 0xffff0000u));
+    }
+    const int c8 = gidx * 8;
+    char* d = dst + m * 4L * kp + (long)(c8 >> 5) * 128 + (c8 & 31) * 2;
+    *(uint4*)d = make_uint4(h[0], h[1], h[2], h[3]);
+    *(uint4*)(d + 64) = make_uint4(l[0], l[1], l[2], l[3]);
+  }
+}
+
 // Pair-layout im2col (only for the weight gradient of a 3x3, which contracts over the rows): src [R,H,W,C] pair
 // layout -> dst [R*H*W, T*C] pair layout, tap-major; out-of-map taps are zero rows.  Pure 16-byte copies: a thread
 // moves one 16-byte slot of one (pixel, tap).  4 B/element read (L2-served re-reads), 4*T B/element written.
@@ -601,6 +643,24 @@ extern "C" int ovis_gate_split_pair_f32(const float* dy, long dy_row_stride, con
   if (gate_is_pair) { if (g_f32) OVIS_GS(true, true); else OVIS_GS(true, false); }
   else { if (g_f32) OVIS_GS(false, true); else OVIS_GS(false, false); }
 #undef OVIS_GS
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}
+
+extern "C" int ovis_im2col_nchw_pair_f32(const float* src, void* dst_pair, int num, int channels, int height,
+                                         int width, int kh, int kw, int stride, int pad, int k_padded, void* stream) {
+  if (num < 0 || channels <= 0 || height <= 0 || width <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0)
+    return OVIS_EINVAL;
+  if (num == 0) return OVIS_OK;
+  if (!src || !dst_pair) return OVIS_EINVAL;
+  if (k_padded % 32 != 0 || k_padded < kh * kw * channels || ((uintptr_t)dst_pair & 15)) return OVIS_ERANGE;
+  const int ho = (height + 2 * pad - kh) / stride + 1, wo = (width + 2 * pad - kw) / stride + 1;
+  if (ho <= 0 || wo <= 0) return OVIS_EINVAL;
+  const long total = (long)num * ho * wo * (k_padded / 8);
+  const long blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 16L * OVIS_NUM_CU ? blocks : 16L * OVIS_NUM_CU);
+  hipLaunchKernelGGL(im2col_nchw_pair_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (char*)dst_pair, num,
+                     channels, height, width, kh, kw, stride, pad, ho, wo, k_padded);
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
 }

@@ -17,8 +17,16 @@ class FrozenBatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(n))
 
     def fold(self):
+        # the four buffers are constants of the step: the pair is computed once per buffer state (in-place updates such
+        # as load_state_dict bump the version counters, .to() replaces the tensors)
+        bufs = (self.weight, self.bias, self.running_mean, self.running_var)
+        key = tuple((id(b), b._version) for b in bufs)
+        cached = getattr(self, "_fold_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1], cached[2]
         scale = self.weight * self.running_var.rsqrt()
         shift = self.bias - self.running_mean * scale
+        self._fold_cache = (key, scale, shift)
         return scale, shift
 
     def forward(self, x):

@@ -237,6 +237,31 @@ class Stem(nn.Module):
         x = F.relu_(self._f[0](x))
         return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
 
+    def forward_gemm(self, x):
+        """Frozen stem on the GPU: patches -> pair rows (csrc/split_gemm.hip::im2col_nchw_pair_kernel), the 7x7 as one
+        split GEMM with the FrozenBN shift and the ReLU in its epilogue, max-pool on the NHWC result.  Returns the
+        channels_last view [N, 64, H/4, W/4] (MIOpen's fp32 kernel for this 3-channel convolution runs at 6 TFLOP/s)."""
+        from .. import _C
+        w, b = self._f[0].folded()
+        c = self.conv1
+        key = (id(w), w._version)
+        if getattr(self, "_wp", None) is None or self._wp[0] != key:
+            k = w.shape[1] * w.shape[2] * w.shape[3]
+            kp = -(-k // 32) * 32
+            wm = w.new_zeros((w.shape[0], kp))
+            wm[:, :k] = w.permute(0, 2, 3, 1).reshape(w.shape[0], k)   # k = (ky*KW + kx)*C + c
+            self._wp = (key, pair_weight(wm))
+        rows, (ho, wo) = _C.im2col_nchw_pair(x.contiguous(), c.kernel_size[0], c.kernel_size[1], c.stride[0], c.padding[0])
+        y, _ = _C.split_gemm_pair(rows, self._wp[1], b, None, True)
+        y = y.view(x.shape[0], ho, wo, -1).permute(0, 3, 1, 2)          # NCHW view of NHWC memory (channels_last)
+        return F.max_pool2d(y, kernel_size=3, stride=2, padding=1)
+
+    def gemm_supported(self, x):
+        c = self.conv1
+        return (x.is_cuda and not c.weight.requires_grad and not x.requires_grad and c.groups == 1 and c.dilation == (1, 1)
+                and c.stride[0] == c.stride[1] and c.padding[0] == c.padding[1] and c.out_channels % 4 == 0
+                and os.environ.get("OVIS_STEM_MIOPEN", "0") != "1")
+
 
 def _make_stage(in_channels, bottleneck_channels, out_channels, block_count, num_groups, stride_in_1x1,
                 first_stride, dilation=1):
@@ -286,7 +311,7 @@ class ResNetC4(nn.Module):
                 p.requires_grad = False
 
     def forward(self, x):
-        x = self.stem(x)
+        x = self.stem.forward_gemm(x) if (self.nhwc and self.stem.gemm_supported(x)) else self.stem(x)
         blocks = [b for name in self.stages for b in getattr(self, name)]
         if (x.is_cuda and self.nhwc and not any(p.requires_grad for p in self.parameters())
                 and all(b.nhwc_supported() for b in blocks)):
@@ -298,6 +323,7 @@ class ResNetC4(nn.Module):
             for i, b in enumerate(blocks):
                 y, yp = b.forward_nhwc(y, xp=yp, want_pair=True) if i + 1 < len(blocks) else (b.forward_nhwc(y, xp=yp), None)
             return [y.permute(0, 3, 1, 2).contiguous()]
+        x = x.contiguous()  # the GEMM stem hands over channels_last memory; MIOpen's NCHW kernels are the faster ones here
         for name in self.stages:
             x = getattr(self, name)(x)
         return [x]

@@ -201,7 +201,14 @@ class STGeneralizedRCNN(nn.Module):
         """The trainable half of the step: both student passes and their losses on the outputs of ``forward_frozen``."""
         student = self.roi_heads_student
         self.prepare_model()
-        dummy_loss = self.compute_dummy_loss()
+        # the all-parameter zero loss (st_generalized_rcnn.py:277-282) only enters the graph when a branch has no
+        # images; it is ~3 launches per parameter, so it is built on first use
+        dummy = []
+
+        def dummy_loss():
+            if not dummy:
+                dummy.append(self.compute_dummy_loss())
+            return dummy[0]
 
         # ---- pseudo branch: images that come with caption nouns ------------------------------------------
         loss_pseudo = {}
@@ -218,7 +225,7 @@ class STGeneralizedRCNN(nn.Module):
                     loss_pseudo[k] = loss_pseudo[k] * self.lambda_pseudo_label
         losses = {}
         for k in self.LOSS_NAMES:
-            v = loss_pseudo.get(k, dummy_loss)
+            v = loss_pseudo[k] if k in loss_pseudo else dummy_loss()
             if "mask" in k and self.no_pseudo_mask:
                 v = v * 0.0
             losses[f"{k}_pseudo"] = v
@@ -230,7 +237,7 @@ class STGeneralizedRCNN(nn.Module):
             student["box"].predictor.set_class_embeddings(self.combine_embs(self._seen_cls))
             _, _, loss_gt = student(frozen["gt_features"], frozen["gt_proposals"], gt_targets, compute_uncertain=False)
         for k in self.LOSS_NAMES:
-            losses[k] = loss_gt.get(k, dummy_loss)
+            losses[k] = loss_gt[k] if k in loss_gt else dummy_loss()
 
         self.iter += 1
         if self.uncertainty and self.iter == self.uncertainty_train_iter and self.mask_on:

@@ -191,6 +191,12 @@ int ovis_gate_split_pair_f32(const float* dy, long dy_row_stride, const void* ga
 int ovis_im2col_pair(const void* src_pair, void* dst_pair, long num, int height, int width,
                      int channels, int kh, int kw, void* stream);
 
+/* im2col of a strided convolution on an NCHW f32 image [num, channels, height, width] into pair rows
+ * [num*ho*wo, k_padded]: k = (ky*kw + kx)*channels + c, columns >= kh*kw*channels are zero (k_padded % 32 == 0).
+ * The 7x7 stride-2 stem (mb/modeling/backbone/resnet.py:347-366) then is one ovis_split_gemm_pair. */
+int ovis_im2col_nchw_pair_f32(const float* src, void* dst_pair, int num, int channels, int height, int width,
+                              int kh, int kw, int stride, int pad, int k_padded, void* stream);
+
 /* C[m, n] = act( sum_{tap, c} A[row(m, tap), c] * B[n, tap*channels + c] + bias[n] + residual[m, n] )
  *   a_pair : pair rows of `channels` values, a_row_bytes apart.  taps_h = taps_w = 1: a plain
  *            [m, channels] matrix.  Otherwise an NHWC tensor [m / (height*width), height, width,
