@@ -197,6 +197,45 @@ def im2col_split_bf16x3(x, kh, kw, flip=False):
     return out
 
 
+def match_encode(gt_boxes, gt_labels, proposals, high, low, weights=None, between_keeps_label=False):
+    """IoU match + labels (+ box-delta targets when ``weights`` is given) in one launch; see include/ovis_hip.h.
+    Returns (matched_idx int64 [P], labels int64 [P], regression_targets f32 [P,4] or None)."""
+    gt_boxes, proposals = _dev(gt_boxes, "gt_boxes"), _dev(proposals, "proposals")
+    gt_labels = gt_labels.to(torch.int64).contiguous()
+    g, p = gt_boxes.shape[0], proposals.shape[0]
+    if g == 0:
+        raise ValueError("No ground-truth boxes available for one of the images during training")
+    idx = torch.empty((p,), dtype=torch.int64, device=proposals.device)
+    lab = torch.empty((p,), dtype=torch.int64, device=proposals.device)
+    reg = torch.empty((p, 4), dtype=torch.float32, device=proposals.device) if weights is not None else None
+    if p:
+        wx, wy, ww, wh = weights if weights is not None else (1.0, 1.0, 1.0, 1.0)
+        with torch.cuda.device(proposals.device):
+            rc = _L.ovis_match_encode_f32(gt_boxes.data_ptr(), gt_labels.data_ptr(), proposals.data_ptr(), g, p, high, low,
+                                          int(bool(between_keeps_label)), wx, wy, ww, wh, idx.data_ptr(), lab.data_ptr(),
+                                          0 if reg is None else reg.data_ptr(), _stream())
+        _lib.check(rc, "match_encode")
+    return idx, lab, reg
+
+
+def project_masks(masks, gt_index, boxes, resolution):
+    """masks [G,H,W] bool / uint8, gt_index [P] int64, boxes [P,4] -> [P, M, M] f32 mask targets (one launch)."""
+    if not (masks.is_cuda and masks.dim() == 3 and masks.dtype in (torch.bool, torch.uint8)):
+        raise RuntimeError("project_masks: [G,H,W] bool / uint8 HIP tensor expected")
+    masks = masks.contiguous()
+    boxes = _dev(boxes, "boxes")
+    gt_index = gt_index.to(torch.int64).contiguous()
+    p = boxes.shape[0]
+    out = torch.empty((p, resolution, resolution), dtype=torch.float32, device=boxes.device)
+    if p:
+        with torch.cuda.device(boxes.device):
+            rc = _L.ovis_project_masks_f32(masks.data_ptr(), gt_index.data_ptr(), boxes.data_ptr(), p, masks.shape[1],
+                                           masks.shape[2], resolution, int(masks.dtype == torch.bool), out.data_ptr(),
+                                           _stream())
+        _lib.check(rc, "project_masks")
+    return out
+
+
 def split_pair(x):
     """x [rows, cols] f32 (row-strided view ok, cols % 32 == 0) -> pair layout [rows, 2*cols] bf16: per 32 values
     [hi(32) | lo(32)].  See include/ovis_hip.h."""

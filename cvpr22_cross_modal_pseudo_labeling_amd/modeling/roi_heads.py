@@ -22,6 +22,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import _C
 from ..layers import (Conv2d, ConvTranspose2d, ROIAlign, linear_mfma, smooth_l1_loss, stochastic_mask_bce,
                       text_logits, weighted_cross_entropy)
 from .backbone import ResNetHead
@@ -134,12 +135,18 @@ class FastRCNNLossComputation:
         out = []
         labels_all = []
         for prop, tgt in zip(proposals, targets):
-            matched = self.matcher(box_iou(tgt.bbox, prop.bbox))
-            idx = matched.clamp(min=0)
-            labels = tgt.get_field("labels")[idx].to(torch.int64)
-            labels[matched == Matcher.BELOW_LOW_THRESHOLD] = 0
-            labels[matched == Matcher.BETWEEN_THRESHOLDS] = -1
-            reg = self.box_coder.encode(tgt.bbox[idx], prop.bbox)
+            if prop.bbox.is_cuda and not self.matcher.allow_low_quality_matches:
+                # IoU -> match -> labels -> delta targets in one launch (csrc/targets.hip)
+                idx, labels, reg = _C.match_encode(tgt.bbox, tgt.get_field("labels"), prop.bbox,
+                                                   self.matcher.high_threshold, self.matcher.low_threshold,
+                                                   self.box_coder.weights)
+            else:
+                matched = self.matcher(box_iou(tgt.bbox, prop.bbox))
+                idx = matched.clamp(min=0)
+                labels = tgt.get_field("labels")[idx].to(torch.int64)
+                labels[matched == Matcher.BELOW_LOW_THRESHOLD] = 0
+                labels[matched == Matcher.BETWEEN_THRESHOLDS] = -1
+                reg = self.box_coder.encode(tgt.bbox[idx], prop.bbox)
             prop.add_field("labels", labels)
             prop.add_field("regression_targets", reg)
             prop.add_field("matched_gt", idx)
@@ -350,13 +357,22 @@ class MaskRCNNLossComputation:
                 labels.append(torch.zeros(0, dtype=torch.int64, device=prop.bbox.device))
                 masks.append(torch.empty(0, dtype=torch.float32, device=prop.bbox.device))
                 continue
-            matched = self.matcher(box_iou(tgt.bbox, prop.bbox))
-            idx = matched.clamp(min=0)
-            lab = tgt.get_field("labels")[idx].to(torch.int64)
-            lab[matched == Matcher.BELOW_LOW_THRESHOLD] = 0
+            gt_masks = tgt.get_field("masks")
+            fused = (prop.bbox.is_cuda and not self.matcher.allow_low_quality_matches and gt_masks.dim() == 3
+                     and gt_masks.dtype in (torch.bool, torch.uint8))
+            if fused:
+                idx, lab, _ = _C.match_encode(tgt.bbox, tgt.get_field("labels"), prop.bbox, self.matcher.high_threshold,
+                                              self.matcher.low_threshold, None, between_keeps_label=True)
+            else:
+                matched = self.matcher(box_iou(tgt.bbox, prop.bbox))
+                idx = matched.clamp(min=0)
+                lab = tgt.get_field("labels")[idx].to(torch.int64)
+                lab[matched == Matcher.BELOW_LOW_THRESHOLD] = 0
             pos = torch.nonzero(lab > 0).squeeze(1)
-            masks.append(project_masks_on_boxes(tgt.get_field("masks"), idx[pos], prop.bbox[pos],
-                                                self.discretization_size))
+            if fused:  # crop + bilinear resize of every positive's mask in one launch (csrc/targets.hip)
+                masks.append(_C.project_masks(gt_masks, idx[pos], prop.bbox[pos], self.discretization_size))
+            else:
+                masks.append(project_masks_on_boxes(gt_masks, idx[pos], prop.bbox[pos], self.discretization_size))
             labels.append(lab)
         return labels, masks
 

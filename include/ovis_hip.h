@@ -226,6 +226,27 @@ int ovis_split_gemm_pair_tn(const void* g_pair, long g_row_bytes, const void* x_
                             int taps_w, int height, int width, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Training-target construction on the device (csrc/targets.hip), one launch per image instead of ~100 tensor ops.
+ *
+ * ovis_match_encode_f32: boxlist_iou (mb/structures/boxlist_ops.py:53-89) of gt_boxes [num_gt,4] x proposals
+ * [num_proposals,4] -> Matcher without low-quality matches (mb/modeling/matcher.py:42-81) -> matched_idx
+ * [num_proposals] (argmax gt, 0 when below/between the thresholds, i.e. matched.clamp(min=0)), labels (gt label;
+ * 0 below low_threshold; between the thresholds -1 [between_keeps_label == 0, box head: box_head/loss.py:60-70] or
+ * the label of gt 0 [!= 0, mask head: mask_head/loss.py:60-77]) and, when regression_targets != NULL, BoxCoder.encode
+ * (mb/modeling/box_coder.py:22-52) of the matched gt box with weights (wx, wy, ww, wh).
+ *
+ * ovis_project_masks_f32: project_masks_on_boxes (mb/modeling/roi_heads/mask_head/loss.py:11-42) for binary masks
+ * [G, height, width] (1 byte per pixel; bool or uint8): crop to the rounded box, bilinear resize to resolution^2
+ * (align_corners = False), cast back to the mask dtype -> out [num, resolution, resolution] f32.
+ * ---------------------------------------------------------------------------------- */
+int ovis_match_encode_f32(const float* gt_boxes, const int64_t* gt_labels, const float* proposals, int num_gt,
+                          int num_proposals, float high_threshold, float low_threshold, int between_keeps_label,
+                          float wx, float wy, float ww, float wh, int64_t* matched_idx, int64_t* labels,
+                          float* regression_targets, void* stream);
+int ovis_project_masks_f32(const uint8_t* masks, const int64_t* gt_index, const float* boxes, int num, int height,
+                           int width, int resolution, int masks_are_bool, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Cross-modal head: fp32 GEMM on the matrix cores
  *   mb/modeling/roi_heads/box_head/roi_box_predictors.py:66-71 (emb_pred Linear, einsum('pe,ce->pc'),
  *   bbox_pred Linear) and their autograd transposes.
