@@ -25,6 +25,8 @@
 // consecutive columns of C: 16-byte stores, float4 bias / residual reads, 8-byte pair stores.
 // Workgroups are renumbered so that each XCD owns a contiguous range of tiles (column tiles of one row tile are
 // co-resident on one L2: the A rows are fetched from HBM once).
+#include <stdlib.h>
+
 #include "ovis_common.h"
 
 namespace {
@@ -41,7 +43,7 @@ struct SplitGemmArgs {
   float* C; long ldc;                // fp32 result (may be null)
   char* Cp; long cp_rs;              // pair result (may be null), bytes per row
   const float* bias; const float* res; long ldr;
-  long M; int N; int ch; int T; int H; int W; int KH; int KW; int flip; int relu;
+  long M; int N; int ch; int T; int H; int W; int KH; int KW; int flip; int relu; int gw;
 };
 
 __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
@@ -69,7 +71,13 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
     const int b = blockIdx.x, q = nblocks >> 3, r = nblocks & 7, xcd = b & 7, loc = b >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+  // tile order: column tiles are taken in groups of `p.gw`; within a group row tile-major.  The workgroups resident
+  // on one XCD then share gw weight tiles (gw x 128 rows x 4K bytes: L2-resident) while the A rows stream through.
+  const int gw = p.gw, tiles_m = nblocks / tiles_n;
+  const int per_group = tiles_m * gw;
+  const int grp = tile / per_group;
+  const int in_grp = tile - grp * per_group;
+  const int tile_m = in_grp / gw, tile_n = grp * gw + (in_grp - tile_m * gw);
   const long m0 = (long)tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -762,6 +770,12 @@ extern "C" int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const 
   p.M = m; p.N = n; p.ch = channels; p.T = T; p.H = height; p.W = width; p.KH = taps_h; p.KW = taps_w;
   p.flip = flip; p.relu = relu;
   const int tiles_n = (n + 127) / 128;
+  {
+    int gw = 4;
+    if (const char* e = getenv("OVIS_SG_GW")) gw = atoi(e);
+    if (gw <= 0 || gw > tiles_n || tiles_n % gw != 0) gw = tiles_n;
+    p.gw = gw;
+  }
   hipStream_t s = (hipStream_t)stream;
   int bm = tile_m;
   if (bm == 0) bm = 128;  // two independent 4-wave workgroups per CU beat one 8-wave 256-row workgroup on every shape measured

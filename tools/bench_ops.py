@@ -49,7 +49,7 @@ def bench_rois(r, n_img, g, kind="uniform"):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--ops", default="roi_fwd,roi_bwd,nms,focal,gemm,dcn,res5")
+    ap.add_argument("--ops", default="roi_fwd,roi_bwd,nms,focal,gemm,dcn,res5,split_gemm")
     ap.add_argument("--iters", type=int, default=20)
     args = ap.parse_args()
     ops = args.ops.split(",")
@@ -99,6 +99,46 @@ def main():
         res.append({"op": "im2col_split_bf16x3", "shape": "[1024,7,7,512] 3x3", "ms": ms, "alg_MB": 58 * xi.numel() / 1e6,
                     "GBps": 58 * xi.numel() / ms / 1e6, "frac_hbm": 58 * xi.numel() / ms / 1e6 / HBM_PEAK_GBS})
         del xi
+    if "split_gemm" in ops:  # pair-layout split GEMMs of the res5 head at R = 1024 (M = 50176 rows): forward / dX, 3x3, dW
+        m = 1024 * 49
+        peak = 2500.0  # dense bf16 TFLOP/s; 3 bf16 products per fp32-accurate product
+        for tag, k, n in (("conv1 b0", 1024, 512), ("shortcut", 1024, 2048), ("conv3", 512, 2048), ("conv1 b1", 2048, 512)):
+            ap = _C.split_pair(torch.randn(m, k, generator=g).to(dev))
+            bp = _C.split_pair(torch.randn(n, k, generator=g).to(dev))
+            ms = timeit(lambda: _C.split_gemm_pair(ap, bp), args.iters)
+            fl = 6.0 * m * n * k
+            res.append({"op": "split_gemm_pair", "shape": f"{tag} [{m}x{k}]x[{n}x{k}]^T", "ms": ms, "TFLOPs_bf16": fl / ms / 1e9,
+                        "TFLOPs_fp32_equiv": fl / 3 / ms / 1e9, "frac_mfma": fl / ms / 1e9 / peak})
+            gp = _C.split_pair(torch.randn(m, n, generator=g).to(dev))
+            ms = timeit(lambda: _C.split_gemm_pair_tn(gp, ap), args.iters)
+            res.append({"op": "split_gemm_pair_tn", "shape": f"{tag} dW [{m}x{n}]^T[{m}x{k}]", "ms": ms,
+                        "TFLOPs_bf16": fl / ms / 1e9, "TFLOPs_fp32_equiv": fl / 3 / ms / 1e9, "frac_mfma": fl / ms / 1e9 / peak})
+            del ap, bp, gp
+        xp = _C.split_pair(torch.randn(m, 512, generator=g).to(dev))
+        wp = _C.split_pair(torch.randn(512, 9 * 512, generator=g).to(dev))
+        gp = _C.split_pair(torch.randn(m, 512, generator=g).to(dev))
+        fl = 6.0 * m * 512 * 9 * 512
+        ms = timeit(lambda: _C.split_gemm_pair(xp, wp, conv=(7, 7, 3, 3, False)), args.iters)
+        res.append({"op": "split_gemm_pair(3x3 implicit)", "shape": "[1024,7,7,512]->512", "ms": ms, "TFLOPs_bf16": fl / ms / 1e9,
+                    "TFLOPs_fp32_equiv": fl / 3 / ms / 1e9, "frac_mfma": fl / ms / 1e9 / peak})
+        ms = timeit(lambda: _C.split_gemm_pair_tn(gp, xp, (7, 7, 3, 3)), args.iters)
+        res.append({"op": "split_gemm_pair_tn(3x3 dW)", "shape": "[1024,7,7,512]->512", "ms": ms, "TFLOPs_bf16": fl / ms / 1e9,
+                    "TFLOPs_fp32_equiv": fl / 3 / ms / 1e9, "frac_mfma": fl / ms / 1e9 / peak})
+        for cols in (512, 2048):
+            xm = torch.randn(m, cols, generator=g).to(dev)
+            ms = timeit(lambda: _C.split_pair(xm), args.iters)
+            res.append({"op": "split_pair", "shape": f"{m}x{cols}", "ms": ms, "alg_MB": 8 * xm.numel() / 1e6,
+                        "GBps": 8 * xm.numel() / ms / 1e6, "frac_hbm": 8 * xm.numel() / ms / 1e6 / HBM_PEAK_GBS})
+            ym = torch.randn(m, cols, generator=g).to(dev)
+            ms = timeit(lambda: _C.gate_split_pair(xm, ym, want_f32=True), args.iters)
+            res.append({"op": "gate_split_pair(f32 gate, +f32 out)", "shape": f"{m}x{cols}", "ms": ms, "alg_MB": 16 * xm.numel() / 1e6,
+                        "GBps": 16 * xm.numel() / ms / 1e6, "frac_hbm": 16 * xm.numel() / ms / 1e6 / HBM_PEAK_GBS})
+            del xm, ym
+        img = torch.randn(2, 3, 800, 1333, generator=g).to(dev)
+        ms = timeit(lambda: _C.im2col_nchw_pair(img, 7, 7, 2, 3), args.iters)
+        rows = 2 * 400 * 667
+        res.append({"op": "im2col_nchw_pair(stem 7x7/2)", "shape": "[2,3,800,1333]", "ms": ms, "alg_MB": (img.numel() * 4 + rows * 640) / 1e6,
+                    "GBps": (img.numel() * 4 + rows * 640) / ms / 1e6, "frac_hbm": (img.numel() * 4 + rows * 640) / ms / 1e6 / HBM_PEAK_GBS})
     if "nms" in ops:
         for k in (6000, 12000):
             xy = torch.rand(k, 2, generator=g) * torch.tensor([1200.0, 720.0])
