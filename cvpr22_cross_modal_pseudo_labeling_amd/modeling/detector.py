@@ -177,9 +177,11 @@ class STGeneralizedRCNN(nn.Module):
         out = {"feat": feat}
         idxs_cap = [i for i, t in enumerate(targets) if t.has_field("ids_cap") and len(t.get_field("ids_cap")) > 0]
         out["idxs_cap"] = idxs_cap
+        head_out = self.rpn.head(feat) if (idxs_cap or any(
+            t.has_field("is_det") and t.get_field("is_det") == "Yes" for t in targets)) else None  # one frozen head pass
         if idxs_cap:
             self.rpn.eval()
-            proposals, _ = self.rpn(images, features, None)
+            proposals, _ = self.rpn(images, features, None, head_out=head_out)
             cap_features = [feat[idxs_cap]]
             cap_proposals = [proposals[i] for i in idxs_cap]
             cap_targets = [targets[i] for i in idxs_cap]
@@ -192,7 +194,7 @@ class STGeneralizedRCNN(nn.Module):
         out["idxs_gt"] = idxs_gt
         if idxs_gt:
             self.rpn.train()
-            proposals_target, _ = self.rpn(images, features, targets, compute_loss=False)
+            proposals_target, _ = self.rpn(images, features, targets, compute_loss=False, head_out=head_out)
             out["gt_features"] = [feat[idxs_gt]]
             out["gt_proposals"] = [proposals_target[i] for i in idxs_gt]
         return out

@@ -4,6 +4,8 @@ Counterpart of maskrcnn_benchmark/modeling/rpn/anchor_generator.py:34-128,200-29
 rpn/rpn.py:74-197, rpn/inference.py:15-205 and rpn/loss.py:21-131 for the single-level (C4)
 case every shipped config uses.  The proposal path calls the HIP NMS through ``layers.nms``.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -92,12 +94,51 @@ class RPNHead(nn.Module):  # rpn.py:74-106
             nn.init.constant_(l.bias, 0)
 
     def forward(self, feature):
+        if self._gemm_ok(feature):
+            return self._forward_gemm(feature)
         t = F.relu(self.conv(feature))
         return self.cls_logits(t), self.bbox_pred(t)
 
+    def _gemm_ok(self, feature):
+        c = self.conv
+        no_grad = not torch.is_grad_enabled() or not (feature.requires_grad or any(p.requires_grad for p in self.parameters()))
+        return (feature.is_cuda and no_grad and c.in_channels % 32 == 0 and c.out_channels % 32 == 0
+                and c.kernel_size == (3, 3) and c.padding == (1, 1) and c.stride == (1, 1)
+                and os.environ.get("OVIS_RPN_MIOPEN", "0") != "1")
+
+    def _forward_gemm(self, feature):
+        """Frozen head on the split GEMM (csrc/split_gemm.hip): the 3x3 as an implicit GEMM with bias + ReLU in the
+        epilogue and its result only in pair layout, the two 1x1 predictors as ONE GEMM over the concatenated (zero-
+        padded) weight; returns NCHW views of the NHWC result.  MIOpen's fp32 Winograd kernel for the 3x3
+        (1024 -> 1024 on 50x84) takes 1.6 ms per batch."""
+        from .. import _C
+        from ..layers.pair_bottleneck import conv_weight_matrix, pair_weight
+        n, c, h, w = feature.shape
+        ws = (self.conv.weight, self.conv.bias, self.cls_logits.weight, self.cls_logits.bias, self.bbox_pred.weight,
+              self.bbox_pred.bias)
+        key = tuple((id(t), t._version) for t in ws)
+        if getattr(self, "_gemm_cache", None) is None or self._gemm_cache[0] != key:
+            a = self.cls_logits.out_channels
+            n11 = -(-(5 * a) // 4) * 4
+            w11 = feature.new_zeros((n11, c))
+            b11 = feature.new_zeros((n11,))
+            w11[:a] = self.cls_logits.weight.detach().view(a, c)
+            w11[a:5 * a] = self.bbox_pred.weight.detach().view(4 * a, c)
+            b11[:a] = self.cls_logits.bias.detach()
+            b11[a:5 * a] = self.bbox_pred.bias.detach()
+            self._gemm_cache = (key, pair_weight(conv_weight_matrix(self.conv.weight.detach())),
+                                self.conv.bias.detach().contiguous(), pair_weight(w11), b11)
+        _, w3p, b3, w11p, b11 = self._gemm_cache
+        a = self.cls_logits.out_channels
+        xp = _C.split_pair(feature.detach().permute(0, 2, 3, 1).contiguous().view(-1, c))
+        _, tp = _C.split_gemm_pair(xp, w3p, b3, None, True, False, True, conv=(h, w, 3, 3, False))
+        y, _ = _C.split_gemm_pair(tp, w11p, b11)
+        y = y.view(n, h, w, -1)
+        return y[..., :a].permute(0, 3, 1, 2), y[..., a:5 * a].permute(0, 3, 1, 2)
+
 
 def permute_and_flatten(layer, n, a, c, h, w):  # rpn/utils.py
-    return layer.view(n, -1, c, h, w).permute(0, 3, 4, 1, 2).reshape(n, -1, c)
+    return layer.reshape(n, -1, c, h, w).permute(0, 3, 4, 1, 2).reshape(n, -1, c)
 
 
 class RPNPostProcessor(nn.Module):  # inference.py:15-140 (single feature map)
@@ -179,9 +220,12 @@ class RPNModule(nn.Module):  # rpn.py:109-197
             Matcher(r.FG_IOU_THRESHOLD, r.BG_IOU_THRESHOLD, allow_low_quality_matches=True),
             BalancedPositiveNegativeSampler(r.BATCH_SIZE_PER_IMAGE, r.POSITIVE_FRACTION), coder)
 
-    def forward(self, images, features, targets=None, compute_loss=True):
+    def forward(self, images, features, targets=None, compute_loss=True, head_out=None):
+        """``head_out``: (objectness, box_regression) of ``self.head`` on the same features, when the caller already
+        has them (the student-teacher step selects test-mode AND train-mode proposals from one frozen head pass; the
+        reference runs the head twice, st_generalized_rcnn.py:296-309, with identical results)."""
         feature = features[0]
-        objectness, box_regression = self.head(feature)
+        objectness, box_regression = self.head(feature) if head_out is None else head_out
         anchors = self.anchor_generator(images.image_sizes, feature)
         if self.training:
             with torch.no_grad():

@@ -213,3 +213,22 @@ def test_stem_gemm_matches_convolution():
     hi, lo = _unpair(rows)
     cols = F.unfold(x, (7, 7), padding=3, stride=2).view(2, 3, 49, ho * wo).permute(0, 3, 2, 1).reshape(2 * ho * wo, 147)
     assert torch.equal(hi[:, :147], cols.to(torch.bfloat16)) and not hi[:, 147:].any() and not lo[:, 147:].any()
+
+
+def test_rpn_head_gemm_matches_convolutions():
+    """Frozen RPN head (3x3 + the two 1x1 predictors) on the split GEMM vs fp64 convolutions."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.rpn import RPNHead
+    torch.manual_seed(9)
+    head = RPNHead(64, 15).cuda()
+    for p in head.parameters():
+        p.data.normal_(0, 0.05)
+        p.requires_grad = False
+    x = torch.randn(2, 64, 13, 21, device="cuda")
+    assert head._gemm_ok(x)
+    obj, reg = head(x)
+    t = F.relu(F.conv2d(x.double(), head.conv.weight.double(), head.conv.bias.double(), padding=1))
+    obj_ref = F.conv2d(t, head.cls_logits.weight.double(), head.cls_logits.bias.double())
+    reg_ref = F.conv2d(t, head.bbox_pred.weight.double(), head.bbox_pred.bias.double())
+    assert obj.shape == obj_ref.shape and reg.shape == reg_ref.shape
+    assert (obj.double() - obj_ref).abs().max().item() <= 1e-5 * obj_ref.abs().max().item()
+    assert (reg.double() - reg_ref).abs().max().item() <= 1e-5 * reg_ref.abs().max().item()
