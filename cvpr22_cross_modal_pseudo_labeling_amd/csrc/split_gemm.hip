@@ -131,25 +131,30 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
   };
   set_tap(0);
 
-  auto issue = [&](int stage, int kb) {
+  // one LDS-DMA piece of the A / B tile of k-step kb into `stage` (the tap state is the one of kb; `advance` steps it)
+  auto issue_a = [&](int stage, int kb, int i) {
     char* base = smem + stage * STAGE;
     const long a_shift = conv ? ((long)dy * p.W + dx) * p.a_rs + (long)ld_cb * 128 : (long)kb * 128;
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const char* src = p.A + a_off[i] + a_shift;
-      if (conv) {
-        const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xffff) + dx;
-        if ((unsigned)y >= (unsigned)p.H || (unsigned)x >= (unsigned)p.W) src = zero_src;
-      }
-      glds16(src, base + a_lds[i]);
+    const char* src = p.A + a_off[i] + a_shift;
+    if (conv) {
+      const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xffff) + dx;
+      if ((unsigned)y >= (unsigned)p.H || (unsigned)x >= (unsigned)p.W) src = zero_src;
     }
-    const long b_shift = (long)kb * 128;
-#pragma unroll
-    for (int i = 0; i < BI; ++i) glds16(p.B + b_off[i] + b_shift, base + b_lds[i]);
+    glds16(src, base + a_lds[i]);
+  };
+  auto issue_b = [&](int stage, int kb, int i) { glds16(p.B + b_off[i] + (long)kb * 128, smem + stage * STAGE + b_lds[i]); };
+  auto advance = [&]() {
     if (++ld_cb == cpb) {
       ld_cb = 0;
       set_tap(++ld_tap);
     }
+  };
+  auto issue = [&](int stage, int kb) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) issue_a(stage, kb, i);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) issue_b(stage, kb, i);
+    advance();
   };
 
   // ---- fragment read addresses ----
@@ -178,9 +183,14 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
   if (NS == 3 && nk > 1) issue(1, 1);
   int st = 0;  // ring slot of stage kb
   for (int kb = 0; kb < nk; ++kb) {
+    // ABL == 3 (A/B probe): the 8 DMA pieces of the next stage spread over the MFMA groups below (one piece per 4
+    // MFMAs, order pinned by sched_barrier) instead of issued back to back after the barrier.  Measured 0-8 % SLOWER
+    // than the burst on the res5 shapes (pinning the order costs more than the cheaper DMA issue slots give back).
+    constexpr bool ILV = NS == 2 && ABL == 3;
+    const bool more = kb + 1 < nk;
     if (NS == 2) {
       __syncthreads();
-      if (kb + 1 < nk && (ABL != 1 || kb == 0)) issue((kb + 1) & 1, kb + 1);
+      if (!ILV && more && (ABL != 1 || kb == 0)) issue((kb + 1) & 1, kb + 1);
     } else {
       if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -209,6 +219,32 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
         acc[f][2] += __builtin_bit_cast(f32x4, bh[f]);
         acc[f][3] += __builtin_bit_cast(f32x4, bl[f]);
       }
+      continue;
+    }
+    if (ILV) {
+      const int nst = (kb + 1) & 1;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[g], ah[f], acc[f][g], 0, 0, 0);
+        if (more && f < AI) issue_a(nst, kb + 1, f);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[g], al[f], acc[f][g], 0, 0, 0);
+        if (more && f < BI) issue_b(nst, kb + 1, f);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (more) advance();
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[g], ah[f], acc[f][g], 0, 0, 0);
       continue;
     }
 #pragma unroll
@@ -799,6 +835,14 @@ extern "C" int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const 
     if (abl == 1) {
       OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       hipLaunchKernelGGL((split_gemm_kernel<2, false, 2, 1>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_n, (int)nblocks);
+    } else if (abl == 3) {
+      if (T > 1) {
+        OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, true, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((split_gemm_kernel<2, true, 2, 3>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_n, (int)nblocks);
+      } else {
+        OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, false, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((split_gemm_kernel<2, false, 2, 3>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_n, (int)nblocks);
+      }
     } else {
       OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       hipLaunchKernelGGL((split_gemm_kernel<2, false, 2, 2>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_n, (int)nblocks);

@@ -75,14 +75,14 @@ def bench_plain(m, k, n, tag):
     a3, b3 = _C.split_bf16x3(a, 0), _C.split_bf16x3(b, 1)
     fl = 2.0 * m * n * k
     out = []
-    for tm in (128, 10128, 20128):
+    for tm in (128, 30128, 10128, 20128, 256):
         ms = t(lambda: _C.split_gemm_pair(ap, bp, tile_m=tm))
         out.append(f"tile{tm} {ms:.3f} ms {fl / ms / 1e9:.0f} TF")
     def padded(x, pad):
         buf = torch.empty(x.shape[0], x.shape[1] + pad, dtype=x.dtype, device=x.device)
         buf[:, :x.shape[1]] = x
         return buf[:, :x.shape[1]]
-    for pad in (64, 192, 576):
+    for pad in ():
         app, bpp = padded(ap, pad), padded(bp, pad)
         ms = t(lambda: _C.split_gemm_pair(app, bpp, tile_m=128))
         out.append(f"pad{2 * pad}B {ms:.3f} ms {fl / ms / 1e9:.0f} TF")
@@ -102,7 +102,7 @@ def bench_conv(r, h, w, c, n, tag):
     w3 = _C.split_bf16x3(wm, 1)
     fl = 2.0 * r * h * w * n * 9 * c
     out = []
-    for tm in (128, 256):
+    for tm in (128, 30128, 256):
         ms = t(lambda: _C.split_gemm_pair(xp, wp, conv=(h, w, 3, 3, False), tile_m=tm))
         out.append(f"tile{tm} {ms:.3f} ms {fl / ms / 1e9:.0f} TF")
     ms_i = t(lambda: _C.im2col_split_bf16x3(x, 3, 3))
