@@ -192,14 +192,15 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
       __syncthreads();
       if (!ILV && more && (ABL != 1 || kb == 0)) issue((kb + 1) & 1, kb + 1);
     } else {
-      if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+      if (kb + 1 < nk && ABL != 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (kb + 2 < nk) issue(st == 0 ? 2 : st - 1, kb + 2);
+      if (kb + 2 < nk && ABL != 1) issue(st == 0 ? 2 : st - 1, kb + 2);
     }
     const char* base = smem + st * STAGE;
     st = (st + 1 == NS) ? 0 : st + 1;
+    if (ABL == 4) continue;  // ablation: the DMA stream alone (no LDS reads, no MFMAs)
     bf16x8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -830,11 +831,25 @@ extern "C" int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const 
     hipLaunchKernelGGL((split_gemm_kernel<WM_, CONV_, NS_>), dim3((unsigned)nblocks), dim3(WM_ * 128), lds, s,  \
                        p, tiles_n, (int)nblocks);                                                               \
   } while (0)
-  if (abl) {
+  if (abl && bm == 256 && stages == 3 && T == 1) {  // ablations of the 256-row, 3-stage ring (probe only)
+    constexpr int lds3 = 3 * (256 * 128 + 128 * 128);
+#define OVIS_ABL3(A_)                                                                                                    \
+  do {                                                                                                                   \
+    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<4, false, 3, A_>,                                    \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds3));                                 \
+    hipLaunchKernelGGL((split_gemm_kernel<4, false, 3, A_>), dim3((unsigned)nblocks), dim3(512), lds3, s, p, tiles_n,    \
+                       (int)nblocks);                                                                                    \
+  } while (0)
+    if (abl == 1) OVIS_ABL3(1); else if (abl == 2) OVIS_ABL3(2); else OVIS_ABL3(4);
+#undef OVIS_ABL3
+  } else if (abl) {
     constexpr int lds = 2 * (128 * 128 + 128 * 128);
     if (abl == 1) {
       OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       hipLaunchKernelGGL((split_gemm_kernel<2, false, 2, 1>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_n, (int)nblocks);
+    } else if (abl == 4) {
+      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, false, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      hipLaunchKernelGGL((split_gemm_kernel<2, false, 2, 4>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_n, (int)nblocks);
     } else if (abl == 3) {
       if (T > 1) {
         OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, true, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
