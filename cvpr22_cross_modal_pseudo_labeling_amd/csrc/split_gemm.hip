@@ -117,6 +117,7 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
     b_lds[i] = A_BYTES + piece * 1024;
   }
   const char* zero_src = g_zero_line + lchunk * 16;
+  uint4 sink = make_uint4(0u, 0u, 0u, 0u);
 
   const int cpb = p.ch >> 5;         // 32-value blocks per tap
   const int nk = p.T * cpb;
@@ -140,9 +141,22 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
       const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xffff) + dx;
       if ((unsigned)y >= (unsigned)p.H || (unsigned)x >= (unsigned)p.W) src = zero_src;
     }
-    glds16(src, base + a_lds[i]);
+    if (ABL == 5) {  // probe: the same bytes as plain 16-byte loads into registers (no LDS write)
+      const uint4 v = *(const uint4*)src;
+      sink.x ^= v.x; sink.y ^= v.y; sink.z ^= v.z; sink.w ^= v.w;
+    } else {
+      glds16(src, base + a_lds[i]);
+    }
   };
-  auto issue_b = [&](int stage, int kb, int i) { glds16(p.B + b_off[i] + (long)kb * 128, smem + stage * STAGE + b_lds[i]); };
+  auto issue_b = [&](int stage, int kb, int i) {
+    const char* src = p.B + b_off[i] + (long)kb * 128;
+    if (ABL == 5) {
+      const uint4 v = *(const uint4*)src;
+      sink.x ^= v.x; sink.y ^= v.y; sink.z ^= v.z; sink.w ^= v.w;
+    } else {
+      glds16(src, smem + stage * STAGE + b_lds[i]);
+    }
+  };
   auto advance = [&]() {
     if (++ld_cb == cpb) {
       ld_cb = 0;
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
     }
     const char* base = smem + st * STAGE;
     st = (st + 1 == NS) ? 0 : st + 1;
-    if (ABL == 4) continue;  // ablation: the DMA stream alone (no LDS reads, no MFMAs)
+    if (ABL == 4 || ABL == 5) continue;  // ablation: the DMA / load stream alone (no LDS reads, no MFMAs)
     bf16x8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -265,6 +279,7 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
         acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[g], ah[f], acc[f][g], 0, 0, 0);
   }
 
+  if (ABL == 5) acc[0][0].x += __uint_as_float(sink.x ^ sink.y ^ sink.z ^ sink.w);
   // ---- epilogue: lane owns row m = .. + (lane & 15), columns n = .. + (lane >> 4) * 4 + {0..3} of each tile ----
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
@@ -850,6 +865,9 @@ extern "C" int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const 
     } else if (abl == 4) {
       OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, false, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       hipLaunchKernelGGL((split_gemm_kernel<2, false, 2, 4>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_n, (int)nblocks);
+    } else if (abl == 5) {
+      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, false, 2, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      hipLaunchKernelGGL((split_gemm_kernel<2, false, 2, 5>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_n, (int)nblocks);
     } else if (abl == 3) {
       if (T > 1) {
         OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, true, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
