@@ -101,9 +101,9 @@ class BucketedGradReducer:
             self.pending[bi] = len(bucket)
             self.handles[bi] = None
             self.launched[bi] = False
-            off = 0
-            for p in bucket:
-                if p.grad is None or p.grad.data_ptr() != flat[off:off + 1].data_ptr():
+            off, base, esz = 0, flat.data_ptr(), flat.element_size()
+            for p in bucket:  # pointer comparison only: no tensor op per parameter on the per-step path
+                if p.grad is None or p.grad.data_ptr() != base + off * esz:
                     p.grad = flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
 

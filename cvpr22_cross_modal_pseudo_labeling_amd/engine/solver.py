@@ -22,7 +22,50 @@ def make_optimizer(cfg, model):
         if "uncertain_pred" in key:
             lr = lr * cfg.SOLVER.UNCERTAINTY_LR_FACTOR
         params.append({"params": [value], "lr": lr, "weight_decay": weight_decay})
-    return torch.optim.SGD(params, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM)
+    return GroupFusedSGD(params, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM)
+
+
+class GroupFusedSGD(torch.optim.SGD):
+    """``torch.optim.SGD`` with the reference's one-group-per-parameter layout (same ``param_groups`` / ``state``, so
+    optimizer checkpoints interchange) whose ``step`` runs the update of ALL groups as six multi-tensor ops with
+    per-tensor scalars, instead of four launches per parameter:  d = g + wd_i p;  buf = momentum_i buf + d (buf = d on
+    the first step);  p -= lr_i buf.  Falls back to the stock step for closures, dampening, nesterov, maximize or sparse
+    gradients."""
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        groups = self.param_groups
+        if closure is not None or any(g["dampening"] != 0 or g["nesterov"] or g.get("maximize", False) for g in groups):
+            return super().step(closure)
+        params, grads, wds, lrs, moms = [], [], [], [], []
+        for g in groups:
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    return super().step(closure)
+                params.append(p)
+                grads.append(p.grad)
+                wds.append(float(g["weight_decay"]))
+                lrs.append(float(g["lr"]))
+                moms.append(float(g["momentum"]))
+        if not params:
+            return None
+        d = torch._foreach_add(grads, torch._foreach_mul(params, wds)) if any(wds) else grads
+        if any(moms):
+            fresh = {i for i, p in enumerate(params) if self.state[p].get("momentum_buffer") is None}
+            for i in fresh:
+                self.state[params[i]]["momentum_buffer"] = torch.clone(d[i]).detach()
+            old = [i for i in range(len(params)) if i not in fresh]
+            if old:
+                bufs = [self.state[params[i]]["momentum_buffer"] for i in old]
+                torch._foreach_mul_(bufs, [moms[i] for i in old])
+                torch._foreach_add_(bufs, [d[i] for i in old])
+            upd = [self.state[p]["momentum_buffer"] if m != 0 else di for p, m, di in zip(params, moms, d)]
+        else:
+            upd = d
+        torch._foreach_add_(params, torch._foreach_mul(upd, [-lr for lr in lrs]))
+        return None
 
 
 class WarmupMultiStepLR(torch.optim.lr_scheduler._LRScheduler):
