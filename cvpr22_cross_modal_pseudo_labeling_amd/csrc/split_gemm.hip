@@ -189,6 +189,67 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // ABL == 6 (NS == 3): FRAGMENT DOUBLE BUFFERING.  One 8-wave workgroup per CU has every wave at the same barrier,
+  // so the LDS reads of a k-step are exposed (no second workgroup fills the matrix cores meanwhile).  Here the
+  // fragments of stage kb+1 are read into a second register set right after the barrier of step kb, and the 48 MFMAs
+  // of step kb run on the set that was read one step earlier: the matrix cores never wait for LDS.  Three LDS
+  // buffers: compute reads none, fragment reads take stage kb+1, the DMA fills stage kb+2.
+  if (NS == 3 && ABL == 6) {
+    bf16x8 f0[16], f1[16];
+    auto read_frags = [&](bf16x8* fr, int buf) {
+      const char* base = smem + buf * STAGE;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        fr[8 + f] = *(const bf16x8*)(base + b_rd[f]);
+        fr[f] = *(const bf16x8*)(base + a_rd[f]);
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        fr[12 + f] = *(const bf16x8*)(base + (b_rd[f] ^ 64));
+        fr[4 + f] = *(const bf16x8*)(base + (a_rd[f] ^ 64));
+      }
+    };
+    auto mfmas = [&](const bf16x8* fr) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[8 + g], fr[f], acc[f][g], 0, 0, 0);
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[8 + g], fr[4 + f], acc[f][g], 0, 0, 0);
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[12 + g], fr[f], acc[f][g], 0, 0, 0);
+    };
+    issue(0, 0);
+    __syncthreads();
+    if (nk > 1) issue(1, 1);
+    read_frags(f0, 0);
+    int b1 = 1, b2 = 2;  // ring slots of stages kb+1 and kb+2
+    for (int kb = 0; kb < nk; kb += 2) {
+      if (kb + 1 < nk) {
+        __syncthreads();                       // stage kb+1 landed everywhere; slot b2 (stage kb-1) no longer read
+        if (kb + 2 < nk) issue(b2, kb + 2);
+        read_frags(f1, b1);
+      }
+      mfmas(f0);
+      b1 = b2; b2 = b2 == 2 ? 0 : b2 + 1;
+      if (kb + 1 < nk) {
+        if (kb + 2 < nk) {
+          __syncthreads();
+          if (kb + 3 < nk) issue(b2, kb + 3);
+          read_frags(f0, b1);
+        }
+        mfmas(f1);
+        b1 = b2; b2 = b2 == 2 ? 0 : b2 + 1;
+      }
+    }
+  } else {
   // NS == 2: one __syncthreads per k-step (its fence drains this wave's DMAs: stage kb landed, stage kb-1's buffer
   // free), the next stage in flight under the MFMAs.  NS == 3: a ring with TWO stages in flight -- the wait is a
   // counted vmcnt that leaves the younger stage outstanding, and the barrier is a raw s_barrier (a __syncthreads
@@ -279,6 +340,7 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
         acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[g], ah[f], acc[f][g], 0, 0, 0);
   }
 
+  }  // legacy loop
   if (ABL == 5) acc[0][0].x += __uint_as_float(sink.x ^ sink.y ^ sink.z ^ sink.w);
   // ---- epilogue: lane owns row m = .. + (lane & 15), columns n = .. + (lane >> 4) * 4 + {0..3} of each tile ----
 #pragma unroll
@@ -846,7 +908,16 @@ extern "C" int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const 
     hipLaunchKernelGGL((split_gemm_kernel<WM_, CONV_, NS_>), dim3((unsigned)nblocks), dim3(WM_ * 128), lds, s,  \
                        p, tiles_n, (int)nblocks);                                                               \
   } while (0)
-  if (abl && bm == 256 && stages == 3 && T == 1) {  // ablations of the 256-row, 3-stage ring (probe only)
+  if (abl == 6 && bm == 256 && stages == 3) {
+    constexpr int lds3 = 3 * (256 * 128 + 128 * 128);
+    if (T > 1) {
+      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<4, true, 3, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
+      hipLaunchKernelGGL((split_gemm_kernel<4, true, 3, 6>), dim3((unsigned)nblocks), dim3(512), lds3, s, p, tiles_n, (int)nblocks);
+    } else {
+      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<4, false, 3, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
+      hipLaunchKernelGGL((split_gemm_kernel<4, false, 3, 6>), dim3((unsigned)nblocks), dim3(512), lds3, s, p, tiles_n, (int)nblocks);
+    }
+  } else if (abl && bm == 256 && stages == 3 && T == 1) {  // ablations of the 256-row, 3-stage ring (probe only)
     constexpr int lds3 = 3 * (256 * 128 + 128 * 128);
 #define OVIS_ABL3(A_)                                                                                                    \
   do {                                                                                                                   \
