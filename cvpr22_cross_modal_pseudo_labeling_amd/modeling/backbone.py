@@ -302,6 +302,7 @@ class ResNetC4(nn.Module):
             in_channels = out_channels
         self.out_channels = in_channels
         self.nhwc = os.environ.get("OVIS_TRUNK_NCHW", "0") != "1"
+        self.train_nhwc = os.environ.get("OVIS_TRUNK_TRAIN_PAIR", "0") == "1"  # opt-in: measured 50.5 vs 47.1 ms (MIOpen)
         self._freeze(cfg.MODEL.BACKBONE.FREEZE_CONV_BODY_AT)
 
     def _freeze(self, freeze_at):
@@ -313,12 +314,15 @@ class ResNetC4(nn.Module):
     def forward(self, x):
         x = self.stem.forward_gemm(x) if (self.nhwc and self.stem.gemm_supported(x)) else self.stem(x)
         blocks = [b for name in self.stages for b in getattr(self, name)]
-        if (x.is_cuda and self.nhwc and not any(p.requires_grad for p in self.parameters())
-                and all(b.nhwc_supported() for b in blocks)):
-            # fully frozen trunk (student-teacher configuration): layer1-3 in NHWC with the split-GEMM bottlenecks of
-            # the res5 head (1x1 = row-major GEMM, 3x3 = GEMM over split-im2col rows); one layout copy in (64
-            # channels) and one out (the C4 map, 34 MB).  With trainable stages (teacher training) MIOpen's
-            # backward kernels at these large spatial sizes are faster than the im2col route: 55 vs 69 ms per step.
+        frozen = not any(p.requires_grad for p in self.parameters())
+        if (x.is_cuda and self.nhwc and all(b.nhwc_supported() for b in blocks)
+                and (frozen or (self.train_nhwc and all(b.pair_gemm and b.pair_supported() for b in blocks)))):
+            # layer1-3 in NHWC with the split-GEMM bottlenecks of the res5 head (1x1 = row-major GEMM, 3x3 = implicit
+            # GEMM); one layout copy out (the C4 map, 34 MB).  Frozen trunk (student-teacher configuration): always.
+            # Trainable stages (teacher training): MIOpen by default -- at these large maps / small channel counts its
+            # kernels beat the pair-layout autograd nodes (47.1 vs 50.5 ms per step; the 3x3 weight gradient of layer2
+            # falls back to im2col rows because its 100x167 tap table exceeds the LDS budget of the transpose-read
+            # kernel); OVIS_TRUNK_TRAIN_PAIR=1 selects the nodes.
             y, yp = x.permute(0, 2, 3, 1).contiguous(), None
             for i, b in enumerate(blocks):
                 y, yp = b.forward_nhwc(y, xp=yp, want_pair=True) if i + 1 < len(blocks) else (b.forward_nhwc(y, xp=yp), None)
