@@ -70,6 +70,7 @@ class BucketedGradReducer:
             self.buckets.append(cur)
         self.flat, self.pending, self.handles, self.launched = [], [], [], []
         self._hooks = []
+        self._next = 0  # first bucket whose all-reduce has not been issued yet
         for bi, bucket in enumerate(self.buckets):
             flat = torch.zeros(sum(p.numel() for p in bucket), dtype=bucket[0].dtype, device=bucket[0].device)
             off = 0
@@ -85,9 +86,16 @@ class BucketedGradReducer:
     def _make_hook(self, bi):
         def hook(param):
             self.pending[bi] -= 1
-            if self.pending[bi] == 0:
-                self._launch(bi)
+            self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """Collectives are issued strictly in bucket order on every rank: a bucket whose gradients are complete waits
+        for the buckets before it (a rank on which some parameter got no gradient this step -- an image without
+        positives, say -- would otherwise issue its all-reduces in a different order than its peers)."""
+        while self._next < len(self.buckets) and self.pending[self._next] <= 0:
+            self._launch(self._next)
+            self._next += 1
 
     def _launch(self, bi):
         self.launched[bi] = True
@@ -96,6 +104,7 @@ class BucketedGradReducer:
 
     def zero_grad(self):
         """Replaces optimizer.zero_grad(): grads stay views of the flat buffers."""
+        self._next = 0
         for bi, (flat, bucket) in enumerate(zip(self.flat, self.buckets)):
             flat.zero_()
             self.pending[bi] = len(bucket)
@@ -110,9 +119,9 @@ class BucketedGradReducer:
     def finish(self):
         """Call after backward(): flush buckets whose hooks did not all fire (parameters that got no
         gradient this step contribute zeros), wait for the collectives and average."""
-        for bi in range(len(self.buckets)):
-            if not self.launched[bi]:
-                self._launch(bi)
+        for bi in range(self._next, len(self.buckets)):  # in order, after everything the hooks issued
+            self._launch(bi)
+        self._next = len(self.buckets)
         if self.world > 1:
             for bi, h in enumerate(self.handles):
                 if h is not None:

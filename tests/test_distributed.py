@@ -90,3 +90,50 @@ def test_reducer_single_process_is_passthrough():
         if p.requires_grad and q.grad is not None:
             assert torch.equal(p.grad, q.grad), n
     assert model.unused.grad is not None and float(model.unused.grad.abs().sum()) == 0.0
+
+
+class TwoHeads(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.trunk = nn.Linear(8, 8)
+        self.h1 = nn.Linear(8, 4)
+        self.h2 = nn.Linear(8, 4)
+
+
+def _worker_asym(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm
+
+    torch.manual_seed(5)
+    model = TwoHeads()
+    comm.broadcast_parameters(model)
+    reducer = comm.BucketedGradReducer(model, bucket_bytes=64)  # one bucket per parameter
+    x = torch.randn(3, 8, generator=torch.Generator().manual_seed(11 + rank))
+    reducer.zero_grad()
+    t = torch.relu(model.trunk(x))
+    # rank 1 has "no positives": h2 gets no gradient there, so its buckets complete in a different order than on rank 0
+    loss = model.h1(t).pow(2).mean() + (model.h2(t).pow(2).mean() if rank == 0 else 0.0)
+    loss.backward()
+    reducer.finish()
+    torch.save({n: p.grad.clone() for n, p in model.named_parameters()}, out + str(rank))
+    dist.destroy_process_group()
+
+
+def test_allreduce_order_is_rank_independent(tmp_path):
+    """A parameter without gradient on ONE rank must not reorder (or hang) the bucket all-reduces."""
+    out = str(tmp_path / "g")
+    mp.spawn(_worker_asym, args=(2, _free_port(), out), nprocs=2, join=True)
+    g0, g1 = torch.load(out + "0"), torch.load(out + "1")
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+    torch.manual_seed(5)
+    ref = TwoHeads()
+    tot = 0.0
+    for rank in range(2):
+        x = torch.randn(3, 8, generator=torch.Generator().manual_seed(11 + rank))
+        t = torch.relu(ref.trunk(x))
+        tot = tot + ref.h1(t).pow(2).mean() + (ref.h2(t).pow(2).mean() if rank == 0 else 0.0)
+    (tot / 2).backward()
+    for n, p in ref.named_parameters():
+        assert torch.allclose(g0[n], p.grad, atol=1e-6), n
