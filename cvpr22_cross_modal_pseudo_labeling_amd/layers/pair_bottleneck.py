@@ -79,6 +79,7 @@ class _BottleneckPair(Function):
         out, outp = _C.split_gemm_pair(o2p, wpairs["w3"], b3, res, True, True, want_pair)
         ctx.save_for_backward(xp, o1p, o2p, out, w1, w2, w3, wd)
         ctx.geom = (h, w, kh, kw)
+        ctx.set_materialize_grads(False)  # no zero tensor for the (non-differentiable) pair output's gradient slot
         if outp is not None:
             ctx.mark_non_differentiable(outp)
         return out, outp
@@ -86,6 +87,8 @@ class _BottleneckPair(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dout, _dpair):
+        if dout is None:
+            return (None,) * 12
         xp, o1p, o2p, out, w1, w2, w3, wd = ctx.saved_tensors
         h, w, kh, kw = ctx.geom
         need = ctx.needs_input_grad

@@ -100,7 +100,15 @@ class FastRCNNPredictor(nn.Module):
         nn.init.constant_(self.bbox_pred.bias, 0)
 
     def pooled(self, x):
-        return x.mean(dim=(2, 3)) if x.dim() == 4 else x
+        if x.dim() != 4:
+            return x
+        xl = x.permute(0, 2, 3, 1)
+        if xl.is_contiguous():
+            # the res5 head hands over an NCHW view of NHWC memory: reduce over the contiguous [R, H*W, C] form, so
+            # that the gradient (an expand over H*W) is born contiguous in the layout the head's backward reads --
+            # mean(dim=(2, 3)) on the view made autograd clone 411 MB through a strided copy (0.47 ms per pass)
+            return xl.reshape(x.shape[0], -1, x.shape[1]).mean(dim=1)
+        return x.mean(dim=(2, 3))
 
     def forward(self, x):
         x = self.pooled(x)
@@ -462,7 +470,16 @@ class ROIMaskHead(nn.Module):
             positive_inds = [p.get_field("labels") > 0 for p in proposals]
             proposals = [p[i] for p, i in zip(proposals, positive_inds)]
         if self.training and self.share:
-            x = features[_cat(positive_inds, 0)]
+            sel = _cat(positive_inds, 0)
+            fl = features.permute(0, 2, 3, 1) if features.dim() == 4 else None
+            if fl is not None and fl.is_contiguous() and not features.is_contiguous():
+                # box-head features arrive as an NCHW view of NHWC memory: select the positives in that layout, so the
+                # gradient autograd scatters back (zeros + index_put) is NHWC-dense like the pooled gradient it is
+                # added to -- the NCHW zeros of a plain features[sel] made that add strided and forced a 411 MB
+                # relayout copy in front of the res5 backward (0.8 ms per pass)
+                x = fl[sel].permute(0, 3, 1, 2)
+            else:
+                x = features[sel]
         else:
             x = self.feature_extractor(features, proposals)
         if self.training and self.cls_agnostic_mask:
