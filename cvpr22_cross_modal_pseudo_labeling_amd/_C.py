@@ -253,27 +253,43 @@ def split_pair(x):
     return out
 
 
-def gate_split_pair(dy, gate=None, want_f32=False):
-    """g = dy * (y > 0) in pair layout (and as fp32 when ``want_f32``); gate = y as fp32 [rows, cols] or as its pair
-    form [rows, 2*cols] bf16 (contiguous), None = plain split.  Returns (g_pair, g_f32 or None)."""
-    if not (dy.is_cuda and dy.dtype == torch.float32 and dy.dim() == 2):
-        raise RuntimeError("gate_split_pair: 2-D float32 HIP tensor expected")
-    if dy.stride(1) != 1 or dy.stride(0) % 4 or dy.data_ptr() % 16:
-        dy = dy.contiguous()
-    rows, cols = dy.shape
+def gate_split_pair(dy, gate=None, want_f32=False, pooled=None, pool_rows=0):
+    """g = (dy + pooled[row // pool_rows] / pool_rows) * (y > 0) in pair layout (and as fp32 when ``want_f32``); gate =
+    y as fp32 [rows, cols] or as its pair form [rows, 2*cols] bf16 (contiguous), None = no gate; ``pooled`` = the
+    gradient of a mean over every ``pool_rows`` consecutive rows ([rows / pool_rows, cols] f32) or None; ``dy`` may be
+    None when ``pooled`` is given.  Returns (g_pair, g_f32 or None)."""
+    if dy is None and pooled is None:
+        raise RuntimeError("gate_split_pair: dy or pooled must be given")
+    if pooled is not None:
+        if not (pooled.is_cuda and pooled.dtype == torch.float32 and pooled.dim() == 2):
+            raise RuntimeError("gate_split_pair: pooled must be a 2-D float32 HIP tensor")
+        pooled = pooled.contiguous()
+    if dy is not None:
+        if not (dy.is_cuda and dy.dtype == torch.float32 and dy.dim() == 2):
+            raise RuntimeError("gate_split_pair: 2-D float32 HIP tensor expected")
+        if dy.stride(1) != 1 or dy.stride(0) % 4 or dy.data_ptr() % 16:
+            dy = dy.contiguous()
+        rows, cols = dy.shape
+    else:
+        rows, cols = pooled.shape[0] * pool_rows, pooled.shape[1]
+    if pooled is not None and (pool_rows <= 0 or pooled.shape != (rows // max(pool_rows, 1), cols) or rows % pool_rows):
+        raise RuntimeError("gate_split_pair: pooled must be [rows / pool_rows, cols]")
+    dev = dy.device if dy is not None else pooled.device
     is_pair = 0
     if gate is not None:
         is_pair = int(gate.dtype == torch.bfloat16)
         if not (gate.is_cuda and gate.is_contiguous() and gate.shape == (rows, cols * (2 if is_pair else 1))
                 and gate.dtype in (torch.bfloat16, torch.float32)):
             raise RuntimeError("gate_split_pair: gate must be the contiguous fp32 or pair form of the forward output")
-    out = torch.empty((rows, 2 * cols), dtype=torch.bfloat16, device=dy.device)
-    g32 = torch.empty((rows, cols), dtype=torch.float32, device=dy.device) if want_f32 else None
+    out = torch.empty((rows, 2 * cols), dtype=torch.bfloat16, device=dev)
+    g32 = torch.empty((rows, cols), dtype=torch.float32, device=dev) if want_f32 else None
     if out.numel() == 0:
         return out, g32
-    with torch.cuda.device(dy.device):
-        rc = _L.ovis_gate_split_pair_f32(dy.data_ptr(), dy.stride(0), 0 if gate is None else gate.data_ptr(), is_pair,
-                                         out.data_ptr(), 0 if g32 is None else g32.data_ptr(), rows, cols, _stream())
+    with torch.cuda.device(dev):
+        rc = _L.ovis_gate_split_pair_f32(0 if dy is None else dy.data_ptr(), 0 if dy is None else dy.stride(0),
+                                         0 if gate is None else gate.data_ptr(), is_pair, out.data_ptr(),
+                                         0 if g32 is None else g32.data_ptr(), rows, cols,
+                                         0 if pooled is None else pooled.data_ptr(), pool_rows, _stream())
     _lib.check(rc, "gate_split_pair")
     return out, g32
 

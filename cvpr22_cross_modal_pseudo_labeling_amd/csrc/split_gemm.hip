@@ -622,15 +622,30 @@ __global__ __launch_bounds__(256) void split_pair_kernel(const float* __restrict
 template <bool GATE_PAIR, bool WRITE_F32>
 __global__ __launch_bounds__(256) void gate_split_pair_kernel(const float* __restrict__ dy, long dy_rs,
                                                              const void* __restrict__ gate, char* __restrict__ dst,
-                                                             float* __restrict__ g32, long rows, int cols) {
+                                                             float* __restrict__ g32, long rows, int cols,
+                                                             const float* __restrict__ gpool, int pool_rows,
+                                                             float pool_scale) {
   const int oc = cols >> 3;
   const long total = rows * oc;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long r = i / oc;
     const int c = (int)(i - r * oc) * 8;
     float v[8];
-    *(float4*)v = *(const float4*)(dy + r * dy_rs + c);
-    *(float4*)(v + 4) = *(const float4*)(dy + r * dy_rs + c + 4);
+    if (dy) {
+      *(float4*)v = *(const float4*)(dy + r * dy_rs + c);
+      *(float4*)(v + 4) = *(const float4*)(dy + r * dy_rs + c + 4);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = 0.f;
+    }
+    if (gpool) {  // + the gradient of the mean over every `pool_rows` consecutive rows (average pooling behind this layer)
+      const float* gp = gpool + (r / pool_rows) * (long)cols + c;
+      float q[8];
+      *(float4*)q = *(const float4*)gp;
+      *(float4*)(q + 4) = *(const float4*)(gp + 4);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = dy ? v[k] + q[k] * pool_scale : q[k] * pool_scale;
+    }
     const long poff = r * 4L * cols + (long)(c >> 5) * 128 + (c & 31) * 2;
     if (gate) {
       if (GATE_PAIR) {
@@ -748,20 +763,22 @@ extern "C" int ovis_split_pair_f32(const float* src, long src_row_stride, void* 
 }
 
 extern "C" int ovis_gate_split_pair_f32(const float* dy, long dy_row_stride, const void* gate, int gate_is_pair,
-                                        void* dst_pair, float* g_f32, long rows, int cols, void* stream) {
+                                        void* dst_pair, float* g_f32, long rows, int cols, const float* g_pooled,
+                                        int pool_rows, void* stream) {
   if (rows < 0 || cols < 0) return OVIS_EINVAL;
   if (rows == 0 || cols == 0) return OVIS_OK;
-  if (!dy || !dst_pair) return OVIS_EINVAL;
+  if ((!dy && !g_pooled) || !dst_pair || (g_pooled && (pool_rows <= 0 || rows % pool_rows != 0))) return OVIS_EINVAL;
   if (cols % 32 != 0 || dy_row_stride % 4 != 0 || ((uintptr_t)dy & 15) || ((uintptr_t)dst_pair & 15) ||
-      ((uintptr_t)gate & 15) || ((uintptr_t)g_f32 & 15))
+      ((uintptr_t)gate & 15) || ((uintptr_t)g_f32 & 15) || ((uintptr_t)g_pooled & 15))
     return OVIS_ERANGE;
+  const float pool_scale = g_pooled ? 1.f / (float)pool_rows : 0.f;
   const long total = rows * (cols / 8);
   const long blocks = (total + 255) / 256;
   const unsigned grid = (unsigned)(blocks < 8L * OVIS_NUM_CU ? blocks : 8L * OVIS_NUM_CU);
   hipStream_t s = (hipStream_t)stream;
 #define OVIS_GS(GP_, WF_)                                                                                          \
   hipLaunchKernelGGL((gate_split_pair_kernel<GP_, WF_>), dim3(grid), dim3(256), 0, s, dy, dy_row_stride, gate,      \
-                     (char*)dst_pair, g_f32, rows, cols)
+                     (char*)dst_pair, g_f32, rows, cols, g_pooled, pool_rows, pool_scale)
   if (gate_is_pair) { if (g_f32) OVIS_GS(true, true); else OVIS_GS(true, false); }
   else { if (g_f32) OVIS_GS(false, true); else OVIS_GS(false, false); }
 #undef OVIS_GS

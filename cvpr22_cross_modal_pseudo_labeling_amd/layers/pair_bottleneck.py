@@ -57,7 +57,7 @@ def dw_pair(gp, xp, conv=None):
 
 class _BottleneckPair(Function):
     @staticmethod
-    def forward(ctx, x, xp, geom, w1, b1, w2, b2, w3, b3, wd, want_pair, wpairs):
+    def forward(ctx, x, xp, geom, w1, b1, w2, b2, w3, b3, wd, want_pair, wpairs, pool):
         """x [M, Cin] f32 rows conv1 reads (may be None when wd is given and no input gradient is wanted), xp its pair
         form or None; geom = (h, w) of the map the rows tile; w1/w2/w3/wd folded weights (wd None = identity
         shortcut), b1/b2 shifts, b3 the conv3 (+ shortcut) shift; wpairs: optional cached pair weights."""
@@ -77,25 +77,30 @@ class _BottleneckPair(Function):
         else:
             res = x
         out, outp = _C.split_gemm_pair(o2p, wpairs["w3"], b3, res, True, True, want_pair)
+        # pool: also return the mean over the h*w rows of every map (the head's average pooling) as an output of THIS
+        # node, so that its gradient is broadcast inside the fused gate + split kernel of the backward instead of
+        # being materialised ([rows, C] expand) and added to the dense gradient by two tensor ops
+        pooled = out.view(-1, h * w, out.shape[1]).mean(dim=1) if pool else None
         ctx.save_for_backward(xp, o1p, o2p, out, w1, w2, w3, wd)
         ctx.geom = (h, w, kh, kw)
-        ctx.set_materialize_grads(False)  # no zero tensor for the (non-differentiable) pair output's gradient slot
+        ctx.set_materialize_grads(False)  # no zero tensors for absent / non-differentiable gradient slots
         if outp is not None:
             ctx.mark_non_differentiable(outp)
-        return out, outp
+        return out, outp, pooled
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dout, _dpair):
-        if dout is None:
-            return (None,) * 12
+    def backward(ctx, dout, _dpair, dpooled):
+        if dout is None and dpooled is None:
+            return (None,) * 13
         xp, o1p, o2p, out, w1, w2, w3, wd = ctx.saved_tensors
         h, w, kh, kw = ctx.geom
         need = ctx.needs_input_grad
         need_x, need_w1, need_w2, need_w3, need_wd = need[0], need[3], need[5], need[7], need[9]
         n1, n2, n3 = w1.shape[0], w2.shape[0], w3.shape[0]
         # gate of the block's last ReLU, fused with the split; the identity shortcut also needs the gated gradient in fp32
-        g3p, g3 = _C.gate_split_pair(dout.reshape(-1, n3), out, want_f32=(wd is None and need_x))
+        g3p, g3 = _C.gate_split_pair(None if dout is None else dout.reshape(-1, n3), out, want_f32=(wd is None and need_x),
+                                     pooled=dpooled, pool_rows=h * w)
         dw3 = dw_pair(g3p, o2p) if need_w3 else None
         d2, _ = _C.split_gemm_pair(g3p, pair_weight(w3.reshape(n3, -1).t()))                      # dY W3
         g2p, _ = _C.gate_split_pair(d2, o2p)
@@ -120,9 +125,11 @@ class _BottleneckPair(Function):
             dwd = dw_pair(g3p, xp).view_as(wd)
         if dw3 is not None:
             dw3 = dw3.view_as(w3)
-        return dx, None, None, dw1, None, dw2, None, dw3, None, dwd, None, None
+        return dx, None, None, dw1, None, dw2, None, dw3, None, dwd, None, None, None
 
 
-def bottleneck_pair(x, xp, geom, w1, b1, w2, b2, w3, b3, wd=None, want_pair=False, wpairs=None):
-    """(out f32 [M, Cout], out in pair layout or None) of one bottleneck on the rows x [M, Cin] of an (h, w) map."""
-    return _BottleneckPair.apply(x, xp, geom, w1, b1, w2, b2, w3, b3, wd, want_pair, wpairs)
+def bottleneck_pair(x, xp, geom, w1, b1, w2, b2, w3, b3, wd=None, want_pair=False, wpairs=None, pool=False):
+    """(out f32 [M, Cout], out in pair layout or None[, mean of out over the h*w rows of every map when ``pool``]) of
+    one bottleneck on the rows x [M, Cin] of an (h, w) map."""
+    out, outp, pooled = _BottleneckPair.apply(x, xp, geom, w1, b1, w2, b2, w3, b3, wd, want_pair, wpairs, pool)
+    return (out, outp, pooled) if pool else (out, outp)

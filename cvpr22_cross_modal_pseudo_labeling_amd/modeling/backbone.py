@@ -106,7 +106,7 @@ class Bottleneck(nn.Module):
                                    and d.stride == c1.stride))
                 and (d is not None or (c1.stride == (1, 1) and c1.in_channels == c3.out_channels)))
 
-    def _forward_pair(self, x, prestrided, xp, want_pair):
+    def _forward_pair(self, x, prestrided, xp, want_pair, pool=False):
         """The block as ONE autograd node on the pair-layout split GEMM (layers/pair_bottleneck.py): bias, shortcut,
         ReLU and the next layer's operand split live in the GEMM epilogues, the 3x3 is an implicit GEMM."""
         r, h, w, c = x.shape
@@ -141,11 +141,13 @@ class Bottleneck(nn.Module):
             wpairs, b3s = self._pair_cache[1], self._pair_cache[2]
         else:
             b3s = b3 if bd is None else b3 + bd
-        out, outp = bottleneck_pair(x2d, xp, (hs, ws), w1, b1, w2, b2, w3, b3s, wd, want_pair, wpairs)
-        out = out.view(r, hs, ws, out.shape[-1])
-        return (out, outp) if want_pair else out
+        res = bottleneck_pair(x2d, xp, (hs, ws), w1, b1, w2, b2, w3, b3s, wd, want_pair, wpairs, pool)
+        out = res[0].view(r, hs, ws, res[0].shape[-1])
+        if pool:
+            out._ovis_pooled = res[2]  # [R, C] mean over the map, an output of the same autograd node (see pooled())
+        return (out, res[1]) if want_pair else out
 
-    def forward_nhwc(self, x, prestrided=False, xp=None, want_pair=False):
+    def forward_nhwc(self, x, prestrided=False, xp=None, want_pair=False, pool=False):
         """Same block on an NHWC tensor ``x`` [R, H, W, C] (contiguous); ``prestrided``: x already holds only the
         positions conv1 / the shortcut read (the pooler applied their common stride).  The 1x1 convolutions -- 53 % of the
         res5 FLOPs -- become ONE row-major GEMM over all R*H*W positions each ([R*H*W, Cin] x [Cin, Cout], bias
@@ -156,7 +158,7 @@ class Bottleneck(nn.Module):
         ``xp``: the pair-layout form of x when the producer already wrote it; ``want_pair``: also return the pair
         form of the result (or None) for the next block -- both only used by the pair-layout route."""
         if self.pair_gemm and x.is_cuda and self.pair_supported():
-            return self._forward_pair(x, prestrided, xp, want_pair)
+            return self._forward_pair(x, prestrided, xp, want_pair, pool)
         r, h, w, c = x.shape
         sy, sx = self.conv1.stride
         if prestrided:
@@ -384,5 +386,9 @@ class ResNetHead(nn.Module):
             if i + 1 < len(self.layer4):
                 y, yp = b.forward_nhwc(y, prestrided=(i == 0), xp=yp, want_pair=True)
             else:
-                y = b.forward_nhwc(y, prestrided=(i == 0), xp=yp)
-        return y.permute(0, 3, 1, 2)
+                y = b.forward_nhwc(y, prestrided=(i == 0), xp=yp, pool=True)
+        out = y.permute(0, 3, 1, 2)
+        pooled = getattr(y, "_ovis_pooled", None)
+        if pooled is not None:
+            out._ovis_pooled = pooled
+        return out

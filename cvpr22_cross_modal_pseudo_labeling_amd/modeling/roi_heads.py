@@ -102,6 +102,9 @@ class FastRCNNPredictor(nn.Module):
     def pooled(self, x):
         if x.dim() != 4:
             return x
+        p = getattr(x, "_ovis_pooled", None)
+        if p is not None and p.shape == (x.shape[0], x.shape[1]):
+            return p  # the res5 head's last autograd node already produced the pooled map (backbone.py::_forward_pair)
         xl = x.permute(0, 2, 3, 1)
         if xl.is_contiguous():
             # the res5 head hands over an NCHW view of NHWC memory: reduce over the contiguous [R, H*W, C] form, so

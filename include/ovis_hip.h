@@ -181,9 +181,13 @@ int ovis_split_pair_f32(const float* src, long src_row_stride, void* dst_pair, l
 /* Backward ReLU gate fused with the operand split: g = dy * (y > 0) -> dst_pair (pair rows, dense) and, when
  * g_f32 != NULL, also as dense fp32.  dy [rows, cols] f32 (row stride in elements); gate = the saved forward
  * output y, dense: its pair form (gate_is_pair != 0; only the hi halves are read) or fp32, or NULL (no gate:
- * a plain split).  threshold_backward of mb/modeling/backbone/resnet.py:323-344's relu_ calls.  cols % 32 == 0. */
+ * a plain split).  threshold_backward of mb/modeling/backbone/resnet.py:323-344's relu_ calls.  cols % 32 == 0.
+ * g_pooled != NULL: [rows / pool_rows, cols] f32, the gradient of the mean over every pool_rows consecutive rows
+ * (the 7x7 average pooling of FastRCNNPredictor.forward, roi_box_predictors.py:62-66, behind the res5 head) is
+ * added on the fly, g = (dy + g_pooled[row / pool_rows] / pool_rows) * (y > 0); dy may then be NULL. */
 int ovis_gate_split_pair_f32(const float* dy, long dy_row_stride, const void* gate, int gate_is_pair,
-                             void* dst_pair, float* g_f32, long rows, int cols, void* stream);
+                             void* dst_pair, float* g_f32, long rows, int cols, const float* g_pooled,
+                             int pool_rows, void* stream);
 
 /* Pair-layout im2col (the M-contracting weight gradient of a 3x3 needs the rows materialised):
  * src NHWC [num, height, width, channels] pair rows -> dst [num*height*width, kh*kw*channels]

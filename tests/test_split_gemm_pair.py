@@ -232,3 +232,43 @@ def test_rpn_head_gemm_matches_convolutions():
     assert obj.shape == obj_ref.shape and reg.shape == reg_ref.shape
     assert (obj.double() - obj_ref).abs().max().item() <= 1e-5 * obj_ref.abs().max().item()
     assert (reg.double() - reg_ref).abs().max().item() <= 1e-5 * reg_ref.abs().max().item()
+
+
+def test_bottleneck_pair_pooled_output_and_fused_pool_gradient():
+    """pool=True: the node also returns the mean over the map; its gradient is broadcast inside gate_split_pair and must
+    equal the tensor-op route (mean of the fp32 output -> autograd)."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers.pair_bottleneck import bottleneck_pair
+    torch.manual_seed(4)
+    r, h, w, cin, cb, cout = 5, 7, 7, 128, 128, 128
+    dev = "cuda"
+    ws = [(torch.randn(cb, cin, 1, 1, device=dev) / cin ** 0.5), (torch.randn(cb, cb, 3, 3, device=dev) / (9 * cb) ** 0.5),
+          (torch.randn(cout, cb, 1, 1, device=dev) / cb ** 0.5)]
+    bs = [torch.randn(n, device=dev) * 0.1 for n in (cb, cb, cout)]
+    gp = torch.randn(r, cout, device=dev)
+    gd = torch.randn(r * h * w, cout, device=dev)
+
+    def run(pool, dense):
+        x = torch.randn(r * h * w, cin, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).requires_grad_(True)
+        wl = [t.clone().requires_grad_(True) for t in ws]
+        res = bottleneck_pair(x, None, (h, w), wl[0], bs[0], wl[1], bs[1], wl[2], bs[2], None, False, None, pool)
+        out = res[0]
+        pooled = res[2] if pool else out.view(r, h * w, cout).mean(1)
+        loss = (pooled * gp).sum() + ((out * gd).sum() if dense else 0.0)
+        grads = torch.autograd.grad(loss, [x] + wl)
+        return pooled.detach(), grads
+
+    for dense in (True, False):
+        p_ref, g_ref = run(False, dense)
+        p_got, g_got = run(True, dense)
+        assert torch.equal(p_ref, p_got)
+        for a, b in zip(g_got, g_ref):
+            assert (a - b).norm().item() <= 1e-5 * b.norm().item()
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C as C
+    dy = torch.randn(14, 32, device=dev)
+    y = torch.randn(14, 32, device=dev)
+    pl = torch.randn(2, 32, device=dev)
+    want = (dy + (pl * (1.0 / 7)).repeat_interleave(7, 0)) * (y > 0)
+    g_pair, g32 = C.gate_split_pair(dy, y, want_f32=True, pooled=pl, pool_rows=7)
+    assert torch.equal(g32, want) and torch.equal(g_pair, C.split_pair(want))
+    g_pair, g32 = C.gate_split_pair(None, y, want_f32=True, pooled=pl, pool_rows=7)
+    assert torch.equal(g32, (pl * (1.0 / 7)).repeat_interleave(7, 0) * (y > 0))
