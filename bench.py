@@ -108,6 +108,7 @@ class OpTimer:
         self._wrap("roi_align_forward", roi_fwd_bytes)
         self._wrap("roi_align_forward_mfma", roi_fwd_bytes)
         self._wrap("roi_align_forward_strided_nhwc", roi_fwd_strided_bytes)
+        self._wrap("roi_align_forward_strided_pair", roi_fwd_strided_bytes)
         self._wrap("roi_align_backward", roi_bwd_bytes)
         self._wrap("nms_padded", nms_bytes)
         self._wrap("split_bf16x3", split_bytes)

@@ -85,6 +85,25 @@ def roi_align_forward_strided_nhwc(input, rois, spatial_scale, pooled_height, po
     return out
 
 
+def roi_align_forward_strided_pair(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio, bin_stride):
+    """``roi_align_forward_strided_nhwc`` written in pair layout: [R*oh*ow, 2*C] bf16 (exactly ``split_pair`` of the fp32
+    bins), the operand of the res5 head's first split GEMM.  Returns (pair rows, (oh, ow))."""
+    input, rois = _dev(input, "input"), _dev(rois, "rois")
+    if rois.dim() != 2 or rois.size(1) != 5 or input.dim() != 4:
+        raise RuntimeError("roi_align_forward_strided_pair: expected input [N,C,H,W] and rois [R,5]")
+    n, c, h, w = input.shape
+    r = rois.size(0)
+    oh, ow = -(-pooled_height // bin_stride), -(-pooled_width // bin_stride)
+    out = torch.empty((r * oh * ow, 2 * c), dtype=torch.bfloat16, device=input.device)
+    if out.numel():
+        with torch.cuda.device(input.device):
+            rc = _L.ovis_roi_align_forward_strided_pair_f32(input.data_ptr(), rois.data_ptr(), out.data_ptr(), r, n, c, h, w,
+                                                            pooled_height, pooled_width, bin_stride, spatial_scale,
+                                                            sampling_ratio, _stream())
+        _lib.check(rc, "roi_align_forward_strided_pair")
+    return out, (oh, ow)
+
+
 def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels, height,
                        width, sampling_ratio):
     grad, rois = _dev(grad, "grad"), _dev(rois, "rois")

@@ -243,9 +243,34 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_kernel(
 // Per-bin arithmetic is the bit-exact kernel's, so out[r, i, j, c] == roi_align_forward(...)[r, c, bs*i, bs*j].
 // Work item = (output bin, 4-channel group): every lane pools one float4 and stores 16 contiguous bytes.
 // ---------------------------------------------------------------------------------------
+// Pair-layout stores (csrc/split_gemm.hip: per 32 channels 64 B bf16 hi | 64 B bf16 lo): the strided pooler can hand
+// its bins to the res5 head's first GEMM directly, without an fp32 copy and a split pass in between.
+typedef __bf16 pool_b2 __attribute__((ext_vector_type(2)));
+typedef float pool_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pool_pack_bf16(float a, float b) {
+  pool_f2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pool_b2));
+}
+__device__ __forceinline__ void pool_store4_pair(char* pair_r, long obin, int c, int C, f4 o) {
+  const unsigned h01 = pool_pack_bf16(o.x, o.y), h23 = pool_pack_bf16(o.z, o.w);
+  const unsigned l01 = pool_pack_bf16(o.x - __uint_as_float(h01 << 16), o.y - __uint_as_float(h01 & 0xffff0000u));
+  const unsigned l23 = pool_pack_bf16(o.z - __uint_as_float(h23 << 16), o.w - __uint_as_float(h23 & 0xffff0000u));
+  char* d = pair_r + obin * 4L * C + (long)(c >> 5) * 128 + (c & 31) * 2;
+  *(uint2*)d = make_uint2(h01, h23);
+  *(uint2*)(d + 64) = make_uint2(l01, l23);
+}
+__device__ __forceinline__ void pool_store1_pair(char* pair_r, long obin, int c, int C, float o) {
+  const __bf16 h = (__bf16)o;
+  const __bf16 l = (__bf16)(o - (float)h);
+  char* d = pair_r + obin * 4L * C + (long)(c >> 5) * 128 + (c & 31) * 2;
+  *(__bf16*)d = h;
+  *(__bf16*)(d + 64) = l;
+}
+
 template <int NCS, bool FAST>
 __device__ __forceinline__ void fwd_pool4_strided(const f4* win4, int rs, const RoiGeom& g, int H, int W, int bs,
-                                                  int OH, int OW, float* __restrict__ out_rc, int C) {
+                                                  int OH, int OW, float* __restrict__ out_rc, int C,
+                                                  char* pair_r = nullptr, int c_abs = 0) {
   constexpr int NG = NCS / 4;
   constexpr int SG = kFwdLdsFloats / NCS;
   const int items = OH * OW * NG;
@@ -272,7 +297,8 @@ __device__ __forceinline__ void fwd_pool4_strided(const f4* win4, int rs, const 
       }
     }
     const f4 o = FAST ? acc * g.inv_count : acc / g.count;
-    *(f4*)(out_rc + (long)obin * C + 4 * k) = o;
+    if (pair_r) pool_store4_pair(pair_r, obin, c_abs + 4 * k, C, o);
+    else *(f4*)(out_rc + (long)obin * C + 4 * k) = o;
   }
 }
 
@@ -280,7 +306,7 @@ __device__ __forceinline__ void fwd_pool4_strided(const f4* win4, int rs, const 
 template <int NCS>
 __device__ __forceinline__ void fwd_pool_strided(const float* src, int cs, int rs, int oy, int ox, const RoiGeom& g,
                                                  int H, int W, int bs, int OH, int OW, float* __restrict__ out_rc,
-                                                 int C) {
+                                                 int C, char* pair_r = nullptr, int c_abs = 0) {
   for (int obin = threadIdx.x; obin < OH * OW; obin += kThreads) {
     const int oh = obin / OW;
     const int ph = oh * bs, pw = (obin - oh * OW) * bs;
@@ -306,7 +332,10 @@ __device__ __forceinline__ void fwd_pool_strided(const float* src, int cs, int r
       }
     }
 #pragma unroll
-    for (int c = 0; c < NCS; ++c) out_rc[(long)obin * C + c] = acc[c] / g.count;
+    for (int c = 0; c < NCS; ++c) {
+      if (pair_r) pool_store1_pair(pair_r, obin, c_abs + c, C, acc[c] / g.count);
+      else out_rc[(long)obin * C + c] = acc[c] / g.count;
+    }
   }
 }
 
@@ -337,19 +366,19 @@ __device__ __forceinline__ void stage_window4(float* win, const float* __restric
 template <int NCS>
 __device__ __forceinline__ void strided_batch4(float* win, const float* __restrict__ plane, int HW, int H, int W,
                                                const RoiGeom& g, int wh, int ww, int bs, int OH, int OW,
-                                               float* __restrict__ out_rc, int C) {
+                                               float* __restrict__ out_rc, int C, char* pair_r, int c_abs) {
   stage_window4<NCS>(win, plane, HW, W, g, wh, ww);
   __syncthreads();
   if (g.pow2)
-    fwd_pool4_strided<NCS, true>((const f4*)win, ww, g, H, W, bs, OH, OW, out_rc, C);
+    fwd_pool4_strided<NCS, true>((const f4*)win, ww, g, H, W, bs, OH, OW, out_rc, C, pair_r, c_abs);
   else
-    fwd_pool4_strided<NCS, false>((const f4*)win, ww, g, H, W, bs, OH, OW, out_rc, C);
+    fwd_pool4_strided<NCS, false>((const f4*)win, ww, g, H, W, bs, OH, OW, out_rc, C, pair_r, c_abs);
   __syncthreads();
 }
 
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_strided_nhwc_kernel(
     const float* __restrict__ in, const float* __restrict__ rois, float* __restrict__ out, int R, int batch, int C,
-    int H, int W, int PH, int PW, int bs, int OH, int OW, float scale, int sampling_ratio) {
+    int H, int W, int PH, int PW, int bs, int OH, int OW, float scale, int sampling_ratio, int pair_out) {
   __shared__ __attribute__((aligned(16))) float win[kFwdLdsFloats];
   const int r = blockIdx.x % R;
   const int ct = blockIdx.x / R;
@@ -357,10 +386,15 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_strided_nhwc_kernel(
   const int c_end = min(C, c_begin + kCPB);
   const int HW = H * W;
   const RoiGeom g = make_geom(rois + (long)r * 5, scale, H, W, PH, PW, sampling_ratio, batch);
-  float* out_r = out + (long)r * OH * OW * C;
+  float* out_r = out + (long)r * OH * OW * C;   // both layouts take 4*C bytes per bin
+  char* pair_r = pair_out ? (char*)out_r : nullptr;
   if (g.empty) {
-    for (int i = threadIdx.x; i < OH * OW * (c_end - c_begin); i += kThreads)
-      out_r[(long)(i / (c_end - c_begin)) * C + c_begin + i % (c_end - c_begin)] = 0.f;
+    for (int i = threadIdx.x; i < OH * OW * (c_end - c_begin); i += kThreads) {
+      const long obin = i / (c_end - c_begin);
+      const int c = c_begin + i % (c_end - c_begin);
+      if (pair_r) pool_store1_pair(pair_r, obin, c, C, 0.f);
+      else out_r[obin * C + c] = 0.f;
+    }
     return;
   }
   const int wh = g.wy1 - g.wy0 + 1, ww = g.wx1 - g.wx0 + 1;
@@ -375,13 +409,13 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_strided_nhwc_kernel(
     float* o = out_r + c;
     const int n = min(left, cs_max);
     if (n >= 16 && vec_ok) {
-      strided_batch4<16>(win, plane, HW, H, W, g, wh, ww, bs, OH, OW, o, C);
+      strided_batch4<16>(win, plane, HW, H, W, g, wh, ww, bs, OH, OW, o, C, pair_r, c);
       c += 16;
     } else if (n >= 8 && vec_ok) {
-      strided_batch4<8>(win, plane, HW, H, W, g, wh, ww, bs, OH, OW, o, C);
+      strided_batch4<8>(win, plane, HW, H, W, g, wh, ww, bs, OH, OW, o, C, pair_r, c);
       c += 8;
     } else if (n >= 4 && vec_ok) {
-      strided_batch4<4>(win, plane, HW, H, W, g, wh, ww, bs, OH, OW, o, C);
+      strided_batch4<4>(win, plane, HW, H, W, g, wh, ww, bs, OH, OW, o, C, pair_r, c);
       c += 4;
     } else if (n >= 1) {  // one channel through LDS in the plain layout
       for (int idx = threadIdx.x; idx < warea; idx += kThreads) {
@@ -389,11 +423,11 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_strided_nhwc_kernel(
         win[idx] = plane[(g.wy0 + y) * W + (g.wx0 + x)];
       }
       __syncthreads();
-      fwd_pool_strided<1>(win, warea, ww, g.wy0, g.wx0, g, H, W, bs, OH, OW, o, C);
+      fwd_pool_strided<1>(win, warea, ww, g.wy0, g.wx0, g, H, W, bs, OH, OW, o, C, pair_r, c);
       __syncthreads();
       c += 1;
     } else {  // window larger than the LDS budget: gather from global
-      fwd_pool_strided<1>(plane, HW, W, 0, 0, g, H, W, bs, OH, OW, o, C);
+      fwd_pool_strided<1>(plane, HW, W, 0, 0, g, H, W, bs, OH, OW, o, C, pair_r, c);
       c += 1;
     }
   }
@@ -671,10 +705,30 @@ extern "C" int ovis_roi_align_forward_ws_f32(const float* input, const float* ro
                                     spatial_scale, sampling_ratio, stream);
 }
 
+static int strided_nhwc_launch(const float* input, const float* rois, float* output, int num_rois, int batch,
+                               int channels, int height, int width, int pooled_h, int pooled_w, int bin_stride,
+                               float spatial_scale, int sampling_ratio, int pair_out, void* stream);
+
 extern "C" int ovis_roi_align_forward_strided_nhwc_f32(const float* input, const float* rois, float* output,
                                                        int num_rois, int batch, int channels, int height, int width,
                                                        int pooled_h, int pooled_w, int bin_stride,
                                                        float spatial_scale, int sampling_ratio, void* stream) {
+  return strided_nhwc_launch(input, rois, output, num_rois, batch, channels, height, width, pooled_h, pooled_w, bin_stride,
+                             spatial_scale, sampling_ratio, 0, stream);
+}
+
+extern "C" int ovis_roi_align_forward_strided_pair_f32(const float* input, const float* rois, void* output_pair,
+                                                       int num_rois, int batch, int channels, int height, int width,
+                                                       int pooled_h, int pooled_w, int bin_stride,
+                                                       float spatial_scale, int sampling_ratio, void* stream) {
+  if (channels % 32 != 0 || ((uintptr_t)output_pair & 15)) return OVIS_ERANGE;
+  return strided_nhwc_launch(input, rois, (float*)output_pair, num_rois, batch, channels, height, width, pooled_h,
+                             pooled_w, bin_stride, spatial_scale, sampling_ratio, 1, stream);
+}
+
+static int strided_nhwc_launch(const float* input, const float* rois, float* output, int num_rois, int batch,
+                               int channels, int height, int width, int pooled_h, int pooled_w, int bin_stride,
+                               float spatial_scale, int sampling_ratio, int pair_out, void* stream) {
   if (num_rois < 0 || batch < 0 || channels < 0 || height <= 0 || width <= 0 || pooled_h <= 0 || pooled_w <= 0 ||
       bin_stride <= 0)
     return OVIS_EINVAL;
@@ -685,7 +739,7 @@ extern "C" int ovis_roi_align_forward_strided_nhwc_f32(const float* input, const
   if (blocks > 0x7fffffffL) return OVIS_ERANGE;
   hipLaunchKernelGGL(roi_align_fwd_strided_nhwc_kernel, dim3((unsigned)blocks), dim3(kThreads), 0,
                      (hipStream_t)stream, input, rois, output, num_rois, batch, channels, height, width, pooled_h,
-                     pooled_w, bin_stride, oh, ow, spatial_scale, sampling_ratio);
+                     pooled_w, bin_stride, oh, ow, spatial_scale, sampling_ratio, pair_out);
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
 }

@@ -122,6 +122,15 @@ class Bottleneck(nn.Module):
         else:
             hs, ws = h, w
             x2d = x.view(-1, c)
+        return self._pair_node(x2d, xp, r, hs, ws, want_pair, pool)
+
+    def forward_pair_rows(self, xp, r, hs, ws, want_pair=False, pool=False):
+        """The block on rows that exist only in pair layout ([r*hs*ws, 2*Cin] bf16, e.g. written by the pooler): needs
+        the projection shortcut (no fp32 rows for an identity shortcut) and no gradient w.r.t. the input."""
+        assert self._fd is not None
+        return self._pair_node(None, xp, r, hs, ws, want_pair, pool)
+
+    def _pair_node(self, x2d, xp, r, hs, ws, want_pair, pool):
         w1, b1 = self._f1[0].folded()
         w2, b2 = self._f2[0].folded()
         w3, b3 = self._f3[0].folded()
@@ -379,11 +388,19 @@ class ResNetHead(nn.Module):
               and (b0.downsample is None or b0.downsample[0].stride == s))
         return s[0] if ok else 0
 
-    def forward_pooled_nhwc(self, y):
-        """y [R, 7, 7, C]: the pooled bins conv1 reads, NHWC (from ``forward_strided_nhwc``) -> [R, 2048, 7, 7] view."""
-        yp = None
+    def pooled_pair_ok(self):
+        """The pooler may hand its bins over in pair layout only (no fp32 rows): the first block runs on the pair GEMM
+        route and has a projection shortcut."""
+        b0 = self.layer4[0]
+        return bool(self.pooler_stride()) and b0.pair_gemm and b0.pair_supported() and b0._fd is not None
+
+    def forward_pooled_nhwc(self, y, yp=None, shape=None):
+        """y [R, 7, 7, C]: the pooled bins conv1 reads, NHWC (from ``forward_strided_nhwc``) -> [R, 2048, 7, 7] view;
+        or y None and yp the same bins in pair layout with shape = (R, 7, 7) (from ``roi_align_forward_strided_pair``)."""
         for i, b in enumerate(self.layer4):
-            if i + 1 < len(self.layer4):
+            if i == 0 and y is None:
+                y, yp = b.forward_pair_rows(yp, shape[0], shape[1], shape[2], want_pair=True)
+            elif i + 1 < len(self.layer4):
                 y, yp = b.forward_nhwc(y, prestrided=(i == 0), xp=yp, want_pair=True)
             else:
                 y = b.forward_nhwc(y, prestrided=(i == 0), xp=yp, pool=True)

@@ -69,6 +69,14 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
     def forward(self, x, proposals):
         s = self.head.pooler_stride() if x[0].is_cuda else 0
         if s:  # the head's first 1x1 has stride s: pool only the bins it reads, straight into NHWC
+            need_grad = torch.is_grad_enabled() and x[0].requires_grad
+            if not need_grad and x[0].shape[1] % 32 == 0 and self.head.pooled_pair_ok():
+                # frozen features: the bins go to the first GEMM in pair layout, no fp32 copy / split pass in between
+                p = self.pooler.pooler
+                rois = self.pooler.convert_to_roi_format(proposals)
+                ph, pw = p.output_size
+                yp, (oh, ow) = _C.roi_align_forward_strided_pair(x[0], rois, p.spatial_scale, ph, pw, p.sampling_ratio, s)
+                return self.head.forward_pooled_nhwc(None, yp, (rois.shape[0], oh, ow))
             return self.head.forward_pooled_nhwc(self.pooler.forward_strided_nhwc(x, proposals, s))
         return self.head(self.pooler(x, proposals))
 

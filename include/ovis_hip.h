@@ -78,6 +78,14 @@ int ovis_roi_align_forward_strided_nhwc_f32(const float* input, const float* roi
                                             int width, int pooled_h, int pooled_w, int bin_stride,
                                             float spatial_scale, int sampling_ratio, void* stream);
 
+/* The same bins written in PAIR layout (see ovis_split_pair_f32 below: per 32 channels 64 B bf16 hi | 64 B bf16 lo;
+ * the values are the exact split of the fp32 results above), [num_rois * oh * ow, channels] pair rows: the operand of
+ * the res5 head's first split GEMM without an fp32 copy and a split pass.  channels % 32 == 0. */
+int ovis_roi_align_forward_strided_pair_f32(const float* input, const float* rois, void* output_pair,
+                                            int num_rois, int batch, int channels, int height, int width,
+                                            int pooled_h, int pooled_w, int bin_stride,
+                                            float spatial_scale, int sampling_ratio, void* stream);
+
 /* grad_input [batch, channels, height, width] is fully overwritten (zero-filled, then
  * accumulated into) by this call; the caller does not need to clear it. */
 int ovis_roi_align_backward_f32(const float* grad_output, const float* rois,

@@ -272,3 +272,20 @@ def test_bottleneck_pair_pooled_output_and_fused_pool_gradient():
     assert torch.equal(g32, want) and torch.equal(g_pair, C.split_pair(want))
     g_pair, g32 = C.gate_split_pair(None, y, want_f32=True, pooled=pl, pool_rows=7)
     assert torch.equal(g32, (pl * (1.0 / 7)).repeat_interleave(7, 0) * (y > 0))
+
+
+def test_strided_pooler_pair_output_is_split_of_fp32_output():
+    """roi_align_forward_strided_pair == split_pair(roi_align_forward_strided_nhwc) bit for bit (small, large, clipped and
+    empty RoIs), and the res5 head gives identical results from either hand-over."""
+    C = _C()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 64, 50, 84, generator=g).cuda()
+    rois = torch.tensor([[0, 10.0, 20.0, 200.0, 150.0], [1, 0.0, 0.0, 1332.0, 799.0], [0, 500.5, 300.25, 503.0, 301.0],
+                         [1, -40.0, -30.0, 90.0, 60.0], [0, 1300.0, 780.0, 1400.0, 900.0], [1, 64.0, 64.0, 64.0, 64.0]]).cuda()
+    more = torch.cat([torch.randint(0, 2, (40, 1), generator=g).float(), torch.rand(40, 2, generator=g) * 600], 1)
+    more = torch.cat([more, more[:, 1:] + torch.rand(40, 2, generator=g) * 500 + 4], 1).cuda()
+    rois = torch.cat([rois, more], 0)
+    f32 = C.roi_align_forward_strided_nhwc(x, rois, 1 / 16, 14, 14, 0, 2)
+    pair, (oh, ow) = C.roi_align_forward_strided_pair(x, rois, 1 / 16, 14, 14, 0, 2)
+    assert (oh, ow) == (7, 7) and pair.shape == (rois.shape[0] * 49, 128)
+    assert torch.equal(pair, C.split_pair(f32.view(-1, 64)))
