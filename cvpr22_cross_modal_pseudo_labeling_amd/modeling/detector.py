@@ -177,12 +177,18 @@ class STGeneralizedRCNN(nn.Module):
         out = {"feat": feat}
         idxs_cap = [i for i, t in enumerate(targets) if t.has_field("ids_cap") and len(t.get_field("ids_cap")) > 0]
         out["idxs_cap"] = idxs_cap
-        head_out = self.rpn.head(feat) if (idxs_cap or any(
-            t.has_field("is_det") and t.get_field("is_det") == "Yes" for t in targets)) else None  # one frozen head pass
+        idxs_gt = [i for i, t in enumerate(targets) if t.has_field("is_det") and t.get_field("is_det") == "Yes"]
+        head_out = self.rpn.head(feat) if (idxs_cap or idxs_gt) else None  # one frozen head pass for both selections
+        proposals = proposals_target = None
+        if idxs_cap and idxs_gt:
+            # test-mode proposals (pseudo branch) and train-mode proposals (ground-truth branch) from ONE decode + NMS
+            # pass per image (rpn.py::RPNPostProcessor.forward_with); the reference runs the whole RPN twice
+            proposals_target, proposals = self.rpn.proposals_train_and_test(images, features, targets, head_out)
         if idxs_cap:
-            self.rpn.eval()
-            proposals, _ = self.rpn(images, features, None, head_out=head_out)
-            cap_features = [feat[idxs_cap]]
+            if proposals is None:
+                self.rpn.eval()
+                proposals, _ = self.rpn(images, features, None, head_out=head_out)
+            cap_features = [feat if idxs_cap == list(range(feat.shape[0])) else feat[idxs_cap]]  # no copy for "all images"
             cap_proposals = [proposals[i] for i in idxs_cap]
             cap_targets = [targets[i] for i in idxs_cap]
             noun_embs = [t.get_field("cap_embs") if t.has_field("cap_embs") else self.cap_embs[t.get_field("ids_cap")]
@@ -190,12 +196,12 @@ class STGeneralizedRCNN(nn.Module):
             out["cap_features"] = cap_features
             out["cap_proposals"] = cap_proposals
             out["pseudo_targets"] = self.generate_pseudo_label(cap_features, cap_proposals, noun_embs, cap_targets)
-        idxs_gt = [i for i, t in enumerate(targets) if t.has_field("is_det") and t.get_field("is_det") == "Yes"]
         out["idxs_gt"] = idxs_gt
         if idxs_gt:
-            self.rpn.train()
-            proposals_target, _ = self.rpn(images, features, targets, compute_loss=False, head_out=head_out)
-            out["gt_features"] = [feat[idxs_gt]]
+            if proposals_target is None:
+                self.rpn.train()
+                proposals_target, _ = self.rpn(images, features, targets, compute_loss=False, head_out=head_out)
+            out["gt_features"] = [feat if idxs_gt == list(range(feat.shape[0])) else feat[idxs_gt]]
             out["gt_proposals"] = [proposals_target[i] for i in idxs_gt]
         return out
 

@@ -176,6 +176,43 @@ class RPNPostProcessor(nn.Module):  # inference.py:15-140 (single feature map)
         return result
 
 
+    def forward_with(self, other, anchors, objectness, box_regression, targets=None, add_gt=False):
+        """Proposals of THIS selector and of ``other`` (same threshold / min size, other.pre_nms_top_n <= ours) from ONE
+        decode + NMS pass: candidates are sorted by score and greedy NMS only lets higher-scored boxes suppress, so the
+        survivors among the first ``other.pre_nms_top_n`` candidates ARE ``other``'s NMS result.  Returns
+        (ours, theirs) -- what two separate ``forward`` calls return (ours with the ground truth appended)."""
+        assert other.pre_nms_top_n <= self.pre_nms_top_n and other.nms_thresh == self.nms_thresh \
+            and other.min_size == self.min_size
+        n, a, h, w = objectness.shape
+        objectness = permute_and_flatten(objectness, n, a, 1, h, w).view(n, -1).sigmoid()
+        box_regression = permute_and_flatten(box_regression, n, a, 4, h, w)
+        pre = min(self.pre_nms_top_n, a * h * w)
+        pre_other = min(other.pre_nms_top_n, a * h * w)
+        objectness, topk_idx = objectness.topk(pre, dim=1, sorted=True)
+        batch_idx = torch.arange(n, device=objectness.device)[:, None]
+        box_regression = box_regression[batch_idx, topk_idx]
+        concat_anchors = torch.stack([b.bbox for b in anchors], 0)[batch_idx, topk_idx]
+        proposals = self.box_coder.decode(box_regression.reshape(-1, 4), concat_anchors.reshape(-1, 4)).view(n, -1, 4)
+        rank = torch.arange(pre, device=objectness.device)
+        ours, theirs = [], []
+        for i in range(n):
+            boxlist = BoxList(proposals[i], anchors[i].size)
+            boxlist.add_field("objectness", objectness[i])
+            boxlist.add_field("rank", rank)
+            boxlist = boxlist.clip_to_image(remove_empty=False)
+            boxlist = remove_small_boxes(boxlist, self.min_size)
+            kept = boxlist_nms(boxlist, self.nms_thresh, max_proposals=-1, score_field="objectness")
+            sub = kept[torch.nonzero(kept.get_field("rank") < pre_other).squeeze(1)[:other.post_nms_top_n]]
+            theirs.append(sub.copy_with_fields(["objectness"]))
+            mine = kept[:self.post_nms_top_n].copy_with_fields(["objectness"])
+            if add_gt and targets is not None:
+                gt = BoxList(targets[i].bbox, targets[i].size)
+                gt.add_field("objectness", torch.ones(len(gt), device=gt.bbox.device))
+                mine = cat_boxlist((mine, gt))
+            ours.append(mine)
+        return ours, theirs
+
+
 class RPNLossComputation:  # loss.py:21-131
     def __init__(self, matcher, sampler, box_coder):
         self.matcher, self.sampler, self.box_coder = matcher, sampler, box_coder
@@ -235,3 +272,16 @@ class RPNModule(nn.Module):  # rpn.py:109-197
             lo, lb = self.loss_evaluator(anchors, objectness, box_regression, targets)
             return boxes, {"loss_objectness": lo, "loss_rpn_box_reg": lb}
         return self.box_selector_test(anchors, objectness, box_regression), {}
+
+    @torch.no_grad()
+    def proposals_train_and_test(self, images, features, targets, head_out=None):
+        """(train-mode proposals with the ground truth appended, test-mode proposals) from one head pass and one
+        NMS per image (``RPNPostProcessor.forward_with``); falls back to two selections when the selectors differ in
+        more than their top-n counts."""
+        feature = features[0]
+        objectness, box_regression = self.head(feature) if head_out is None else head_out
+        anchors = self.anchor_generator(images.image_sizes, feature)
+        tr, te = self.box_selector_train, self.box_selector_test
+        if te.pre_nms_top_n <= tr.pre_nms_top_n and te.nms_thresh == tr.nms_thresh and te.min_size == tr.min_size:
+            return tr.forward_with(te, anchors, objectness, box_regression, targets, add_gt=True)
+        return (tr(anchors, objectness, box_regression, targets, add_gt=True), te(anchors, objectness, box_regression))

@@ -126,3 +126,27 @@ def test_pipelined_trainer_matches_plain_steps():
             for k in b:
                 # not bit-identical run to run: split-K slices of the head GEMM add with fp32 atomics (~1e-5)
                 assert abs(a[k] - b[k]) <= 2e-4 * max(abs(b[k]), 1e-3), (kind, k, a[k], b[k])
+
+
+def test_rpn_shared_selection_matches_two_selections():
+    """RPNModule.proposals_train_and_test (one decode + NMS pass per image) returns exactly the proposals of the
+    train-mode and the test-mode selection run separately."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.structures import to_image_list
+
+    model, e_vocab, e_seen, images, targets = _build("student_teacher_mask_rcnn_uncertainty")
+    model = model.cuda()
+    images = images.cuda()
+    tg = [t.to("cuda") for t in targets]
+    with torch.no_grad():
+        il = to_image_list(images)
+        feats = model.backbone(il.tensors)
+        head_out = model.rpn.head(feats[0])
+        model.rpn.eval()
+        test_ref, _ = model.rpn(il, feats, None, head_out=head_out)
+        model.rpn.train()
+        train_ref, _ = model.rpn(il, feats, tg, compute_loss=False, head_out=head_out)
+        train_got, test_got = model.rpn.proposals_train_and_test(il, feats, tg, head_out)
+    for a, b in zip(train_got + test_got, train_ref + test_ref):
+        assert len(a) == len(b) and len(a) > 0
+        assert torch.equal(a.bbox, b.bbox)
+        assert torch.equal(a.get_field("objectness"), b.get_field("objectness"))
