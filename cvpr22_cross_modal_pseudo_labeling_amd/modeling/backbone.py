@@ -313,7 +313,7 @@ class ResNetC4(nn.Module):
             in_channels = out_channels
         self.out_channels = in_channels
         self.nhwc = os.environ.get("OVIS_TRUNK_NCHW", "0") != "1"
-        self.train_nhwc = os.environ.get("OVIS_TRUNK_TRAIN_PAIR", "0") == "1"  # opt-in: measured 50.5 vs 47.1 ms (MIOpen)
+        self.train_nhwc = os.environ.get("OVIS_TRUNK_TRAIN_MIOPEN", "0") != "1"
         self._freeze(cfg.MODEL.BACKBONE.FREEZE_CONV_BODY_AT)
 
     def _freeze(self, freeze_at):
@@ -330,10 +330,10 @@ class ResNetC4(nn.Module):
                 and (frozen or (self.train_nhwc and all(b.pair_gemm and b.pair_supported() for b in blocks)))):
             # layer1-3 in NHWC with the split-GEMM bottlenecks of the res5 head (1x1 = row-major GEMM, 3x3 = implicit
             # GEMM); one layout copy out (the C4 map, 34 MB).  Frozen trunk (student-teacher configuration): always.
-            # Trainable stages (teacher training): MIOpen by default -- at these large maps / small channel counts its
-            # kernels beat the pair-layout autograd nodes (47.1 vs 50.5 ms per step; the 3x3 weight gradient of layer2
-            # falls back to im2col rows because its 100x167 tap table exceeds the LDS budget of the transpose-read
-            # kernel); OVIS_TRUNK_TRAIN_PAIR=1 selects the nodes.
+            # Trainable stages (teacher training): through the pair-layout autograd nodes as well -- 39.4 vs 42.2 ms per
+            # step against MIOpen's NCHW kernels (both with a warm MIOpen kernel cache; OVIS_TRUNK_TRAIN_MIOPEN=1 selects
+            # MIOpen).  The 3x3 weight gradient of layer2 falls back to pair-layout im2col rows + a library GEMM: its
+            # 100x167 tap table exceeds the LDS budget of the transpose-read kernel.
             y, yp = x.permute(0, 2, 3, 1).contiguous(), None
             for i, b in enumerate(blocks):
                 y, yp = b.forward_nhwc(y, xp=yp, want_pair=True) if i + 1 < len(blocks) else (b.forward_nhwc(y, xp=yp), None)
