@@ -392,7 +392,7 @@ def split_gemm_pair_tn_supported(n, ch, conv=None):
         return False
     if conv is not None:
         h, w, kh, kw = conv
-        return kh * kw <= 16 and h * w <= 8192 and kh % 2 == 1 and kw % 2 == 1
+        return kh % 2 == 1 and kw % 2 == 1
     return True
 
 

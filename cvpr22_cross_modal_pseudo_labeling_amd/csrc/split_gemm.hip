@@ -412,7 +412,7 @@ struct SplitGemmTnArgs {
 
 template <bool CONV>
 __global__ __launch_bounds__(256) void split_gemm_tn_kernel(SplitGemmTnArgs p, int tiles_i, int tiles_j, int nblocks) {
-  constexpr int TILE_BYTES = 32 * 512, STAGE = 2 * TILE_BYTES, TAB = 2 * STAGE;
+  constexpr int TILE_BYTES = 32 * 512, STAGE = 2 * TILE_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int id;
@@ -426,21 +426,14 @@ __global__ __launch_bounds__(256) void split_gemm_tn_kernel(SplitGemmTnArgs p, i
   const int tile_j = rem / tiles_i, tile_i = rem - tile_j * tiles_i;
   const int i0 = tile_i * 128, j0 = tile_j * 128;
   const int tap = CONV ? j0 / p.ch : 0, c0 = CONV ? j0 - tap * p.ch : j0;
-  const int HW = p.H * p.W;
-  int off_rows = 0;
+  // tap of this workgroup's column tile: X rows are read shifted by (tdy, tdx); a row whose shifted pixel lies outside
+  // the map reads the zero line.  The (y, x) position of every DMA row is tracked incrementally (rows advance by 32
+  // per step: x += 32 % W with carry into y), so maps of any size work and no table is needed.
+  int off_rows = 0, tdy = 0, tdx = 0;
   if (CONV) {
-    // tap mask table: bit t of tab[r] = tap t of map position r = (y, x) lies inside the map
-    unsigned short* tab = (unsigned short*)(smem + TAB);
-    for (int r = threadIdx.x; r < HW; r += 256) {
-      const int y = r / p.W, x = r - y * p.W;
-      unsigned m = 0;
-      for (int t = 0; t < p.T; ++t) {
-        const int yy = y + t / p.KW - p.KH / 2, xx = x + t % p.KW - p.KW / 2;
-        if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) m |= 1u << t;
-      }
-      tab[r] = (unsigned short)m;
-    }
-    off_rows = (tap / p.KW - p.KH / 2) * p.W + (tap % p.KW - p.KW / 2);
+    tdy = tap / p.KW - p.KH / 2;
+    tdx = tap % p.KW - p.KW / 2;
+    off_rows = tdy * p.W + tdx;
   }
   const long step0 = (long)slice * p.steps_per_slice;
   const long steps_total = (p.M + 31) >> 5;
@@ -452,7 +445,7 @@ __global__ __launch_bounds__(256) void split_gemm_tn_kernel(SplitGemmTnArgs p, i
   const int prow = lane >> 5, pseg = (lane & 31) >> 1, phalf = lane & 1;
   int rows[4];          // tile row of the lane in its 4 pieces
   long g_off[4], x_off[4];
-  int x_r[4];           // (m mod HW) of the X row, kept incrementally
+  int x_y[4], x_x[4];   // map position of the X row, kept incrementally
   int m_row[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -465,26 +458,27 @@ __global__ __launch_bounds__(256) void split_gemm_tn_kernel(SplitGemmTnArgs p, i
     m_row[i] = m;
     g_off[i] = (long)m * p.g_rs + (long)i0 * 4 + seg * 32 + phalf * 16;
     x_off[i] = ((long)m + off_rows) * p.x_rs + (long)c0 * 4 + seg * 32 + phalf * 16;
-    x_r[i] = CONV ? m % HW : 0;
+    x_x[i] = CONV ? m % p.W : 0;
+    x_y[i] = CONV ? (m / p.W) % p.H : 0;
   }
-  const int inc = CONV ? 32 % HW : 0;
+  const int step_dx = CONV ? 32 % p.W : 0, step_dy = CONV ? 32 / p.W : 0;
+  const bool y_single = step_dy + 1 <= p.H;  // one conditional subtraction brings y back into [0, H)
   const char* zero_src = g_zero_line + (lane & 7) * 16;
   const int Mi = (int)p.M;
-  if (CONV) __syncthreads();  // table visible
 
   auto issue = [&](int stage) {
     char* base = smem + stage * STAGE;
-    // the tap-mask look-ups come first: an LDS read while DMAs are in flight makes hipcc wait vmcnt(0), and right
-    // after the barrier nothing is
     bool x_ok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       x_ok[i] = m_row[i] < Mi;
       if (CONV) {
-        const unsigned short* tab = (const unsigned short*)(smem + TAB);
-        x_ok[i] = x_ok[i] && ((tab[x_r[i]] >> tap) & 1);
-        x_r[i] += inc;
-        if (x_r[i] >= HW) x_r[i] -= HW;
+        x_ok[i] = x_ok[i] && (unsigned)(x_y[i] + tdy) < (unsigned)p.H && (unsigned)(x_x[i] + tdx) < (unsigned)p.W;
+        int x = x_x[i] + step_dx, y = x_y[i] + step_dy;
+        if (x >= p.W) { x -= p.W; ++y; }
+        if (y_single) { if (y >= p.H) y -= p.H; } else { y %= p.H; }
+        x_x[i] = x;
+        x_y[i] = y;
       }
     }
 #pragma unroll
@@ -839,7 +833,7 @@ extern "C" int ovis_split_gemm_pair_tn(const void* g_pair, long g_row_bytes, con
   if (!g_pair || !x_pair || !c_slabs || m > 0x7fffff00L) return OVIS_EINVAL;
   const int T = taps_h * taps_w;
   if (T > 1 && (height <= 0 || width <= 0)) return OVIS_EINVAL;
-  if (n % 128 != 0 || channels % 128 != 0 || T > 16 || (T > 1 && (long)height * width > 8192) ||
+  if (n % 128 != 0 || channels % 128 != 0 ||
       g_row_bytes % 16 != 0 || x_row_bytes % 16 != 0 || ((uintptr_t)g_pair & 15) || ((uintptr_t)x_pair & 15) ||
       ((uintptr_t)c_slabs & 15))
     return OVIS_ERANGE;
@@ -853,12 +847,12 @@ extern "C" int ovis_split_gemm_pair_tn(const void* g_pair, long g_row_bytes, con
   const long nblocks = (long)tiles_i * tiles_j * slices;
   if (nblocks > 0x7fffffffL) return OVIS_ERANGE;
   hipStream_t s = (hipStream_t)stream;
-  const int lds = 2 * 2 * 32 * 512 + (T > 1 ? 2 * height * width : 0);
+  const int lds = 2 * 2 * 32 * 512;
   if (T > 1) {
-    static int lds_set = 0;
-    if (lds_set < lds) {
+    static bool attr_set_c = false;
+    if (!attr_set_c) {
       OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      lds_set = lds;
+      attr_set_c = true;
     }
     hipLaunchKernelGGL(split_gemm_tn_kernel<true>, dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_i, tiles_j, (int)nblocks);
   } else {

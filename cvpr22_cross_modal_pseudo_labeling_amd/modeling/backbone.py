@@ -332,8 +332,7 @@ class ResNetC4(nn.Module):
             # GEMM); one layout copy out (the C4 map, 34 MB).  Frozen trunk (student-teacher configuration): always.
             # Trainable stages (teacher training): through the pair-layout autograd nodes as well -- 39.4 vs 42.2 ms per
             # step against MIOpen's NCHW kernels (both with a warm MIOpen kernel cache; OVIS_TRUNK_TRAIN_MIOPEN=1 selects
-            # MIOpen).  The 3x3 weight gradient of layer2 falls back to pair-layout im2col rows + a library GEMM: its
-            # 100x167 tap table exceeds the LDS budget of the transpose-read kernel.
+            # MIOpen).
             y, yp = x.permute(0, 2, 3, 1).contiguous(), None
             for i, b in enumerate(blocks):
                 y, yp = b.forward_nhwc(y, xp=yp, want_pair=True) if i + 1 < len(blocks) else (b.forward_nhwc(y, xp=yp), None)

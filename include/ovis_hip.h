@@ -231,7 +231,7 @@ int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const void* b_pai
  * G[m, n] * X[row(m, tap), c]  (G = gated output gradient [m, n], X = the layer input [m, channels], both pair
  * rows; taps as in ovis_split_gemm_pair, X read shifted with zeros outside the map).  The rows are cut into
  * `slices` (ovis_split_gemm_tn_slices gives a count that fills the chip); the caller sums the slabs.
- * n % 128 == 0, channels % 128 == 0, taps <= 16, height*width <= 8192 (else OVIS_ERANGE). */
+ * n % 128 == 0, channels % 128 == 0 (else OVIS_ERANGE); any map size. */
 int ovis_split_gemm_tn_slices(long m, int n, int channels, int taps);
 int ovis_split_gemm_pair_tn(const void* g_pair, long g_row_bytes, const void* x_pair, long x_row_bytes,
                             float* c_slabs, int slices, long m, int n, int channels, int taps_h,

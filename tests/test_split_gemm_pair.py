@@ -124,6 +124,7 @@ def test_dw_pair_vs_fp64():
 
 @pytest.mark.parametrize("m,n,ch,conv", [(64, 128, 128, None), (1000, 128, 256, None), (49 * 37, 256, 128, (7, 7, 3, 3)),
                                          (5 * 9 * 13, 128, 128, (9, 13, 3, 5)), (49 * 300, 512, 512, (7, 7, 3, 3)),
+                                         (2 * 100 * 167, 128, 128, (100, 167, 3, 3)), (18 * 3 * 3, 128, 128, (3, 3, 3, 3)),
                                          (31, 128, 128, None)])
 def test_split_gemm_pair_tn_vs_fp64(m, n, ch, conv):
     """The transpose-read weight-gradient kernel (row slices + slab sum), plain and with shifted tap reads."""
