@@ -133,3 +133,43 @@ def bottleneck_pair(x, xp, geom, w1, b1, w2, b2, w3, b3, wd=None, want_pair=Fals
     one bottleneck on the rows x [M, Cin] of an (h, w) map."""
     out, outp, pooled = _BottleneckPair.apply(x, xp, geom, w1, b1, w2, b2, w3, b3, wd, want_pair, wpairs, pool)
     return (out, outp, pooled) if pool else (out, outp)
+
+
+class _ConvSamePair(Function):
+    """y = relu?(conv(x, w) + b) for a stride-1 "same" odd-kernel convolution on NHWC rows, trainable: forward = implicit
+    split GEMM with the bias / ReLU epilogue, backward = fused gate + split, implicit GEMM with negated taps for dX,
+    transpose-read GEMM for dW (csrc/split_gemm.hip).  Used for the RPN head's 3x3 (rpn.py:74-106) when it trains."""
+
+    @staticmethod
+    def forward(ctx, x2d, geom, w, b, relu):
+        h, wd_ = geom
+        n, c, kh, kw = w.shape
+        xp = _C.split_pair(x2d)
+        y, _ = _C.split_gemm_pair(xp, pair_weight(conv_weight_matrix(w)), b, None, relu, True, False,
+                                  conv=(h, wd_, kh, kw, False))
+        ctx.save_for_backward(xp, y if relu else None, w)
+        ctx.geom = (h, wd_, kh, kw)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        xp, y, w = ctx.saved_tensors
+        h, wd_, kh, kw = ctx.geom
+        n, c = w.shape[0], w.shape[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[3]
+        gp, g32 = _C.gate_split_pair(dy.reshape(-1, n), y, want_f32=need_b)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx, _ = _C.split_gemm_pair(gp, pair_weight(conv_weight_matrix_t(w)), conv=(h, wd_, kh, kw, True))
+        if ctx.needs_input_grad[2]:
+            dw = dw_pair(gp, xp, (h, wd_, kh, kw)).view(n, kh, kw, c).permute(0, 3, 1, 2)
+        if need_b:
+            db = g32.sum(0)
+        return dx, None, dw, db, None
+
+
+def conv_same_pair(x2d, geom, w, b=None, relu=False):
+    """x2d [N*H*W, C] f32 NHWC rows of (H, W) maps -> [N*H*W, Cout] f32 (C, Cout % 32 == 0)."""
+    return _ConvSamePair.apply(x2d, geom, w, b, relu)

@@ -96,6 +96,16 @@ class RPNHead(nn.Module):  # rpn.py:74-106
     def forward(self, feature):
         if self._gemm_ok(feature):
             return self._forward_gemm(feature)
+        c = self.conv
+        if (feature.is_cuda and c.in_channels % 128 == 0 and c.out_channels % 128 == 0 and c.kernel_size == (3, 3)
+                and c.padding == (1, 1) and c.stride == (1, 1) and os.environ.get("OVIS_RPN_MIOPEN", "0") != "1"):
+            # trainable head (teacher configuration): the 3x3 through the split-GEMM autograd node, the two small
+            # predictors stay convolutions on the NCHW view of its NHWC result
+            from ..layers.pair_bottleneck import conv_same_pair
+            n, ch, h, w = feature.shape
+            t = conv_same_pair(feature.permute(0, 2, 3, 1).reshape(-1, ch), (h, w), c.weight, c.bias, True)
+            t = t.view(n, h, w, -1).permute(0, 3, 1, 2)
+            return self.cls_logits(t), self.bbox_pred(t)
         t = F.relu(self.conv(feature))
         return self.cls_logits(t), self.bbox_pred(t)
 

@@ -290,3 +290,24 @@ def test_strided_pooler_pair_output_is_split_of_fp32_output():
     pair, (oh, ow) = C.roi_align_forward_strided_pair(x, rois, 1 / 16, 14, 14, 0, 2)
     assert (oh, ow) == (7, 7) and pair.shape == (rois.shape[0] * 49, 128)
     assert torch.equal(pair, C.split_pair(f32.view(-1, 64)))
+
+
+def test_conv_same_pair_node_vs_fp64_autograd():
+    """Trainable 3x3 "same" convolution node (implicit GEMM fwd / dX, transpose-read dW, bias, ReLU) vs fp64 autograd."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers.pair_bottleneck import conv_same_pair
+    torch.manual_seed(8)
+    n, h, w, c, co = 2, 9, 11, 128, 128
+    x = torch.randn(n * h * w, c, device="cuda", requires_grad=True)
+    wt = (torch.randn(co, c, 3, 3, device="cuda") / (9 * c) ** 0.5).requires_grad_(True)
+    b = (torch.randn(co, device="cuda") * 0.1).requires_grad_(True)
+    y = conv_same_pair(x, (h, w), wt, b, True)
+    gy = torch.randn_like(y)
+    gx, gw, gb = torch.autograd.grad(y, [x, wt, b], gy)
+    xd = x.detach().double().view(n, h, w, c).permute(0, 3, 1, 2).requires_grad_(True)
+    wd, bd = wt.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    ref = F.relu(F.conv2d(xd, wd, bd, padding=1)).permute(0, 2, 3, 1).reshape(-1, co)
+    rx, rw, rb = torch.autograd.grad(ref, [xd, wd, bd], gy.double())
+    assert (y.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    assert (gx.double() - rx.permute(0, 2, 3, 1).reshape(-1, c)).norm().item() <= 1e-4 * rx.norm().item()
+    assert (gw.double() - rw).norm().item() <= 1e-4 * rw.norm().item()
+    assert (gb.double() - rb).norm().item() <= 1e-4 * rb.norm().item()
