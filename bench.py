@@ -101,7 +101,7 @@ class OpTimer:
         def split_gemm_flops(a_pair, b_pair, *args, **kwargs):
             return 6.0 * a_pair.shape[0] * b_pair.shape[0] * (b_pair.shape[1] // 2)  # 3 products x 2*M*N*K
 
-        def split_gemm_tn_flops(g_pair, x_pair, conv=None):
+        def split_gemm_tn_flops(g_pair, x_pair, conv=None, scale=None, weight_shape=None):
             taps = 1 if conv is None else conv[2] * conv[3]
             return 6.0 * g_pair.shape[0] * (g_pair.shape[1] // 2) * (x_pair.shape[1] // 2) * taps
 

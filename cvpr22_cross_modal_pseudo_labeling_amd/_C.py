@@ -387,6 +387,25 @@ def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f3
     return c, cp
 
 
+def weight_prep_pair(w, scale=None, want_transposed=False):
+    """w [N, C, KH, KW] f32 (times scale[N]) -> (pair [N, 2*KH*KW*C] tap-major, transposed pair [C, 2*KH*KW*N] or None)
+    in one launch; see include/ovis_hip.h."""
+    if not (w.is_cuda and w.dtype == torch.float32 and w.dim() == 4):
+        raise RuntimeError("weight_prep_pair: [N,C,KH,KW] float32 HIP tensor expected")
+    w = w.detach().contiguous()
+    n, c, kh, kw = w.shape
+    t = kh * kw
+    fwd = torch.empty((n, 2 * t * c), dtype=torch.bfloat16, device=w.device)
+    bwd = torch.empty((c, 2 * t * n), dtype=torch.bfloat16, device=w.device) if want_transposed else None
+    if scale is not None:
+        scale = _dev(scale.detach(), "scale")
+    with torch.cuda.device(w.device):
+        rc = _L.ovis_weight_prep_pair_f32(w.data_ptr(), 0 if scale is None else scale.data_ptr(), fwd.data_ptr(),
+                                          0 if bwd is None else bwd.data_ptr(), n, c, t, _stream())
+    _lib.check(rc, "weight_prep_pair")
+    return fwd, bwd
+
+
 def split_gemm_pair_tn_supported(n, ch, conv=None):
     if n % 128 or ch % 128:
         return False
@@ -396,9 +415,11 @@ def split_gemm_pair_tn_supported(n, ch, conv=None):
     return True
 
 
-def split_gemm_pair_tn(g_pair, x_pair, conv=None):
+def split_gemm_pair_tn(g_pair, x_pair, conv=None, scale=None, weight_shape=None):
     """dW [N, taps*ch] = G^T X over the rows: G [M, 2N], X [M, 2*ch] in pair layout; conv = (h, w, kh, kw): X is an
-    NHWC tensor read shifted by every tap (the 3x3 weight gradient without im2col rows).  csrc/split_gemm.hip."""
+    NHWC tensor read shifted by every tap (the 3x3 weight gradient without im2col rows).  With ``weight_shape`` =
+    (N, ch, kh, kw) the slabs are reduced straight into that layout, times ``scale[N]`` (the folded FrozenBN scale) --
+    the gradient of the raw convolution weight in one extra launch.  csrc/split_gemm.hip."""
     for t, name in ((g_pair, "g_pair"), (x_pair, "x_pair")):
         if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1):
             raise RuntimeError(f"split_gemm_pair_tn: {name} must be a 2-D bfloat16 HIP tensor in pair layout")
@@ -411,15 +432,27 @@ def split_gemm_pair_tn(g_pair, x_pair, conv=None):
         h, w, kh, kw = conv
         if m % (h * w):
             raise RuntimeError("split_gemm_pair_tn: rows must be a multiple of h*w")
+    dev = g_pair.device
     if m == 0:
-        return torch.zeros((n, kh * kw * ch), dtype=torch.float32, device=g_pair.device)
+        z = torch.zeros((n, kh * kw * ch), dtype=torch.float32, device=dev)
+        return z if weight_shape is None else z.new_zeros(weight_shape)
     slices = _L.ovis_split_gemm_tn_slices(m, n, ch, kh * kw)
-    slabs = torch.empty((slices, n, kh * kw * ch), dtype=torch.float32, device=g_pair.device)
-    with torch.cuda.device(g_pair.device):
+    slabs = torch.empty((slices, n, kh * kw * ch), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
         rc = _L.ovis_split_gemm_pair_tn(g_pair.data_ptr(), 2 * g_pair.stride(0), x_pair.data_ptr(), 2 * x_pair.stride(0),
                                         slabs.data_ptr(), slices, m, n, ch, kh, kw, h, w, _stream())
-    _lib.check(rc, "split_gemm_pair_tn")
-    return slabs[0] if slices == 1 else slabs.sum(0)
+        _lib.check(rc, "split_gemm_pair_tn")
+        if weight_shape is None:
+            return slabs[0] if slices == 1 else slabs.sum(0)
+        if tuple(weight_shape) != (n, ch, kh, kw):
+            raise RuntimeError("split_gemm_pair_tn: weight_shape must be (N, ch, kh, kw)")
+        dw = torch.empty(weight_shape, dtype=torch.float32, device=dev)
+        if scale is not None:
+            scale = _dev(scale.detach(), "scale")
+        rc = _L.ovis_slab_reduce_f32(slabs.data_ptr(), 0 if scale is None else scale.data_ptr(), dw.data_ptr(), slices, n,
+                                     ch, kh * kw, _stream())
+    _lib.check(rc, "slab_reduce")
+    return dw
 
 
 def bias_act_(y, bias=None, residual=None, relu=True):

@@ -35,6 +35,8 @@ SIGNATURES = {
     "ovis_split_pair_f32": (_i, [_vp, _l, _vp, _l, _i, _vp]),
     "ovis_gate_split_pair_f32": (_i, [_vp, _l, _vp, _i, _vp, _vp, _l, _i, _vp, _i, _vp]),
     "ovis_im2col_nchw_pair_f32": (_i, [_vp, _vp] + [_i] * 9 + [_vp]),
+    "ovis_weight_prep_pair_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ovis_slab_reduce_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ovis_im2col_pair": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _i, _vp]),
     "ovis_split_gemm_tn_slices": (_i, [_l, _i, _i, _i]),
     "ovis_split_gemm_pair_tn": (_i, [_vp, _l, _vp, _l, _vp, _i, _l, _i, _i, _i, _i, _i, _i, _vp]),

@@ -717,6 +717,72 @@ __global__ __launch_bounds__(256) void im2col_nchw_pair_kernel(const float* __re
   }
 }
 
+// Weight preparation of a trainable convolution in ONE launch: FrozenBN fold (per-output-channel scale), the tap-major
+// matrix form and the operand split -- and the same for the transposed matrix the data gradient multiplies with.
+//   w [N, C, T] f32 (T = KH*KW taps, contiguous)  ->  fwd  [N, T*C] pair rows, k  = t*C + c   (forward / dW layout)
+//                                                      bwd  [C, T*N] pair rows, k' = t*N + n   (dX operand)
+// both holding w[n, c, t] * scale[n] (scale may be null).  Replaces mul + permute-copy + split (+ transpose-copy +
+// split in the backward) per convolution and step; weights are at most a few MB, the kernel is latency-trivial.
+__global__ __launch_bounds__(256) void weight_prep_pair_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                              char* __restrict__ fwd, char* __restrict__ bwd, int N, int C,
+                                                              int T) {
+  const long nf = (long)N * T * (C >> 3);            // 8-value groups of the forward matrix
+  const long nb = bwd ? (long)C * T * (N >> 3) : 0;  // of the transposed matrix
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nf + nb; i += (long)gridDim.x * 256) {
+    float v[8];
+    char* d;
+    if (i < nf) {
+      const int cg = (int)(i % (C >> 3));
+      const long r = i / (C >> 3);
+      const int t = (int)(r % T), n = (int)(r / T);
+      const float sc = scale ? scale[n] : 1.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = w[((long)n * C + cg * 8 + j) * T + t] * sc;
+      const int k = t * C + cg * 8;
+      d = fwd + (long)n * 4L * T * C + (long)(k >> 5) * 128 + (k & 31) * 2;
+    } else {
+      const long ib = i - nf;
+      const int ng = (int)(ib % (N >> 3));
+      const long r = ib / (N >> 3);
+      const int t = (int)(r % T), c = (int)(r / T);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int n = ng * 8 + j;
+        v[j] = w[((long)n * C + c) * T + t] * (scale ? scale[n] : 1.f);
+      }
+      const int k = t * N + ng * 8;
+      d = bwd + (long)c * 4L * T * N + (long)(k >> 5) * 128 + (k & 31) * 2;
+    }
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h[j] = pack_bf16(v[2 * j], v[2 * j + 1]);
+      l[j] = pack_bf16(v[2 * j] - __uint_as_float(h[j] << 16), v[2 * j + 1] - __uint_as_float(h[j] & 0xffff0000u));
+    }
+    *(uint4*)d = make_uint4(h[0], h[1], h[2], h[3]);
+    *(uint4*)(d + 64) = make_uint4(l[0], l[1], l[2], l[3]);
+  }
+}
+
+// Sum of the weight-gradient slabs of split_gemm_tn_kernel, times the FrozenBN scale of the output channel, written in
+// the weight's own [N, C, T] order: dw[n, c, t] = scale[n] * sum_s slabs[s, n, t*C + c].
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ scale,
+                                                         float* __restrict__ dw, int S, int N, int C, int T) {
+  const long total = (long)N * T * (C >> 2);
+  const long slab = (long)N * T * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cg = (int)(i % (C >> 2));
+    const long r = i / (C >> 2);
+    const int t = (int)(r % T), n = (int)(r / T);
+    const float* p = slabs + ((long)n * T + t) * C + cg * 4;
+    f32x4 a = *(const f32x4*)p;
+    for (int s_ = 1; s_ < S; ++s_) a += *(const f32x4*)(p + s_ * slab);
+    const float sc = scale ? scale[n] : 1.f;
+    float* o = dw + ((long)n * C + cg * 4) * T + t;
+    o[0] = a.x * sc; o[T] = a.y * sc; o[2 * T] = a.z * sc; o[3 * T] = a.w * sc;
+  }
+}
+
 // Pair-layout im2col (only for the weight gradient of a 3x3, which contracts over the rows): src [R,H,W,C] pair
 // layout -> dst [R*H*W, T*C] pair layout, tap-major; out-of-map taps are zero rows.  Pure 16-byte copies: a thread
 // moves one 16-byte slot of one (pixel, tap).  4 B/element read (L2-served re-reads), 4*T B/element written.
@@ -794,6 +860,36 @@ extern "C" int ovis_im2col_nchw_pair_f32(const float* src, void* dst_pair, int n
   const unsigned grid = (unsigned)(blocks < 16L * OVIS_NUM_CU ? blocks : 16L * OVIS_NUM_CU);
   hipLaunchKernelGGL(im2col_nchw_pair_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (char*)dst_pair, num,
                      channels, height, width, kh, kw, stride, pad, ho, wo, k_padded);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}
+
+extern "C" int ovis_weight_prep_pair_f32(const float* weight, const float* scale, void* fwd_pair, void* bwd_pair,
+                                        int out_channels, int in_channels, int taps, void* stream) {
+  if (out_channels <= 0 || in_channels <= 0 || taps <= 0) return OVIS_EINVAL;
+  if (!weight || !fwd_pair) return OVIS_EINVAL;
+  if (in_channels % 32 != 0 || (bwd_pair && out_channels % 32 != 0) || ((uintptr_t)fwd_pair & 15) ||
+      ((uintptr_t)bwd_pair & 15))
+    return OVIS_ERANGE;
+  const long total = (long)out_channels * taps * (in_channels / 8) + (bwd_pair ? (long)in_channels * taps * (out_channels / 8) : 0);
+  const long blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 8L * OVIS_NUM_CU ? blocks : 8L * OVIS_NUM_CU);
+  hipLaunchKernelGGL(weight_prep_pair_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, weight, scale, (char*)fwd_pair,
+                     (char*)bwd_pair, out_channels, in_channels, taps);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}
+
+extern "C" int ovis_slab_reduce_f32(const float* slabs, const float* scale, float* dweight, int slices, int out_channels,
+                                    int in_channels, int taps, void* stream) {
+  if (slices <= 0 || out_channels <= 0 || in_channels <= 0 || taps <= 0) return OVIS_EINVAL;
+  if (!slabs || !dweight) return OVIS_EINVAL;
+  if (in_channels % 4 != 0 || ((uintptr_t)slabs & 15)) return OVIS_ERANGE;
+  const long total = (long)out_channels * taps * (in_channels / 4);
+  const long blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 8L * OVIS_NUM_CU ? blocks : 8L * OVIS_NUM_CU);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slabs, scale, dweight, slices,
+                     out_channels, in_channels, taps);
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
 }

@@ -55,21 +55,37 @@ def dw_pair(gp, xp, conv=None):
     return q.view(n // 32, 2, 32, k // 32, 2, 32).sum(dim=(1, 4)).reshape(n, k)
 
 
+def _dw(gp, xp, w, scale, conv=None):
+    """Gradient of the RAW weight w [N, C, KH, KW] of a convolution evaluated with w * scale[n]: transpose-read GEMM
+    slabs reduced, scaled and laid out in one launch; library fallback for shapes the kernel does not take."""
+    n, c = w.shape[0], w.shape[1]
+    if _C.split_gemm_pair_tn_supported(n, c, conv):
+        return _C.split_gemm_pair_tn(gp, xp, conv, scale=scale, weight_shape=tuple(w.shape))
+    d = dw_pair(gp, xp, conv).view(n, w.shape[2], w.shape[3], c).permute(0, 3, 1, 2)
+    return d if scale is None else d * scale.view(-1, 1, 1, 1)
+
+
 class _BottleneckPair(Function):
     @staticmethod
-    def forward(ctx, x, xp, geom, w1, b1, w2, b2, w3, b3, wd, want_pair, wpairs, pool):
+    def forward(ctx, x, xp, geom, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, want_pair, wpairs, pool):
         """x [M, Cin] f32 rows conv1 reads (may be None when wd is given and no input gradient is wanted), xp its pair
-        form or None; geom = (h, w) of the map the rows tile; w1/w2/w3/wd folded weights (wd None = identity
-        shortcut), b1/b2 shifts, b3 the conv3 (+ shortcut) shift; wpairs: optional cached pair weights."""
+        form or None; geom = (h, w) of the map the rows tile; w1/w2/w3/wd RAW convolution weights (wd None = identity
+        shortcut) with their folded FrozenBN scales s1/s2/s3/sd (per output channel, no gradient) and shifts b1/b2,
+        b3 = the conv3 (+ shortcut) shift; wpairs: optional cached pair weights of a frozen block."""
         h, w = geom
         if xp is None:
             xp = _C.split_pair(x)
-        n1, n2, n3 = w1.shape[0], w2.shape[0], w3.shape[0]
         kh, kw = w2.shape[2], w2.shape[3]
+        need_bwd = any(ctx.needs_input_grad)
+        wts = None
         if wpairs is None:
-            wpairs = {"w1": pair_weight(w1.reshape(n1, -1)), "w2": pair_weight(conv_weight_matrix(w2)),
-                      "w3": pair_weight(w3.reshape(n3, -1)),
-                      "wd": pair_weight(wd.reshape(wd.shape[0], -1)) if wd is not None else None}
+            # fold + matrix form + split (+ the transposed operands of the data gradients) in one launch per weight
+            p1, t1 = _C.weight_prep_pair(w1, s1, need_bwd)
+            p2, t2 = _C.weight_prep_pair(w2, s2, need_bwd)
+            p3, t3 = _C.weight_prep_pair(w3, s3, need_bwd)
+            pd, td = _C.weight_prep_pair(wd, sd, need_bwd) if wd is not None else (None, None)
+            wpairs = {"w1": p1, "w2": p2, "w3": p3, "wd": pd}
+            wts = (t1, t2, t3, td)
         _, o1p = _C.split_gemm_pair(xp, wpairs["w1"], b1, None, True, False, True)
         _, o2p = _C.split_gemm_pair(o1p, wpairs["w2"], b2, None, True, False, True, conv=(h, w, kh, kw, False))
         if wd is not None:
@@ -81,7 +97,8 @@ class _BottleneckPair(Function):
         # node, so that its gradient is broadcast inside the fused gate + split kernel of the backward instead of
         # being materialised ([rows, C] expand) and added to the dense gradient by two tensor ops
         pooled = out.view(-1, h * w, out.shape[1]).mean(dim=1) if pool else None
-        ctx.save_for_backward(xp, o1p, o2p, out, w1, w2, w3, wd)
+        ctx.save_for_backward(xp, o1p, o2p, out, w1, w2, w3, wd, s1, s2, s3, sd)
+        ctx.wts = wts
         ctx.geom = (h, w, kh, kw)
         ctx.set_materialize_grads(False)  # no zero tensors for absent / non-differentiable gradient slots
         if outp is not None:
@@ -92,46 +109,51 @@ class _BottleneckPair(Function):
     @once_differentiable
     def backward(ctx, dout, _dpair, dpooled):
         if dout is None and dpooled is None:
-            return (None,) * 13
-        xp, o1p, o2p, out, w1, w2, w3, wd = ctx.saved_tensors
+            return (None,) * 17
+        xp, o1p, o2p, out, w1, w2, w3, wd, s1, s2, s3, sd = ctx.saved_tensors
         h, w, kh, kw = ctx.geom
         need = ctx.needs_input_grad
-        need_x, need_w1, need_w2, need_w3, need_wd = need[0], need[3], need[5], need[7], need[9]
-        n1, n2, n3 = w1.shape[0], w2.shape[0], w3.shape[0]
+        need_x, need_w1, need_w2, need_w3, need_wd = need[0], need[3], need[6], need[9], need[12]
+        wts = ctx.wts
+        if wts is None:  # cached (frozen) weights in the forward: only the input gradient can be wanted
+            wts = tuple(_C.weight_prep_pair(t, sc, True)[1] if t is not None else None
+                        for t, sc in ((w1, s1), (w2, s2), (w3, s3), (wd, sd)))
+        t1, t2, t3, td = wts
+        n3 = w3.shape[0]
         # gate of the block's last ReLU, fused with the split; the identity shortcut also needs the gated gradient in fp32
         g3p, g3 = _C.gate_split_pair(None if dout is None else dout.reshape(-1, n3), out, want_f32=(wd is None and need_x),
                                      pooled=dpooled, pool_rows=h * w)
-        dw3 = dw_pair(g3p, o2p) if need_w3 else None
-        d2, _ = _C.split_gemm_pair(g3p, pair_weight(w3.reshape(n3, -1).t()))                      # dY W3
+        dw3 = _dw(g3p, o2p, w3, s3) if need_w3 else None
+        d2, _ = _C.split_gemm_pair(g3p, t3)                                                        # dY W3
         g2p, _ = _C.gate_split_pair(d2, o2p)
         del d2
-        dw2 = None
-        if need_w2:
-            dw2 = dw_pair(g2p, o1p, (h, w, kh, kw)).view(n2, kh, kw, n1).permute(0, 3, 1, 2)
+        dw2 = _dw(g2p, o1p, w2, s2, (h, w, kh, kw)) if need_w2 else None
         dx = dw1 = dwd = None
         if need_x or need_w1:
-            d1, _ = _C.split_gemm_pair(g2p, pair_weight(conv_weight_matrix_t(w2)), conv=(h, w, kh, kw, True))
+            d1, _ = _C.split_gemm_pair(g2p, t2, conv=(h, w, kh, kw, True))
             g1p, _ = _C.gate_split_pair(d1, o1p)
             del d1
             if need_w1:
-                dw1 = dw_pair(g1p, xp).view_as(w1)
+                dw1 = _dw(g1p, xp, w1, s1)
             if need_x:
                 if wd is not None:
-                    res, _ = _C.split_gemm_pair(g3p, pair_weight(wd.reshape(wd.shape[0], -1).t()))
+                    res, _ = _C.split_gemm_pair(g3p, td)
                 else:
                     res = g3
-                dx, _ = _C.split_gemm_pair(g1p, pair_weight(w1.reshape(n1, -1).t()), None, res)
+                dx, _ = _C.split_gemm_pair(g1p, t1, None, res)
         if wd is not None and need_wd:
-            dwd = dw_pair(g3p, xp).view_as(wd)
-        if dw3 is not None:
-            dw3 = dw3.view_as(w3)
-        return dx, None, None, dw1, None, dw2, None, dw3, None, dwd, None, None, None
+            dwd = _dw(g3p, xp, wd, sd)
+        return dx, None, None, dw1, None, None, dw2, None, None, dw3, None, None, dwd, None, None, None, None
 
 
-def bottleneck_pair(x, xp, geom, w1, b1, w2, b2, w3, b3, wd=None, want_pair=False, wpairs=None, pool=False):
+def bottleneck_pair(x, xp, geom, w1, b1, w2, b2, w3, b3, wd=None, want_pair=False, wpairs=None, pool=False,
+                    scales=(None, None, None, None)):
     """(out f32 [M, Cout], out in pair layout or None[, mean of out over the h*w rows of every map when ``pool``]) of
-    one bottleneck on the rows x [M, Cin] of an (h, w) map."""
-    out, outp, pooled = _BottleneckPair.apply(x, xp, geom, w1, b1, w2, b2, w3, b3, wd, want_pair, wpairs, pool)
+    one bottleneck on the rows x [M, Cin] of an (h, w) map.  w1/w2/w3/wd are the convolution weights as the model
+    stores them; ``scales`` = their folded FrozenBN scales (None = weights already folded)."""
+    s1, s2, s3, sd = scales
+    out, outp, pooled = _BottleneckPair.apply(x, xp, geom, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, want_pair, wpairs,
+                                              pool)
     return (out, outp, pooled) if pool else (out, outp)
 
 
@@ -145,8 +167,9 @@ class _ConvSamePair(Function):
         h, wd_ = geom
         n, c, kh, kw = w.shape
         xp = _C.split_pair(x2d)
-        y, _ = _C.split_gemm_pair(xp, pair_weight(conv_weight_matrix(w)), b, None, relu, True, False,
-                                  conv=(h, wd_, kh, kw, False))
+        wp, wt = _C.weight_prep_pair(w, None, ctx.needs_input_grad[0])
+        y, _ = _C.split_gemm_pair(xp, wp, b, None, relu, True, False, conv=(h, wd_, kh, kw, False))
+        ctx.wt = wt
         ctx.save_for_backward(xp, y if relu else None, w)
         ctx.geom = (h, wd_, kh, kw)
         ctx.has_bias = b is not None
@@ -162,9 +185,9 @@ class _ConvSamePair(Function):
         gp, g32 = _C.gate_split_pair(dy.reshape(-1, n), y, want_f32=need_b)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx, _ = _C.split_gemm_pair(gp, pair_weight(conv_weight_matrix_t(w)), conv=(h, wd_, kh, kw, True))
+            dx, _ = _C.split_gemm_pair(gp, ctx.wt, conv=(h, wd_, kh, kw, True))
         if ctx.needs_input_grad[2]:
-            dw = dw_pair(gp, xp, (h, wd_, kh, kw)).view(n, kh, kw, c).permute(0, 3, 1, 2)
+            dw = _dw(gp, xp, w, None, (h, wd_, kh, kw))
         if need_b:
             db = g32.sum(0)
         return dx, None, dw, db, None

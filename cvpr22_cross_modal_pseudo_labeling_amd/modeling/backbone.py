@@ -131,26 +131,30 @@ class Bottleneck(nn.Module):
         return self._pair_node(None, xp, r, hs, ws, want_pair, pool)
 
     def _pair_node(self, x2d, xp, r, hs, ws, want_pair, pool):
-        w1, b1 = self._f1[0].folded()
-        w2, b2 = self._f2[0].folded()
-        w3, b3 = self._f3[0].folded()
-        wd = bd = None
-        if self._fd is not None:
-            wd, bd = self._fd[0].folded()
+        from .. import _C
+        # RAW weights + folded FrozenBN (scale, shift) pairs: the fold itself happens inside the node's weight-prep kernel
+        w1, w2, w3 = self.conv1.weight, self.conv2.weight, self.conv3.weight
+        (s1, b1), (s2, b2), (s3, b3) = self.bn1.fold(), self.bn2.fold(), self.bn3.fold()
+        wd = sd = bd = None
+        if self.downsample is not None:
+            wd = self.downsample[0].weight
+            sd, bd = self.downsample[1].fold()
         ws_all = [t for t in (w1, w2, w3, wd) if t is not None]
+        bns = [self.bn1, self.bn2, self.bn3] + ([self.downsample[1]] if self.downsample is not None else [])
         wpairs = None
         if not any(t.requires_grad for t in ws_all):
             # frozen block: the pair forms of the folded weights (and the summed shift) are computed once
-            key = tuple((id(t), t._version, t.device) for t in ws_all)
+            key = tuple((id(t), t._version, t.device) for t in ws_all) + tuple(id(bn._fold_cache[1]) for bn in bns)
             if self._pair_cache is None or self._pair_cache[0] != key:
-                wp = {"w1": pair_weight(w1.reshape(w1.shape[0], -1)), "w2": pair_weight(conv_weight_matrix(w2)),
-                      "w3": pair_weight(w3.reshape(w3.shape[0], -1)),
-                      "wd": pair_weight(wd.reshape(wd.shape[0], -1)) if wd is not None else None}
+                wp = {"w1": _C.weight_prep_pair(w1, s1)[0], "w2": _C.weight_prep_pair(w2, s2)[0],
+                      "w3": _C.weight_prep_pair(w3, s3)[0],
+                      "wd": _C.weight_prep_pair(wd, sd)[0] if wd is not None else None}
                 self._pair_cache = (key, wp, (b3 if bd is None else b3 + bd).contiguous())
             wpairs, b3s = self._pair_cache[1], self._pair_cache[2]
         else:
             b3s = b3 if bd is None else b3 + bd
-        res = bottleneck_pair(x2d, xp, (hs, ws), w1, b1, w2, b2, w3, b3s, wd, want_pair, wpairs, pool)
+        res = bottleneck_pair(x2d, xp, (hs, ws), w1, b1, w2, b2, w3, b3s, wd, want_pair, wpairs, pool,
+                              scales=(s1, s2, s3, sd))
         out = res[0].view(r, hs, ws, res[0].shape[-1])
         if pool:
             out._ovis_pooled = res[2]  # [R, C] mean over the map, an output of the same autograd node (see pooled())

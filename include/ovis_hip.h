@@ -197,6 +197,17 @@ int ovis_gate_split_pair_f32(const float* dy, long dy_row_stride, const void* ga
                              void* dst_pair, float* g_f32, long rows, int cols, const float* g_pooled,
                              int pool_rows, void* stream);
 
+/* Weight preparation of a (trainable) convolution in one launch: weight [out_channels, in_channels, taps] f32 times the
+ * folded FrozenBN scale [out_channels] (may be NULL; mb/layers/batch_norm.py:19-31) -> fwd_pair [out_channels, taps*in]
+ * pair rows, k = tap*in + c (the forward / weight-gradient layout) and, when bwd_pair != NULL, [in_channels, taps*out]
+ * pair rows, k' = tap*out + n (the data-gradient operand).  in_channels % 32 == 0 (out_channels too for bwd_pair). */
+int ovis_weight_prep_pair_f32(const float* weight, const float* scale, void* fwd_pair, void* bwd_pair,
+                              int out_channels, int in_channels, int taps, void* stream);
+
+/* dweight [out, in, taps] = scale[out] * sum over the slabs of ovis_split_gemm_pair_tn ([slices, out, taps*in]). */
+int ovis_slab_reduce_f32(const float* slabs, const float* scale, float* dweight, int slices, int out_channels,
+                         int in_channels, int taps, void* stream);
+
 /* Pair-layout im2col (the M-contracting weight gradient of a 3x3 needs the rows materialised):
  * src NHWC [num, height, width, channels] pair rows -> dst [num*height*width, kh*kw*channels]
  * pair rows, tap-major, zero rows for taps outside the map.  channels % 32 == 0. */
