@@ -18,6 +18,8 @@ projection, no per-mask python loop there), the fg/bg class weights are built on
 device instead of a hard-coded ``.cuda()``, and the mask head handles any number of
 images per process.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -295,8 +297,38 @@ class MaskRCNNC4Predictor(nn.Module):
             nn.init.normal_(self.uncertain_pred.weight, mean=0, std=0.001)
             nn.init.constant_(self.uncertain_pred.bias, 1)
 
+    def _gemm_ok(self, x):
+        c = self.conv5_mask
+        return (x.is_cuda and x.dim() == 4 and c.kernel_size == (2, 2) and c.stride == (2, 2) and c.padding == (0, 0)
+                and c.output_padding == (0, 0) and c.groups == 1 and c.in_channels % 128 == 0
+                and (4 * c.out_channels) % 128 == 0 and os.environ.get("OVIS_MASK_MIOPEN", "0") != "1")
+
+    def _upsampled_rows(self, x):
+        """relu(conv5_mask(x)) as NHWC rows [P*2H*2W, dim_reduced]: the 2x2 / stride-2 transposed convolution is ONE
+        GEMM over the input pixels with the 4 sub-pixel kernels stacked along N (split-GEMM autograd node, bias + ReLU
+        in its epilogue), followed by the pixel shuffle.  Keeps MIOpen -- whose kernels are compiled per input shape,
+        and the number of positives changes every step -- out of the training step."""
+        from ..layers.pair_bottleneck import conv_same_pair
+        c = self.conv5_mask
+        p, ci, h, w = x.shape
+        co = c.out_channels
+        rows = x.permute(0, 2, 3, 1).reshape(-1, ci)
+        wm = c.weight.permute(2, 3, 1, 0).reshape(4 * co, ci, 1, 1)          # n = (dy, dx, co)
+        y = conv_same_pair(rows, (h, w), wm, c.bias.repeat(4) if c.bias is not None else None, True)
+        return y.view(p, h, w, 2, 2, co).permute(0, 1, 3, 2, 4, 5).reshape(p * 2 * h * 2 * w, co), (p, 2 * h, 2 * w)
+
+    def _rows_conv1x1(self, rows, shape, conv):
+        p, h, w = shape
+        y = linear_mfma(rows, conv.weight.view(conv.out_channels, -1), conv.bias)
+        return y.view(p, h, w, conv.out_channels).permute(0, 3, 1, 2)
+
     def forward_parts(self, x):
         """-> (mask logits mu [P,C,M,M], predicted std-dev sigma [P,1,M,M]) for the fused stochastic BCE."""
+        if self._gemm_ok(x):
+            rows, shape = self._upsampled_rows(x)
+            mu = self._rows_conv1x1(rows, shape, self.mask_fcn_logits)
+            sigma = torch.exp(0.5 * self._rows_conv1x1(rows.detach(), shape, self.uncertain_pred)) if self.uncertainty else None
+            return mu, sigma
         x_ = F.relu(self.conv5_mask(x))
         mu = self.mask_fcn_logits(x_)
         sigma = torch.exp(0.5 * self.uncertain_pred(x_.detach())) if self.uncertainty else None
@@ -307,10 +339,16 @@ class MaskRCNNC4Predictor(nn.Module):
         ``mask_logits*0+scale``, i.e. independently per logit channel, roi_mask_predictors.py:47-53,62)
         can be injected for reproducible tests; by default it is drawn on the device (the reference
         draws on the host and copies)."""
-        x_ = F.relu(self.conv5_mask(x))
-        mask_logits = self.mask_fcn_logits(x_)
+        if self._gemm_ok(x):
+            rows, shape = self._upsampled_rows(x)
+            mask_logits = self._rows_conv1x1(rows, shape, self.mask_fcn_logits)
+            unc = (lambda: self._rows_conv1x1(rows.detach(), shape, self.uncertain_pred))
+        else:
+            x_ = F.relu(self.conv5_mask(x))
+            mask_logits = self.mask_fcn_logits(x_)
+            unc = (lambda: self.uncertain_pred(x_.detach()))
         if self.uncertainty and compute_uncertain:
-            scale = torch.exp(0.5 * self.uncertain_pred(x_.detach()))  # [P,1,M,M] std-dev
+            scale = torch.exp(0.5 * unc())  # [P,1,M,M] std-dev
             if self.training:
                 std = mask_logits * 0.0 + scale  # [P,C,M,M]
                 if eps is None:

@@ -336,3 +336,38 @@ def test_weight_prep_pair_and_scaled_slab_reduce():
     got = C.split_gemm_pair_tn(gp, xp, (7, 7, 3, 3), scale=sc, weight_shape=(n, ch, 3, 3))
     want = plain.view(n, 3, 3, ch).permute(0, 3, 1, 2) * sc.view(-1, 1, 1, 1)
     assert got.shape == (n, ch, 3, 3) and (got - want).abs().max().item() <= 1e-6 * want.abs().max().item()
+
+
+def test_mask_predictor_gemm_path_matches_convolutions():
+    """MaskRCNNC4Predictor: transposed conv as a split GEMM + pixel shuffle, 1x1 heads as fp32 GEMMs, vs the module's own
+    convolution path (outputs and all parameter / input gradients)."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.roi_heads import MaskRCNNC4Predictor
+    cfg = get_defaults()
+    cfg.merge_from_list(["MODEL.UNCERTAINTY", True, "MODEL.CLS_AGNOSTIC_MASK", True])
+    cfg.freeze()
+    torch.manual_seed(2)
+    m = MaskRCNNC4Predictor(cfg, 2048).cuda()
+    x = torch.randn(5, 7, 7, 2048, device="cuda").permute(0, 3, 1, 2)   # NCHW view of NHWC memory, as the head hands over
+    gm = torch.randn(5, 2, 14, 14, device="cuda")
+    gs = torch.randn(5, 1, 14, 14, device="cuda")
+
+    def run(gemm):
+        os.environ["OVIS_MASK_MIOPEN"] = "0" if gemm else "1"
+        xx = x.clone().requires_grad_(True)
+        m.zero_grad()
+        mu, sigma = m.forward_parts(xx)
+        ((mu * gm).sum() + (sigma * gs).sum()).backward()
+        return [mu.detach(), sigma.detach(), xx.grad] + [p.grad.clone() for p in m.parameters()]
+
+    import os
+    try:
+        ref, got = run(False), run(True)
+    finally:
+        os.environ.pop("OVIS_MASK_MIOPEN", None)
+    assert m._gemm_ok(x)
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape
+        assert (a - b).norm().item() <= 2e-5 * b.norm().item() + 1e-7
+    mu0, s0 = m.forward_parts(x[:0])
+    assert mu0.shape == (0, 2, 14, 14) and s0.shape == (0, 1, 14, 14)
