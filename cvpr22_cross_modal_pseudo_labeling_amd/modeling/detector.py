@@ -218,12 +218,22 @@ class STGeneralizedRCNN(nn.Module):
                 dummy.append(self.compute_dummy_loss())
             return dummy[0]
 
+        loss_pseudo, loss_gt = {}, {}
+        batched = bool(frozen["idxs_cap"] and frozen["idxs_gt"]) and student.branches_batchable(frozen["feat"])
+        if batched:
+            # both branches share the student heads: ONE pooler + res5 pass (and one backward) over the RoIs of both
+            gt_targets = [targets[i] for i in frozen["idxs_gt"]]
+            loss_pseudo, loss_gt = student.forward_branches(frozen["feat"], [
+                dict(image_ids=frozen["idxs_cap"], proposals=frozen["cap_proposals"], targets=frozen["pseudo_targets"],
+                     cls_embs=self.combine_embs(self.cap_embs), compute_uncertain=self.uncertainty, eps=eps),
+                dict(image_ids=frozen["idxs_gt"], proposals=frozen["gt_proposals"], targets=gt_targets,
+                     cls_embs=self.combine_embs(self._seen_cls), compute_uncertain=False, eps=None)])
         # ---- pseudo branch: images that come with caption nouns ------------------------------------------
-        loss_pseudo = {}
         if frozen["idxs_cap"]:
-            student["box"].predictor.set_class_embeddings(self.combine_embs(self.cap_embs))
-            _, _, loss_pseudo = student(frozen["cap_features"], frozen["cap_proposals"], frozen["pseudo_targets"],
-                                        compute_uncertain=self.uncertainty, eps=eps)
+            if not batched:
+                student["box"].predictor.set_class_embeddings(self.combine_embs(self.cap_embs))
+                _, _, loss_pseudo = student(frozen["cap_features"], frozen["cap_proposals"], frozen["pseudo_targets"],
+                                            compute_uncertain=self.uncertainty, eps=eps)
             for k in loss_pseudo:
                 if self.uncertainty and self.reweight:
                     if "mask" not in k:
@@ -239,8 +249,7 @@ class STGeneralizedRCNN(nn.Module):
             losses[f"{k}_pseudo"] = v
 
         # ---- seen-class branch: images with box / mask ground truth -----------------------------------------
-        loss_gt = {}
-        if frozen["idxs_gt"]:
+        if frozen["idxs_gt"] and not batched:
             gt_targets = [targets[i] for i in frozen["idxs_gt"]]
             student["box"].predictor.set_class_embeddings(self.combine_embs(self._seen_cls))
             _, _, loss_gt = student(frozen["gt_features"], frozen["gt_proposals"], gt_targets, compute_uncertain=False)

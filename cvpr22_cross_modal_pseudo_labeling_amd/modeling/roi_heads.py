@@ -69,18 +69,22 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
         self.out_channels = self.head.out_channels
 
     def forward(self, x, proposals):
+        return self.forward_rois(x, self.pooler.convert_to_roi_format(proposals))
+
+    def forward_rois(self, x, rois):
+        """``rois`` [R, 5] = (image index into x[0], x1, y1, x2, y2): the same pass on an explicit RoI tensor (lets a
+        caller pool RoIs of several proposal lists / image subsets in one go)."""
+        p = self.pooler.pooler
         s = self.head.pooler_stride() if x[0].is_cuda else 0
         if s:  # the head's first 1x1 has stride s: pool only the bins it reads, straight into NHWC
             need_grad = torch.is_grad_enabled() and x[0].requires_grad
             if not need_grad and x[0].shape[1] % 32 == 0 and self.head.pooled_pair_ok():
                 # frozen features: the bins go to the first GEMM in pair layout, no fp32 copy / split pass in between
-                p = self.pooler.pooler
-                rois = self.pooler.convert_to_roi_format(proposals)
                 ph, pw = p.output_size
                 yp, (oh, ow) = _C.roi_align_forward_strided_pair(x[0], rois, p.spatial_scale, ph, pw, p.sampling_ratio, s)
                 return self.head.forward_pooled_nhwc(None, yp, (rois.shape[0], oh, ow))
-            return self.head.forward_pooled_nhwc(self.pooler.forward_strided_nhwc(x, proposals, s))
-        return self.head(self.pooler(x, proposals))
+            return self.head.forward_pooled_nhwc(p.forward_strided_nhwc(x[0], rois, s))
+        return self.head(p(x[0], rois))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -532,18 +536,7 @@ class ROIMaskHead(nn.Module):
         else:
             x = self.feature_extractor(features, proposals)
         if self.training and self.cls_agnostic_mask:
-            # training: fused stochastic BCE (noise drawn on the device unless injected)
-            mu, sigma = self.predictor.forward_parts(x)
-            if compute_uncertain and sigma is not None:
-                self.log, self.avg_uncertain = sigma.max(), sigma.mean()
-                if eps is None:
-                    eps = torch.randn((1, *mu.shape), device=mu.device, dtype=mu.dtype)
-                else:  # injected noise (tests): a pool at least as large as the positives
-                    eps = eps[:, : mu.shape[0]].to(mu.device)
-                loss_mask = self.loss_evaluator.fused(proposals, mu, sigma, eps, targets)
-            else:
-                loss_mask = self.loss_evaluator.fused(proposals, mu, None, None, targets)
-            return x, proposals, dict(loss_mask=loss_mask)
+            return x, proposals, dict(loss_mask=self.fused_training_loss(x, proposals, targets, compute_uncertain, eps))
         if compute_uncertain:
             mask_logits, scale = self.predictor(x, True, eps=eps)
             self.log, self.avg_uncertain = scale.max(), scale.mean()
@@ -566,6 +559,23 @@ class ROIMaskHead(nn.Module):
         return x, proposals, dict(loss_mask=loss_mask)
 
 
+def _mask_fused_training_loss(self, x, proposals, targets, compute_uncertain=False, eps=None):
+    """Training loss of the class-agnostic mask head on the positives' features x (fused stochastic BCE; noise drawn on
+    the device unless injected)."""
+    mu, sigma = self.predictor.forward_parts(x)
+    if compute_uncertain and sigma is not None:
+        self.log, self.avg_uncertain = sigma.max(), sigma.mean()
+        if eps is None:
+            eps = torch.randn((1, *mu.shape), device=mu.device, dtype=mu.dtype)
+        else:  # injected noise (tests): a pool at least as large as the positives
+            eps = eps[:, : mu.shape[0]].to(mu.device)
+        return self.loss_evaluator.fused(proposals, mu, sigma, eps, targets)
+    return self.loss_evaluator.fused(proposals, mu, None, None, targets)
+
+
+ROIMaskHead.fused_training_loss = _mask_fused_training_loss
+
+
 class CombinedROIHeads(nn.ModuleDict):
     def __init__(self, cfg, in_channels, is_teacher=False):
         heads = [("box", ROIBoxHead(cfg, in_channels, is_teacher))]
@@ -576,6 +586,52 @@ class CombinedROIHeads(nn.ModuleDict):
         self.mask_on = cfg.MODEL.MASK_ON
         if self.mask_on and cfg.MODEL.ROI_MASK_HEAD.SHARE_BOX_FEATURE_EXTRACTOR:
             self.mask.feature_extractor = self.box.feature_extractor
+
+    def branches_batchable(self, feat):
+        return (self.training and feat.is_cuda and (not self.mask_on or (self.mask.share and self.mask.cls_agnostic_mask))
+                and os.environ.get("OVIS_STUDENT_BATCHED", "1") != "0")
+
+    def forward_branches(self, feat, branches):
+        """Training losses of several independent branches (the student's pseudo-label branch and ground-truth branch,
+        st_generalized_rcnn.py:284-408) that share these heads' weights, with ONE pooler + res5 pass over the RoIs of
+        all of them: the per-RoI work does not depend on the branch, only the class-embedding matrix of the predictor,
+        the targets and the losses do.  ``branches``: dicts with ``image_ids`` (rows of ``feat`` the proposals belong
+        to), ``proposals``, ``targets``, ``cls_embs``, ``compute_uncertain``, ``eps``.  Returns one loss dict per
+        branch -- the values the sequential calls give (same sampling order), with half the launches and GEMMs of twice
+        the height."""
+        box = self.box
+        with torch.no_grad():
+            sampled = [box.loss_evaluator.subsample(br["proposals"], br["targets"]) for br in branches]
+        parts = []
+        for br, props in zip(branches, sampled):
+            for img, p in zip(br["image_ids"], props):
+                ids = torch.full((len(p), 1), float(img), dtype=p.bbox.dtype, device=p.bbox.device)
+                parts.append(torch.cat([ids, p.bbox], dim=1))
+        x = box.feature_extractor.forward_rois([feat], _cat(parts, 0))
+        pooled = box.predictor.pooled(x)
+        counts = [sum(len(p) for p in props) for props in sampled]
+        out, off = [], 0
+        for br, props, cnt in zip(branches, sampled, counts):
+            box.predictor.set_class_embeddings(br["cls_embs"])
+            class_logits, box_regression = box.predictor(pooled[off:off + cnt])
+            box.loss_evaluator._proposals = props
+            lc, lb = box.loss_evaluator(class_logits, box_regression)
+            out.append(dict(loss_classifier=lc, loss_box_reg=lb))
+            off += cnt
+        if self.mask_on:
+            mask = self.mask
+            pos_masks = [[p.get_field("labels") > 0 for p in props] for props in sampled]
+            sel = _cat([m for ms in pos_masks for m in ms], 0)
+            fl = x.permute(0, 2, 3, 1)
+            xs = fl[sel].permute(0, 3, 1, 2) if (fl.is_contiguous() and not x.is_contiguous()) else x[sel]  # ONE index op
+            off = 0
+            for br, props, ms, losses in zip(branches, sampled, pos_masks, out):
+                pos_props = [p[m] for p, m in zip(props, ms)]
+                k = sum(len(p) for p in pos_props)
+                losses["loss_mask"] = mask.fused_training_loss(xs[off:off + k], pos_props, br["targets"],
+                                                               br.get("compute_uncertain", False), br.get("eps"))
+                off += k
+        return out
 
     def forward(self, features, proposals, targets=None, bbox_only=False, compute_uncertain=False, eps=None):
         losses, package_x = {}, {}

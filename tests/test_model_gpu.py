@@ -150,3 +150,39 @@ def test_rpn_shared_selection_matches_two_selections():
         assert len(a) == len(b) and len(a) > 0
         assert torch.equal(a.bbox, b.bbox)
         assert torch.equal(a.get_field("objectness"), b.get_field("objectness"))
+
+
+def test_batched_student_branches_match_sequential_branches():
+    """forward_student with ONE pooler + res5 pass over the RoIs of both branches (CombinedROIHeads.forward_branches)
+    gives the losses and gradients of the two sequential head calls (same sampler stream, injected noise)."""
+    import copy
+
+    model, e_vocab, e_seen, images, targets = _build("student_teacher_mask_rcnn_uncertainty")
+    model = model.cuda()
+    model.set_class_embeddings(e_seen.cuda())
+    model.set_caption_vocab(e_vocab.cuda())
+    model.train()
+    tg = [t.to("cuda") for t in targets]
+    with torch.no_grad():
+        frozen = model.forward_frozen(images.cuda(), tg)
+    res = {}
+    for mode in ("0", "1"):
+        os.environ["OVIS_STUDENT_BATCHED"] = mode
+        try:
+            m = copy.deepcopy(model)
+            m.iter = model.iter
+            torch.manual_seed(99)
+            eps = torch.randn(1, 4096, 2, 14, 14, generator=torch.Generator().manual_seed(7))
+            losses = m.forward_student(frozen, tg, eps=eps)
+            sum(losses.values()).backward()
+            res[mode] = ({k: float(v.detach()) for k, v in losses.items()},
+                         {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+        finally:
+            os.environ.pop("OVIS_STUDENT_BATCHED", None)
+    (l0, g0), (l1, g1) = res["0"], res["1"]
+    assert set(l0) == set(l1)
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-5 * max(abs(l0[k]), 1e-3), (k, l0[k], l1[k])
+    assert set(g0) == set(g1) and len(g0) >= 10
+    for n in g0:
+        assert (g0[n] - g1[n]).norm().item() <= 2e-4 * g0[n].norm().item() + 1e-9, n
