@@ -44,6 +44,7 @@ struct SplitGemmArgs {
   char* Cp; long cp_rs;              // pair result (may be null), bytes per row
   const float* bias; const float* res; long ldr;
   long M; int N; int ch; int T; int H; int W; int KH; int KW; int flip; int relu; int gw;
+  int bm_eff;  // rows a tile really covers (<= BM, % 8 == 0; = BM unless the OVIS_SG_BALANCE probe is on)
 };
 
 __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
   const int grp = tile / per_group;
   const int in_grp = tile - grp * per_group;
   const int tile_m = in_grp / gw, tile_n = grp * gw + (in_grp - tile_m * gw);
-  const long m0 = (long)tile_m * BM;
+  const long m0 = (long)tile_m * p.bm_eff;
   const int n0 = tile_n * BN;
 
   // ---- per-lane load geometry (no memory reads: hipcc would wait vmcnt(0) on them inside the DMA pipeline) ----
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
 
   // one LDS-DMA piece of the A / B tile of k-step kb into `stage` (the tap state is the one of kb; `advance` steps it)
   auto issue_a = [&](int stage, int kb, int i) {
+    if ((wave * AI + i) * 8 >= p.bm_eff) return;  // wave-uniform: this 8-row piece lies beyond the shrunk tile
     char* base = smem + stage * STAGE;
     const long a_shift = conv ? ((long)dy * p.W + dx) * p.a_rs + (long)ld_cb * 128 : (long)kb * 128;
     const char* src = p.A + a_off[i] + a_shift;
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     const long m = m0 + wm * 64 + f * 16 + frow;
-    if (m >= p.M) continue;
+    if (m >= p.M || wm * 64 + f * 16 + frow >= p.bm_eff) continue;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int n = n0 + wn * 64 + g * 16 + fc * 4;
@@ -1000,7 +1002,26 @@ extern "C" int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const 
   hipStream_t s = (hipStream_t)stream;
   int bm = tile_m;
   if (bm == 0) bm = 128;  // two independent 4-wave workgroups per CU beat one 8-wave 256-row workgroup on every shape measured
-  const long tiles_m = (m + bm - 1) / bm;
+  // OVIS_SG_BALANCE=1 (probe): spread the rows over ceil(blocks / resident workgroups) FULL rounds of slightly shorter
+  // tiles.  Measured 0-12 % SLOWER on the res5 shapes (M = 50176 / 100352): the last, mostly empty round of the
+  // uniform tiling costs less than the extra weight-tile traffic of more, shorter row tiles.  Off by default.
+  p.bm_eff = bm;
+  if (bm == 128 && stages == 2 && !abl) {
+    const long slots = 2L * OVIS_NUM_CU;
+    const long blocks0 = ((m + 127) / 128) * tiles_n;
+    const long rounds = (blocks0 + slots - 1) / slots;
+    const char* e = getenv("OVIS_SG_BALANCE");
+    if (!e || atoi(e) == 0) goto no_balance;
+    {
+      const long rt = rounds * slots / tiles_n;            // row tiles that fill `rounds` rounds
+      if (rt > 0) {
+        long be = ((m + rt - 1) / rt + 7) / 8 * 8;
+        if (be >= 64 && be < 128) p.bm_eff = (int)be;
+      }
+    }
+  }
+no_balance:
+  const long tiles_m = (m + p.bm_eff - 1) / p.bm_eff;
   const long nblocks = tiles_m * tiles_n;
   if (nblocks > 0x7fffffffL) return OVIS_ERANGE;
  #define OVIS_SG_LAUNCH(WM_, CONV_, NS_)                                                                         \

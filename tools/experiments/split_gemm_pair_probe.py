@@ -75,7 +75,7 @@ def bench_plain(m, k, n, tag):
     a3, b3 = _C.split_bf16x3(a, 0), _C.split_bf16x3(b, 1)
     fl = 2.0 * m * n * k
     out = []
-    for tm in (128, 3256, 63256):
+    for tm in (128,):
         ms = t(lambda: _C.split_gemm_pair(ap, bp, tile_m=tm))
         out.append(f"tile{tm} {ms:.3f} ms {fl / ms / 1e9:.0f} TF")
     def padded(x, pad):
@@ -102,7 +102,7 @@ def bench_conv(r, h, w, c, n, tag):
     w3 = _C.split_bf16x3(wm, 1)
     fl = 2.0 * r * h * w * n * 9 * c
     out = []
-    for tm in (128, 63256):
+    for tm in (128,):
         ms = t(lambda: _C.split_gemm_pair(xp, wp, conv=(h, w, 3, 3, False), tile_m=tm))
         out.append(f"tile{tm} {ms:.3f} ms {fl / ms / 1e9:.0f} TF")
     ms_i = t(lambda: _C.im2col_split_bf16x3(x, 3, 3))
@@ -153,7 +153,7 @@ if __name__ == "__main__":
     check_tn(49 * 37, 256, 128, (7, 7, 3, 3))
     check_tn(5 * 9 * 13, 128, 128, (9, 13, 3, 5))
     check_tn(49 * 300, 512, 512, (7, 7, 3, 3))
-    R = 1024
+    R = int(os.environ.get("PROBE_R", "1024"))
     bench_tn(R * 49, 512, 1024, None, "b0 conv1")
     bench_tn(R * 49, 2048, 1024, None, "b0 shortcut")
     bench_tn(R * 49, 2048, 512, None, "conv3")
@@ -171,7 +171,7 @@ if __name__ == "__main__":
         check_conv(2, 13, 11, 64, 96, kh=3, kw=5, tile_m=tm)
         check_conv(1, 50, 84, 256, 256, flip=True, tile_m=tm)
     print("correctness ok")
-    R = 1024
+    R = int(os.environ.get("PROBE_R", "1024"))
     bench_plain(R * 49, 1024, 512, "res5 b0 conv1")
     bench_plain(R * 49, 1024, 2048, "res5 b0 shortcut")
     bench_plain(R * 49, 512, 2048, "res5 conv3")
