@@ -117,6 +117,7 @@ class OpTimer:
         self._wrap("split_pair", split_pair_bytes)
         self._wrap("gate_split_pair", gate_split_bytes)
         self._wrap("split_gemm_pair", split_gemm_flops, "mfma")
+        self._wrap("split_gemm_pair_gated", split_gemm_flops, "mfma")
         self._wrap("split_gemm_pair_tn", split_gemm_tn_flops, "mfma")
 
     def summary(self):

@@ -406,6 +406,35 @@ def weight_prep_pair(w, scale=None, want_transposed=False):
     return fwd, bwd
 
 
+def split_gemm_pair_gated(a_pair, b_pair, gate_pair, conv=None, out_f32=False, out_pair=True):
+    """(A @ B^T) * (y > 0) with y given in pair layout (``gate_pair`` [M, 2N]): the data gradient of a layer behind a
+    ReLU, gated and split for the next backward GEMM in the epilogue.  Returns (f32 or None, pair or None)."""
+    for t, name in ((a_pair, "a_pair"), (b_pair, "b_pair"), (gate_pair, "gate_pair")):
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1):
+            raise RuntimeError(f"split_gemm_pair_gated: {name} must be a 2-D bfloat16 HIP tensor in pair layout")
+    m, ch = a_pair.shape[0], a_pair.shape[1] // 2
+    n, k = b_pair.shape[0], b_pair.shape[1] // 2
+    h = w = 0
+    kh = kw = 1
+    flip = False
+    if conv is not None:
+        h, w, kh, kw, flip = conv
+    if k != kh * kw * ch or gate_pair.shape != (m, 2 * n):
+        raise RuntimeError("split_gemm_pair_gated: shape mismatch")
+    dev = a_pair.device
+    c = torch.empty((m, n), dtype=torch.float32, device=dev) if out_f32 else None
+    cp = torch.empty((m, 2 * n), dtype=torch.bfloat16, device=dev) if out_pair else None
+    if m == 0 or n == 0:
+        return c, cp
+    with torch.cuda.device(dev):
+        rc = _L.ovis_split_gemm_pair_gated(a_pair.data_ptr(), 2 * a_pair.stride(0), b_pair.data_ptr(), 2 * b_pair.stride(0),
+                                           0 if c is None else c.data_ptr(), n, 0 if cp is None else cp.data_ptr(), 4 * n,
+                                           gate_pair.data_ptr(), 2 * gate_pair.stride(0), m, n, ch, kh, kw, h, w,
+                                           int(bool(flip)), _stream())
+    _lib.check(rc, "split_gemm_pair_gated")
+    return c, cp
+
+
 def split_gemm_pair_tn_supported(n, ch, conv=None):
     if n % 128 or ch % 128:
         return False

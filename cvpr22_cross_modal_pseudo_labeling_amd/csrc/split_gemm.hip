@@ -43,6 +43,7 @@ struct SplitGemmArgs {
   float* C; long ldc;                // fp32 result (may be null)
   char* Cp; long cp_rs;              // pair result (may be null), bytes per row
   const float* bias; const float* res; long ldr;
+  const char* gate; long gate_rs;    // optional ReLU gate of a backward pass: pair rows of the forward activation (hi > 0)
   long M; int N; int ch; int T; int H; int W; int KH; int KW; int flip; int relu; int gw;
   int bm_eff;  // rows a tile really covers (<= BM, % 8 == 0; = BM unless the OVIS_SG_BALANCE probe is on)
 };
@@ -364,6 +365,14 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
       }
       if (p.relu) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      if (p.gate) {  // data gradient of a layer whose input went through a ReLU: zero where that activation was <= 0
+        const uint2 h = *(const uint2*)(p.gate + m * p.gate_rs + (long)(n >> 5) * 128 + (n & 31) * 2);
+        const unsigned a0 = h.x & 0xffffu, a1 = h.x >> 16, a2 = h.y & 0xffffu, a3 = h.y >> 16;
+        if (a0 == 0u || a0 >= 0x8000u) v.x = 0.f;
+        if (a1 == 0u || a1 >= 0x8000u) v.y = 0.f;
+        if (a2 == 0u || a2 >= 0x8000u) v.z = 0.f;
+        if (a3 == 0u || a3 >= 0x8000u) v.w = 0.f;
       }
       if (p.C) *(f32x4*)(p.C + m * p.ldc + n) = v;
       if (p.Cp) {
@@ -965,11 +974,36 @@ extern "C" int ovis_split_gemm_pair_tn(const void* g_pair, long g_row_bytes, con
   return OVIS_OK;
 }
 
+static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
+                                float* c, long ldc, void* c_pair, long c_pair_row_bytes, const float* bias,
+                                const float* residual, long ldr, const void* gate_pair, long gate_row_bytes, long m,
+                                int n, int channels, int taps_h, int taps_w, int height, int width, int flip, int relu,
+                                int tile_m, void* stream);
+
 extern "C" int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
                                     float* c, long ldc, void* c_pair, long c_pair_row_bytes, const float* bias,
                                     const float* residual, long ldr, long m, int n, int channels, int taps_h,
                                     int taps_w, int height, int width, int flip, int relu, int tile_m,
                                     void* stream) {
+  return split_gemm_pair_impl(a_pair, a_row_bytes, b_pair, b_row_bytes, c, ldc, c_pair, c_pair_row_bytes, bias, residual,
+                              ldr, nullptr, 0, m, n, channels, taps_h, taps_w, height, width, flip, relu, tile_m, stream);
+}
+
+extern "C" int ovis_split_gemm_pair_gated(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
+                                          float* c, long ldc, void* c_pair, long c_pair_row_bytes,
+                                          const void* gate_pair, long gate_row_bytes, long m, int n, int channels,
+                                          int taps_h, int taps_w, int height, int width, int flip, void* stream) {
+  if (!gate_pair || gate_row_bytes % 16 != 0 || ((uintptr_t)gate_pair & 15) || n % 32 != 0) return OVIS_ERANGE;
+  return split_gemm_pair_impl(a_pair, a_row_bytes, b_pair, b_row_bytes, c, ldc, c_pair, c_pair_row_bytes, nullptr,
+                              nullptr, 0, gate_pair, gate_row_bytes, m, n, channels, taps_h, taps_w, height, width, flip,
+                              0, 0, stream);
+}
+
+static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
+                                float* c, long ldc, void* c_pair, long c_pair_row_bytes, const float* bias,
+                                const float* residual, long ldr, const void* gate_pair, long gate_row_bytes, long m,
+                                int n, int channels, int taps_h, int taps_w, int height, int width, int flip, int relu,
+                                int tile_m, void* stream) {
   if (m < 0 || n < 0 || channels < 0 || taps_h <= 0 || taps_w <= 0 || !(taps_h & 1) || !(taps_w & 1))
     return OVIS_EINVAL;
   if (m == 0 || n == 0) return OVIS_OK;
@@ -990,6 +1024,7 @@ extern "C" int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const 
   p.B = (const char*)b_pair; p.b_rs = b_row_bytes;
   p.C = c; p.ldc = ldc; p.Cp = (char*)c_pair; p.cp_rs = c_pair_row_bytes;
   p.bias = bias; p.res = residual; p.ldr = ldr;
+  p.gate = (const char*)gate_pair; p.gate_rs = gate_row_bytes;
   p.M = m; p.N = n; p.ch = channels; p.T = T; p.H = height; p.W = width; p.KH = taps_h; p.KW = taps_w;
   p.flip = flip; p.relu = relu;
   const int tiles_n = (n + 127) / 128;

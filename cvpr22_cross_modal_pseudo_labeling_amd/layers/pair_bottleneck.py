@@ -124,15 +124,11 @@ class _BottleneckPair(Function):
         g3p, g3 = _C.gate_split_pair(None if dout is None else dout.reshape(-1, n3), out, want_f32=(wd is None and need_x),
                                      pooled=dpooled, pool_rows=h * w)
         dw3 = _dw(g3p, o2p, w3, s3) if need_w3 else None
-        d2, _ = _C.split_gemm_pair(g3p, t3)                                                        # dY W3
-        g2p, _ = _C.gate_split_pair(d2, o2p)
-        del d2
+        _, g2p = _C.split_gemm_pair_gated(g3p, t3, o2p)                  # (dY W3) gated by relu(o2), split: one kernel
         dw2 = _dw(g2p, o1p, w2, s2, (h, w, kh, kw)) if need_w2 else None
         dx = dw1 = dwd = None
         if need_x or need_w1:
-            d1, _ = _C.split_gemm_pair(g2p, t2, conv=(h, w, kh, kw, True))
-            g1p, _ = _C.gate_split_pair(d1, o1p)
-            del d1
+            _, g1p = _C.split_gemm_pair_gated(g2p, t2, o1p, conv=(h, w, kh, kw, True))
             if need_w1:
                 dw1 = _dw(g1p, xp, w1, s1)
             if need_x:

@@ -214,6 +214,15 @@ int ovis_slab_reduce_f32(const float* slabs, const float* scale, float* dweight,
 int ovis_im2col_pair(const void* src_pair, void* dst_pair, long num, int height, int width,
                      int channels, int kh, int kw, void* stream);
 
+/* ovis_split_gemm_pair for a data gradient whose result passes a ReLU gate: C = (A B^T) * (y > 0) with y the forward
+ * activation in pair layout (gate_pair, rows gate_row_bytes apart; only the hi halves are read), written as fp32 (c)
+ * and / or in pair layout (c_pair) -- the gate and the operand split of the NEXT backward GEMM in this epilogue.
+ * n % 32 == 0. */
+int ovis_split_gemm_pair_gated(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
+                               float* c, long ldc, void* c_pair, long c_pair_row_bytes, const void* gate_pair,
+                               long gate_row_bytes, long m, int n, int channels, int taps_h, int taps_w,
+                               int height, int width, int flip, void* stream);
+
 /* im2col of a strided convolution on an NCHW f32 image [num, channels, height, width] into pair rows
  * [num*ho*wo, k_padded]: k = (ky*kw + kx)*channels + c, columns >= kh*kw*channels are zero (k_padded % 32 == 0).
  * The 7x7 stride-2 stem (mb/modeling/backbone/resnet.py:347-366) then is one ovis_split_gemm_pair. */

@@ -371,3 +371,23 @@ def test_mask_predictor_gemm_path_matches_convolutions():
         assert (a - b).norm().item() <= 2e-5 * b.norm().item() + 1e-7
     mu0, s0 = m.forward_parts(x[:0])
     assert mu0.shape == (0, 2, 14, 14) and s0.shape == (0, 1, 14, 14)
+
+
+def test_split_gemm_pair_gated_epilogue():
+    """Gated data-gradient GEMM == gate_split_pair(split_gemm_pair(...), y) bit for bit (plain and implicit 3x3)."""
+    C = _C()
+    torch.manual_seed(6)
+    m, k, n = 49 * 11, 256, 128
+    a, b = torch.randn(m, k, device="cuda"), torch.randn(n, k, device="cuda")
+    y = torch.randn(m, n, device="cuda").clamp(min=0)
+    ap, bp, yp = C.split_pair(a), C.split_pair(b), C.split_pair(y)
+    d, _ = C.split_gemm_pair(ap, bp)
+    want_p, want = C.gate_split_pair(d, yp, want_f32=True)
+    got, got_p = C.split_gemm_pair_gated(ap, bp, yp, out_f32=True, out_pair=True)
+    assert torch.equal(got, want) and torch.equal(got_p, want_p)
+    wm = torch.randn(n, 9 * k, device="cuda")
+    wp = C.split_pair(wm)
+    d, _ = C.split_gemm_pair(ap, wp, conv=(7, 7, 3, 3, True))
+    want_p, _ = C.gate_split_pair(d, yp)
+    _, got_p = C.split_gemm_pair_gated(ap, wp, yp, conv=(7, 7, 3, 3, True))
+    assert torch.equal(got_p, want_p)
