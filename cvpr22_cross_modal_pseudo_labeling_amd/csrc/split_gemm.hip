@@ -59,7 +59,7 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 }
 
 template <int WM, bool CONV, int NS, int ABL = 0>
-__global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, int tiles_n, int nblocks) {
+__global__ __launch_bounds__(WM * 128, (NS == 1 && ABL == 7) ? 4 : 1) void split_gemm_kernel(SplitGemmArgs p, int tiles_n, int nblocks) {
   constexpr int BM = WM * 64, BN = 128, NW = WM * 2;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int AI = BM / 8 / NW;  // LDS-DMA instructions per wave per stage for A (8 rows each): 4
@@ -197,6 +197,42 @@ __global__ __launch_bounds__(WM * 128) void split_gemm_kernel(SplitGemmArgs p, i
   // fragments of stage kb+1 are read into a second register set right after the barrier of step kb, and the 48 MFMAs
   // of step kb run on the set that was read one step earlier: the matrix cores never wait for LDS.  Three LDS
   // buffers: compute reads none, fragment reads take stage kb+1, the DMA fills stage kb+2.
+  if (NS == 1) {
+    // single LDS stage, three workgroups per CU: no overlap inside a workgroup (load -> barrier -> compute ->
+    // barrier), the other two workgroups fill the gaps.  Probe (tile_m code 1128).
+    for (int kb = 0; kb < nk; ++kb) {
+      issue(0, kb);
+      __syncthreads();
+      const char* base = smem;
+      bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        bh[f] = *(const bf16x8*)(base + b_rd[f]);
+        ah[f] = *(const bf16x8*)(base + a_rd[f]);
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        bl[f] = *(const bf16x8*)(base + (b_rd[f] ^ 64));
+        al[f] = *(const bf16x8*)(base + (a_rd[f] ^ 64));
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[g], ah[f], acc[f][g], 0, 0, 0);
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[g], al[f], acc[f][g], 0, 0, 0);
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[g], ah[f], acc[f][g], 0, 0, 0);
+      __syncthreads();
+    }
+  } else
   if (NS == 3 && ABL == 6) {
     bf16x8 f0[16], f1[16];
     auto read_frags = [&](bf16x8* fr, int buf) {
@@ -1018,7 +1054,7 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
   int stages = 2, abl = 0;
   if (tile_m >= 10000) { abl = tile_m / 10000; tile_m %= 10000; }  // ablation probes (tools/experiments only)
   if (tile_m >= 1000) { stages = tile_m / 1000; tile_m %= 1000; }
-  if ((tile_m != 0 && tile_m != 128 && tile_m != 256) || (stages != 2 && stages != 3)) return OVIS_ERANGE;
+  if ((tile_m != 0 && tile_m != 128 && tile_m != 256) || (stages != 1 && stages != 2 && stages != 3)) return OVIS_ERANGE;
   SplitGemmArgs p;
   p.A = (const char*)a_pair; p.a_rs = a_row_bytes;
   p.B = (const char*)b_pair; p.b_rs = b_row_bytes;
@@ -1036,7 +1072,17 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
   }
   hipStream_t s = (hipStream_t)stream;
   int bm = tile_m;
-  if (bm == 0) bm = 128;  // two independent 4-wave workgroups per CU beat one 8-wave 256-row workgroup on every shape measured
+  if (bm == 0) {
+    bm = 128;  // independent 4-wave workgroups beat one 8-wave 256-row workgroup per CU on every shape measured
+    // Large grids: ONE LDS stage and three / four workgroups per CU instead of two double-buffered ones -- nothing
+    // overlaps inside a workgroup, but more independent workgroups hide each other's load phases better (measured on
+    // M = 50176: N = 2048 1x1 +9...17 %, 3x3 +3 %, N = 512 1x1 +-2 %; grids below ~2 rounds lose: they keep 2 stages).
+    const long nb = ((m + 127) / 128) * tiles_n;
+    const char* e = getenv("OVIS_SG_STAGES");
+    if (e) stages = atoi(e) == 1 ? 1 : 2;
+    else if (nb >= 4L * OVIS_NUM_CU && (T > 1 || tiles_n >= 8)) stages = 1;
+    if (stages == 1 && T == 1) abl = 7;  // the plain kernel fits 128 VGPRs: four workgroups per CU
+  }
   // OVIS_SG_BALANCE=1 (probe): spread the rows over ceil(blocks / resident workgroups) FULL rounds of slightly shorter
   // tiles.  Measured 0-12 % SLOWER on the res5 shapes (M = 50176 / 100352): the last, mostly empty round of the
   // uniform tiling costs less than the extra weight-tile traffic of more, shorter row tiles.  Off by default.
@@ -1071,7 +1117,18 @@ no_balance:
     hipLaunchKernelGGL((split_gemm_kernel<WM_, CONV_, NS_>), dim3((unsigned)nblocks), dim3(WM_ * 128), lds, s,  \
                        p, tiles_n, (int)nblocks);                                                               \
   } while (0)
-  if (abl == 6 && bm == 256 && stages == 3) {
+  if (stages == 1 && bm == 128) {
+    constexpr int lds1 = 128 * 128 + 128 * 128;
+    if (abl == 7) {  // 4 waves per SIMD (<= 128 VGPRs): four workgroups per CU
+      if (T > 1) hipLaunchKernelGGL((split_gemm_kernel<2, true, 1, 7>), dim3((unsigned)nblocks), dim3(256), lds1, s, p, tiles_n, (int)nblocks);
+      else hipLaunchKernelGGL((split_gemm_kernel<2, false, 1, 7>), dim3((unsigned)nblocks), dim3(256), lds1, s, p, tiles_n, (int)nblocks);
+    } else {
+      if (T > 1) hipLaunchKernelGGL((split_gemm_kernel<2, true, 1, 0>), dim3((unsigned)nblocks), dim3(256), lds1, s, p, tiles_n, (int)nblocks);
+      else hipLaunchKernelGGL((split_gemm_kernel<2, false, 1, 0>), dim3((unsigned)nblocks), dim3(256), lds1, s, p, tiles_n, (int)nblocks);
+    }
+  } else if (stages == 1) {
+    return OVIS_ERANGE;
+  } else if (abl == 6 && bm == 256 && stages == 3) {
     constexpr int lds3 = 3 * (256 * 128 + 128 * 128);
     if (T > 1) {
       OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<4, true, 3, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3));

@@ -75,7 +75,7 @@ def bench_plain(m, k, n, tag):
     a3, b3 = _C.split_bf16x3(a, 0), _C.split_bf16x3(b, 1)
     fl = 2.0 * m * n * k
     out = []
-    for tm in (128,):
+    for tm in (128, 1128, 71128):
         ms = t(lambda: _C.split_gemm_pair(ap, bp, tile_m=tm))
         out.append(f"tile{tm} {ms:.3f} ms {fl / ms / 1e9:.0f} TF")
     def padded(x, pad):
@@ -102,7 +102,7 @@ def bench_conv(r, h, w, c, n, tag):
     w3 = _C.split_bf16x3(wm, 1)
     fl = 2.0 * r * h * w * n * 9 * c
     out = []
-    for tm in (128,):
+    for tm in (128, 1128, 71128):
         ms = t(lambda: _C.split_gemm_pair(xp, wp, conv=(h, w, 3, 3, False), tile_m=tm))
         out.append(f"tile{tm} {ms:.3f} ms {fl / ms / 1e9:.0f} TF")
     ms_i = t(lambda: _C.im2col_split_bf16x3(x, 3, 3))
@@ -159,7 +159,7 @@ if __name__ == "__main__":
     bench_tn(R * 49, 2048, 512, None, "conv3")
     bench_tn(R * 49, 512, 2048, None, "b1 conv1")
     bench_tn(R * 49, 512, 512, (7, 7, 3, 3), "conv2")
-    for tm in (128, 63256):
+    for tm in (128, 1128, 71128):
         check_plain(128, 32, 128, tile_m=tm)
         check_plain(300, 64, 64, tile_m=tm)
         check_plain(1000, 512, 192, bias=True, res=True, relu=True, tile_m=tm)
