@@ -457,8 +457,9 @@ struct SplitGemmTnArgs {
                : "n"(N)                                                                                            \
                : "memory")
 
-template <bool CONV>
-__global__ __launch_bounds__(256) void split_gemm_tn_kernel(SplitGemmTnArgs p, int tiles_i, int tiles_j, int nblocks) {
+template <bool CONV, int NS = 2>
+__global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void split_gemm_tn_kernel(SplitGemmTnArgs p, int tiles_i, int tiles_j,
+                                                                            int nblocks) {
   constexpr int TILE_BYTES = 32 * 512, STAGE = 2 * TILE_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -565,11 +566,17 @@ __global__ __launch_bounds__(256) void split_gemm_tn_kernel(SplitGemmTnArgs p, i
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (nk > 0) issue(0);
+  // NS == 2: the next stage loads under this stage's MFMAs, two workgroups per CU.  NS == 1: one stage, no overlap
+  // inside the workgroup, three workgroups per CU (<= 168 VGPRs) fill each other's load phases.
+  if (NS == 2 && nk > 0) issue(0);
   for (int kb = 0; kb < nk; ++kb) {
+    if (NS == 1) {
+      if (kb > 0) __syncthreads();  // everyone is done reading the stage
+      issue(0);
+    }
     __syncthreads();
-    if (kb + 1 < nk) issue((kb + 1) & 1);
-    const int so = (kb & 1) * STAGE;  // the dynamic LDS segment starts at LDS address 0 (no static LDS in this TU's kernels)
+    if (NS == 2 && kb + 1 < nk) issue((kb + 1) & 1);
+    const int so = NS == 1 ? 0 : (kb & 1) * STAGE;  // the dynamic LDS segment starts at LDS address 0 (no static LDS in this TU's kernels)
     bf16x4 xa[4][2], xb[4][2], ga[4][2], gb[4][2];  // [fragment][hi/lo]: first / second 4 rows of the lane's 8 k values
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -990,7 +997,16 @@ extern "C" int ovis_split_gemm_pair_tn(const void* g_pair, long g_row_bytes, con
   const long nblocks = (long)tiles_i * tiles_j * slices;
   if (nblocks > 0x7fffffffL) return OVIS_ERANGE;
   hipStream_t s = (hipStream_t)stream;
-  const int lds = 2 * 2 * 32 * 512;
+  int lds = 2 * 2 * 32 * 512;
+  if (const char* e = getenv("OVIS_TN_STAGES")) {
+    if (atoi(e) == 1) {
+      lds = 2 * 32 * 512;
+      if (T > 1) hipLaunchKernelGGL((split_gemm_tn_kernel<true, 1>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_i, tiles_j, (int)nblocks);
+      else hipLaunchKernelGGL((split_gemm_tn_kernel<false, 1>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_i, tiles_j, (int)nblocks);
+      OVIS_LAUNCH_CHECK();
+      return OVIS_OK;
+    }
+  }
   if (T > 1) {
     static bool attr_set_c = false;
     if (!attr_set_c) {
@@ -1076,11 +1092,12 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
     bm = 128;  // independent 4-wave workgroups beat one 8-wave 256-row workgroup per CU on every shape measured
     // Large grids: ONE LDS stage and three / four workgroups per CU instead of two double-buffered ones -- nothing
     // overlaps inside a workgroup, but more independent workgroups hide each other's load phases better (measured on
-    // M = 50176: N = 2048 1x1 +9...17 %, 3x3 +3 %, N = 512 1x1 +-2 %; grids below ~2 rounds lose: they keep 2 stages).
+    // M = 50176: N = 2048 1x1 +9...17 %, 3x3 +3 %, N = 512 1x1 +-2 %; on M = 100352: every 1x1 +7...16 %, 3x3 +7 %;
+    // grids below ~2 rounds lose: they keep 2 stages).
     const long nb = ((m + 127) / 128) * tiles_n;
     const char* e = getenv("OVIS_SG_STAGES");
     if (e) stages = atoi(e) == 1 ? 1 : 2;
-    else if (nb >= 4L * OVIS_NUM_CU && (T > 1 || tiles_n >= 8)) stages = 1;
+    else if ((nb >= 8L * OVIS_NUM_CU && !getenv("OVIS_SG_NARROW")) || (nb >= 4L * OVIS_NUM_CU && (T > 1 || tiles_n >= 8))) stages = 1;
     if (stages == 1 && T == 1) abl = 7;  // the plain kernel fits 128 VGPRs: four workgroups per CU
   }
   // OVIS_SG_BALANCE=1 (probe): spread the rows over ceil(blocks / resident workgroups) FULL rounds of slightly shorter
