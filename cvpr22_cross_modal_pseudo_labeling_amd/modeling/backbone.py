@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..layers import Conv2d, FrozenBatchNorm2d, bias_relu_, split_conv_same, split_linear
-from ..layers.pair_bottleneck import bottleneck_pair, conv_weight_matrix, pair_weight
+from ..layers.pair_bottleneck import bottleneck_pair, pair_weight
 
 
 class ConvBN(nn.Module):
