@@ -183,6 +183,40 @@ def sigmoid_focalloss_backward(logits, targets, d_losses, num_classes, gamma, al
     return d_logits
 
 
+# ---- ROIPool (csrc/ROIPool.h:11-48) ---------------------------------------------------------------
+def roi_pool_forward(input, rois, spatial_scale, pooled_height, pooled_width):
+    """The reference's `_C.roi_pool_forward`: (output, argmax int32), exact vs cuda/ROIPool_cuda.cu:17-77."""
+    input, rois = _dev(input, "input"), _dev(rois, "rois")
+    if rois.dim() != 2 or rois.size(1) != 5 or input.dim() != 4:
+        raise RuntimeError("roi_pool_forward: expected input [N,C,H,W] and rois [R,5]")
+    n, c, h, w = input.shape
+    r = rois.size(0)
+    out = torch.empty((r, c, pooled_height, pooled_width), dtype=input.dtype, device=input.device)
+    argmax = torch.zeros((r, c, pooled_height, pooled_width), dtype=torch.int32, device=input.device)
+    if out.numel():
+        with torch.cuda.device(input.device):
+            rc = _L.ovis_roi_pool_forward_f32(input.data_ptr(), rois.data_ptr(), out.data_ptr(), argmax.data_ptr(), r, n, c, h,
+                                              w, pooled_height, pooled_width, spatial_scale, _stream())
+        _lib.check(rc, "roi_pool_forward")
+    return out, argmax
+
+
+def roi_pool_backward(grad, input, rois, argmax, spatial_scale, pooled_height, pooled_width, batch_size, channels,
+                      height, width):
+    """The reference's `_C.roi_pool_backward` (cuda/ROIPool_cuda.cu:80-108); `input` / `spatial_scale` are part of
+    the reference signature and unused, as upstream."""
+    grad, rois = _dev(grad, "grad"), _dev(rois, "rois")
+    argmax = argmax.to(torch.int32).contiguous()
+    gin = torch.empty((batch_size, channels, height, width), dtype=grad.dtype, device=grad.device)
+    if gin.numel():
+        with torch.cuda.device(grad.device):
+            rc = _L.ovis_roi_pool_backward_f32(grad.data_ptr(), argmax.data_ptr(), rois.data_ptr(), gin.data_ptr(),
+                                               rois.size(0), batch_size, channels, height, width, pooled_height,
+                                               pooled_width, _stream())
+        _lib.check(rc, "roi_pool_backward")
+    return gin
+
+
 # ---- cross-modal head + student losses (extensions beyond vision.cpp; include/ovis_hip.h) --------------
 def split_bf16x3(x, mode):
     """x [rows, cols] f32 (row-strided view ok) -> [rows, 3*cols] bf16, rows = [hi|hi|lo] (mode 0) / [hi|lo|hi]

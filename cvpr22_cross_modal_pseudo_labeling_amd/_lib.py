@@ -25,6 +25,8 @@ SIGNATURES = {
     "ovis_roi_align_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ovis_roi_align_backward_plane_supported": (_i, [_i, _i, _i, _i]),
     "ovis_roi_align_backward_ws_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
+    "ovis_roi_pool_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "ovis_roi_pool_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ovis_nms_workspace_bytes": (_sz, [_i]),
     "ovis_nms_f32": (_i, [_vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp]),
     "ovis_sigmoid_focal_loss_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),

@@ -5,6 +5,7 @@ from .dcn import DeformConv, ModulatedDeformConv, ModulatedDeformConvPack, defor
 from .misc import BatchNorm2d, Conv2d, ConvTranspose2d, DFConv2d, interpolate
 from .nms import nms, nms_padded
 from .roi_align import ROIAlign, roi_align
+from .roi_pool import ROIPool, roi_pool
 from .sigmoid_focal_loss import SigmoidFocalLoss
 from .smooth_l1_loss import smooth_l1_loss
 
@@ -13,6 +14,8 @@ __all__ = [
     "nms_padded",
     "roi_align",
     "ROIAlign",
+    "roi_pool",
+    "ROIPool",
     "smooth_l1_loss",
     "Conv2d",
     "ConvTranspose2d",

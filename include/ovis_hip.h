@@ -129,6 +129,21 @@ int ovis_nms_f32(const float* boxes, const float* scores, int num_boxes, float t
                  int32_t* num_keep, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * ROIPool                                    mb/csrc/ROIPool.h:11-48
+ *   kernels: mb/csrc/cuda/ROIPool_cuda.cu:17-77 (fwd), :80-108 (bwd)
+ * input [batch, channels, height, width] f32, rois [num_rois, 5] (batch index, x1, y1, x2, y2);
+ * output / argmax [num_rois, channels, pooled_h, pooled_w] (f32 max per bin / int32 index into the
+ * H*W plane, -1 for an empty bin whose value is 0).  Backward fully writes grad_input
+ * [batch, channels, height, width] (zero fill + scatter-add to the argmax positions).
+ * ---------------------------------------------------------------------------------- */
+int ovis_roi_pool_forward_f32(const float* input, const float* rois, float* output, int32_t* argmax,
+                              int num_rois, int batch, int channels, int height, int width,
+                              int pooled_h, int pooled_w, float spatial_scale, void* stream);
+int ovis_roi_pool_backward_f32(const float* grad_output, const int32_t* argmax, const float* rois,
+                               float* grad_input, int num_rois, int batch, int channels, int height,
+                               int width, int pooled_h, int pooled_w, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Sigmoid focal loss                         mb/csrc/SigmoidFocalLoss.h:10-41
  *   kernels: mb/csrc/cuda/SigmoidFocalLoss_cuda.cu:21-58 (fwd), :62-101 (bwd)
  * logits [num, num_classes] f32; targets [num] int32 (-1 ignore, 0 background,

@@ -105,3 +105,24 @@ def sigmoid_focal_loss_backward(logits, targets, d_losses, gamma, alpha):
     out = torch.empty_like(logits)
     lib().oracle_sigmoid_focal_loss_backward_f32(_p(logits), _p(targets), _p(d_losses), _p(out), logits.shape[0], logits.shape[1], ctypes.c_float(gamma), ctypes.c_float(alpha))
     return out
+
+
+def roi_pool_forward(inp, rois, scale, ph, pw):
+    """(output, argmax int32) -- csrc/cuda/ROIPool_cuda.cu:17-77."""
+    inp, rois = _f(inp), _f(rois)
+    n, c, h, w = inp.shape
+    r = rois.shape[0]
+    out = torch.empty((r, c, ph, pw), dtype=torch.float32)
+    arg = torch.empty((r, c, ph, pw), dtype=torch.int32)
+    lib().oracle_roi_pool_forward_f32(_p(inp), _p(rois), _p(out), _p(arg), r, c, h, w, ph, pw, ctypes.c_float(scale))
+    return out, arg
+
+
+def roi_pool_backward(grad, argmax, rois, n, c, h, w):
+    """csrc/cuda/ROIPool_cuda.cu:80-108."""
+    grad, rois = _f(grad), _f(rois)
+    argmax = argmax.detach().to("cpu", torch.int32).contiguous()
+    r, _, ph, pw = grad.shape
+    gin = torch.empty((n, c, h, w), dtype=torch.float32)
+    lib().oracle_roi_pool_backward_f32(_p(grad), _p(argmax), _p(rois), _p(gin), r, n, c, h, w, ph, pw)
+    return gin

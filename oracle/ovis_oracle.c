@@ -228,3 +228,51 @@ void oracle_sigmoid_focal_loss_backward_f32(const float* logits, const int32_t* 
     d_logits[i] = g * d_losses[i];
   }
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* ROIPool (max pooling per bin).  cuda/ROIPool_cuda.cu:17-77 (forward: rounded RoI, bin  */
+/* extents floor/ceil, clip to the map, empty bin -> 0 / argmax -1, first maximum in      */
+/* (h, w) scan order), :80-108 (backward: scatter-add of the bin gradient to its argmax). */
+/* The reference has no CPU implementation (csrc/ROIPool.h:20,37) and no tests: "parity    */
+/* unpinned" by reference vectors; pinned by an independent tensor-op formulation in      */
+/* tests/test_oracle.py.                                                                  */
+/* ------------------------------------------------------------------------------------ */
+
+void oracle_roi_pool_forward_f32(const float* in, const float* rois, float* out, int32_t* argmax,
+                                 int R, int C, int H, int W, int PH, int PW, float scale) {
+  for (long index = 0; index < (long)R * C * PH * PW; ++index) {
+    int pw = (int)(index % PW), ph = (int)((index / PW) % PH);
+    int c = (int)((index / PW / PH) % C), n = (int)(index / PW / PH / C);
+    const float* r = rois + (long)n * 5;
+    int b = (int)r[0];
+    int sw = (int)roundf(r[1] * scale), sh = (int)roundf(r[2] * scale);
+    int ew = (int)roundf(r[3] * scale), eh = (int)roundf(r[4] * scale);
+    int rw = ew - sw + 1 > 1 ? ew - sw + 1 : 1, rh = eh - sh + 1 > 1 ? eh - sh + 1 : 1;
+    float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+    int hs = (int)floorf((float)ph * bh), ws = (int)floorf((float)pw * bw);
+    int he = (int)ceilf((float)(ph + 1) * bh), we = (int)ceilf((float)(pw + 1) * bw);
+    hs = hs + sh < 0 ? 0 : (hs + sh > H ? H : hs + sh);
+    he = he + sh < 0 ? 0 : (he + sh > H ? H : he + sh);
+    ws = ws + sw < 0 ? 0 : (ws + sw > W ? W : ws + sw);
+    we = we + sw < 0 ? 0 : (we + sw > W ? W : we + sw);
+    int empty = (he <= hs) || (we <= ws);
+    float maxval = empty ? 0.f : -FLT_MAX;
+    int maxidx = -1;
+    const float* p = in + ((long)b * C + c) * H * W;
+    for (int h = hs; h < he; ++h)
+      for (int w = ws; w < we; ++w)
+        if (p[h * W + w] > maxval) { maxval = p[h * W + w]; maxidx = h * W + w; }
+    out[index] = maxval;
+    argmax[index] = maxidx;
+  }
+}
+
+void oracle_roi_pool_backward_f32(const float* grad, const int32_t* argmax, const float* rois,
+                                  float* gin, int R, int N, int C, int H, int W, int PH, int PW) {
+  for (long i = 0; i < (long)N * C * H * W; ++i) gin[i] = 0.f;
+  for (long index = 0; index < (long)R * C * PH * PW; ++index) {
+    int c = (int)((index / PW / PH) % C), n = (int)(index / PW / PH / C);
+    int b = (int)rois[(long)n * 5];
+    if (argmax[index] != -1) gin[((long)b * C + c) * H * W + argmax[index]] += grad[index];
+  }
+}

@@ -76,3 +76,53 @@ def test_focal_vs_reference_python_formula(oracle_mod, golden_dir):
         # expected = the reference's Python formula evaluated in fp64 (see make_golden.py)
         assert torch.allclose(loss.double(), torch.from_numpy(z["loss" + sfx]), rtol=2e-5, atol=1e-7)
         assert torch.allclose(grad.double(), torch.from_numpy(z["grad" + sfx]), rtol=2e-5, atol=1e-7)
+
+
+def _roi_pool_tensor_formulation(x, rois, scale, PH, PW):
+    """Independent restatement of ROIPool_cuda.cu:17-77 with numpy float32 scalars + torch slicing (no shared code with
+    the C oracle): the reference has neither a CPU kernel nor tests for this op."""
+    import math
+    R = rois.shape[0]
+    N, C, H, W = x.shape
+    out = torch.zeros(R, C, PH, PW)
+    arg = torch.full((R, C, PH, PW), -1, dtype=torch.int32)
+
+    def cuda_round(v):  # round half away from zero
+        return int(math.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1)
+
+    for n in range(R):
+        b = int(rois[n, 0])
+        sw, sh, ew, eh = (cuda_round(float(np.float32(rois[n, k]) * np.float32(scale))) for k in (1, 2, 3, 4))
+        rw, rh = max(ew - sw + 1, 1), max(eh - sh + 1, 1)
+        bh, bw = np.float32(rh) / np.float32(PH), np.float32(rw) / np.float32(PW)
+        for ph in range(PH):
+            for pw in range(PW):
+                hs, he = int(np.floor(np.float32(ph) * bh)), int(np.ceil(np.float32(ph + 1) * bh))
+                ws, we = int(np.floor(np.float32(pw) * bw)), int(np.ceil(np.float32(pw + 1) * bw))
+                hs, he = min(max(hs + sh, 0), H), min(max(he + sh, 0), H)
+                ws, we = min(max(ws + sw, 0), W), min(max(we + sw, 0), W)
+                if he <= hs or we <= ws:
+                    continue
+                reg = x[b, :, hs:he, ws:we].reshape(C, -1)
+                v, i = reg.max(1)
+                # first maximum in scan order
+                i = (reg == v[:, None]).float().argmax(1)
+                out[n, :, ph, pw] = v
+                arg[n, :, ph, pw] = ((hs + i // (we - ws)) * W + ws + i % (we - ws)).int()
+    return out, arg
+
+
+def test_roi_pool_oracle_vs_independent_formulation(oracle_mod):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 3, 10, 12, generator=g)
+    x[0, 0, 2:4, 2:5] = 7.0  # ties: the first maximum in (h, w) order wins
+    rois = torch.tensor([[0, 0.0, 0.0, 40.0, 30.0], [1, 8.0, 4.0, 100.0, 80.0], [0, -10.0, -5.0, 5.0, 6.0],
+                         [1, 200.0, 200.0, 210.0, 220.0], [0, 10.0, 10.0, 9.0, 9.0], [1, 2.0, 2.0, 2.5, 2.5]])
+    for (ph, pw) in ((3, 3), (7, 7), (2, 5)):
+        out, arg = oracle_mod.roi_pool_forward(x, rois, 0.25, ph, pw)
+        o2, a2 = _roi_pool_tensor_formulation(x, rois, 0.25, ph, pw)
+        assert torch.equal(out, o2) and torch.equal(arg, a2)
+        gout = torch.randn(out.shape, generator=g)
+        gin = oracle_mod.roi_pool_backward(gout, arg, rois, 2, 3, 10, 12)
+        # adjoint identity of the (piecewise linear) max-pool selection: <out, g> == <x, gin> for the selected elements
+        assert abs(float((out * gout)[arg >= 0].sum()) - float((x * gin).sum())) < 1e-4
