@@ -2,7 +2,8 @@
 DDP set-up of tools/train_net.py:43-126, rebuilt around ``BucketedGradReducer``.
 
 Only the step itself is here (forward -> sum of losses -> backward with overlapped all-reduce -> SGD ->
-LR schedule) plus rank-0 logging at LOG_PERIOD; checkpoint / evaluation cadence is outside the
+LR schedule) plus rank-0 logging at LOG_PERIOD and the reference's checkpoint cadence (``model_<iter>.pth`` every
+CHECKPOINT_PERIOD, ``model_final.pth`` at the end: trainer.py:172-173, 252-253); periodic evaluation is outside the
 hot-path scope.
 """
 import logging
@@ -134,7 +135,8 @@ class PipelinedTrainer:
             self.pending = None
 
 
-def do_train(cfg, model, data_iter, optimizer, scheduler, max_iter, start_iter=0, log_period=None, logger=None):
+def do_train(cfg, model, data_iter, optimizer, scheduler, max_iter, start_iter=0, log_period=None, logger=None,
+             checkpointer=None, checkpoint_period=None):
     logger = logger or logging.getLogger("ovis.trainer")
     log_period = log_period or cfg.SOLVER.LOG_PERIOD
     model.train()
@@ -173,8 +175,13 @@ def do_train(cfg, model, data_iter, optimizer, scheduler, max_iter, start_iter=0
                             "  ".join(f"{k} {v:.4f}" for k, v in vals.items()), optimizer.param_groups[0]["lr"],
                             (now - last) / log_period)
                 last = now
+        if checkpointer is not None and checkpoint_period and (iteration + 1) % checkpoint_period == 0:
+            pipe.drain()  # the look-ahead half holds no state, but the weights must be quiescent while they are read
+            checkpointer.save("model_{:07d}".format(iteration + 1), iteration=iteration + 1)
     pipe.drain()
     reducer.remove()
+    if checkpointer is not None and max_iter > start_iter:
+        checkpointer.save("model_final", iteration=max_iter)
     total = time.time() - start
     logger.info("Total training time: %.1f s (%.4f s / it)", total, total / max(max_iter - start_iter, 1))
     return history

@@ -251,3 +251,66 @@ def test_group_fused_sgd_matches_torch_sgd():
             assert (p - q).abs().max().item() <= 1e-6
     b.load_state_dict(a.state_dict())
     assert len(a.state_dict()["param_groups"]) == 3
+
+
+def test_checkpoint_suffix_alignment_and_roundtrip(tmp_path):
+    """Reference wire format (utils/model_serialization.py:10-89, utils/checkpoint.py:14-154): DDP ``module.`` prefix,
+    longest-suffix key alignment, substring rewrites, strict load, model_<iter>.pth + last_checkpoint tag file."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import solver
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.detector import build_detection_model
+    from cvpr22_cross_modal_pseudo_labeling_amd.utils.checkpoint import (DetectronCheckpointer, align_and_update_state_dicts,
+                                                                           load_state_dict, strip_prefix_if_present)
+    cfg = get_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, "configs/coco_cap_det/zeroshot_mask.yaml"))
+    cfg.freeze()
+    torch.manual_seed(0)
+    src = build_detection_model(cfg)
+    torch.manual_seed(1)
+    dst = build_detection_model(cfg)
+    sd = src.state_dict()
+    assert any(k.startswith("backbone.body.layer1.0.conv1") for k in sd) and "rpn.head.conv.weight" in sd
+    # (a) a DDP checkpoint: every key prefixed with "module."
+    ddp = {"module." + k: v for k, v in sd.items()}
+    assert set(strip_prefix_if_present(dict(ddp), "module.")) == set(sd)
+    matched = load_state_dict(dst, ddp)
+    assert len(matched) == len(sd)
+    for k, v in dst.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    # (b) backbone-only weights saved WITHOUT the "backbone.body." nesting (an ImageNet-style trunk file), plus a decoy
+    # shorter suffix that must lose against the longer match
+    torch.manual_seed(2)
+    dst2 = build_detection_model(cfg)
+    before = {k: v.clone() for k, v in dst2.state_dict().items()}
+    trunk = {k[len("backbone.body."):]: v for k, v in sd.items() if k.startswith("backbone.body.")}
+    assert sum(k.endswith("stem.conv1.weight") for k in sd) == 1
+    trunk["conv1.weight"] = torch.zeros_like(sd["backbone.body.stem.conv1.weight"])  # a shorter suffix of the same key
+    model_sd = {"backbone.body.stem.conv1.weight": before["backbone.body.stem.conv1.weight"].clone()}
+    align_and_update_state_dicts(model_sd, trunk)
+    assert torch.equal(model_sd["backbone.body.stem.conv1.weight"], sd["backbone.body.stem.conv1.weight"])  # longest won
+    del trunk["conv1.weight"]
+    matched = load_state_dict(dst2, trunk)
+    after = dst2.state_dict()
+    assert matched and all(k.startswith("backbone.body.") for k in matched)
+    assert torch.equal(after["backbone.body.layer3.5.conv3.weight"], sd["backbone.body.layer3.5.conv3.weight"])
+    assert torch.equal(after["rpn.head.conv.weight"], before["rpn.head.conv.weight"])  # unmatched keys untouched
+    # (c) rewrite rule: an MMSS projection head becomes emb_pred; cls_score kept out
+    model_sd = {"roi_heads.box.predictor.emb_pred.weight": torch.zeros(2, 2)}
+    loaded = {"mmss_heads.GroundingHead.v2l_projection.weight": torch.ones(2, 2)}
+    align_and_update_state_dicts(model_sd, loaded, {"mmss_heads.GroundingHead.v2l_projection": "roi_heads.box.predictor.emb_pred"})
+    assert bool((model_sd["roi_heads.box.predictor.emb_pred.weight"] == 1).all())
+    # (d) save / resume round trip in the reference's directory layout
+    opt = solver.make_optimizer(cfg, src)
+    sched = solver.make_lr_scheduler(cfg, opt)
+    ck = DetectronCheckpointer(cfg, src, opt, sched, save_dir=str(tmp_path))
+    path = ck.save("model_0000007", iteration=7)
+    assert os.path.basename(path) == "model_0000007.pth" and open(tmp_path / "last_checkpoint").read() == path
+    torch.manual_seed(3)
+    fresh = build_detection_model(cfg)
+    opt2 = solver.make_optimizer(cfg, fresh)
+    extra = DetectronCheckpointer(cfg, fresh, opt2, solver.make_lr_scheduler(cfg, opt2), save_dir=str(tmp_path)).load()
+    assert extra == {"iteration": 7}
+    for k, v in fresh.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    with pytest.raises(NotImplementedError):
+        ck._load_file("catalog://ImageNetPretrained/MSRA/R-50")

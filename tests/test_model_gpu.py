@@ -186,3 +186,48 @@ def test_batched_student_branches_match_sequential_branches():
     assert set(g0) == set(g1) and len(g0) >= 10
     for n in g0:
         assert (g0[n] - g1[n]).norm().item() <= 2e-4 * g0[n].norm().item() + 1e-9, n
+
+
+def test_do_train_checkpoint_cadence_and_resume(tmp_path):
+    """do_train writes model_<iter>.pth every CHECKPOINT_PERIOD and model_final.pth (trainer.py:172-173, 252-253); a
+    second run in the same directory resumes weights, momentum, LR schedule and the iteration counter from the tag file,
+    and continues exactly like the uninterrupted run (the teacher configuration: no random sampling with these sizes)."""
+    import copy
+
+    from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import solver, trainer
+    from cvpr22_cross_modal_pseudo_labeling_amd.utils.checkpoint import DetectronCheckpointer
+
+    model, e_vocab, e_seen, images, targets = _build("zeroshot_mask")
+    cfg = get_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, "configs/coco_cap_det/zeroshot_mask.yaml"))
+    cfg.merge_from_list(["SOLVER.BASE_LR", 1e-4, "SOLVER.LOG_PERIOD", 1])
+    cfg.freeze()
+    images = images.cuda()
+    tg = [t.to("cuda") for t in targets]
+
+    def run(save_dir, start_model, max_iter, resume):
+        m = copy.deepcopy(start_model).cuda()
+        m.set_class_embeddings(e_seen.cuda())
+        m.train()
+        opt = solver.make_optimizer(cfg, m)
+        sched = solver.make_lr_scheduler(cfg, opt)
+        ck = DetectronCheckpointer(cfg, m, opt, sched, save_dir=save_dir)
+        start = int(ck.load("").get("iteration", 0)) if resume else 0
+        hist = trainer.do_train(cfg, m, iter([(images, tg)] * (max_iter - start)), opt, sched, max_iter, start_iter=start,
+                                checkpointer=ck, checkpoint_period=2)
+        return m, hist
+
+    full_dir, part_dir = str(tmp_path / "full"), str(tmp_path / "part")
+    m_full, h_full = run(full_dir, model, 4, False)
+    assert sorted(os.listdir(full_dir)) == ["last_checkpoint", "model_0000002.pth", "model_0000004.pth", "model_final.pth"]
+    assert open(os.path.join(full_dir, "last_checkpoint")).read().endswith("model_final.pth")
+    run(part_dir, model, 2, False)
+    m_res, h_res = run(part_dir, model, 4, True)  # weights come from the checkpoint, not from ``model``
+    assert [i for i, _ in h_res] == [3, 4]
+    for (i, a), (j, b) in zip(h_res, h_full[2:]):
+        assert i == j
+        for k in b:
+            assert abs(a[k] - b[k]) <= 2e-4 * max(abs(b[k]), 1e-3), (i, k, a[k], b[k])
+    for (n, p), (_, q) in zip(m_res.named_parameters(), m_full.named_parameters()):
+        assert (p - q).norm().item() <= 1e-4 * q.norm().item() + 1e-7, n

@@ -3,8 +3,9 @@
     python -m torch.distributed.run --nproc-per-node N tools/train_net.py --config-file CFG [--skip-test] KEY VALUE ...
 
 One process per GPU (RCCL via torch.distributed, env:// rendezvous), config = defaults <- yaml <- trailing overrides,
-frozen before use.  There is no dataset / checkpoint access in this build, so the data stream is the synthetic
-COCO-shaped generator (cvpr22_cross_modal_pseudo_labeling_amd/data/synthetic.py); evaluation, checkpointing and
+frozen before use.  There is no dataset access in this build, so the data stream is the synthetic COCO-shaped generator
+(cvpr22_cross_modal_pseudo_labeling_amd/data/synthetic.py).  MODEL.WEIGHT (a ``.pth`` in the reference's wire format),
+OUTPUT_DIR resume and SOLVER.CHECKPOINT_PERIOD behave as in the reference (utils/checkpoint.py); evaluation and
 TensorBoard are outside the hot-path scope.
 """
 import argparse
@@ -22,9 +23,10 @@ from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults  # noqa: 
 from cvpr22_cross_modal_pseudo_labeling_amd.data.synthetic import calibrate_stem_bn, make_batch, make_embeddings  # noqa: E402
 from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm, solver, trainer  # noqa: E402
 from cvpr22_cross_modal_pseudo_labeling_amd.modeling.detector import build_detection_model  # noqa: E402
+from cvpr22_cross_modal_pseudo_labeling_amd.utils.checkpoint import DetectronCheckpointer  # noqa: E402
 
 
-def train(cfg, local_rank, distributed, max_iter, ims_per_gpu):
+def train(cfg, local_rank, distributed, max_iter, ims_per_gpu, save_checkpoints=False):
     device = torch.device(cfg.MODEL.DEVICE, local_rank) if cfg.MODEL.DEVICE == "cuda" else torch.device(cfg.MODEL.DEVICE)
     model = build_detection_model(cfg).to(device)
     e_vocab, e_seen = make_embeddings(cfg.MODEL.ROI_BOX_HEAD.EMB_DIM, device=device)
@@ -33,6 +35,14 @@ def train(cfg, local_rank, distributed, max_iter, ims_per_gpu):
         model.set_caption_vocab(e_vocab)
     optimizer = solver.make_optimizer(cfg, model)
     scheduler = solver.make_lr_scheduler(cfg, optimizer)
+    # tools/train_net.py:76-87: resume from OUTPUT_DIR's last checkpoint, else initialise from MODEL.WEIGHT
+    checkpointer = DetectronCheckpointer(
+        cfg, model, optimizer, scheduler, cfg.OUTPUT_DIR if save_checkpoints else "", comm.get_rank() == 0,
+        backbone_prefix=cfg.MODEL.BACKBONE_PREFIX,
+        load_emb_pred_from=(cfg.MODEL.MMSS_HEAD.DEFAULT_HEAD if cfg.MODEL.LOAD_EMB_PRED_FROM_MMSS_HEAD else None),
+        load_classifier=cfg.MODEL.LOAD_CLASSIFIER)
+    extra = checkpointer.load(cfg.MODEL.WEIGHT, load_trainer_state=cfg.MODEL.LOAD_TRAINER_STATE)
+    start_iter = int(extra.get("iteration", 0)) if cfg.MODEL.LOAD_TRAINER_STATE else 0
     if distributed:
         comm.broadcast_parameters(model)
 
@@ -43,9 +53,12 @@ def train(cfg, local_rank, distributed, max_iter, ims_per_gpu):
             it += 1
 
     data = stream()
-    images, _ = make_batch(1, device=device, seed=7)
-    calibrate_stem_bn(model, images)
-    return trainer.do_train(cfg, model, data, optimizer, scheduler, max_iter)
+    if not cfg.MODEL.WEIGHT and not checkpointer.has_checkpoint():  # random init only: give the frozen BN usable statistics
+        images, _ = make_batch(1, device=device, seed=7)
+        calibrate_stem_bn(model, images)
+    return trainer.do_train(cfg, model, data, optimizer, scheduler, max_iter, start_iter=start_iter,
+                            checkpointer=checkpointer if save_checkpoints else None,
+                            checkpoint_period=cfg.SOLVER.CHECKPOINT_PERIOD)
 
 
 def main():
@@ -54,6 +67,8 @@ def main():
     parser.add_argument("--local_rank", type=int, default=int(os.environ.get("LOCAL_RANK", 0)))
     parser.add_argument("--skip-test", dest="skip_test", action="store_true", help="accepted for compatibility")
     parser.add_argument("--max-iter", type=int, default=None, help="override SOLVER.MAX_ITER for a short run")
+    parser.add_argument("--save-checkpoints", action="store_true",
+                        help="write model_<iter>.pth / model_final.pth / last_checkpoint under OUTPUT_DIR and resume from them")
     parser.add_argument("opts", default=None, nargs=argparse.REMAINDER, help="KEY VALUE overrides")
     args = parser.parse_args()
 
@@ -74,7 +89,7 @@ def main():
                         format="%(asctime)s %(name)s %(levelname)s: %(message)s")
     logging.getLogger("ovis.trainer").info("Using %d GPUs\n%s", num_gpus, args)
     ims_per_gpu = max(cfg.SOLVER.IMS_PER_BATCH // num_gpus, 1)
-    train(cfg, args.local_rank, distributed, args.max_iter or cfg.SOLVER.MAX_ITER, ims_per_gpu)
+    train(cfg, args.local_rank, distributed, args.max_iter or cfg.SOLVER.MAX_ITER, ims_per_gpu, args.save_checkpoints)
     if distributed:
         dist.destroy_process_group()
 
