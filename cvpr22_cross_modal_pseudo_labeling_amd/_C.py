@@ -144,6 +144,33 @@ def nms_padded(dets, scores, threshold, ge_mode=False):
     return keep, num
 
 
+def nms_grouped_padded(dets, scores, groups, threshold, ge_mode=False):
+    """NMS inside every group of boxes in one launch (groups [K] integer labels): (keep[K] int64 -- first n entries
+    valid, ascending indices into the K candidates; n as a 1-element int32 device tensor).  Equals ``nms`` run on
+    every group separately (the per-class loop of box_head/inference.py:137-150)."""
+    dets, scores = _dev(dets, "dets"), _dev(scores, "scores")
+    groups = _dev(groups.to(torch.int32), "groups", torch.int32)
+    k = dets.size(0)
+    keep = torch.empty((k,), dtype=torch.int64, device=dets.device)
+    num = torch.zeros((1,), dtype=torch.int32, device=dets.device)
+    if k == 0:
+        return keep, num
+    if dets.dim() != 2 or dets.size(1) != 4 or scores.numel() != k or groups.numel() != k:
+        raise RuntimeError("nms_grouped: expected dets [K,4], scores [K] and groups [K]")
+    with torch.cuda.device(dets.device):
+        nbytes = _L.ovis_nms_workspace_bytes(k)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dets.device)
+        rc = _L.ovis_nms_grouped_f32(dets.data_ptr(), scores.data_ptr(), groups.data_ptr(), k, threshold,
+                                     int(bool(ge_mode)), ws.data_ptr(), nbytes, keep.data_ptr(), num.data_ptr(), _stream())
+    _lib.check(rc, "nms_grouped")
+    return keep, num
+
+
+def nms_grouped(dets, scores, groups, threshold):
+    keep, num = nms_grouped_padded(dets, scores, groups, threshold)
+    return keep[: int(num.item())]
+
+
 def nms(dets, scores, threshold):
     if dets.is_cuda and dets.numel() == 0:
         # the reference returns a CPU tensor for the empty case (csrc/nms.h:17-18)

@@ -29,6 +29,7 @@ SIGNATURES = {
     "ovis_roi_pool_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ovis_nms_workspace_bytes": (_sz, [_i]),
     "ovis_nms_f32": (_i, [_vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp]),
+    "ovis_nms_grouped_f32": (_i, [_vp, _vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp]),
     "ovis_sigmoid_focal_loss_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "ovis_sigmoid_focal_loss_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "ovis_split_bf16x3_f32": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),

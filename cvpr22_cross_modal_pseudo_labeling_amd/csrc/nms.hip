@@ -52,8 +52,11 @@ __device__ __forceinline__ float iou_xyxy(const float4 a, const float4 b) {
 }
 
 // grid (nb, nb); block (row_blk = y, col_blk = x), tiles below the diagonal exit.
-template <bool GE>
+// GROUPED: a box only suppresses boxes of its own group (the per-class NMS of the detection post-processing,
+// roi_heads/box_head/inference.py:121-163, as ONE launch over the candidates of every class).
+template <bool GE, bool GROUPED>
 __global__ __launch_bounds__(kTile) void nms_mask_kernel(const float4* __restrict__ boxes,
+                                                         const int* __restrict__ groups,
                                                          const int* __restrict__ order, int K,
                                                          int nb, float thr,
                                                          unsigned long long* __restrict__ mask,
@@ -61,17 +64,25 @@ __global__ __launch_bounds__(kTile) void nms_mask_kernel(const float4* __restric
   const int row_blk = blockIdx.y, col_blk = blockIdx.x;
   if (row_blk > col_blk) return;
   __shared__ float4 col_boxes[kTile];
+  __shared__ int col_group[kTile];
   const int lane = threadIdx.x;
   const int col = col_blk * kTile + lane;
-  if (col < K) col_boxes[lane] = boxes[order[col]];
+  if (col < K) {
+    const int o = order[col];
+    col_boxes[lane] = boxes[o];
+    if (GROUPED) col_group[lane] = groups[o];
+  }
   __syncthreads();
   const int row = row_blk * kTile + lane;
   unsigned long long bits = 0;
   if (row < K) {
-    const float4 a = boxes[order[row]];
+    const int orow = order[row];
+    const float4 a = boxes[orow];
+    const int ga = GROUPED ? groups[orow] : 0;
     const int ncol = min(K - col_blk * kTile, kTile);
     const int start = (row_blk == col_blk) ? lane + 1 : 0;
     for (int j = start; j < ncol; ++j) {
+      if (GROUPED && col_group[j] != ga) continue;
       const float v = iou_xyxy(a, col_boxes[j]);
       const bool hit = GE ? (v >= thr) : (v > thr);
       if (hit) bits |= 1ull << j;
@@ -328,10 +339,29 @@ extern "C" size_t ovis_nms_workspace_bytes(int num_boxes) {
   return L.total;
 }
 
+static int nms_impl(const float* boxes, const float* scores, const int* groups, int num_boxes, float threshold,
+                    int ge_mode, void* workspace, size_t workspace_bytes, int64_t* keep_out, int32_t* num_keep,
+                    void* stream);
+
 extern "C" int ovis_nms_f32(const float* boxes, const float* scores, int num_boxes,
                             float threshold, int ge_mode, void* workspace,
                             size_t workspace_bytes, int64_t* keep_out, int32_t* num_keep,
                             void* stream) {
+  return nms_impl(boxes, scores, nullptr, num_boxes, threshold, ge_mode, workspace, workspace_bytes, keep_out, num_keep,
+                  stream);
+}
+
+extern "C" int ovis_nms_grouped_f32(const float* boxes, const float* scores, const int32_t* groups, int num_boxes,
+                                    float threshold, int ge_mode, void* workspace, size_t workspace_bytes,
+                                    int64_t* keep_out, int32_t* num_keep, void* stream) {
+  if (num_boxes > 0 && !groups) return OVIS_EINVAL;
+  return nms_impl(boxes, scores, groups, num_boxes, threshold, ge_mode, workspace, workspace_bytes, keep_out, num_keep,
+                  stream);
+}
+
+static int nms_impl(const float* boxes, const float* scores, const int* groups, int num_boxes, float threshold,
+                    int ge_mode, void* workspace, size_t workspace_bytes, int64_t* keep_out, int32_t* num_keep,
+                    void* stream) {
   if (num_boxes < 0 || !num_keep) return OVIS_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (num_boxes == 0) {
@@ -360,12 +390,12 @@ extern "C" int ovis_nms_f32(const float* boxes, const float* scores, int num_box
       (void*)(ws + L.cub_temp), cub_bytes, scores, keys_out, (const int*)idx_in, order, K, 0,
       32, s));
   dim3 grid(nb, nb);
-  if (ge_mode)
-    hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(kTile), 0, s, (const float4*)boxes,
-                       order, K, nb, threshold, mask, diag_t);
-  else
-    hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(kTile), 0, s, (const float4*)boxes,
-                       order, K, nb, threshold, mask, diag_t);
+#define OVIS_NMS_MASK(GE_, GR_)                                                                            \
+  hipLaunchKernelGGL((nms_mask_kernel<GE_, GR_>), grid, dim3(kTile), 0, s, (const float4*)boxes, groups, order, K, nb, \
+                     threshold, mask, diag_t)
+  if (groups) { if (ge_mode) OVIS_NMS_MASK(true, true); else OVIS_NMS_MASK(false, true); }
+  else { if (ge_mode) OVIS_NMS_MASK(true, false); else OVIS_NMS_MASK(false, false); }
+#undef OVIS_NMS_MASK
   OVIS_LAUNCH_CHECK();
   const size_t lds = sizeof(unsigned long long) * 3 * (size_t)nb + sizeof(int) * kReduceThreads;
   if (nb <= kFastBlocks)

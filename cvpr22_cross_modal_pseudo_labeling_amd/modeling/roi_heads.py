@@ -228,6 +228,30 @@ class PostProcessor(nn.Module):
         return results
 
     def filter_results(self, boxlist, num_classes):  # inference.py:121-163
+        """Score threshold -> per-class NMS -> keep the DETECTIONS_PER_IMG best.  On the device the per-class loop of the
+        reference (one ``nonzero`` + one NMS + host syncs per class) is ONE grouped NMS over the candidates of every
+        class (``_C.nms_grouped``: a box only suppresses boxes of its class); same detections in the same order
+        (class-major, proposal index ascending inside a class)."""
+        if not boxlist.bbox.is_cuda:
+            return self.filter_results_per_class(boxlist, num_classes)
+        boxes = boxlist.bbox.reshape(-1, num_classes, 4)
+        scores = boxlist.get_field("scores").reshape(-1, num_classes)
+        cls, row = (scores.t()[1:] > self.score_thresh).nonzero(as_tuple=True)  # class-major candidate order
+        cls = cls + 1
+        cand_boxes, cand_scores = boxes[row, cls], scores[row, cls]
+        keep = _C.nms_grouped(cand_boxes, cand_scores, cls, self.nms) if cls.numel() else cls
+        result = BoxList(cand_boxes[keep], boxlist.size)
+        result.add_field("scores", cand_scores[keep])
+        result.add_field("labels", cls[keep])
+        n = len(result)
+        if n > self.detections_per_img > 0:
+            s = result.get_field("scores")
+            thresh = torch.kthvalue(s, n - self.detections_per_img + 1).values
+            result = result[torch.nonzero(s >= thresh).squeeze(1)]
+        return result
+
+    def filter_results_per_class(self, boxlist, num_classes):
+        """The reference's loop as written (inference.py:137-150); the oracle-backed CPU runs of the tests use it."""
         boxes = boxlist.bbox.reshape(-1, num_classes * 4)
         scores = boxlist.get_field("scores").reshape(-1, num_classes)
         inds_all = scores > self.score_thresh

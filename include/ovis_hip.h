@@ -127,6 +127,13 @@ size_t ovis_nms_workspace_bytes(int num_boxes);
 int ovis_nms_f32(const float* boxes, const float* scores, int num_boxes, float threshold,
                  int ge_mode, void* workspace, size_t workspace_bytes, int64_t* keep_out,
                  int32_t* num_keep, void* stream);
+/* Grouped form: `groups` [K] int32; a box only suppresses boxes of its own group.  One launch replaces the
+ * per-class loop of the detection post-processing (mb/modeling/roi_heads/box_head/inference.py:121-163:
+ * `for j in range(1, num_classes): boxlist_nms(boxes of class j)`) -- same survivors as running ovis_nms_f32
+ * on every group separately, returned as ascending indices into the K candidates. */
+int ovis_nms_grouped_f32(const float* boxes, const float* scores, const int32_t* groups, int num_boxes,
+                         float threshold, int ge_mode, void* workspace, size_t workspace_bytes,
+                         int64_t* keep_out, int32_t* num_keep, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * ROIPool                                    mb/csrc/ROIPool.h:11-48

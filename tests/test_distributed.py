@@ -137,3 +137,59 @@ def test_allreduce_order_is_rank_independent(tmp_path):
     (tot / 2).backward()
     for n, p in ref.named_parameters():
         assert torch.allclose(g0[n], p.grad, atol=1e-6), n
+
+
+class _FakeDetector(nn.Module):
+    """Stands in for the detector on CPU: image i (value of its first pixel) yields i % 3 detections (so some images --
+    and, for rank 1 of the second case, a whole rank -- contribute none), with box / score / label / mask fields."""
+
+    def set_class_embeddings(self, e):
+        self.emb = e
+
+    def forward(self, images, targets=None):
+        from cvpr22_cross_modal_pseudo_labeling_amd.modeling.structures import BoxList
+
+        out = []
+        for img in images:
+            i = int(img[0, 0, 0])
+            n = i % 3
+            det = BoxList(torch.arange(n * 4, dtype=torch.float32).reshape(n, 4) + i, (100 + i, 50 + i))
+            det.add_field("scores", torch.full((n,), i / 10.0))
+            det.add_field("labels", torch.full((n,), i, dtype=torch.int64))
+            det.add_field("mask", torch.full((n, 1, 28, 28), float(i)))
+            out.append(det)
+        return out
+
+
+def _eval_worker(rank, world, port, out, ids_per_rank):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import inference
+
+    ids = ids_per_rank[rank]
+    batches = []
+    for k in range(0, len(ids), 2):
+        chunk = ids[k:k + 2]
+        batches.append((torch.stack([torch.full((3, 4, 4), float(i)) for i in chunk]), None, chunk))
+    res = inference.inference(_FakeDetector(), batches, device="cpu", output_folder=out if rank == 0 else None,
+                              class_embeddings=torch.zeros(2, 3))
+    assert (res is None) == (rank != 0)
+    dist.destroy_process_group()
+
+
+def test_inference_gathers_every_ranks_detections_in_image_order(tmp_path):
+    """engine.inference: tensor all-gather of the per-rank detections == the reference's pickle all_gather + merge
+    (engine/inference.py:82-101): ordered by image id on rank 0, empty images and an empty rank included."""
+    for case, ids_per_rank in enumerate(([[0, 2, 4, 6, 7], [1, 3, 5]], [[0, 1, 2, 3], []])):
+        out = str(tmp_path / f"case{case}")
+        mp.spawn(_eval_worker, args=(2, _free_port(), out, ids_per_rank), nprocs=2, join=True)
+        preds = torch.load(os.path.join(out, "predictions.pth"), weights_only=False)
+        n = sum(len(x) for x in ids_per_rank)
+        assert len(preds) == n
+        for i, det in enumerate(preds):
+            k = i % 3
+            assert len(det) == k and det.size == (100 + i, 50 + i)
+            assert torch.equal(det.bbox, torch.arange(k * 4, dtype=torch.float32).reshape(k, 4) + i)
+            assert torch.equal(det.get_field("labels"), torch.full((k,), i, dtype=torch.int64))
+            assert torch.equal(det.get_field("scores"), torch.full((k,), i / 10.0))
+            assert det.get_field("mask").shape == (k, 1, 28, 28) and bool((det.get_field("mask") == i).all())
