@@ -244,6 +244,61 @@ def roi_pool_backward(grad, input, rois, argmax, spatial_scale, pooled_height, p
     return gin
 
 
+# ---- deformable position-sensitive RoI pooling (csrc/deform_pool.h:11-70) -----------------------------
+def _psroi_dims(input, bbox, trans, out, no_trans):
+    for t, name in ((input, "input"), (bbox, "bbox"), (out, "out")):
+        if not (t.is_cuda and t.dtype == torch.float32):
+            raise RuntimeError(f"deform_psroi_pooling: {name} must be a float32 HIP tensor: this package has no CPU implementation")
+    if not input.is_contiguous():
+        raise RuntimeError("input tensor has to be contiguous")  # deform_pool_cuda.cu:45
+    if bbox.size(0) != out.size(0):
+        raise RuntimeError(f"Output shape and bbox number wont match: ({out.size(0)} vs {bbox.size(0)}).")
+    channels_trans = 2 if no_trans else trans.size(1)
+    return input.size(0), input.size(1), input.size(2), input.size(3), channels_trans, bbox.size(0)
+
+
+def deform_psroi_pooling_forward(input, bbox, trans, out, top_count, no_trans, spatial_scale, output_dim, group_size,
+                                 pooled_size, part_size, sample_per_part, trans_std):
+    """The reference's `_C.deform_psroi_pooling_forward` (deform_pool.h:11-38): fills ``out`` and ``top_count`` in place."""
+    batch, channels, height, width, channels_trans, n = _psroi_dims(input, bbox, trans, out, no_trans)
+    bbox = bbox.contiguous()
+    tr = 0 if no_trans else _dev(trans, "trans").data_ptr()
+    if not (out.is_contiguous() and top_count.is_contiguous() and top_count.dtype == torch.float32):
+        raise RuntimeError("deform_psroi_pooling_forward: out / top_count must be contiguous float32")
+    with torch.cuda.device(input.device):
+        rc = _L.ovis_deform_psroi_pool_forward_f32(input.data_ptr(), bbox.data_ptr(), tr, out.data_ptr(),
+                                                   top_count.data_ptr(), n, batch, channels, height, width, channels_trans,
+                                                   int(bool(no_trans)), spatial_scale, output_dim, group_size,
+                                                   pooled_size, part_size, sample_per_part, trans_std, _stream())
+    _lib.check(rc, "deform_psroi_pooling_forward")
+
+
+def deform_psroi_pooling_backward(out_grad, input, bbox, trans, top_count, input_grad, trans_grad, no_trans,
+                                  spatial_scale, output_dim, group_size, pooled_size, part_size, sample_per_part,
+                                  trans_std):
+    """The reference's `_C.deform_psroi_pooling_backward` (deform_pool.h:40-70): ACCUMULATES into ``input_grad`` and
+    ``trans_grad`` (zero-filled by the caller, deform_pool_func.py:68-70)."""
+    if not out_grad.is_contiguous():
+        raise RuntimeError("out_grad tensor has to be contiguous")  # deform_pool_cuda.cu:71
+    batch, channels, height, width, channels_trans, n = _psroi_dims(input, bbox, trans, out_grad, no_trans)
+    bbox = bbox.contiguous()
+    if not (input_grad.is_cuda and input_grad.is_contiguous() and input_grad.shape == input.shape):
+        raise RuntimeError("deform_psroi_pooling_backward: input_grad must be a contiguous HIP tensor shaped like input")
+    tr = tg = 0
+    if not no_trans:
+        tr = _dev(trans, "trans").data_ptr()
+        if not (trans_grad.is_cuda and trans_grad.is_contiguous() and trans_grad.shape == trans.shape):
+            raise RuntimeError("deform_psroi_pooling_backward: trans_grad must be a contiguous HIP tensor shaped like trans")
+        tg = trans_grad.data_ptr()
+    with torch.cuda.device(input.device):
+        rc = _L.ovis_deform_psroi_pool_backward_f32(out_grad.data_ptr(), top_count.data_ptr(), input.data_ptr(),
+                                                    bbox.data_ptr(), tr, input_grad.data_ptr(), tg, n, batch, channels,
+                                                    height, width, channels_trans, int(bool(no_trans)), spatial_scale,
+                                                    output_dim, group_size, pooled_size, part_size, sample_per_part,
+                                                    trans_std, _stream())
+    _lib.check(rc, "deform_psroi_pooling_backward")
+
+
 # ---- cross-modal head + student losses (extensions beyond vision.cpp; include/ovis_hip.h) --------------
 def split_bf16x3(x, mode):
     """x [rows, cols] f32 (row-strided view ok) -> [rows, 3*cols] bf16, rows = [hi|hi|lo] (mode 0) / [hi|lo|hi]

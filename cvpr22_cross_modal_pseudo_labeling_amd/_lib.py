@@ -27,6 +27,8 @@ SIGNATURES = {
     "ovis_roi_align_backward_ws_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "ovis_roi_pool_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "ovis_roi_pool_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ovis_deform_psroi_pool_forward_f32": (_i, [_vp] * 5 + [_i] * 7 + [_f] + [_i] * 5 + [_f, _vp]),
+    "ovis_deform_psroi_pool_backward_f32": (_i, [_vp] * 7 + [_i] * 7 + [_f] + [_i] * 5 + [_f, _vp]),
     "ovis_nms_workspace_bytes": (_sz, [_i]),
     "ovis_nms_f32": (_i, [_vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp]),
     "ovis_nms_grouped_f32": (_i, [_vp, _vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp]),

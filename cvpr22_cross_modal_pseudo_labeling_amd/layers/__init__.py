@@ -2,6 +2,7 @@
 from .batch_norm import FrozenBatchNorm2d
 from .cross_modal import bias_relu_, linear_mfma, split_conv_same, split_linear, stochastic_mask_bce, text_logits, weighted_cross_entropy
 from .dcn import DeformConv, ModulatedDeformConv, ModulatedDeformConvPack, deform_conv, modulated_deform_conv
+from .dcn import DeformRoIPooling, DeformRoIPoolingPack, ModulatedDeformRoIPoolingPack, deform_roi_pooling
 from .misc import BatchNorm2d, Conv2d, ConvTranspose2d, DFConv2d, interpolate
 from .nms import nms, nms_padded
 from .roi_align import ROIAlign, roi_align
@@ -29,6 +30,10 @@ __all__ = [
     "DeformConv",
     "ModulatedDeformConv",
     "ModulatedDeformConvPack",
+    "deform_roi_pooling",
+    "DeformRoIPooling",
+    "DeformRoIPoolingPack",
+    "ModulatedDeformRoIPoolingPack",
     "linear_mfma",
     "split_linear",
     "split_conv_same",

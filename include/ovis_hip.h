@@ -151,6 +151,28 @@ int ovis_roi_pool_backward_f32(const float* grad_output, const int32_t* argmax, 
                                int width, int pooled_h, int pooled_w, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Deformable position-sensitive RoI pooling  mb/csrc/deform_pool.h:11-70
+ *   kernels: mb/csrc/cuda/deform_pool_kernel_cuda.cu:31-139 (fwd), :141-263 (bwd); host: deform_pool_cuda.cu:38-90
+ * data [batch, channels, height, width] f32; rois [num_rois, 5] (batch index, x1, y1, x2, y2);
+ * trans [num_rois, channels_trans, part_size, part_size] (channels_trans = 2 * classes; ignored when no_trans);
+ * out / out_count [num_rois, output_dim, pooled_size, pooled_size]: the mean of the bilinear samples of every bin that
+ * fall inside the map, read from plane (ctop * group_size + gh) * group_size + gw, and their number (f32, as upstream).
+ * Backward ACCUMULATES into grad_data (and grad_trans unless no_trans): the caller zero-fills them, as the reference's
+ * autograd function does (layers/dcn/deform_pool_func.py:68-70).
+ * ---------------------------------------------------------------------------------- */
+int ovis_deform_psroi_pool_forward_f32(const float* data, const float* rois, const float* trans, float* out,
+                                       float* out_count, int num_rois, int batch, int channels, int height, int width,
+                                       int channels_trans, int no_trans, float spatial_scale, int output_dim,
+                                       int group_size, int pooled_size, int part_size, int sample_per_part,
+                                       float trans_std, void* stream);
+int ovis_deform_psroi_pool_backward_f32(const float* grad_out, const float* out_count, const float* data,
+                                        const float* rois, const float* trans, float* grad_data, float* grad_trans,
+                                        int num_rois, int batch, int channels, int height, int width,
+                                        int channels_trans, int no_trans, float spatial_scale, int output_dim,
+                                        int group_size, int pooled_size, int part_size, int sample_per_part,
+                                        float trans_std, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Sigmoid focal loss                         mb/csrc/SigmoidFocalLoss.h:10-41
  *   kernels: mb/csrc/cuda/SigmoidFocalLoss_cuda.cu:21-58 (fwd), :62-101 (bwd)
  * logits [num, num_classes] f32; targets [num] int32 (-1 ignore, 0 background,
