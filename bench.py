@@ -44,13 +44,15 @@ class OpTimer:
         self.C = C
         self.records = {}   # name -> list of (start_event, end_event, work)
         self.kind = {}      # name -> "hbm" | "mfma"
+        self.bytes = {}     # name -> algorithmic HBM bytes of the matrix-core ops (every operand / result once)
         self.enabled = False
         self._orig = {}
 
-    def _wrap(self, name, work_fn, kind="hbm"):
+    def _wrap(self, name, work_fn, kind="hbm", bytes_fn=None):
         orig = getattr(self.C, name)
         self._orig[name] = orig
         self.kind[name] = kind
+        self.bytes.setdefault(name, 0.0)
 
         def wrapped(*args, **kwargs):
             if not self.enabled:
@@ -60,6 +62,8 @@ class OpTimer:
             out = orig(*args, **kwargs)
             b.record()
             self.records.setdefault(name, []).append((a, b, work_fn(*args, **kwargs)))
+            if bytes_fn is not None:
+                self.bytes[name] += bytes_fn(*args, **kwargs)
             return out
 
         setattr(self.C, name, wrapped)
@@ -101,6 +105,20 @@ class OpTimer:
         def split_gemm_flops(a_pair, b_pair, *args, **kwargs):
             return 6.0 * a_pair.shape[0] * b_pair.shape[0] * (b_pair.shape[1] // 2)  # 3 products x 2*M*N*K
 
+        def split_gemm_bytes(a_pair, b_pair, bias=None, residual=None, relu=False, out_f32=True, out_pair=False, **kwargs):
+            # every operand once: A and B pair rows (4 B / value), the fp32 and / or pair result, the shortcut
+            m, n = a_pair.shape[0], b_pair.shape[0]
+            return (2 * a_pair.numel() + 2 * b_pair.numel() + 4 * m * n * (int(bool(out_f32)) + int(bool(out_pair)))
+                    + (4 * m * n if residual is not None else 0))
+
+        def split_gemm_gated_bytes(a_pair, b_pair, gate_pair, conv=None, out_f32=False, out_pair=True):
+            m, n = a_pair.shape[0], b_pair.shape[0]
+            return 2 * a_pair.numel() + 2 * b_pair.numel() + 4 * m * n * (int(bool(out_f32)) + int(bool(out_pair))) + 2 * m * n
+
+        def split_gemm_tn_bytes(g_pair, x_pair, conv=None, scale=None, weight_shape=None):
+            taps = 1 if conv is None else conv[2] * conv[3]
+            return 2 * g_pair.numel() + 2 * x_pair.numel() + 4 * (g_pair.shape[1] // 2) * (x_pair.shape[1] // 2) * taps
+
         def split_gemm_tn_flops(g_pair, x_pair, conv=None, scale=None, weight_shape=None):
             taps = 1 if conv is None else conv[2] * conv[3]
             return 6.0 * g_pair.shape[0] * (g_pair.shape[1] // 2) * (x_pair.shape[1] // 2) * taps
@@ -116,9 +134,9 @@ class OpTimer:
         self._wrap("bias_act_", bias_act_bytes)
         self._wrap("split_pair", split_pair_bytes)
         self._wrap("gate_split_pair", gate_split_bytes)
-        self._wrap("split_gemm_pair", split_gemm_flops, "mfma")
-        self._wrap("split_gemm_pair_gated", split_gemm_flops, "mfma")
-        self._wrap("split_gemm_pair_tn", split_gemm_tn_flops, "mfma")
+        self._wrap("split_gemm_pair", split_gemm_flops, "mfma", split_gemm_bytes)
+        self._wrap("split_gemm_pair_gated", split_gemm_flops, "mfma", split_gemm_gated_bytes)
+        self._wrap("split_gemm_pair_tn", split_gemm_tn_flops, "mfma", split_gemm_tn_bytes)
 
     def summary(self):
         out = {}
@@ -129,12 +147,37 @@ class OpTimer:
                 out[name] = {"launches": len(recs), "avg_us": 1e3 * ms / len(recs), "bound": "mfma",
                              "alg_GFLOP_per_launch": work / len(recs) / 1e9,
                              "achieved_TFLOPs": work / ms / 1e9 if ms > 0 else 0.0,
-                             "fp32_equiv_TFLOPs": work / 3.0 / ms / 1e9 if ms > 0 else 0.0}
+                             "fp32_equiv_TFLOPs": work / 3.0 / ms / 1e9 if ms > 0 else 0.0,
+                             "alg_MB_per_launch": self.bytes.get(name, 0.0) / len(recs) / 1e6}
             else:
                 out[name] = {"launches": len(recs), "avg_us": 1e3 * ms / len(recs), "bound": "hbm",
                              "alg_MB_per_launch": work / len(recs) / 1e6,
                              "achieved_GBps": work / ms / 1e6 if ms > 0 else 0.0}
         return out
+
+
+# bench.py op name -> kernel family of the committed PMC summary (profiles/r1_pmc_step_hbm_traffic_<workload>.json)
+PMC_KERNEL = {"split_gemm_pair": "split_gemm_kernel", "split_gemm_pair_gated": "split_gemm_kernel",
+              "split_gemm_pair_tn": "split_gemm_tn_kernel", "gate_split_pair": "gate_split_pair_kernel",
+              "split_pair": "split_pair_kernel", "roi_align_forward_strided_pair": "roi_align_fwd_strided_nhwc_kernel",
+              "roi_align_forward_strided_nhwc": "roi_align_fwd_strided_nhwc_kernel"}
+
+
+def pmc_traffic(workload, op):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes over this same step (FETCH_SIZE and
+    WRITE_SIZE in separate passes, gfx950 correction applied: tools/pmc_step.sh); counters cannot be collected from
+    inside the process, so the committed summary of the last pass is reported -- or null when there is none."""
+    path = os.path.join(ROOT, "profiles", f"r1_pmc_step_hbm_traffic_{workload}.json")
+    fam = PMC_KERNEL.get(op)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        k = d["kernels"][fam]
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC summary for this kernel under profiles/"
+    return (k["hbm_MB_per_launch"] * 1e6,
+            f"bytes per launch of {fam} (all {k['launches']} launches, gated ones included): read {k['read_MB_per_launch']} MB "
+            f"+ write {k['write_MB_per_launch']} MB, from profiles/{os.path.basename(path)} ({d['correction']})")
 
 
 def cpu_baseline(workload):
@@ -311,15 +354,18 @@ def main():
         k = kernels.get(dom, {"bound": "hbm", "achieved_GBps": 0.0})
         measured_in = (f"{replay_steps} sequential replay steps after the timed region (the timed steps overlap two "
                        "streams)") if replay_steps else "the timed region"
+        traffic, traffic_note = pmc_traffic(args.workload, dom)
         if k["bound"] == "mfma":
             roofline = {"bound": "mfma", "kernel": dom, "achieved": k["achieved_TFLOPs"], "peak": MFMA_BF16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": k["achieved_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                        "unit": "TFLOP/s", "frac": k["achieved_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                        "traffic_note": traffic_note,
                         "note": ("bf16 matrix-core flops issued: 3 hi/lo products x 2*M*N*K per fp32-accurate product "
                                  f"({k['fp32_equiv_TFLOPs']:.0f} TFLOP/s fp32-equivalent)"),
                         "measured_in": measured_in}
         else:
             roofline = {"bound": "hbm", "kernel": dom, "achieved": k["achieved_GBps"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": k["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None,
+                        "unit": "GB/s", "frac": k["achieved_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                        "traffic_note": traffic_note,
                         "measured_in": measured_in}
         global_batch = IMS_PER_GPU * world
         out = {
