@@ -267,12 +267,12 @@ __device__ __forceinline__ void pool_store1_pair(char* pair_r, long obin, int c,
   *(__bf16*)(d + 64) = l;
 }
 
-template <int NCS, bool FAST>
+template <int NCS, bool FAST, int LDSF = kFwdLdsFloats>
 __device__ __forceinline__ void fwd_pool4_strided(const f4* win4, int rs, const RoiGeom& g, int H, int W, int bs,
                                                   int OH, int OW, float* __restrict__ out_rc, int C,
                                                   char* pair_r = nullptr, int c_abs = 0) {
   constexpr int NG = NCS / 4;
-  constexpr int SG = kFwdLdsFloats / NCS;
+  constexpr int SG = LDSF / NCS;
   const int items = OH * OW * NG;
   for (int item = threadIdx.x; item < items; item += kThreads) {
     const int k = item % NG, obin = item / NG;
@@ -339,11 +339,11 @@ __device__ __forceinline__ void fwd_pool_strided(const float* src, int cs, int r
   }
 }
 
-template <int NCS>
+template <int NCS, int LDSF = kFwdLdsFloats>
 __device__ __forceinline__ void stage_window4(float* win, const float* __restrict__ plane_c0, int HW, int W,
                                               const RoiGeom& g, int wh, int ww) {
   constexpr int NG = NCS / 4;
-  constexpr int SG = kFwdLdsFloats / NCS;
+  constexpr int SG = LDSF / NCS;
   f4* win4 = (f4*)win;
   const int warea = wh * ww;
   const float inv_ww = 1.f / (float)ww;
@@ -363,23 +363,31 @@ __device__ __forceinline__ void stage_window4(float* win, const float* __restric
   }
 }
 
-template <int NCS>
+template <int NCS, int LDSF = kFwdLdsFloats>
 __device__ __forceinline__ void strided_batch4(float* win, const float* __restrict__ plane, int HW, int H, int W,
                                                const RoiGeom& g, int wh, int ww, int bs, int OH, int OW,
                                                float* __restrict__ out_rc, int C, char* pair_r, int c_abs) {
-  stage_window4<NCS>(win, plane, HW, W, g, wh, ww);
+  stage_window4<NCS, LDSF>(win, plane, HW, W, g, wh, ww);
   __syncthreads();
   if (g.pow2)
-    fwd_pool4_strided<NCS, true>((const f4*)win, ww, g, H, W, bs, OH, OW, out_rc, C, pair_r, c_abs);
+    fwd_pool4_strided<NCS, true, LDSF>((const f4*)win, ww, g, H, W, bs, OH, OW, out_rc, C, pair_r, c_abs);
   else
-    fwd_pool4_strided<NCS, false>((const f4*)win, ww, g, H, W, bs, OH, OW, out_rc, C, pair_r, c_abs);
+    fwd_pool4_strided<NCS, false, LDSF>((const f4*)win, ww, g, H, W, bs, OH, OW, out_rc, C, pair_r, c_abs);
   __syncthreads();
 }
 
+// Two launches share the RoIs by window size: windows of up to kSmallWindow cells (most proposals) run with the 17 KB
+// window budget and eight workgroups per CU; larger windows with a 64 KB budget, so that they still stage 8-16
+// channels per batch instead of 1-4 (a 30x40-cell window took 32 single-channel batches per workgroup and those
+// few RoIs set the kernel's duration).  A workgroup whose RoI belongs to the other launch exits after the geometry.
+constexpr int kSmallWindow = 272;      // 4352 / 16: the 17 KB budget still holds 16 channels
+constexpr int kBigLdsFloats = 16384;   // 64 KB
+
+template <int LDSF, bool BIG>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_strided_nhwc_kernel(
     const float* __restrict__ in, const float* __restrict__ rois, float* __restrict__ out, int R, int batch, int C,
     int H, int W, int PH, int PW, int bs, int OH, int OW, float scale, int sampling_ratio, int pair_out) {
-  __shared__ __attribute__((aligned(16))) float win[kFwdLdsFloats];
+  __shared__ __attribute__((aligned(16))) float win[LDSF];
   const int r = blockIdx.x % R;
   const int ct = blockIdx.x / R;
   const int c_begin = ct * kCPB;
@@ -389,6 +397,7 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_strided_nhwc_kernel(
   float* out_r = out + (long)r * OH * OW * C;   // both layouts take 4*C bytes per bin
   char* pair_r = pair_out ? (char*)out_r : nullptr;
   if (g.empty) {
+    if (BIG) return;
     for (int i = threadIdx.x; i < OH * OW * (c_end - c_begin); i += kThreads) {
       const long obin = i / (c_end - c_begin);
       const int c = c_begin + i % (c_end - c_begin);
@@ -399,7 +408,10 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_strided_nhwc_kernel(
   }
   const int wh = g.wy1 - g.wy0 + 1, ww = g.wx1 - g.wx0 + 1;
   const int warea = wh * ww;
-  const int cs_max = min(kMaxBatch, kFwdLdsFloats / warea);
+  if ((warea > kSmallWindow) != BIG) return;  // the other launch owns this RoI (empty RoIs: handled above, by the small one)
+  // small windows (most proposals: <= 136 cells): all 32 channels of the block in ONE batch -- half the barriers, and
+  // every bin is written as a whole 128-byte line (fp32: 32 channels; pair layout: 64 B hi | 64 B lo)
+  const int cs_max = min(2 * kMaxBatch, LDSF / warea);
   const float* img = in + (long)g.b * C * HW;
   const bool vec_ok = (C & 3) == 0;  // float4 stores need 16-byte aligned channel groups
   int c = c_begin;
@@ -408,14 +420,17 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_strided_nhwc_kernel(
     const float* plane = img + (long)c * HW;
     float* o = out_r + c;
     const int n = min(left, cs_max);
-    if (n >= 16 && vec_ok) {
-      strided_batch4<16>(win, plane, HW, H, W, g, wh, ww, bs, OH, OW, o, C, pair_r, c);
+    if (n >= 32 && vec_ok) {
+      strided_batch4<32, LDSF>(win, plane, HW, H, W, g, wh, ww, bs, OH, OW, o, C, pair_r, c);
+      c += 32;
+    } else if (n >= 16 && vec_ok) {
+      strided_batch4<16, LDSF>(win, plane, HW, H, W, g, wh, ww, bs, OH, OW, o, C, pair_r, c);
       c += 16;
     } else if (n >= 8 && vec_ok) {
-      strided_batch4<8>(win, plane, HW, H, W, g, wh, ww, bs, OH, OW, o, C, pair_r, c);
+      strided_batch4<8, LDSF>(win, plane, HW, H, W, g, wh, ww, bs, OH, OW, o, C, pair_r, c);
       c += 8;
     } else if (n >= 4 && vec_ok) {
-      strided_batch4<4>(win, plane, HW, H, W, g, wh, ww, bs, OH, OW, o, C, pair_r, c);
+      strided_batch4<4, LDSF>(win, plane, HW, H, W, g, wh, ww, bs, OH, OW, o, C, pair_r, c);
       c += 4;
     } else if (n >= 1) {  // one channel through LDS in the plain layout
       for (int idx = threadIdx.x; idx < warea; idx += kThreads) {
@@ -737,9 +752,15 @@ static int strided_nhwc_launch(const float* input, const float* rois, float* out
   const int oh = (pooled_h + bin_stride - 1) / bin_stride, ow = (pooled_w + bin_stride - 1) / bin_stride;
   const long blocks = (long)ovis_ceil_div(channels, kCPB) * num_rois;
   if (blocks > 0x7fffffffL) return OVIS_ERANGE;
-  hipLaunchKernelGGL(roi_align_fwd_strided_nhwc_kernel, dim3((unsigned)blocks), dim3(kThreads), 0,
+  hipLaunchKernelGGL((roi_align_fwd_strided_nhwc_kernel<kFwdLdsFloats, false>), dim3((unsigned)blocks), dim3(kThreads), 0,
                      (hipStream_t)stream, input, rois, output, num_rois, batch, channels, height, width, pooled_h,
                      pooled_w, bin_stride, oh, ow, spatial_scale, sampling_ratio, pair_out);
   OVIS_LAUNCH_CHECK();
+  if ((long)height * width > kSmallWindow) {  // larger windows can exist at all
+    hipLaunchKernelGGL((roi_align_fwd_strided_nhwc_kernel<kBigLdsFloats, true>), dim3((unsigned)blocks), dim3(kThreads), 0,
+                       (hipStream_t)stream, input, rois, output, num_rois, batch, channels, height, width, pooled_h,
+                       pooled_w, bin_stride, oh, ow, spatial_scale, sampling_ratio, pair_out);
+    OVIS_LAUNCH_CHECK();
+  }
   return OVIS_OK;
 }
