@@ -968,11 +968,27 @@ extern "C" int ovis_split_gemm_tn_slices(long m, int n, int channels, int taps) 
   if (m <= 0 || n <= 0 || channels <= 0 || taps <= 0) return 1;
   const long tiles = (long)(n / 128) * ((long)taps * channels / 128);
   const long steps = (m + 31) / 32;
-  long s = (4L * OVIS_NUM_CU + tiles - 1) / (tiles > 0 ? tiles : 1);   // ~2 rounds of 2 workgroups per CU
-  if (s > steps / 8) s = steps / 8;                                      // at least 8 k-steps per slice
-  if (s < 1) s = 1;
-  if (s > 256) s = 256;
-  return (int)s;
+  if (tiles <= 0) return 1;
+  // Two workgroups are resident per CU (64 KB of LDS each): the grid runs in rounds of 512 workgroups, and a last round
+  // that is mostly empty costs as much as a full one (the 3x3 weight gradient of res5, 144 tiles: 8 slices = 1152
+  // workgroups = 2.25 rounds ran at 75 %; 7 slices = 1008 fill two rounds to 98 %).  Among the slice counts of up to
+  // ~4 rounds pick the one whose rounds are fullest, preferring about two rounds (enough parallelism, few slabs).
+  const long slots = 2L * OVIS_NUM_CU;
+  long s_max = (4 * slots + tiles - 1) / tiles;
+  if (s_max > steps / 8) s_max = steps / 8;                              // at least 8 k-steps per slice
+  if (s_max > 256) s_max = 256;
+  if (s_max < 1) s_max = 1;
+  long best = 1;
+  double best_score = -1.0;
+  for (long s = 1; s <= s_max; ++s) {
+    const long blocks = s * tiles, rounds = (blocks + slots - 1) / slots;
+    double score = (double)blocks / (double)(rounds * slots);            // fill of the rounds
+    if (rounds == 1) score *= 0.97 * (double)blocks / (double)slots;     // a single round: no tail balancing, and an
+                                                                         // underfilled one idles CUs twice over
+    if (rounds > 2) score -= 0.01 * (double)(rounds - 2);                // slabs cost traffic: mild preference for 2 rounds
+    if (score > best_score + 1e-9) { best_score = score; best = s; }
+  }
+  return (int)best;
 }
 
 extern "C" int ovis_split_gemm_pair_tn(const void* g_pair, long g_row_bytes, const void* x_pair, long x_row_bytes,
