@@ -973,7 +973,8 @@ extern "C" int ovis_split_gemm_tn_slices(long m, int n, int channels, int taps) 
   // that is mostly empty costs as much as a full one (the 3x3 weight gradient of res5, 144 tiles: 8 slices = 1152
   // workgroups = 2.25 rounds ran at 75 %; 7 slices = 1008 fill two rounds to 98 %).  Among the slice counts of up to
   // ~4 rounds pick the one whose rounds are fullest, preferring about two rounds (enough parallelism, few slabs).
-  const long slots = 2L * OVIS_NUM_CU;
+  long slots = 2L * OVIS_NUM_CU;
+  if (const char* e = getenv("OVIS_TN_STAGES")) { if (atoi(e) == 1) slots = 3L * OVIS_NUM_CU; }  // probe: single-stage variant
   long s_max = (4 * slots + tiles - 1) / tiles;
   if (s_max > steps / 8) s_max = steps / 8;                              // at least 8 k-steps per slice
   if (s_max > 256) s_max = 256;
