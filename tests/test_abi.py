@@ -55,3 +55,28 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M) or "libovis_oracle" in src:
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_tn_slice_count_fills_the_rounds_of_resident_workgroups():
+    """ovis_split_gemm_tn_slices (host-side, no GPU): two weight-gradient workgroups are resident per CU, so the grid runs
+    in rounds of 512; the slice count must not leave a mostly empty last round (the res5 3x3 weight gradient: 144 tiles x 8
+    slices = 2.25 rounds ran at 75 %), must keep >= 8 k-steps per slice and stay within [1, 256]."""
+    import ctypes
+
+    from cvpr22_cross_modal_pseudo_labeling_amd import _lib
+
+    f = _lib.load().ovis_split_gemm_tn_slices
+    f.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    f.restype = ctypes.c_int
+    slots = 512
+    for m, n, ch, taps in [(100352, 512, 512, 9), (100352, 512, 1024, 1), (100352, 2048, 1024, 1), (98000, 2048, 512, 1),
+                           (8400, 256, 256, 9), (33400, 128, 128, 9), (8400, 1024, 1024, 9), (50176, 512, 2048, 1)]:
+        s = f(m, n, ch, taps)
+        tiles = (n // 128) * (taps * ch // 128)
+        steps = (m + 31) // 32
+        assert 1 <= s <= 256 and steps // s >= 8, (m, n, ch, taps, s)
+        blocks = s * tiles
+        rounds = -(-blocks // slots)
+        assert blocks / (rounds * slots) >= 0.88, (m, n, ch, taps, s, blocks)
+    assert f(100352, 512, 512, 9) == 7          # 1008 workgroups: two rounds, 98 % full
+    assert f(64, 128, 128, 1) == 1 and f(0, 128, 128, 1) == 1   # tiny / empty problems: one slice
