@@ -521,13 +521,33 @@ class Masker:
         self.threshold, self.padding = threshold, padding
 
     def __call__(self, masks, boxlist):
-        """masks [P,1,M,M], boxlist -> bool [P,1,H,W]"""
+        """masks [P,1,M,M], boxlist -> bool [P,1,H,W].  Same arithmetic per mask as ``paste_mask_in_image`` (the
+        reference's loop, mask_head/inference.py:124-205), restructured for the device: the expanded integer boxes of ALL
+        masks come back in one host read instead of one per mask, padding and the image-size canvas are one fill each,
+        and only the resize to the box size (a data-dependent shape) stays per mask."""
         im_w, im_h = boxlist.size
-        res = [paste_mask_in_image(m[0], b, im_h, im_w, self.threshold, self.padding)
-               for m, b in zip(masks, boxlist.bbox)]
-        if res:
-            return torch.stack(res, 0)[:, None]
-        return masks.new_empty((0, 1, im_h, im_w), dtype=torch.bool)
+        P = masks.shape[0]
+        if P == 0:
+            return masks.new_empty((0, 1, im_h, im_w), dtype=torch.bool)
+        M, pad = masks.shape[-1], self.padding
+        scale = float(M + 2 * pad) / M
+        b = boxlist.bbox
+        w_half = (b[:, 2] - b[:, 0]) * 0.5 * scale
+        h_half = (b[:, 3] - b[:, 1]) * 0.5 * scale
+        x_c, y_c = (b[:, 2] + b[:, 0]) * 0.5, (b[:, 3] + b[:, 1]) * 0.5
+        boxes = torch.stack((x_c - w_half, y_c - h_half, x_c + w_half, y_c + h_half), 1).to(torch.int32).tolist()
+        padded = masks.new_zeros((P, 1, M + 2 * pad, M + 2 * pad), dtype=torch.float32)
+        padded[:, 0, pad:-pad, pad:-pad] = masks[:, 0]
+        out = torch.zeros((P, 1, im_h, im_w), dtype=torch.bool, device=masks.device)
+        for i, bx in enumerate(boxes):
+            w = max(bx[2] - bx[0] + 1, 1)
+            h = max(bx[3] - bx[1] + 1, 1)
+            x0, x1 = max(bx[0], 0), min(bx[2] + 1, im_w)
+            y0, y1 = max(bx[1], 0), min(bx[3] + 1, im_h)
+            if x1 > x0 and y1 > y0:
+                resized = F.interpolate(padded[i:i + 1], size=(h, w), mode="bilinear", align_corners=False)[0, 0]
+                out[i, 0, y0:y1, x0:x1] = resized[(y0 - bx[1]):(y1 - bx[1]), (x0 - bx[0]):(x1 - bx[0])] > self.threshold
+        return out
 
 
 class ROIMaskHead(nn.Module):
