@@ -193,3 +193,50 @@ def test_inference_gathers_every_ranks_detections_in_image_order(tmp_path):
             assert torch.equal(det.get_field("labels"), torch.full((k,), i, dtype=torch.int64))
             assert torch.equal(det.get_field("scores"), torch.full((k,), i / 10.0))
             assert det.get_field("mask").shape == (k, 1, 28, 28) and bool((det.get_field("mask") == i).all())
+
+
+def _nccl_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm
+
+    torch.manual_seed(5)
+    model = Tiny().cuda()
+    comm.broadcast_parameters(model)
+    x = torch.randn(16, 8, device="cuda")
+    want = {}
+    model(x).pow(2).mean().backward()
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            want[n] = p.grad.clone()
+            p.grad = None
+    reducer = comm.BucketedGradReducer(model, bucket_bytes=256)
+    reducer.world = 2  # take the collective path on the one-rank communicator: sum over 1 rank, then the division by 2
+    side = torch.cuda.Stream()
+    for _ in range(2):
+        reducer.zero_grad()
+        with torch.cuda.stream(side):  # the hooks must issue the all-reduce behind the stream the backward runs on
+            side.wait_stream(torch.cuda.current_stream())
+            model(x).pow(2).mean().backward()
+            reducer.finish()
+        torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ok = all(torch.allclose(p.grad, want[n] / 2, rtol=1e-6, atol=1e-8) for n, p in model.named_parameters() if n in want)
+    red = comm.reduce_loss_dict({"l": torch.tensor(3.0, device="cuda")})
+    torch.save({"ok": bool(ok), "loss": float(red["l"]), "buckets": len(reducer.buckets)}, out)
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bucketed_allreduce_on_rccl_one_rank(tmp_path):
+    """The reducer's collective path (async all-reduce issued from autograd hooks, wait, average) on a real RCCL
+    communicator -- one rank, the only configuration a 1-GPU box allows -- incl. a backward that runs on a side stream."""
+    out = str(tmp_path / "nccl.pt")
+    mp.spawn(_nccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    got = torch.load(out)
+    assert got["ok"] and got["buckets"] > 1 and abs(got["loss"] - 3.0) < 1e-6
