@@ -391,3 +391,49 @@ def test_split_gemm_pair_gated_epilogue():
     want_p, _ = C.gate_split_pair(d, yp)
     _, got_p = C.split_gemm_pair_gated(ap, wp, yp, conv=(7, 7, 3, 3, True))
     assert torch.equal(got_p, want_p)
+
+
+def test_split_gemm_full_size_properties():
+    """BASELINE-size res5 shapes (2048 RoIs x 49 positions = 100352 rows) through size-independent properties: a block of
+    rows / maps computed alone is bit-identical to the same rows of the full launch (tile and XCD renumbering, 64-bit
+    addressing), sampled entries agree with fp64 dot products, and the weight gradient over all rows equals the sum
+    over two halves."""
+    C = _C()
+    g = torch.Generator(device="cuda").manual_seed(77)
+    m, k, n = 2048 * 49, 1024, 2048
+    a = torch.randn(m, k, device="cuda", generator=g)
+    b = torch.randn(n, k, device="cuda", generator=g) / k ** 0.5
+    bias = torch.randn(n, device="cuda", generator=g)
+    ap, bp = C.split_pair(a), C.split_pair(b)
+    full, full_p = C.split_gemm_pair(ap, bp, bias, None, True, True, True)
+    assert torch.equal(full_p, C.split_pair(full))
+    for r0, r1 in ((0, 128), (50000, 50999), (m - 777, m)):
+        part, _ = C.split_gemm_pair(C.split_pair(a[r0:r1]), bp, bias, None, True, True, False)
+        assert torch.equal(part, full[r0:r1]), (r0, r1)
+    rows = torch.randint(0, m, (64,), device="cuda", generator=g)
+    cols = torch.randint(0, n, (64,), device="cuda", generator=g)
+    ref = ((a[rows].double() * b[cols].double()).sum(1) + bias[cols].double()).clamp(min=0)
+    bound = (a[rows].abs().double() * b[cols].abs().double()).sum(1) + 1
+    assert ((full[rows, cols].double() - ref).abs() / bound).max().item() < TOL
+    del full, full_p
+    # implicit 3x3 on [2048, 7, 7, 512] -> 512: maps 1000..1010 alone == the same maps of the full launch
+    r, h, w, c, n2 = 2048, 7, 7, 512, 512
+    x = torch.randn(r * h * w, c, device="cuda", generator=g)
+    wm = torch.randn(n2, 9 * c, device="cuda", generator=g) / (9 * c) ** 0.5
+    xp, wp = C.split_pair(x), C.split_pair(wm)
+    y, _ = C.split_gemm_pair(xp, wp, conv=(h, w, 3, 3, False))
+    sub, _ = C.split_gemm_pair(C.split_pair(x[1000 * 49:1010 * 49]), wp, conv=(h, w, 3, 3, False))
+    assert torch.equal(sub, y[1000 * 49:1010 * 49])
+    # weight gradient: all rows == first half + second half (fp32 slab sums: 1e-5 relative), sampled entries vs fp64
+    gy = torch.randn(r * h * w, n2, device="cuda", generator=g)
+    gp = C.split_pair(gy)
+    dw = C.split_gemm_pair_tn(gp, xp, (h, w, 3, 3))
+    half = (r // 2) * h * w
+    dw2 = C.split_gemm_pair_tn(C.split_pair(gy[:half]), C.split_pair(x[:half]), (h, w, 3, 3)) + \
+        C.split_gemm_pair_tn(C.split_pair(gy[half:]), C.split_pair(x[half:]), (h, w, 3, 3))
+    assert (dw - dw2).abs().max().item() <= 1e-5 * dw.abs().max().item()
+    center = dw.view(n2, 9, c)[:, 4]                      # the centre tap is the plain product G^T X
+    i, j = torch.randint(0, n2, (32,), device="cuda", generator=g), torch.randint(0, c, (32,), device="cuda", generator=g)
+    ref = (gy[:, i].double() * x[:, j].double()).sum(0)
+    bound = (gy[:, i].abs().double() * x[:, j].abs().double()).sum(0) + 1
+    assert ((center[i, j].double() - ref).abs() / bound).max().item() < TOL
