@@ -1,0 +1,91 @@
+"""Host -> device staging of the input stream, off the training thread.
+
+The reference feeds the step from a ``torch.utils.data.DataLoader`` and moves every batch with a blocking
+``images.to(device)`` inside the loop (maskrcnn_benchmark/engine/trainer.py:100-104).  On this design the training thread
+must keep two HIP streams fed (engine/trainer.py::PipelinedTrainer), and a pageable host-to-device copy issued from it
+waits behind everything already queued on its stream.  ``DevicePrefetcher`` therefore runs the source iterator on its own
+thread, stages every batch through pinned memory on a dedicated copy stream a few batches ahead, and hands the consumer
+device tensors plus an event its current stream waits on -- the copies overlap the previous steps' compute.
+"""
+import queue
+import threading
+
+import torch
+
+
+def _map(obj, fn):
+    if torch.is_tensor(obj):
+        return fn(obj)
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_map(o, fn) for o in obj)
+    if isinstance(obj, dict):
+        return {k: _map(v, fn) for k, v in obj.items()}
+    if hasattr(obj, "bbox") and hasattr(obj, "extra_fields"):  # BoxList
+        out = type(obj)(fn(obj.bbox), obj.size)
+        for k, v in obj.extra_fields.items():
+            out.add_field(k, _map(v, fn))
+        return out
+    return obj
+
+
+class DevicePrefetcher:
+    """Iterates ``source`` (host batches: tensors / BoxLists / nested lists, tuples, dicts of them) ``depth`` batches
+    ahead on a worker thread and yields the same structures on ``device``.  On a CPU device it is a plain look-ahead
+    queue.  Exceptions of the source are re-raised in the consumer."""
+
+    _END = object()
+
+    def __init__(self, source, device, depth=2):
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        if self.cuda and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self.q = queue.Queue(maxsize=max(int(depth), 1))
+        self.stop = False
+        self.thread = threading.Thread(target=self._run, args=(iter(source),), daemon=True)
+        self.thread.start()
+
+    def _stage(self, batch):
+        if not self.cuda:
+            return _map(batch, lambda t: t.to(self.device)), None
+        torch.cuda.set_device(self.device)
+        with torch.cuda.stream(self.stream):
+            moved = _map(batch, lambda t: t if t.is_cuda else t.pin_memory().to(self.device, non_blocking=True))
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return moved, ev
+
+    def _run(self, it):
+        try:
+            for batch in it:
+                if self.stop:
+                    return
+                self.q.put(self._stage(batch))
+            self.q.put((self._END, None))
+        except BaseException as e:  # handed to the consumer
+            self.q.put((e, None))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item, ev = self.q.get()
+        if item is self._END:
+            self.q.put((self._END, None))
+            raise StopIteration
+        if isinstance(item, BaseException):
+            raise item
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            _map(item, lambda t: (t.record_stream(cur), t)[1] if t.is_cuda else t)  # allocated on the copy stream
+        return item
+
+    def close(self):
+        self.stop = True
+        try:
+            while True:
+                self.q.get_nowait()
+        except queue.Empty:
+            pass

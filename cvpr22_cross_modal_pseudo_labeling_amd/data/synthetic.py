@@ -7,6 +7,7 @@ maskrcnn_benchmark/data/datasets/coco_cap_det.py:166-171), and unit-norm text em
 for the BERT word-embedding rows (language_backbone/transformers.py:24,67).
 """
 import torch
+import torch.utils.data
 
 from ..modeling.structures import BoxList
 
@@ -44,6 +45,26 @@ def make_batch(batch, device="cpu", seed=1234, height=800, width=1333, num_gt=7,
         t.add_field("is_det", "Yes")
         targets.append(t.to(device))
     return images.to(device), targets
+
+
+class SyntheticBatches(torch.utils.data.IterableDataset):
+    """Endless stream of host batches for ``torch.utils.data.DataLoader(batch_size=None, num_workers=N)``: batch ``it`` is
+    ``make_batch(seed = seed0 + 1000 * it + rank)`` whichever worker PROCESS produces it (worker w of N takes
+    it = w, w + N, ...; the loader collects the workers round-robin, so the order is it = 0, 1, 2, ...).  Worker
+    processes keep the generation (dozens of small host ops per batch) off the training process' interpreter lock --
+    the role of DATALOADER.NUM_WORKERS in the reference (data/build.py:154-172)."""
+
+    def __init__(self, batch, seed0=1234, rank=0, **make_batch_kwargs):
+        self.batch, self.seed0, self.rank, self.kw = batch, seed0, rank, make_batch_kwargs
+
+    def __iter__(self):
+        info = torch.utils.data.get_worker_info()
+        it, step = (0, 1) if info is None else (info.id, info.num_workers)
+        if info is not None:
+            torch.set_num_threads(1)
+        while True:
+            yield make_batch(self.batch, device="cpu", seed=self.seed0 + 1000 * it + self.rank, **self.kw)
+            it += step
 
 
 @torch.no_grad()

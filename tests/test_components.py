@@ -333,3 +333,46 @@ def test_masker_batched_host_read_equals_per_mask_paste():
     want = torch.stack([paste_mask_in_image(m[0], b, 240, 320, 0.5, 1) for m, b in zip(masks, boxes)])[:, None]
     assert got.dtype == torch.bool and torch.equal(got, want) and int(got[4].sum()) == 0
     assert Masker()(masks[:0], BoxList(boxes[:0], (320, 240))).shape == (0, 1, 240, 320)
+
+
+def test_device_prefetcher_order_structure_and_errors():
+    """data.prefetch.DevicePrefetcher: batches come out in source order with the same nested structure (tensors, BoxLists
+    with tensor and non-tensor fields), the source ends cleanly, and a source exception surfaces in the consumer."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.data.prefetch import DevicePrefetcher
+    from cvpr22_cross_modal_pseudo_labeling_amd.data.synthetic import make_batch
+
+    def source(n, fail_at=None):
+        for i in range(n):
+            if i == fail_at:
+                raise RuntimeError("broken sample")
+            yield make_batch(1, seed=i, height=32, width=48, num_gt=2, num_nouns=2)
+
+    got = list(DevicePrefetcher(source(5), "cpu", depth=2))
+    assert len(got) == 5
+    for i, (images, targets) in enumerate(got):
+        want_images, want_targets = make_batch(1, seed=i, height=32, width=48, num_gt=2, num_nouns=2)
+        assert torch.equal(images, want_images) and len(targets) == 1
+        t, w = targets[0], want_targets[0]
+        assert torch.equal(t.bbox, w.bbox) and t.size == w.size and t.get_field("is_det") == "Yes"
+        assert torch.equal(t.get_field("masks"), w.get_field("masks")) and torch.equal(t.get_field("ids_cap"), w.get_field("ids_cap"))
+    it = DevicePrefetcher(source(4, fail_at=2), "cpu", depth=1)
+    assert next(it) is not None and next(it) is not None
+    with pytest.raises(RuntimeError, match="broken sample"):
+        next(it)
+
+
+def test_synthetic_batches_through_worker_processes_keep_their_order():
+    """SyntheticBatches behind a 2-worker DataLoader + DevicePrefetcher: batch it == make_batch(seed0 + 1000 * it + rank)."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.data.prefetch import DevicePrefetcher
+    from cvpr22_cross_modal_pseudo_labeling_amd.data.synthetic import SyntheticBatches, make_batch
+
+    kw = dict(height=32, width=48, num_gt=2, num_nouns=2)
+    loader = torch.utils.data.DataLoader(SyntheticBatches(2, seed0=77, rank=3, **kw), batch_size=None, num_workers=2,
+                                         prefetch_factor=2)
+    pre = DevicePrefetcher(loader, "cpu", depth=2)
+    for it in range(5):
+        images, targets = next(pre)
+        want_images, want_targets = make_batch(2, seed=77 + 1000 * it + 3, **kw)
+        assert torch.equal(images, want_images)
+        assert all(torch.equal(a.bbox, b.bbox) for a, b in zip(targets, want_targets))
+    pre.close()

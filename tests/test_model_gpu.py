@@ -278,3 +278,21 @@ def test_eval_forward_and_inference_collects_detections(tmp_path):
     for a, b in zip(preds, loop):
         assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("labels"), b.get_field("labels"))
         assert torch.equal(a.get_field("scores"), b.get_field("scores"))
+
+
+def test_device_prefetcher_stages_batches_on_a_copy_stream():
+    """DevicePrefetcher on the GPU: device batches equal the host batches, in order, usable on the consumer's stream
+    right away (event hand-over + record_stream), also while the consumer's stream is busy."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.data.prefetch import DevicePrefetcher
+    from cvpr22_cross_modal_pseudo_labeling_amd.data.synthetic import make_batch
+
+    host = [make_batch(2, seed=i, height=96, width=128, num_gt=3, num_nouns=2) for i in range(6)]
+    busy = torch.randn(4096, 4096, device="cuda")
+    sums = []
+    for images, targets in DevicePrefetcher(iter(host), "cuda", depth=2):
+        for _ in range(3):
+            busy = busy @ busy * 1e-4  # keep the consumer stream occupied
+        assert images.is_cuda and targets[0].bbox.is_cuda and targets[0].get_field("masks").is_cuda
+        sums.append((images.double().sum() + targets[1].get_field("masks").sum() + targets[0].bbox.sum()).item())
+    want = [(im.double().sum() + t[1].get_field("masks").sum() + t[0].bbox.sum()).item() for im, t in host]
+    assert len(sums) == 6 and all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(sums, want))
