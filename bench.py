@@ -49,7 +49,7 @@ class OpTimer:
         self.enabled = False
         self._orig = {}
 
-    def _wrap(self, name, work_fn, kind="hbm", bytes_fn=None):
+    def _wrap(self, name, work_fn, kind="hbm", bytes_fn=None, shape_fn=None):
         orig = getattr(self.C, name)
         self._orig[name] = orig
         self.kind[name] = kind
@@ -62,7 +62,8 @@ class OpTimer:
             a.record()
             out = orig(*args, **kwargs)
             b.record()
-            self.records.setdefault(name, []).append((a, b, work_fn(*args, **kwargs)))
+            self.records.setdefault(name, []).append((a, b, work_fn(*args, **kwargs),
+                                                      shape_fn(*args, **kwargs) if shape_fn else None))
             if bytes_fn is not None:
                 self.bytes[name] += bytes_fn(*args, **kwargs)
             return out
@@ -135,14 +136,22 @@ class OpTimer:
         self._wrap("bias_act_", bias_act_bytes)
         self._wrap("split_pair", split_pair_bytes)
         self._wrap("gate_split_pair", gate_split_bytes)
-        self._wrap("split_gemm_pair", split_gemm_flops, "mfma", split_gemm_bytes)
-        self._wrap("split_gemm_pair_gated", split_gemm_flops, "mfma", split_gemm_gated_bytes)
-        self._wrap("split_gemm_pair_tn", split_gemm_tn_flops, "mfma", split_gemm_tn_bytes)
+        def nt_shape(a_pair, b_pair, *args, conv=None, **kwargs):
+            taps = 1 if conv is None else conv[2] * conv[3]
+            return (a_pair.shape[0], b_pair.shape[0], b_pair.shape[1] // 2, taps)
+
+        def tn_shape(g_pair, x_pair, conv=None, scale=None, weight_shape=None):
+            taps = 1 if conv is None else conv[2] * conv[3]
+            return (g_pair.shape[0], g_pair.shape[1] // 2, x_pair.shape[1] // 2 * taps, taps)
+
+        self._wrap("split_gemm_pair", split_gemm_flops, "mfma", split_gemm_bytes, nt_shape)
+        self._wrap("split_gemm_pair_gated", split_gemm_flops, "mfma", split_gemm_gated_bytes, nt_shape)
+        self._wrap("split_gemm_pair_tn", split_gemm_tn_flops, "mfma", split_gemm_tn_bytes, tn_shape)
 
     def summary(self):
         out = {}
         for name, recs in self.records.items():
-            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
             work = sum(r[2] for r in recs)
             if self.kind[name] == "mfma":
                 out[name] = {"launches": len(recs), "avg_us": 1e3 * ms / len(recs), "bound": "mfma",
@@ -155,6 +164,31 @@ class OpTimer:
                              "alg_MB_per_launch": work / len(recs) / 1e6,
                              "achieved_GBps": work / ms / 1e6 if ms > 0 else 0.0}
         return out
+
+
+def per_shape_rows(timer, steps):
+    """One row per distinct (op, M, N, K, taps) of the split GEMM family: launches per step, mean microseconds, bf16
+    TFLOP/s issued (6*M*N*K), fp32-equivalent TFLOP/s (2*M*N*K), 128x128 tiles and rounds of resident workgroups."""
+    rows = []
+    for name, recs in timer.records.items():
+        if timer.kind[name] != "mfma":
+            continue
+        by = {}
+        for r in recs:
+            by.setdefault(r[3], []).append((r[0].elapsed_time(r[1]), r[2]))
+        for shape, lst in by.items():
+            m, n, k, taps = shape
+            ms = sum(x[0] for x in lst) / len(lst)
+            fl = lst[0][1]
+            if name == "split_gemm_pair_tn":
+                tiles, slots = (n // 128) * (k // 128), 512
+            else:
+                tiles = -(-m // 128) * -(-n // 128)
+                slots = 1024 if (taps == 1 and tiles >= 2048) else 768 if (taps > 1 and tiles >= 1024) else 512
+            rows.append((name, m, n, k, taps, len(lst) / steps, 1e3 * ms, fl / ms / 1e9, fl / 3 / ms / 1e9, tiles,
+                         tiles / slots, 1e3 * ms * len(lst) / steps))
+    rows.sort(key=lambda r: -r[-1])
+    return rows
 
 
 # bench.py op name -> kernel family of the committed PMC summary (profiles/r1_pmc_step_hbm_traffic_<workload>.json)
@@ -241,6 +275,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--burn-seconds", type=float, default=3.0, help="GPU clock warm-up before the warm-up steps")
     ap.add_argument("--no-pipeline", action="store_true", help="plain sequential step (no side-stream overlap)")
+    ap.add_argument("--per-shape-csv", default="", help="write one row per distinct split-GEMM shape of the step")
     ap.add_argument("--channels-last", action="store_true", help="experiment: run the trunk / heads in NHWC")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen exhaustive find)")
     args = ap.parse_args()
@@ -393,6 +428,12 @@ def main():
             "kernels": {n: {kk: round(vv, 3) if isinstance(vv, float) else vv for kk, vv in v.items()}
                         for n, v in kernels.items()},
         }
+        if args.per_shape_csv:
+            with open(args.per_shape_csv, "w") as f:
+                f.write("op,M,N,K,taps,launches_per_step,avg_us,bf16_TFLOPs_issued,fp32_equiv_TFLOPs,tiles_or_tn_tiles,"
+                        "rounds_of_resident_workgroups,us_per_step\n")
+                for r in per_shape_rows(timer, replay_steps or args.steps):
+                    f.write(",".join(str(round(x, 3)) if isinstance(x, float) else str(x) for x in r) + "\n")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out))

@@ -30,12 +30,14 @@ def synchronize():
 
 
 def broadcast_parameters(model, src=0):
-    """Initial parameter + buffer broadcast (the DDP constructor's job in the reference)."""
+    """Initial parameter + buffer broadcast (the DDP constructor's job in the reference).  The tensors themselves are
+    written (not ``t.data``, which carries its own version counter), so every cache keyed on ``_version`` -- folded
+    FrozenBN weights, pair-layout weight forms -- sees the new values."""
     if get_world_size() == 1:
         return
     with torch.no_grad():
         for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, src)
+            dist.broadcast(t, src)
 
 
 def reduce_loss_dict(loss_dict):
@@ -53,10 +55,21 @@ def reduce_loss_dict(loss_dict):
 
 
 class BucketedGradReducer:
-    def __init__(self, model, bucket_bytes=32 << 20):
+    """``never_used``: parameters that are trainable but take part in no loss (the reference's ``lambda_exemplar``,
+    st_generalized_rcnn.py:50): their hooks never fire, so they are left out of the per-bucket hook count (their slots
+    of the flat buffer stay zero) -- otherwise their bucket, and every bucket behind it, would only be reduced in
+    ``finish()``, after the backward.  Parameters whose ``requires_grad`` is turned off during the run (the student's
+    ``uncertain_pred`` at MODEL.UNCERTAINTY_TRAIN_ITER) are dropped from the count by the next ``zero_grad()`` and get
+    ``grad = None`` (no weight decay / momentum update on a frozen parameter)."""
+
+    def __init__(self, model, bucket_bytes=32 << 20, never_used=None):
         self.world = get_world_size()
         params = [p for p in model.parameters() if p.requires_grad]
         params.reverse()
+        if never_used is None and hasattr(model, "never_used_parameters"):
+            never_used = model.never_used_parameters()
+        self._never_used = {id(p) for p in (never_used or ())}
+        self.hook_launches = 0  # buckets whose all-reduce was issued from a backward hook in the current step
         self.buckets = []
         cur, cur_bytes = [], 0
         for p in params:
@@ -79,14 +92,24 @@ class BucketedGradReducer:
                 off += p.numel()
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
             self.flat.append(flat)
-            self.pending.append(len(bucket))
+            self.pending.append(self._expected(bucket))
             self.handles.append(None)
             self.launched.append(False)
 
+    def _expected(self, bucket):
+        return sum(1 for p in bucket if p.requires_grad and id(p) not in self._never_used)
+
     def _make_hook(self, bi):
         def hook(param):
+            if id(param) in self._never_used:
+                if self.launched[bi]:
+                    raise RuntimeError("BucketedGradReducer: a parameter declared never_used received a gradient after "
+                                       "its bucket was reduced")
+                return
             self.pending[bi] -= 1
+            before = self._next
             self._launch_ready()
+            self.hook_launches += self._next - before
         return hook
 
     def _launch_ready(self):
@@ -105,14 +128,17 @@ class BucketedGradReducer:
     def zero_grad(self):
         """Replaces optimizer.zero_grad(): grads stay views of the flat buffers."""
         self._next = 0
+        self.hook_launches = 0
         for bi, (flat, bucket) in enumerate(zip(self.flat, self.buckets)):
             flat.zero_()
-            self.pending[bi] = len(bucket)
+            self.pending[bi] = self._expected(bucket)
             self.handles[bi] = None
             self.launched[bi] = False
             off, base, esz = 0, flat.data_ptr(), flat.element_size()
             for p in bucket:  # pointer comparison only: no tensor op per parameter on the per-step path
-                if p.grad is None or p.grad.data_ptr() != base + off * esz:
+                if not p.requires_grad:
+                    p.grad = None  # frozen during the run: its slot stays zero on every rank, the optimizer skips it
+                elif p.grad is None or p.grad.data_ptr() != base + off * esz:
                     p.grad = flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
 

@@ -40,7 +40,7 @@ class GroupFusedSGD(torch.optim.SGD):
         params, grads, wds, lrs, moms = [], [], [], [], []
         for g in groups:
             for p in g["params"]:
-                if p.grad is None:
+                if p.grad is None or not p.requires_grad:  # frozen during the run: no decay / momentum update either
                     continue
                 if p.grad.is_sparse:
                     return super().step(closure)

@@ -83,6 +83,11 @@ class STGeneralizedRCNN(nn.Module):
         self.iter = 0
         self.cap_embs = None  # [V, emb_dim] unit-norm caption-vocabulary (LVIS) embeddings
 
+    def never_used_parameters(self):
+        """Trainable parameters no loss depends on (``update_exemplars`` is commented out upstream): the gradient
+        reducer does not wait for their hooks (engine/comm.py)."""
+        return [self.lambda_exemplar]
+
     # -- text side ----------------------------------------------------------------------------------
     def set_caption_vocab(self, embs):
         """Embeddings of the caption vocabulary (the reference re-extracts them from BERT every

@@ -139,6 +139,71 @@ def test_allreduce_order_is_rank_independent(tmp_path):
         assert torch.allclose(g0[n], p.grad, atol=1e-6), n
 
 
+class LateFreeze(nn.Module):
+    """The last-registered parameters (first in backward order, i.e. bucket 0) get frozen during the run, and one
+    trainable parameter is never used -- the student's ``uncertain_pred`` / ``lambda_exemplar`` situation."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 16)
+        self.b = nn.Linear(16, 4)
+        self.late = nn.Linear(16, 4)
+        self.lam = nn.Parameter(torch.zeros(1))
+
+    def never_used_parameters(self):
+        return [self.lam]
+
+    def forward(self, x):
+        t = torch.relu(self.a(x))
+        return self.b(t) + self.late(t.detach())
+
+
+def _worker_freeze(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm, solver
+
+    torch.manual_seed(3)
+    model = LateFreeze()
+    comm.broadcast_parameters(model)
+    reducer = comm.BucketedGradReducer(model, bucket_bytes=64)  # one bucket per parameter
+    opt = solver.GroupFusedSGD([{"params": [p], "lr": 0.1, "weight_decay": 0.5} for p in model.parameters()], 0.1,
+                               momentum=0.9)
+    x = torch.randn(3, 8, generator=torch.Generator().manual_seed(21 + rank))
+    log = []
+    for step in range(4):
+        if step == 2:
+            model.late.requires_grad_(False)
+        reducer.zero_grad()
+        model(x).pow(2).mean().backward()
+        from_hooks = reducer.hook_launches      # before finish(): what the backward hooks issued on their own
+        reducer.finish()
+        late_before = model.late.weight.detach().clone()
+        opt.step()
+        log.append({"from_hooks": from_hooks, "buckets": len(reducer.buckets),
+                    "late_moved": bool((model.late.weight.detach() != late_before).any()),
+                    "late_grad_none": model.late.weight.grad is None,
+                    "grads": {n: (None if p.grad is None else p.grad.clone()) for n, p in model.named_parameters()}})
+    torch.save(log, out + str(rank))
+    dist.destroy_process_group()
+
+
+def test_reducer_overlap_survives_frozen_and_never_used_parameters(tmp_path):
+    """a parameter frozen mid-run (bucket 0) or never used must not push every all-reduce into finish()."""
+    out = str(tmp_path / "f")
+    mp.spawn(_worker_freeze, args=(2, _free_port(), out), nprocs=2, join=True)
+    l0, l1 = torch.load(out + "0"), torch.load(out + "1")
+    for step, (a, b) in enumerate(zip(l0, l1)):
+        # every bucket except the never-used parameter's own is issued from a hook, before and after the freeze
+        assert a["from_hooks"] >= a["buckets"] - 1 - (2 if step >= 2 else 0), (step, a["from_hooks"], a["buckets"])
+        assert a["from_hooks"] >= 4
+        for n in a["grads"]:
+            ga, gb = a["grads"][n], b["grads"][n]
+            assert (ga is None) == (gb is None) and (ga is None or torch.equal(ga, gb)), (step, n)
+        assert a["late_grad_none"] == (step >= 2)
+        assert a["late_moved"] == (step < 2)  # frozen: no weight decay / momentum update either
+
+
 class _FakeDetector(nn.Module):
     """Stands in for the detector on CPU: image i (value of its first pixel) yields i % 3 detections (so some images --
     and, for rank 1 of the second case, a whole rank -- contribute none), with box / score / label / mask fields."""
