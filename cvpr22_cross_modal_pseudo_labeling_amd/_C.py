@@ -463,16 +463,23 @@ def im2col_nchw_pair(x, kh, kw, stride, pad):
 
 
 def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f32=True, out_pair=False, conv=None,
-                    tile_m=0):
+                    config=0, a2_pair=None):
     """act(A @ B^T + bias + residual) with A [M, 2*ch] / B [N, 2*K] in pair layout (``split_pair``); fp32-accurate
     three-term bf16 hi/lo product on the matrix cores (csrc/split_gemm.hip).  conv = (h, w, kh, kw, flip): A is an
     NHWC tensor [M/(h*w), h, w, ch] and B holds [N, kh*kw*ch] tap-major weights -- stride-1 "same" convolution as an
-    implicit GEMM.  Returns (C f32 [M, N] or None, C in pair layout [M, 2*N] or None)."""
-    for t, name in ((a_pair, "a_pair"), (b_pair, "b_pair")):
+    implicit GEMM.  a2_pair [M, 2*ch2]: a second operand whose products follow A's along K (B = [N, 2*(ch + ch2)]):
+    conv3 + projection shortcut of a bottleneck as one product.  ``config``: 0 = choose; test / measurement bits as in
+    include/ovis_hip.h.  Returns (C f32 [M, N] or None, C in pair layout [M, 2*N] or None)."""
+    for t, name in ((a_pair, "a_pair"), (b_pair, "b_pair")) + (((a2_pair, "a2_pair"),) if a2_pair is not None else ()):
         if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1):
             raise RuntimeError(f"split_gemm_pair: {name} must be a 2-D bfloat16 HIP tensor in pair layout")
     m, ch = a_pair.shape[0], a_pair.shape[1] // 2
     n, k = b_pair.shape[0], b_pair.shape[1] // 2
+    ch2 = 0
+    if a2_pair is not None:
+        if conv is not None or a2_pair.shape[0] != m:
+            raise RuntimeError("split_gemm_pair: a2_pair needs a plain product and as many rows as a_pair")
+        ch2 = a2_pair.shape[1] // 2
     h = w = 0
     kh = kw = 1
     flip = False
@@ -480,8 +487,8 @@ def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f3
         h, w, kh, kw, flip = conv
         if m % (h * w):
             raise RuntimeError("split_gemm_pair: rows must be a multiple of h*w")
-    if k != kh * kw * ch:
-        raise RuntimeError(f"split_gemm_pair: contraction mismatch (A has {ch} channels x {kh * kw} taps, B has {k})")
+    if k != kh * kw * ch + ch2:
+        raise RuntimeError(f"split_gemm_pair: contraction mismatch (A has {ch} channels x {kh * kw} taps + {ch2}, B has {k})")
     dev = a_pair.device
     c = torch.empty((m, n), dtype=torch.float32, device=dev) if out_f32 else None
     cp = torch.empty((m, 2 * n), dtype=torch.bfloat16, device=dev) if out_pair else None
@@ -493,12 +500,18 @@ def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f3
                                      and residual.stride(1) == 1 and residual.shape == (m, n)):
         raise RuntimeError("split_gemm_pair: residual must be a float32 [M, N] HIP tensor with unit column stride")
     with torch.cuda.device(dev):
-        rc = _L.ovis_split_gemm_pair(a_pair.data_ptr(), 2 * a_pair.stride(0), b_pair.data_ptr(), 2 * b_pair.stride(0),
+        nbytes = _L.ovis_split_gemm_pair_workspace_bytes(m, n, ch, ch2, kh, kw, w) if not (config & 8) else 0
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
+        rc = _L.ovis_split_gemm_pair(a_pair.data_ptr(), 2 * a_pair.stride(0),
+                                     0 if a2_pair is None else a2_pair.data_ptr(),
+                                     0 if a2_pair is None else 2 * a2_pair.stride(0),
+                                     b_pair.data_ptr(), 2 * b_pair.stride(0),
                                      0 if c is None else c.data_ptr(), n, 0 if cp is None else cp.data_ptr(), 4 * n,
                                      0 if bias is None else bias.data_ptr(),
                                      0 if residual is None else residual.data_ptr(),
-                                     0 if residual is None else residual.stride(0), m, n, ch, kh, kw, h, w,
-                                     int(bool(flip)), int(bool(relu)), tile_m, _stream())
+                                     0 if residual is None else residual.stride(0), m, n, ch, ch2, kh, kw, h, w,
+                                     int(bool(flip)), int(bool(relu)), 0 if ws is None else ws.data_ptr(), nbytes,
+                                     config, _stream())
     _lib.check(rc, "split_gemm_pair")
     return c, cp
 
@@ -522,7 +535,7 @@ def weight_prep_pair(w, scale=None, want_transposed=False):
     return fwd, bwd
 
 
-def split_gemm_pair_gated(a_pair, b_pair, gate_pair, conv=None, out_f32=False, out_pair=True):
+def split_gemm_pair_gated(a_pair, b_pair, gate_pair, conv=None, out_f32=False, out_pair=True, config=0):
     """(A @ B^T) * (y > 0) with y given in pair layout (``gate_pair`` [M, 2N]): the data gradient of a layer behind a
     ReLU, gated and split for the next backward GEMM in the epilogue.  Returns (f32 or None, pair or None)."""
     for t, name in ((a_pair, "a_pair"), (b_pair, "b_pair"), (gate_pair, "gate_pair")):
@@ -546,7 +559,7 @@ def split_gemm_pair_gated(a_pair, b_pair, gate_pair, conv=None, out_f32=False, o
         rc = _L.ovis_split_gemm_pair_gated(a_pair.data_ptr(), 2 * a_pair.stride(0), b_pair.data_ptr(), 2 * b_pair.stride(0),
                                            0 if c is None else c.data_ptr(), n, 0 if cp is None else cp.data_ptr(), 4 * n,
                                            gate_pair.data_ptr(), 2 * gate_pair.stride(0), m, n, ch, kh, kw, h, w,
-                                           int(bool(flip)), _stream())
+                                           int(bool(flip)), config, _stream())
     _lib.check(rc, "split_gemm_pair_gated")
     return c, cp
 

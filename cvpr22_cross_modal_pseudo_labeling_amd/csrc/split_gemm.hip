@@ -3,26 +3,39 @@
 //   C[M, N] = epilogue( sum_k A[m, k] * B[n, k] ),   A, B fp32 values carried as bf16 hi + lo
 //
 // x = hi + lo + O(2^-17 |x|), hi = bf16(x), lo = bf16(x - hi); the product keeps hi.hi + hi.lo + lo.hi, accumulated
-// in fp32 by v_mfma_f32_16x16x32_bf16 (relative error ~4e-6, cf. 1.7e-6 for an fp32 GEMM).  Unlike the K-concatenated
-// form ([hi | hi | lo] x [hi | lo | hi] through a library GEMM, split_bf16.hip) the three products share their
-// operand fragments here: per 32-deep k-step a wave reads 4 fragments kinds (A_hi, A_lo, B_hi, B_lo) from LDS and
+// in fp32 by v_mfma_f32_16x16x32_bf16 (relative error ~4e-6, cf. 1.7e-6 for an fp32 GEMM).  The three products share
+// their operand fragments: per 32-deep k-step a wave reads 4 fragment kinds (A_hi, A_lo, B_hi, B_lo) from LDS and
 // issues 3 MFMAs per fragment pair, so the kernel moves 2/3 of the bytes and 4/9 of the LDS reads per MFMA of a plain
 // bf16 GEMM over 3K -- that is what lets a simple one-barrier-per-k-step structure keep the matrix cores busy.
 //
-// PAIR LAYOUT (written by split_pair_kernel / im2col_pair_kernel / this kernel's epilogue): a row of K values
-// (K % 32 == 0) is K/32 blocks of 128 bytes: [ hi(32 x bf16) | lo(32 x bf16) ].  One k-step of one row is one full
-// 128-byte line, fetched by 8 lanes of a global_load_lds_dwordx4 (no VGPR round trip).
+// PAIR LAYOUT (written by split_pair_kernel / the poolers / this kernel's epilogue): a row of K values (K % 32 == 0)
+// is K/32 blocks of 128 bytes: [ hi(32 x bf16) | lo(32 x bf16) ].  One k-step of one row is one full 128-byte line,
+// fetched by 8 lanes of a global_load_lds_dwordx4 (no VGPR round trip).
 //
-// IMPLICIT CONVOLUTION: with T = KH*KW > 1 the A operand is an NHWC tensor [R, H, W, ch] in pair layout and
-// k = (tap, channel): row m = (r, y, x) reads pixel (y + dy, x + dx) of tap (dy, dx) ("same" zero padding, stride 1;
-// `flip` negates the offsets = the data-gradient convolution).  Rows outside the map read a 128-byte line of zeros.
-// No im2col matrix exists anywhere: the 9 shifted reads of a pixel hit L2.
+// Three ways the A operand is addressed (template parameter MODE):
+//   PLAIN   : A is [M, ch] (+ an optional SECOND operand [M, ch2] whose k-steps follow: K = ch + ch2 against
+//             B = [N, ch + ch2] -- conv3 and the projection shortcut of a bottleneck as ONE GEMM, no shortcut tensor).
+//   SHIFTED : implicit convolution, any map size.  A is an NHWC tensor [R, H, W, ch]; k = (tap, channel block): row
+//             m = (r, y, x) reads pixel (y + dy, x + dx) of tap (dy, dx) ("same" zero padding, stride 1; `flip`
+//             negates the offsets = the data-gradient convolution); rows outside the map read a 128-byte zero line.
+//   HALO    : implicit convolution on SMALL maps (every tap shift |dy*W + dx| <= 8 rows: the 7x7 maps of the res5
+//             head).  k = (channel block, tap): the rows [m0 - 8, m0 + BM + 8) of one channel block are staged ONCE
+//             and the 9 taps read their fragments from that halo tile at shifted LDS rows (out-of-map lanes read a
+//             zero row kept in LDS) -- the A bytes that cross the L2 -> LDS path drop 9x (32 -> 18 KB per k-step),
+//             which is what bounds the SHIFTED form.
+// No im2col matrix exists anywhere.
 //
-// Tile: (WM x 64) x 128 per workgroup of 2*WM waves, wave tile 64 x 64 (4 x 4 MFMA tiles, 64 accumulator VGPRs),
-// two LDS stages of BM x 128 B (A) + 128 x 128 B (B); the 16-byte chunk index of a row is XOR-ed with (row >> 1) & 7
-// (applied to the SOURCE address of the LDS-DMA, so the LDS image stays lane-linear) which makes every ds_read_b128
-// of a 16-row fragment conflict-free.  Accumulators are computed transposed (D[n][m]) so that a lane owns 4
-// consecutive columns of C: 16-byte stores, float4 bias / residual reads, 8-byte pair stores.
+// Tile: (WM x 64) x (WN x 64) per workgroup of WM*WN waves, wave tile 64 x 64 (4 x 4 MFMA tiles, 64 accumulator
+// VGPRs); LDS stages of BM x 128 B (A) + BN x 128 B (B); the 16-byte chunk index of a row is XOR-ed with
+// (row >> 1) & 7 (applied to the SOURCE address of the LDS-DMA, so the LDS image stays lane-linear) which makes every
+// ds_read_b128 of a 16-row fragment conflict-free.  NS = 2: the next stage loads under this stage's MFMAs, two
+// workgroups per CU (small grids).  NS = 1: one stage, nothing overlaps inside a workgroup, three / four independent
+// workgroups per CU hide each other's load phases (large grids: +7...17 %).
+// Epilogue: the accumulators go through a wave-private LDS staging tile (16 rows x 64 columns, slots XOR-swizzled by
+// row) so that bias / shortcut / gate reads and the fp32 / pair stores touch whole 256-byte row segments (16 lanes x
+// 16 B per row) instead of 64-byte (fp32) and 32-byte (pair) pieces of 16 different rows per instruction.
+// Small-M problems (a handful of workgroups, long K) are cut along K into slices whose raw partial tiles go to fp32
+// slabs; split_gemm_finish_kernel sums them and applies the epilogue (deterministic, no atomics).
 // Workgroups are renumbered so that each XCD owns a contiguous range of tiles (column tiles of one row tile are
 // co-resident on one L2: the A rows are fetched from HBM once).
 #include <stdlib.h>
@@ -37,15 +50,20 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ char g_zero_line[128];  // zero-initialised: the line an out-of-map tap reads
 
+enum { PLAIN = 0, SHIFTED = 1, HALO = 2 };
+constexpr int kHalo = 8;  // rows staged on either side of a HALO tile
+
 struct SplitGemmArgs {
   const char* A; long a_rs;          // pair rows of `ch` values (bytes per row = 4 * ch for a dense tensor)
-  const char* B; long b_rs;          // [N] pair rows of K = T * ch values
+  const char* A2; long a2_rs;        // PLAIN: optional second operand, pair rows of `ch2` values (k-steps after A's)
+  const char* B; long b_rs;          // [N] pair rows of K = T * ch (+ ch2) values
   float* C; long ldc;                // fp32 result (may be null)
   char* Cp; long cp_rs;              // pair result (may be null), bytes per row
   const float* bias; const float* res; long ldr;
   const char* gate; long gate_rs;    // optional ReLU gate of a backward pass: pair rows of the forward activation (hi > 0)
-  long M; int N; int ch; int T; int H; int W; int KH; int KW; int flip; int relu; int gw;
-  int bm_eff;  // rows a tile really covers (<= BM, % 8 == 0; = BM unless the OVIS_SG_BALANCE probe is on)
+  float* slab;                       // split-K: raw partial sums [kslices][M][N] (then C / Cp / bias / ... are unused here)
+  long M; int N; int ch; int ch2; int T; int H; int W; int KH; int KW; int flip; int relu; int gw;
+  int kslices; int steps_per_slice;  // k-steps (PLAIN / SHIFTED) or channel blocks (HALO) per slice
 };
 
 __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
@@ -58,132 +76,164 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));
 }
 
-template <int WM, bool CONV, int NS, int ABL = 0>
-__global__ __launch_bounds__(WM * 128, (NS == 1 && ABL == 7) ? 4 : 1) void split_gemm_kernel(SplitGemmArgs p, int tiles_n, int nblocks) {
-  constexpr int BM = WM * 64, BN = 128, NW = WM * 2;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int AI = BM / 8 / NW;  // LDS-DMA instructions per wave per stage for A (8 rows each): 4
-  constexpr int BI = BN / 8 / NW;  // for B: 4 (WM = 2) or 2 (WM = 4)
+// bias + shortcut + ReLU + gate + fp32 / pair stores of 4 consecutive columns n..n+3 of row m
+__device__ __forceinline__ void epilogue_store4(const SplitGemmArgs& p, long m, int n, f32x4 v) {
+  if (p.bias) v += *(const f32x4*)(p.bias + n);
+  if (p.res) v += *(const f32x4*)(p.res + m * p.ldr + n);
+  if (p.relu) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  }
+  const long poff = (long)(n >> 5) * 128 + (n & 31) * 2;
+  if (p.gate) {  // data gradient of a layer whose input went through a ReLU: zero where that activation was <= 0
+    const uint2 h = *(const uint2*)(p.gate + m * p.gate_rs + poff);
+    const unsigned a0 = h.x & 0xffffu, a1 = h.x >> 16, a2 = h.y & 0xffffu, a3 = h.y >> 16;
+    if (a0 == 0u || a0 >= 0x8000u) v.x = 0.f;
+    if (a1 == 0u || a1 >= 0x8000u) v.y = 0.f;
+    if (a2 == 0u || a2 >= 0x8000u) v.z = 0.f;
+    if (a3 == 0u || a3 >= 0x8000u) v.w = 0.f;
+  }
+  if (p.C) *(f32x4*)(p.C + m * p.ldc + n) = v;
+  if (p.Cp) {
+    const unsigned h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
+    const unsigned l01 = pack_bf16(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+    const unsigned l23 = pack_bf16(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+    char* d = p.Cp + m * p.cp_rs + poff;
+    *(uint2*)d = make_uint2(h01, h23);
+    *(uint2*)(d + 64) = make_uint2(l01, l23);
+  }
+}
+
+template <int WM, int WN, int MODE, int NS, int OCC>
+__global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemmArgs p, int tiles_n, int ntiles) {
+  constexpr int BM = WM * 64, BN = WN * 64, NW = WM * WN;
+  constexpr int A_ROWS = MODE == HALO ? BM + 2 * kHalo + 1 : BM;  // HALO: + one row of zeros
+  constexpr int ZROW = BM + 2 * kHalo;
+  constexpr int A_BYTES = A_ROWS * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_PIECES = (MODE == HALO ? BM + 2 * kHalo : BM) / 8;  // 8-row LDS-DMA pieces of the A tile
+  constexpr int AI = (A_PIECES + NW - 1) / NW;                        // per wave
+  constexpr int BI = BN / 8 / NW;
+  static_assert(MODE != HALO || NS == 1, "the halo tile is single-staged");
+  static_assert(NW * 4096 <= STAGE * NS, "epilogue staging fits the k-loop's LDS");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // XCD-aware renumbering (bijective for any nblocks): workgroup b runs on XCD b % 8
-  int tile;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // XCD-aware renumbering (bijective for any grid): workgroup b runs on XCD b % 8
+  int id;
   {
+    const int nblocks = gridDim.x;
     const int b = blockIdx.x, q = nblocks >> 3, r = nblocks & 7, xcd = b & 7, loc = b >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
+  const int slice = id / ntiles;     // split-K slice (0 when kslices == 1)
+  const int tile = id - slice * ntiles;
   // tile order: column tiles are taken in groups of `p.gw`; within a group row tile-major.  The workgroups resident
-  // on one XCD then share gw weight tiles (gw x 128 rows x 4K bytes: L2-resident) while the A rows stream through.
-  const int gw = p.gw, tiles_m = nblocks / tiles_n;
+  // on one XCD then share gw weight tiles (gw x BN rows x 4K bytes: L2-resident) while the A rows stream through.
+  const int gw = p.gw, tiles_m = ntiles / tiles_n;
   const int per_group = tiles_m * gw;
   const int grp = tile / per_group;
   const int in_grp = tile - grp * per_group;
   const int tile_m = in_grp / gw, tile_n = grp * gw + (in_grp - tile_m * gw);
-  const long m0 = (long)tile_m * p.bm_eff;
+  const long m0 = (long)tile_m * BM;
   const int n0 = tile_n * BN;
+  const int Mi = (int)p.M;           // M < 2^31 (checked by the launcher)
 
-  // ---- per-lane load geometry (no memory reads: hipcc would wait vmcnt(0) on them inside the DMA pipeline) ----
-  const int lrow = lane >> 3;        // row within an 8-row DMA piece
-  const int lchunk = lane & 7;       // 16-byte slot within the 128-byte LDS row
-  constexpr bool conv = CONV;
-  long a_off[AI];                    // byte offset of the lane's source row (chunk swizzle included)
-  int a_yx[AI];                      // (y << 16) | x of that row, for the tap bounds test
-  int a_lds[AI];                     // wave-uniform LDS offset of the piece inside a stage
-#pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    const int piece = wave * AI + i;           // 8-row piece of the A tile
-    const int row = piece * 8 + lrow;
-    int gm = (int)m0 + row;                    // M < 2^31 (checked by the launcher)
-    if (gm > (int)p.M - 1) gm = (int)p.M - 1;  // tail rows: valid memory, results never stored
-    const int chunk = lchunk ^ ((row >> 1) & 7);
-    a_off[i] = (long)gm * p.a_rs + chunk * 16;
-    a_lds[i] = piece * 1024;
-    int x = 0, y = 0;
-    if (conv) {
-      x = gm % p.W;
-      y = (gm / p.W) % p.H;
-    }
-    a_yx[i] = (y << 16) | x;
-  }
-  long b_off[BI];
-  int b_lds[BI];
-#pragma unroll
-  for (int i = 0; i < BI; ++i) {
-    const int piece = wave * BI + i;
-    const int row = piece * 8 + lrow;
-    int gn = n0 + row;
-    if (gn > p.N - 1) gn = p.N - 1;
-    const int chunk = lchunk ^ ((row >> 1) & 7);
-    b_off[i] = (long)gn * p.b_rs + chunk * 16;
-    b_lds[i] = A_BYTES + piece * 1024;
-  }
-  const char* zero_src = g_zero_line + lchunk * 16;
-  uint4 sink = make_uint4(0u, 0u, 0u, 0u);
-
-  const int cpb = p.ch >> 5;         // 32-value blocks per tap
-  const int nk = p.T * cpb;
-  int ld_tap = 0, ld_cb = 0;         // (tap, channel block) of the next stage to load
+  const int cpb = p.ch >> 5;         // 32-value blocks per tap (PLAIN: of the first operand)
+  const int nk = p.T * cpb + (p.ch2 >> 5);
   int dy = 0, dx = 0;
   auto set_tap = [&](int t) {
-    if (conv) {
-      dy = t / p.KW - p.KH / 2;
-      dx = t % p.KW - p.KW / 2;
-      if (p.flip) { dy = -dy; dx = -dx; }
-    }
-  };
-  set_tap(0);
-
-  // one LDS-DMA piece of the A / B tile of k-step kb into `stage` (the tap state is the one of kb; `advance` steps it)
-  auto issue_a = [&](int stage, int kb, int i) {
-    if ((wave * AI + i) * 8 >= p.bm_eff) return;  // wave-uniform: this 8-row piece lies beyond the shrunk tile
-    char* base = smem + stage * STAGE;
-    const long a_shift = conv ? ((long)dy * p.W + dx) * p.a_rs + (long)ld_cb * 128 : (long)kb * 128;
-    const char* src = p.A + a_off[i] + a_shift;
-    if (conv) {
-      const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xffff) + dx;
-      if ((unsigned)y >= (unsigned)p.H || (unsigned)x >= (unsigned)p.W) src = zero_src;
-    }
-    if (ABL == 5) {  // probe: the same bytes as plain 16-byte loads into registers (no LDS write)
-      const uint4 v = *(const uint4*)src;
-      sink.x ^= v.x; sink.y ^= v.y; sink.z ^= v.z; sink.w ^= v.w;
-    } else {
-      glds16(src, base + a_lds[i]);
-    }
-  };
-  auto issue_b = [&](int stage, int kb, int i) {
-    const char* src = p.B + b_off[i] + (long)kb * 128;
-    if (ABL == 5) {
-      const uint4 v = *(const uint4*)src;
-      sink.x ^= v.x; sink.y ^= v.y; sink.z ^= v.z; sink.w ^= v.w;
-    } else {
-      glds16(src, smem + stage * STAGE + b_lds[i]);
-    }
-  };
-  auto advance = [&]() {
-    if (++ld_cb == cpb) {
-      ld_cb = 0;
-      set_tap(++ld_tap);
-    }
-  };
-  auto issue = [&](int stage, int kb) {
-#pragma unroll
-    for (int i = 0; i < AI; ++i) issue_a(stage, kb, i);
-#pragma unroll
-    for (int i = 0; i < BI; ++i) issue_b(stage, kb, i);
-    advance();
+    dy = t / p.KW - p.KH / 2;
+    dx = t % p.KW - p.KW / 2;
+    if (p.flip) { dy = -dy; dx = -dx; }
   };
 
-  // ---- fragment read addresses ----
-  const int wm = wave >> 1, wn = wave & 1;
+  // ---- per-lane load geometry (no memory reads: hipcc would wait vmcnt(0) on them inside the DMA pipeline).
+  // A lane's DMA state is (lr = row within an 8-row piece, s0 / s1 = its swizzled 16-byte chunk offset in even / odd
+  // pieces); the 64-bit source addresses are formed at issue time.  The one-stage loops re-derive even that from an
+  // opaque copy of the lane id in every iteration (a dozen VALU operations against 48 MFMAs): left to itself the
+  // compiler keeps ~30 loop-invariant address registers alive, which costs the fourth workgroup per CU (128 VGPRs).
+  // chunk swizzle of LDS row `row` = piece * 8 + lr: (row >> 1) & 7 = ((piece & 1) * 4 + (lr >> 1)) & 7
+  struct LaneGeom { int lr, s0, s1; };
+  auto lane_geom = [&](int ln) {
+    const int lr = ln >> 3, lc = ln & 7;
+    return LaneGeom{lr, (lc ^ (lr >> 1)) * 16, (lc ^ (4 + (lr >> 1))) * 16};
+  };
+  auto clamp_row = [&](int gm) { return gm < 0 ? 0 : (gm > Mi - 1 ? Mi - 1 : gm); };  // rows outside the matrix:
+                                                                                       // valid memory, never used unmasked
+  int a_yx[MODE == SHIFTED ? AI : 1];  // SHIFTED: map position of the lane's row in each of its A pieces
+  if (MODE == SHIFTED) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int gm = clamp_row((int)m0 + (wave * AI + i) * 8 + (lane >> 3));
+      a_yx[i] = (((gm / p.W) % p.H) << 16) | (gm % p.W);
+    }
+  }
+
+  // ---- LDS-DMA issue of the tiles of one k-step ----
+  auto issue_b = [&](int stage, int kb, const LaneGeom& g) {
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int piece = wave * BI + i;
+      int gn = n0 + piece * 8 + g.lr;
+      if (gn > p.N - 1) gn = p.N - 1;
+      glds16(p.B + (long)gn * p.b_rs + (long)kb * 128 + ((piece & 1) ? g.s1 : g.s0),
+             smem + stage * STAGE + A_BYTES + piece * 1024);
+    }
+  };
+  auto issue_a_plain = [&](int stage, int kb, const LaneGeom& g) {
+    const bool first = kb < cpb;     // wave-uniform: which of the two K-concatenated operands this k-step reads
+    const char* base = first ? p.A : p.A2;
+    const long rs = first ? p.a_rs : p.a2_rs;
+    const long koff = (long)(first ? kb : kb - cpb) * 128;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int piece = wave * AI + i;
+      glds16(base + (long)clamp_row((int)m0 + piece * 8 + g.lr) * rs + koff + ((piece & 1) ? g.s1 : g.s0),
+             smem + stage * STAGE + piece * 1024);
+    }
+  };
+  const char* zero_line = g_zero_line;
+  auto issue_a_shifted = [&](int stage, int cb, const LaneGeom& g) {  // tap state (dy, dx) set by the caller
+    const long shift = ((long)dy * p.W + dx) * p.a_rs + (long)cb * 128;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int piece = wave * AI + i;
+      const char* src = p.A + (long)clamp_row((int)m0 + piece * 8 + g.lr) * p.a_rs + shift + ((piece & 1) ? g.s1 : g.s0);
+      const int y = (a_yx[MODE == SHIFTED ? i : 0] >> 16) + dy, x = (a_yx[MODE == SHIFTED ? i : 0] & 0xffff) + dx;
+      if ((unsigned)y >= (unsigned)p.H || (unsigned)x >= (unsigned)p.W) src = zero_line + (g.s0 & 0x70);
+      glds16(src, smem + stage * STAGE + piece * 1024);
+    }
+  };
+  auto issue_a_halo = [&](int cb, const LaneGeom& g) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int piece = wave + NW * i;
+      if (piece < A_PIECES)  // wave-uniform
+        glds16(p.A + (long)clamp_row((int)m0 + piece * 8 + g.lr - kHalo) * p.a_rs + (long)cb * 128 + ((piece & 1) ? g.s1 : g.s0),
+               smem + piece * 1024);
+    }
+  };
+
+  // ---- fragment read addresses.  Fragment f of a wave covers tile rows .. + f*16 + frow: the swizzle term
+  // ((row >> 1) & 7) does not depend on f, so the four fragments of an operand sit 2048 bytes apart. ----
+  const int wm = wave / WN, wn = wave % WN;
   const int frow = lane & 15, fc = lane >> 4;
-  int a_rd[4], b_rd[4];
+  const int a_rd0 = (wm * 64 + frow) * 128 + ((fc ^ ((frow >> 1) & 7)) << 4);
+  const int b_rd0 = A_BYTES + (wn * 64 + frow) * 128 + ((fc ^ ((frow >> 1) & 7)) << 4);
+  // HALO: which taps of the lane's row (in each of its 4 fragments) fall inside the map: bit t of a 16-bit field
+  unsigned h_ok[2] = {0u, 0u};
+  if (MODE == HALO) {
 #pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    const int ra = wm * 64 + f * 16 + frow;
-    a_rd[f] = ra * 128 + ((fc ^ ((ra >> 1) & 7)) << 4);
-    const int rb = wn * 64 + f * 16 + frow;
-    b_rd[f] = A_BYTES + rb * 128 + ((fc ^ ((rb >> 1) & 7)) << 4);
+    for (int f = 0; f < 4; ++f) {
+      const int gm = clamp_row((int)m0 + wm * 64 + f * 16 + frow);
+      const int x = gm % p.W, y = (gm / p.W) % p.H;
+      unsigned mask = 0u;
+      for (int t = 0; t < p.T; ++t) {
+        set_tap(t);
+        if ((unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W) mask |= 1u << t;
+      }
+      h_ok[f >> 1] |= mask << ((f & 1) * 16);
+    }
+    if (threadIdx.x < 8) *(uint4*)(smem + ZROW * 128 + threadIdx.x * 16) = make_uint4(0u, 0u, 0u, 0u);
   }
 
   f32x4 acc[4][4];
@@ -192,175 +242,20 @@ __global__ __launch_bounds__(WM * 128, (NS == 1 && ABL == 7) ? 4 : 1) void split
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ABL == 6 (NS == 3): FRAGMENT DOUBLE BUFFERING.  One 8-wave workgroup per CU has every wave at the same barrier,
-  // so the LDS reads of a k-step are exposed (no second workgroup fills the matrix cores meanwhile).  Here the
-  // fragments of stage kb+1 are read into a second register set right after the barrier of step kb, and the 48 MFMAs
-  // of step kb run on the set that was read one step earlier: the matrix cores never wait for LDS.  Three LDS
-  // buffers: compute reads none, fragment reads take stage kb+1, the DMA fills stage kb+2.
-  if (NS == 1) {
-    // single LDS stage, three workgroups per CU: no overlap inside a workgroup (load -> barrier -> compute ->
-    // barrier), the other two workgroups fill the gaps.  Probe (tile_m code 1128).
-    for (int kb = 0; kb < nk; ++kb) {
-      issue(0, kb);
-      __syncthreads();
-      const char* base = smem;
-      bf16x8 ah[4], al[4], bh[4], bl[4];
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        bh[f] = *(const bf16x8*)(base + b_rd[f]);
-        ah[f] = *(const bf16x8*)(base + a_rd[f]);
-      }
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        bl[f] = *(const bf16x8*)(base + (b_rd[f] ^ 64));
-        al[f] = *(const bf16x8*)(base + (a_rd[f] ^ 64));
-      }
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[g], ah[f], acc[f][g], 0, 0, 0);
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[g], al[f], acc[f][g], 0, 0, 0);
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[g], ah[f], acc[f][g], 0, 0, 0);
-      __syncthreads();
-    }
-  } else
-  if (NS == 3 && ABL == 6) {
-    bf16x8 f0[16], f1[16];
-    auto read_frags = [&](bf16x8* fr, int buf) {
-      const char* base = smem + buf * STAGE;
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        fr[8 + f] = *(const bf16x8*)(base + b_rd[f]);
-        fr[f] = *(const bf16x8*)(base + a_rd[f]);
-      }
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        fr[12 + f] = *(const bf16x8*)(base + (b_rd[f] ^ 64));
-        fr[4 + f] = *(const bf16x8*)(base + (a_rd[f] ^ 64));
-      }
-    };
-    auto mfmas = [&](const bf16x8* fr) {
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[8 + g], fr[f], acc[f][g], 0, 0, 0);
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[8 + g], fr[4 + f], acc[f][g], 0, 0, 0);
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[12 + g], fr[f], acc[f][g], 0, 0, 0);
-    };
-    issue(0, 0);
-    __syncthreads();
-    if (nk > 1) issue(1, 1);
-    read_frags(f0, 0);
-    int b1 = 1, b2 = 2;  // ring slots of stages kb+1 and kb+2
-    for (int kb = 0; kb < nk; kb += 2) {
-      if (kb + 1 < nk) {
-        __syncthreads();                       // stage kb+1 landed everywhere; slot b2 (stage kb-1) no longer read
-        if (kb + 2 < nk) issue(b2, kb + 2);
-        read_frags(f1, b1);
-      }
-      mfmas(f0);
-      b1 = b2; b2 = b2 == 2 ? 0 : b2 + 1;
-      if (kb + 1 < nk) {
-        if (kb + 2 < nk) {
-          __syncthreads();
-          if (kb + 3 < nk) issue(b2, kb + 3);
-          read_frags(f0, b1);
-        }
-        mfmas(f1);
-        b1 = b2; b2 = b2 == 2 ? 0 : b2 + 1;
-      }
-    }
-  } else {
-  // NS == 2: one __syncthreads per k-step (its fence drains this wave's DMAs: stage kb landed, stage kb-1's buffer
-  // free), the next stage in flight under the MFMAs.  NS == 3: a ring with TWO stages in flight -- the wait is a
-  // counted vmcnt that leaves the younger stage outstanding, and the barrier is a raw s_barrier (a __syncthreads
-  // would drain the DMA queue: an LDS-DMA is a pending LDS write on the VM counter).
-  issue(0, 0);
-  if (NS == 3 && nk > 1) issue(1, 1);
-  int st = 0;  // ring slot of stage kb
-  for (int kb = 0; kb < nk; ++kb) {
-    // ABL == 3 (A/B probe): the 8 DMA pieces of the next stage spread over the MFMA groups below (one piece per 4
-    // MFMAs, order pinned by sched_barrier) instead of issued back to back after the barrier.  Measured 0-8 % SLOWER
-    // than the burst on the res5 shapes (pinning the order costs more than the cheaper DMA issue slots give back).
-    constexpr bool ILV = NS == 2 && ABL == 3;
-    const bool more = kb + 1 < nk;
-    if (NS == 2) {
-      __syncthreads();
-      if (!ILV && more && (ABL != 1 || kb == 0)) issue((kb + 1) & 1, kb + 1);
-    } else {
-      if (kb + 1 < nk && ABL != 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (kb + 2 < nk && ABL != 1) issue(st == 0 ? 2 : st - 1, kb + 2);
-    }
-    const char* base = smem + st * STAGE;
-    st = (st + 1 == NS) ? 0 : st + 1;
-    if (ABL == 4 || ABL == 5) continue;  // ablation: the DMA / load stream alone (no LDS reads, no MFMAs)
+  // one k-step on the staged tiles: 16 fragment reads, 48 MFMAs (hi.hi, lo.hi, hi.lo per fragment pair); a0..a3 =
+  // LDS addresses of the lane's four A fragments
+  auto compute = [&](const char* base, int b0, int a0, int a1, int a2, int a3) {
+    const int ard[4] = {a0, a1, a2, a3};
     bf16x8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-      bh[f] = *(const bf16x8*)(base + b_rd[f]);
-      ah[f] = *(const bf16x8*)(base + a_rd[f]);
+      bh[f] = *(const bf16x8*)(base + b0 + f * 2048);
+      ah[f] = *(const bf16x8*)(base + ard[f]);
     }
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-      bl[f] = *(const bf16x8*)(base + (b_rd[f] ^ 64));
-      al[f] = *(const bf16x8*)(base + (a_rd[f] ^ 64));
-    }
-    if (ABL == 2) {  // ablation: loads + LDS reads only
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        acc[f][0] += __builtin_bit_cast(f32x4, ah[f]);
-        acc[f][1] += __builtin_bit_cast(f32x4, al[f]);
-        acc[f][2] += __builtin_bit_cast(f32x4, bh[f]);
-        acc[f][3] += __builtin_bit_cast(f32x4, bl[f]);
-      }
-      continue;
-    }
-    if (ILV) {
-      const int nst = (kb + 1) & 1;
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[g], ah[f], acc[f][g], 0, 0, 0);
-        if (more && f < AI) issue_a(nst, kb + 1, f);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[g], al[f], acc[f][g], 0, 0, 0);
-        if (more && f < BI) issue_b(nst, kb + 1, f);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (more) advance();
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[g], ah[f], acc[f][g], 0, 0, 0);
-      continue;
+      bl[f] = *(const bf16x8*)(base + ((b0 + f * 2048) ^ 64));
+      al[f] = *(const bf16x8*)(base + (ard[f] ^ 64));
     }
 #pragma unroll
     for (int f = 0; f < 4; ++f)
@@ -377,49 +272,119 @@ __global__ __launch_bounds__(WM * 128, (NS == 1 && ABL == 7) ? 4 : 1) void split
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[g], ah[f], acc[f][g], 0, 0, 0);
-  }
+  };
+  auto compute_static = [&](const char* base) { compute(base, b_rd0, a_rd0, a_rd0 + 2048, a_rd0 + 4096, a_rd0 + 6144); };
 
-  }  // legacy loop
-  if (ABL == 5) acc[0][0].x += __uint_as_float(sink.x ^ sink.y ^ sink.z ^ sink.w);
-  // ---- epilogue: lane owns row m = .. + (lane & 15), columns n = .. + (lane >> 4) * 4 + {0..3} of each tile ----
+  if (MODE == HALO) {
+    // k = (channel block, tap): one halo tile per channel block, one B tile per tap
+    const int cb0 = slice * p.steps_per_slice;
+    int cb1 = cb0 + p.steps_per_slice;
+    if (cb1 > cpb) cb1 = cpb;
+    int t = 0, cb = cb0;
+    for (int it = (cb1 - cb0) * p.T; it > 0; --it) {  // one flat loop: per-tap state is re-derived, not kept per tap
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const LaneGeom g = lane_geom(ln);
+      const int fr = ln & 15, fq = ln >> 4;
+      if (t == 0) issue_a_halo(cb, g);
+      issue_b(0, t * cpb + cb, g);
+      set_tap(t);
+      // the tap's rows sit dy*W + dx LDS rows further (always inside the halo tile); lanes whose shifted pixel lies
+      // outside the map read the zero row instead
+      const int L0 = wm * 64 + fr + kHalo + dy * p.W + dx;
+      const int ard0 = L0 * 128 + ((fq ^ ((L0 >> 1) & 7)) << 4), zrd = ZROW * 128 + (fq << 4);
+      const int b0 = A_BYTES + (wn * 64 + fr) * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
+      int ard[4];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    const long m = m0 + wm * 64 + f * 16 + frow;
-    if (m >= p.M || wm * 64 + f * 16 + frow >= p.bm_eff) continue;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n = n0 + wn * 64 + g * 16 + fc * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[f][g];
-      if (p.bias) {
-        const f32x4 b = *(const f32x4*)(p.bias + n);
-        v += b;
-      }
-      if (p.res) {
-        const f32x4 r = *(const f32x4*)(p.res + m * p.ldr + n);
-        v += r;
-      }
-      if (p.relu) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      }
-      if (p.gate) {  // data gradient of a layer whose input went through a ReLU: zero where that activation was <= 0
-        const uint2 h = *(const uint2*)(p.gate + m * p.gate_rs + (long)(n >> 5) * 128 + (n & 31) * 2);
-        const unsigned a0 = h.x & 0xffffu, a1 = h.x >> 16, a2 = h.y & 0xffffu, a3 = h.y >> 16;
-        if (a0 == 0u || a0 >= 0x8000u) v.x = 0.f;
-        if (a1 == 0u || a1 >= 0x8000u) v.y = 0.f;
-        if (a2 == 0u || a2 >= 0x8000u) v.z = 0.f;
-        if (a3 == 0u || a3 >= 0x8000u) v.w = 0.f;
-      }
-      if (p.C) *(f32x4*)(p.C + m * p.ldc + n) = v;
-      if (p.Cp) {
-        const unsigned h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
-        const unsigned l01 = pack_bf16(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
-        const unsigned l23 = pack_bf16(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
-        char* d = p.Cp + m * p.cp_rs + (long)(n >> 5) * 128 + (n & 31) * 2;
-        *(uint2*)d = make_uint2(h01, h23);
-        *(uint2*)(d + 64) = make_uint2(l01, l23);
+      for (int f = 0; f < 4; ++f) ard[f] = ((h_ok[f >> 1] >> ((f & 1) * 16 + t)) & 1u) ? ard0 + f * 2048 : zrd;
+      __syncthreads();
+      compute(smem, b0, ard[0], ard[1], ard[2], ard[3]);
+      __syncthreads();
+      if (++t == p.T) {
+        t = 0;
+        ++cb;
       }
     }
+  } else {
+    const int kb0 = slice * p.steps_per_slice;
+    int kb1 = kb0 + p.steps_per_slice;
+    if (kb1 > nk) kb1 = nk;
+    int ld_tap = 0, ld_cb = kb0;       // (tap, channel block) of the next stage to load (SHIFTED)
+    if (MODE == SHIFTED) {
+      ld_tap = kb0 / cpb;
+      ld_cb = kb0 - ld_tap * cpb;
+      set_tap(ld_tap);
+    }
+    auto issue = [&](int stage, int kb, const LaneGeom& g) {
+      if (MODE == SHIFTED) {
+        issue_a_shifted(stage, ld_cb, g);
+        if (++ld_cb == cpb) {
+          ld_cb = 0;
+          set_tap(++ld_tap);
+        }
+      } else {
+        issue_a_plain(stage, kb, g);
+      }
+      issue_b(stage, kb, g);
+    };
+    if (NS == 1) {
+      for (int kb = kb0; kb < kb1; ++kb) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        issue(0, kb, lane_geom(ln));
+        __syncthreads();
+        compute_static(smem);
+        __syncthreads();
+      }
+    } else {
+      // one __syncthreads per k-step (its fence drains this wave's DMAs: stage kb landed, stage kb-1's buffer free),
+      // the next stage in flight under the MFMAs
+      const LaneGeom g = lane_geom(lane);
+      if (kb0 < kb1) issue(0, kb0, g);
+      for (int kb = kb0; kb < kb1; ++kb) {
+        __syncthreads();
+        if (kb + 1 < kb1) issue((kb + 1 - kb0) & 1, kb + 1, g);
+        compute_static(smem + ((kb - kb0) & 1) * STAGE);
+      }
+      __syncthreads();  // every wave is done with the stages: the epilogue reuses them
+    }
+  }
+
+  // ---- epilogue through the wave-private staging tile: 16 rows x 64 columns fp32, 16-byte slot s of row r at
+  // slot s ^ r (conflict-free for the fragment-order writes and the row-order reads) ----
+  char* stg = smem + wave * 4096;
+  const int er = lane >> 4, es = lane & 15;   // row within a group of 4, 4-column slot
+  const int n = n0 + wn * 64 + es * 4;
+  float* slab = p.slab ? p.slab + (long)slice * p.M * p.N : nullptr;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *(f32x4*)(stg + frow * 256 + (((g * 4 + fc) ^ frow) << 4)) = acc[f][g];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = it * 4 + er;
+      const f32x4 v = *(const f32x4*)(stg + r * 256 + ((es ^ r) << 4));
+      const long m = m0 + wm * 64 + f * 16 + r;
+      if (m < p.M && n < p.N) {
+        if (slab) *(f32x4*)(slab + m * p.N + n) = v;
+        else epilogue_store4(p, m, n, v);
+      }
+    }
+  }
+}
+
+// Sum of the split-K slabs + the epilogue of split_gemm_kernel, 4 columns per thread.
+__global__ __launch_bounds__(256) void split_gemm_finish_kernel(SplitGemmArgs p) {
+  const int n4 = p.N >> 2;
+  const long total = p.M * n4;
+  const long slab = p.M * p.N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / n4;
+    const int n = (int)(i - m * n4) * 4;
+    const float* s = p.slab + m * p.N + n;
+    f32x4 v = *(const f32x4*)s;
+    for (int k = 1; k < p.kslices; ++k) v += *(const f32x4*)(s + k * slab);
+    epilogue_store4(p, m, n, v);
   }
 }
 
@@ -457,9 +422,9 @@ struct SplitGemmTnArgs {
                : "n"(N)                                                                                            \
                : "memory")
 
-template <bool CONV, int NS = 2>
-__global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void split_gemm_tn_kernel(SplitGemmTnArgs p, int tiles_i, int tiles_j,
-                                                                            int nblocks) {
+template <bool CONV>
+__global__ __launch_bounds__(256, 2) void split_gemm_tn_kernel(SplitGemmTnArgs p, int tiles_i, int tiles_j,
+                                                              int nblocks) {
   constexpr int TILE_BYTES = 32 * 512, STAGE = 2 * TILE_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -566,17 +531,12 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void split_gemm_tn_kernel(Spl
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // NS == 2: the next stage loads under this stage's MFMAs, two workgroups per CU.  NS == 1: one stage, no overlap
-  // inside the workgroup, three workgroups per CU (<= 168 VGPRs) fill each other's load phases.
-  if (NS == 2 && nk > 0) issue(0);
+  // two LDS stages: the next stage loads under this stage's MFMAs, two workgroups per CU
+  if (nk > 0) issue(0);
   for (int kb = 0; kb < nk; ++kb) {
-    if (NS == 1) {
-      if (kb > 0) __syncthreads();  // everyone is done reading the stage
-      issue(0);
-    }
     __syncthreads();
-    if (NS == 2 && kb + 1 < nk) issue((kb + 1) & 1);
-    const int so = NS == 1 ? 0 : (kb & 1) * STAGE;  // the dynamic LDS segment starts at LDS address 0 (no static LDS in this TU's kernels)
+    if (kb + 1 < nk) issue((kb + 1) & 1);
+    const int so = (kb & 1) * STAGE;  // the dynamic LDS segment starts at LDS address 0 (no static LDS in this TU's kernels)
     bf16x4 xa[4][2], xb[4][2], ga[4][2], gb[4][2];  // [fragment][hi/lo]: first / second 4 rows of the lane's 8 k values
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -973,8 +933,7 @@ extern "C" int ovis_split_gemm_tn_slices(long m, int n, int channels, int taps) 
   // that is mostly empty costs as much as a full one (the 3x3 weight gradient of res5, 144 tiles: 8 slices = 1152
   // workgroups = 2.25 rounds ran at 75 %; 7 slices = 1008 fill two rounds to 98 %).  Among the slice counts of up to
   // ~4 rounds pick the one whose rounds are fullest, preferring about two rounds (enough parallelism, few slabs).
-  long slots = 2L * OVIS_NUM_CU;
-  if (const char* e = getenv("OVIS_TN_STAGES")) { if (atoi(e) == 1) slots = 3L * OVIS_NUM_CU; }  // probe: single-stage variant
+  const long slots = 2L * OVIS_NUM_CU;
   long s_max = (4 * slots + tiles - 1) / tiles;
   if (s_max > steps / 8) s_max = steps / 8;                              // at least 8 k-steps per slice
   if (s_max > 256) s_max = 256;
@@ -1014,16 +973,7 @@ extern "C" int ovis_split_gemm_pair_tn(const void* g_pair, long g_row_bytes, con
   const long nblocks = (long)tiles_i * tiles_j * slices;
   if (nblocks > 0x7fffffffL) return OVIS_ERANGE;
   hipStream_t s = (hipStream_t)stream;
-  int lds = 2 * 2 * 32 * 512;
-  if (const char* e = getenv("OVIS_TN_STAGES")) {
-    if (atoi(e) == 1) {
-      lds = 2 * 32 * 512;
-      if (T > 1) hipLaunchKernelGGL((split_gemm_tn_kernel<true, 1>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_i, tiles_j, (int)nblocks);
-      else hipLaunchKernelGGL((split_gemm_tn_kernel<false, 1>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_i, tiles_j, (int)nblocks);
-      OVIS_LAUNCH_CHECK();
-      return OVIS_OK;
-    }
-  }
+  const int lds = 2 * 2 * 32 * 512;
   if (T > 1) {
     static bool attr_set_c = false;
     if (!attr_set_c) {
@@ -1043,176 +993,160 @@ extern "C" int ovis_split_gemm_pair_tn(const void* g_pair, long g_row_bytes, con
   return OVIS_OK;
 }
 
-static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
-                                float* c, long ldc, void* c_pair, long c_pair_row_bytes, const float* bias,
-                                const float* residual, long ldr, const void* gate_pair, long gate_row_bytes, long m,
-                                int n, int channels, int taps_h, int taps_w, int height, int width, int flip, int relu,
-                                int tile_m, void* stream);
+// ---- launch plan of the NT kernel (shared by the launcher and the workspace query) ----
+namespace {
+struct SplitGemmPlan {
+  int mode, narrow, stages, kslices, steps_per_slice, tiles_m, tiles_n;
+};
 
-extern "C" int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
-                                    float* c, long ldc, void* c_pair, long c_pair_row_bytes, const float* bias,
-                                    const float* residual, long ldr, long m, int n, int channels, int taps_h,
-                                    int taps_w, int height, int width, int flip, int relu, int tile_m,
+// config: 0 = choose; otherwise a bit set for tests / A-B probes: 1 = one LDS stage, 2 = two stages, 4 = never use
+// the halo form, 8 = no split-K.
+SplitGemmPlan split_gemm_plan(long m, int n, int channels, int channels2, int taps_h, int taps_w, int width, int config) {
+  SplitGemmPlan q;
+  const int T = taps_h * taps_w;
+  q.narrow = n <= 64;                       // 64-column tiles (2 waves): layer1 / stem, no masked half tile
+  const int bn = q.narrow ? 64 : 128;
+  q.tiles_m = (int)((m + 127) / 128);
+  q.tiles_n = (n + bn - 1) / bn;
+  const long nb = (long)q.tiles_m * q.tiles_n;
+  q.mode = PLAIN;
+  if (T > 1) q.mode = (!q.narrow && !(config & 4) && (taps_h / 2) * width + taps_w / 2 <= kHalo && T <= 16) ? HALO : SHIFTED;
+  const int cpb = channels / 32;
+  const int units = q.mode == HALO ? cpb : T * cpb + channels2 / 32;   // what a K slice is counted in
+  // split-K: a grid that leaves most CUs idle while every workgroup walks a long K
+  q.kslices = 1;
+  q.steps_per_slice = units;
+  if (!(config & 8) && !q.narrow && nb <= OVIS_NUM_CU / 2) {
+    const int min_units = q.mode == HALO ? 1 : 8;
+    long s = units / min_units;
+    const long want = (2L * OVIS_NUM_CU + nb - 1) / nb;
+    if (s > want) s = want;
+    if (s > 64) s = 64;
+    if (s >= 2) {
+      q.steps_per_slice = (int)((units + s - 1) / s);
+      q.kslices = (units + q.steps_per_slice - 1) / q.steps_per_slice;
+    }
+  }
+  // Large grids: ONE LDS stage and three / four workgroups per CU instead of two double-buffered ones -- nothing
+  // overlaps inside a workgroup, but more independent workgroups hide each other's load phases better (measured on
+  // M = 50176: N = 2048 1x1 +9...17 %, 3x3 +3 %; on M = 100352: every 1x1 +7...16 %, 3x3 +7 %; grids below ~2 rounds
+  // of two-stage workgroups lose with one stage -- except when they overflow the two-stage round by a few workgroups
+  // and fit one single-stage round).
+  const long total = nb * q.kslices;
+  q.stages = 2;
+  if (q.mode == HALO || q.narrow) q.stages = 1;
+  else if (total >= 8L * OVIS_NUM_CU || (total >= 4L * OVIS_NUM_CU && (T > 1 || q.tiles_n >= 8))) q.stages = 1;
+  else {
+    const long slots2 = 2L * OVIS_NUM_CU, slots1 = 4L * OVIS_NUM_CU;
+    if (total > slots2 && total <= slots2 + slots2 / 4 && total <= slots1) q.stages = 1;
+  }
+  if (config & 1) q.stages = 1;
+  if ((config & 2) && q.mode != HALO && !q.narrow) q.stages = 2;
+  return q;
+}
+}  // namespace
+
+extern "C" size_t ovis_split_gemm_pair_workspace_bytes(long m, int n, int channels, int channels2, int taps_h,
+                                                       int taps_w, int width) {
+  if (m <= 0 || n <= 0 || channels <= 0 || taps_h <= 0 || taps_w <= 0) return 0;
+  const SplitGemmPlan q = split_gemm_plan(m, n, channels, channels2, taps_h, taps_w, width, 0);
+  return q.kslices > 1 ? (size_t)q.kslices * (size_t)m * (size_t)n * sizeof(float) : 0;
+}
+
+static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void* a2_pair, long a2_row_bytes,
+                                const void* b_pair, long b_row_bytes, float* c, long ldc, void* c_pair,
+                                long c_pair_row_bytes, const float* bias, const float* residual, long ldr,
+                                const void* gate_pair, long gate_row_bytes, long m, int n, int channels, int channels2,
+                                int taps_h, int taps_w, int height, int width, int flip, int relu, void* workspace,
+                                size_t workspace_bytes, int config, void* stream) {
+  if (m < 0 || n < 0 || channels < 0 || channels2 < 0 || taps_h <= 0 || taps_w <= 0 || !(taps_h & 1) || !(taps_w & 1))
+    return OVIS_EINVAL;
+  if (m == 0 || n == 0) return OVIS_OK;
+  if (!a_pair || !b_pair || (!c && !c_pair) || channels == 0 || m > 0x7fffff00L) return OVIS_EINVAL;
+  const int T = taps_h * taps_w;
+  if (T > 1 && (height <= 0 || width <= 0 || height > 32767 || width > 32767 || channels2 != 0)) return OVIS_EINVAL;
+  if (channels2 != 0 && !a2_pair) return OVIS_EINVAL;
+  if (channels % 32 != 0 || channels2 % 32 != 0 || n % 4 != 0 || (c_pair && n % 32 != 0) || a_row_bytes % 16 != 0 ||
+      a2_row_bytes % 16 != 0 || b_row_bytes % 16 != 0 || ((uintptr_t)a_pair & 15) || ((uintptr_t)a2_pair & 15) ||
+      ((uintptr_t)b_pair & 15) || ((uintptr_t)c & 15) || ((uintptr_t)c_pair & 15) || ((uintptr_t)bias & 15) ||
+      ((uintptr_t)residual & 15) || ((uintptr_t)workspace & 15) || ldc % 4 != 0 || ldr % 4 != 0 ||
+      c_pair_row_bytes % 16 != 0)
+    return OVIS_ERANGE;
+  if (config < 0 || config > 15) return OVIS_ERANGE;
+  SplitGemmPlan q = split_gemm_plan(m, n, channels, channels2, taps_h, taps_w, width, config);
+  if (q.kslices > 1 && (!workspace || workspace_bytes < (size_t)q.kslices * (size_t)m * (size_t)n * sizeof(float))) {
+    // no (or too small a) workspace: the un-split grid
+    q = split_gemm_plan(m, n, channels, channels2, taps_h, taps_w, width, config | 8);
+  }
+  SplitGemmArgs p;
+  p.A = (const char*)a_pair; p.a_rs = a_row_bytes;
+  p.A2 = (const char*)a2_pair; p.a2_rs = a2_row_bytes;
+  p.B = (const char*)b_pair; p.b_rs = b_row_bytes;
+  p.C = c; p.ldc = ldc; p.Cp = (char*)c_pair; p.cp_rs = c_pair_row_bytes;
+  p.bias = bias; p.res = residual; p.ldr = ldr;
+  p.gate = (const char*)gate_pair; p.gate_rs = gate_row_bytes;
+  p.slab = q.kslices > 1 ? (float*)workspace : nullptr;
+  p.M = m; p.N = n; p.ch = channels; p.ch2 = channels2; p.T = T; p.H = height; p.W = width; p.KH = taps_h; p.KW = taps_w;
+  p.flip = flip; p.relu = relu;
+  p.kslices = q.kslices; p.steps_per_slice = q.steps_per_slice;
+  p.gw = (q.tiles_n % 4 == 0) ? 4 : q.tiles_n;   // column groups of 4 weight tiles (2 MB) stay in an XCD's L2
+  const long ntiles = (long)q.tiles_m * q.tiles_n;
+  const long nblocks = ntiles * q.kslices;
+  if (nblocks > 0x7fffffffL) return OVIS_ERANGE;
+  hipStream_t s = (hipStream_t)stream;
+#define OVIS_SG_LAUNCH(WM_, WN_, MODE_, NS_, OCC_)                                                                  \
+  do {                                                                                                              \
+    constexpr int a_rows = MODE_ == HALO ? WM_ * 64 + 2 * kHalo + 1 : WM_ * 64;                                      \
+    constexpr int lds = NS_ * (a_rows * 128 + WN_ * 64 * 128);                                                       \
+    static bool attr_set = false;                                                                                   \
+    if (!attr_set) {                                                                                                \
+      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<WM_, WN_, MODE_, NS_, OCC_>,                  \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));                           \
+      attr_set = true;                                                                                              \
+    }                                                                                                               \
+    hipLaunchKernelGGL((split_gemm_kernel<WM_, WN_, MODE_, NS_, OCC_>), dim3((unsigned)nblocks),                    \
+                       dim3(WM_ * WN_ * 64), lds, s, p, q.tiles_n, (int)ntiles);                                    \
+  } while (0)
+  if (q.narrow) {
+    if (q.mode == PLAIN) OVIS_SG_LAUNCH(2, 1, PLAIN, 1, 2); else OVIS_SG_LAUNCH(2, 1, SHIFTED, 1, 2);
+  } else if (q.mode == HALO) {
+    OVIS_SG_LAUNCH(2, 2, HALO, 1, 4);
+  } else if (q.mode == SHIFTED) {
+    if (q.stages == 1) OVIS_SG_LAUNCH(2, 2, SHIFTED, 1, 4); else OVIS_SG_LAUNCH(2, 2, SHIFTED, 2, 2);
+  } else {
+    if (q.stages == 1) OVIS_SG_LAUNCH(2, 2, PLAIN, 1, 4); else OVIS_SG_LAUNCH(2, 2, PLAIN, 2, 2);
+  }
+#undef OVIS_SG_LAUNCH
+  OVIS_LAUNCH_CHECK();
+  if (q.kslices > 1) {
+    p.slab = (float*)workspace;
+    const long total = m * (n / 4);
+    const long blocks = (total + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 8L * OVIS_NUM_CU ? blocks : 8L * OVIS_NUM_CU);
+    hipLaunchKernelGGL(split_gemm_finish_kernel, dim3(grid), dim3(256), 0, s, p);
+    OVIS_LAUNCH_CHECK();
+  }
+  return OVIS_OK;
+}
+
+extern "C" int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const void* a2_pair, long a2_row_bytes,
+                                    const void* b_pair, long b_row_bytes, float* c, long ldc, void* c_pair,
+                                    long c_pair_row_bytes, const float* bias, const float* residual, long ldr, long m,
+                                    int n, int channels, int channels2, int taps_h, int taps_w, int height, int width,
+                                    int flip, int relu, void* workspace, size_t workspace_bytes, int config,
                                     void* stream) {
-  return split_gemm_pair_impl(a_pair, a_row_bytes, b_pair, b_row_bytes, c, ldc, c_pair, c_pair_row_bytes, bias, residual,
-                              ldr, nullptr, 0, m, n, channels, taps_h, taps_w, height, width, flip, relu, tile_m, stream);
+  return split_gemm_pair_impl(a_pair, a_row_bytes, a2_pair, a2_row_bytes, b_pair, b_row_bytes, c, ldc, c_pair,
+                              c_pair_row_bytes, bias, residual, ldr, nullptr, 0, m, n, channels, channels2, taps_h,
+                              taps_w, height, width, flip, relu, workspace, workspace_bytes, config, stream);
 }
 
 extern "C" int ovis_split_gemm_pair_gated(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
                                           float* c, long ldc, void* c_pair, long c_pair_row_bytes,
                                           const void* gate_pair, long gate_row_bytes, long m, int n, int channels,
-                                          int taps_h, int taps_w, int height, int width, int flip, void* stream) {
+                                          int taps_h, int taps_w, int height, int width, int flip, int config,
+                                          void* stream) {
   if (!gate_pair || gate_row_bytes % 16 != 0 || ((uintptr_t)gate_pair & 15) || n % 32 != 0) return OVIS_ERANGE;
-  return split_gemm_pair_impl(a_pair, a_row_bytes, b_pair, b_row_bytes, c, ldc, c_pair, c_pair_row_bytes, nullptr,
-                              nullptr, 0, gate_pair, gate_row_bytes, m, n, channels, taps_h, taps_w, height, width, flip,
-                              0, 0, stream);
-}
-
-static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
-                                float* c, long ldc, void* c_pair, long c_pair_row_bytes, const float* bias,
-                                const float* residual, long ldr, const void* gate_pair, long gate_row_bytes, long m,
-                                int n, int channels, int taps_h, int taps_w, int height, int width, int flip, int relu,
-                                int tile_m, void* stream) {
-  if (m < 0 || n < 0 || channels < 0 || taps_h <= 0 || taps_w <= 0 || !(taps_h & 1) || !(taps_w & 1))
-    return OVIS_EINVAL;
-  if (m == 0 || n == 0) return OVIS_OK;
-  if (!a_pair || !b_pair || (!c && !c_pair) || channels == 0 || m > 0x7fffff00L) return OVIS_EINVAL;
-  const int T = taps_h * taps_w;
-  if (T > 1 && (height <= 0 || width <= 0 || height > 32767 || width > 32767)) return OVIS_EINVAL;
-  if (channels % 32 != 0 || n % 4 != 0 || (c_pair && n % 32 != 0) || a_row_bytes % 16 != 0 || b_row_bytes % 16 != 0 ||
-      ((uintptr_t)a_pair & 15) || ((uintptr_t)b_pair & 15) || ((uintptr_t)c & 15) || ((uintptr_t)c_pair & 15) ||
-      ((uintptr_t)bias & 15) || ((uintptr_t)residual & 15) || ldc % 4 != 0 || ldr % 4 != 0 ||
-      c_pair_row_bytes % 16 != 0)
-    return OVIS_ERANGE;
-  int stages = 2, abl = 0;
-  if (tile_m >= 10000) { abl = tile_m / 10000; tile_m %= 10000; }  // ablation probes (tools/experiments only)
-  if (tile_m >= 1000) { stages = tile_m / 1000; tile_m %= 1000; }
-  if ((tile_m != 0 && tile_m != 128 && tile_m != 256) || (stages != 1 && stages != 2 && stages != 3)) return OVIS_ERANGE;
-  SplitGemmArgs p;
-  p.A = (const char*)a_pair; p.a_rs = a_row_bytes;
-  p.B = (const char*)b_pair; p.b_rs = b_row_bytes;
-  p.C = c; p.ldc = ldc; p.Cp = (char*)c_pair; p.cp_rs = c_pair_row_bytes;
-  p.bias = bias; p.res = residual; p.ldr = ldr;
-  p.gate = (const char*)gate_pair; p.gate_rs = gate_row_bytes;
-  p.M = m; p.N = n; p.ch = channels; p.T = T; p.H = height; p.W = width; p.KH = taps_h; p.KW = taps_w;
-  p.flip = flip; p.relu = relu;
-  const int tiles_n = (n + 127) / 128;
-  {
-    int gw = 4;
-    if (const char* e = getenv("OVIS_SG_GW")) gw = atoi(e);
-    if (gw <= 0 || gw > tiles_n || tiles_n % gw != 0) gw = tiles_n;
-    p.gw = gw;
-  }
-  hipStream_t s = (hipStream_t)stream;
-  int bm = tile_m;
-  if (bm == 0) {
-    bm = 128;  // independent 4-wave workgroups beat one 8-wave 256-row workgroup per CU on every shape measured
-    // Large grids: ONE LDS stage and three / four workgroups per CU instead of two double-buffered ones -- nothing
-    // overlaps inside a workgroup, but more independent workgroups hide each other's load phases better (measured on
-    // M = 50176: N = 2048 1x1 +9...17 %, 3x3 +3 %, N = 512 1x1 +-2 %; on M = 100352: every 1x1 +7...16 %, 3x3 +7 %;
-    // grids below ~2 rounds lose: they keep 2 stages).
-    const long nb = ((m + 127) / 128) * tiles_n;
-    const char* e = getenv("OVIS_SG_STAGES");
-    if (e) stages = atoi(e) == 1 ? 1 : 2;
-    else if ((nb >= 8L * OVIS_NUM_CU && !getenv("OVIS_SG_NARROW")) || (nb >= 4L * OVIS_NUM_CU && (T > 1 || tiles_n >= 8))) stages = 1;
-    if (stages == 1 && T == 1) abl = 7;  // the plain kernel fits 128 VGPRs: four workgroups per CU
-  }
-  // OVIS_SG_BALANCE=1 (probe): spread the rows over ceil(blocks / resident workgroups) FULL rounds of slightly shorter
-  // tiles.  Measured 0-12 % SLOWER on the res5 shapes (M = 50176 / 100352): the last, mostly empty round of the
-  // uniform tiling costs less than the extra weight-tile traffic of more, shorter row tiles.  Off by default.
-  p.bm_eff = bm;
-  if (bm == 128 && stages == 2 && !abl) {
-    const long slots = 2L * OVIS_NUM_CU;
-    const long blocks0 = ((m + 127) / 128) * tiles_n;
-    const long rounds = (blocks0 + slots - 1) / slots;
-    const char* e = getenv("OVIS_SG_BALANCE");
-    if (!e || atoi(e) == 0) goto no_balance;
-    {
-      const long rt = rounds * slots / tiles_n;            // row tiles that fill `rounds` rounds
-      if (rt > 0) {
-        long be = ((m + rt - 1) / rt + 7) / 8 * 8;
-        if (be >= 64 && be < 128) p.bm_eff = (int)be;
-      }
-    }
-  }
-no_balance:
-  const long tiles_m = (m + p.bm_eff - 1) / p.bm_eff;
-  const long nblocks = tiles_m * tiles_n;
-  if (nblocks > 0x7fffffffL) return OVIS_ERANGE;
- #define OVIS_SG_LAUNCH(WM_, CONV_, NS_)                                                                         \
-  do {                                                                                                          \
-    constexpr int lds = NS_ * (WM_ * 64 * 128 + 128 * 128);                                                     \
-    static bool attr_set = false;                                                                               \
-    if (!attr_set) {                                                                                            \
-      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<WM_, CONV_, NS_>,                         \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));                       \
-      attr_set = true;                                                                                          \
-    }                                                                                                           \
-    hipLaunchKernelGGL((split_gemm_kernel<WM_, CONV_, NS_>), dim3((unsigned)nblocks), dim3(WM_ * 128), lds, s,  \
-                       p, tiles_n, (int)nblocks);                                                               \
-  } while (0)
-  if (stages == 1 && bm == 128) {
-    constexpr int lds1 = 128 * 128 + 128 * 128;
-    if (abl == 7) {  // 4 waves per SIMD (<= 128 VGPRs): four workgroups per CU
-      if (T > 1) hipLaunchKernelGGL((split_gemm_kernel<2, true, 1, 7>), dim3((unsigned)nblocks), dim3(256), lds1, s, p, tiles_n, (int)nblocks);
-      else hipLaunchKernelGGL((split_gemm_kernel<2, false, 1, 7>), dim3((unsigned)nblocks), dim3(256), lds1, s, p, tiles_n, (int)nblocks);
-    } else {
-      if (T > 1) hipLaunchKernelGGL((split_gemm_kernel<2, true, 1, 0>), dim3((unsigned)nblocks), dim3(256), lds1, s, p, tiles_n, (int)nblocks);
-      else hipLaunchKernelGGL((split_gemm_kernel<2, false, 1, 0>), dim3((unsigned)nblocks), dim3(256), lds1, s, p, tiles_n, (int)nblocks);
-    }
-  } else if (stages == 1) {
-    return OVIS_ERANGE;
-  } else if (abl == 6 && bm == 256 && stages == 3) {
-    constexpr int lds3 = 3 * (256 * 128 + 128 * 128);
-    if (T > 1) {
-      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<4, true, 3, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
-      hipLaunchKernelGGL((split_gemm_kernel<4, true, 3, 6>), dim3((unsigned)nblocks), dim3(512), lds3, s, p, tiles_n, (int)nblocks);
-    } else {
-      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<4, false, 3, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
-      hipLaunchKernelGGL((split_gemm_kernel<4, false, 3, 6>), dim3((unsigned)nblocks), dim3(512), lds3, s, p, tiles_n, (int)nblocks);
-    }
-  } else if (abl && bm == 256 && stages == 3 && T == 1) {  // ablations of the 256-row, 3-stage ring (probe only)
-    constexpr int lds3 = 3 * (256 * 128 + 128 * 128);
-#define OVIS_ABL3(A_)                                                                                                    \
-  do {                                                                                                                   \
-    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<4, false, 3, A_>,                                    \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds3));                                 \
-    hipLaunchKernelGGL((split_gemm_kernel<4, false, 3, A_>), dim3((unsigned)nblocks), dim3(512), lds3, s, p, tiles_n,    \
-                       (int)nblocks);                                                                                    \
-  } while (0)
-    if (abl == 1) OVIS_ABL3(1); else if (abl == 2) OVIS_ABL3(2); else OVIS_ABL3(4);
-#undef OVIS_ABL3
-  } else if (abl) {
-    constexpr int lds = 2 * (128 * 128 + 128 * 128);
-    if (abl == 1) {
-      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      hipLaunchKernelGGL((split_gemm_kernel<2, false, 2, 1>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_n, (int)nblocks);
-    } else if (abl == 4) {
-      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, false, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      hipLaunchKernelGGL((split_gemm_kernel<2, false, 2, 4>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_n, (int)nblocks);
-    } else if (abl == 5) {
-      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, false, 2, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      hipLaunchKernelGGL((split_gemm_kernel<2, false, 2, 5>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_n, (int)nblocks);
-    } else if (abl == 3) {
-      if (T > 1) {
-        OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, true, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL((split_gemm_kernel<2, true, 2, 3>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_n, (int)nblocks);
-      } else {
-        OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, false, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL((split_gemm_kernel<2, false, 2, 3>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_n, (int)nblocks);
-      }
-    } else {
-      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      hipLaunchKernelGGL((split_gemm_kernel<2, false, 2, 2>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_n, (int)nblocks);
-    }
-  } else if (bm == 256) {
-    if (stages == 3) { if (T > 1) OVIS_SG_LAUNCH(4, true, 3); else OVIS_SG_LAUNCH(4, false, 3); }
-    else { if (T > 1) OVIS_SG_LAUNCH(4, true, 2); else OVIS_SG_LAUNCH(4, false, 2); }
-  } else {
-    if (stages == 3) { if (T > 1) OVIS_SG_LAUNCH(2, true, 3); else OVIS_SG_LAUNCH(2, false, 3); }
-    else { if (T > 1) OVIS_SG_LAUNCH(2, true, 2); else OVIS_SG_LAUNCH(2, false, 2); }
-  }
-#undef OVIS_SG_LAUNCH
-  OVIS_LAUNCH_CHECK();
-  return OVIS_OK;
+  return split_gemm_pair_impl(a_pair, a_row_bytes, nullptr, 0, b_pair, b_row_bytes, c, ldc, c_pair, c_pair_row_bytes,
+                              nullptr, nullptr, 0, gate_pair, gate_row_bytes, m, n, channels, 0, taps_h, taps_w, height,
+                              width, flip, 0, nullptr, 0, config | 8, stream);
 }

@@ -89,10 +89,14 @@ class _BottleneckPair(Function):
         _, o1p = _C.split_gemm_pair(xp, wpairs["w1"], b1, None, True, False, True)
         _, o2p = _C.split_gemm_pair(o1p, wpairs["w2"], b2, None, True, False, True, conv=(h, w, kh, kw, False))
         if wd is not None:
-            res, _ = _C.split_gemm_pair(xp, wpairs["wd"])
+            # conv3 and the projection shortcut as ONE product over K = [conv2 output | block input] against
+            # [w3 | wd] (pair rows concatenate block-wise): the shortcut tensor is never written or re-read
+            w3d = wpairs.get("w3d")
+            if w3d is None:
+                w3d = torch.cat([wpairs["w3"], wpairs["wd"]], 1)
+            out, outp = _C.split_gemm_pair(o2p, w3d, b3, None, True, True, want_pair, a2_pair=xp)
         else:
-            res = x
-        out, outp = _C.split_gemm_pair(o2p, wpairs["w3"], b3, res, True, True, want_pair)
+            out, outp = _C.split_gemm_pair(o2p, wpairs["w3"], b3, x, True, True, want_pair)
         # pool: also return the mean over the h*w rows of every map (the head's average pooling) as an output of THIS
         # node, so that its gradient is broadcast inside the fused gate + split kernel of the backward instead of
         # being materialised ([rows, C] expand) and added to the dense gradient by two tensor ops

@@ -149,6 +149,8 @@ class Bottleneck(nn.Module):
                 wp = {"w1": _C.weight_prep_pair(w1, s1)[0], "w2": _C.weight_prep_pair(w2, s2)[0],
                       "w3": _C.weight_prep_pair(w3, s3)[0],
                       "wd": _C.weight_prep_pair(wd, sd)[0] if wd is not None else None}
+                if wd is not None:
+                    wp["w3d"] = torch.cat([wp["w3"], wp["wd"]], 1)  # conv3 + projection shortcut as one product
                 self._pair_cache = (key, wp, (b3 if bd is None else b3 + bd).contiguous())
             wpairs, b3s = self._pair_cache[1], self._pair_cache[2]
         else:

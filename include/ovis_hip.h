@@ -265,7 +265,7 @@ int ovis_im2col_pair(const void* src_pair, void* dst_pair, long num, int height,
 int ovis_split_gemm_pair_gated(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
                                float* c, long ldc, void* c_pair, long c_pair_row_bytes, const void* gate_pair,
                                long gate_row_bytes, long m, int n, int channels, int taps_h, int taps_w,
-                               int height, int width, int flip, void* stream);
+                               int height, int width, int flip, int config, void* stream);
 
 /* im2col of a strided convolution on an NCHW f32 image [num, channels, height, width] into pair rows
  * [num*ho*wo, k_padded]: k = (ky*kw + kx)*channels + c, columns >= kh*kw*channels are zero (k_padded % 32 == 0).
@@ -273,23 +273,37 @@ int ovis_split_gemm_pair_gated(const void* a_pair, long a_row_bytes, const void*
 int ovis_im2col_nchw_pair_f32(const float* src, void* dst_pair, int num, int channels, int height, int width,
                               int kh, int kw, int stride, int pad, int k_padded, void* stream);
 
-/* C[m, n] = act( sum_{tap, c} A[row(m, tap), c] * B[n, tap*channels + c] + bias[n] + residual[m, n] )
+/* C[m, n] = act( sum_{tap, c} A[row(m, tap), c] * B[n, tap*channels + c] (+ sum_c A2[m, c] * B[n, channels + c])
+ *                + bias[n] + residual[m, n] )
  *   a_pair : pair rows of `channels` values, a_row_bytes apart.  taps_h = taps_w = 1: a plain
  *            [m, channels] matrix.  Otherwise an NHWC tensor [m / (height*width), height, width,
  *            channels]; tap (ty, tx) of row (r, y, x) reads pixel (y + ty - taps_h/2, x + tx -
  *            taps_w/2) (negated offsets when flip != 0: the data-gradient convolution), zeros
- *            outside the map -- stride-1 "same" convolution with no im2col matrix.
- *   b_pair : n pair rows of taps*channels values (weights [n, tap, c]), b_row_bytes apart.
+ *            outside the map -- stride-1 "same" convolution with no im2col matrix.  Maps whose largest
+ *            tap shift (taps_h/2)*width + taps_w/2 is <= 8 rows (the 7x7 maps of the res5 head) are
+ *            staged once per channel block with a halo and read by all taps from LDS.
+ *   a2_pair: optional second operand (taps 1x1 only; NULL / channels2 = 0 otherwise): [m, channels2] pair
+ *            rows whose products follow a_pair's along K, b_pair then holds channels + channels2 values
+ *            per row -- conv3 + projection shortcut of a bottleneck (mb/modeling/backbone/resnet.py:
+ *            323-344) as ONE product, the shortcut tensor is never written.
+ *   b_pair : n pair rows of taps*channels (+ channels2) values (weights [n, tap, c]), b_row_bytes apart.
  *   c      : fp32 result, row stride ldc elements, or NULL;  c_pair: the result in pair layout
  *            (rows c_pair_row_bytes apart; needs n % 32 == 0), or NULL -- the operand split of the
  *            NEXT layer fused into this epilogue.  bias [n] / residual [m, n] (stride ldr) may be NULL.
- *   tile_m : 0 = choose, 128 or 256 rows per workgroup.
- * channels % 32 == 0, n % 4 == 0, 16-byte aligned pointers and strides (else OVIS_ERANGE). */
-int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const void* b_pair,
-                         long b_row_bytes, float* c, long ldc, void* c_pair,
-                         long c_pair_row_bytes, const float* bias, const float* residual,
-                         long ldr, long m, int n, int channels, int taps_h, int taps_w,
-                         int height, int width, int flip, int relu, int tile_m, void* stream);
+ *   workspace : ovis_split_gemm_pair_workspace_bytes(...) bytes (16-byte aligned) or NULL.  Problems with few
+ *            output tiles and a long K (the pseudo-box passes: m = a few hundred rows) are cut along K into
+ *            slices whose partial tiles go to fp32 slabs in the workspace; a second launch sums them and
+ *            applies the epilogue (deterministic).  Without a workspace the un-split grid runs.
+ *   config : 0 = choose.  Otherwise a bit set for tests and A/B measurements: 1 = one LDS stage, 2 = two
+ *            stages, 4 = never use the halo form, 8 = no K slices.
+ * channels % 32 == 0, channels2 % 32 == 0, n % 4 == 0, 16-byte aligned pointers and strides (else OVIS_ERANGE). */
+size_t ovis_split_gemm_pair_workspace_bytes(long m, int n, int channels, int channels2, int taps_h, int taps_w,
+                                            int width);
+int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const void* a2_pair, long a2_row_bytes,
+                         const void* b_pair, long b_row_bytes, float* c, long ldc, void* c_pair,
+                         long c_pair_row_bytes, const float* bias, const float* residual, long ldr, long m,
+                         int n, int channels, int channels2, int taps_h, int taps_w, int height, int width,
+                         int flip, int relu, void* workspace, size_t workspace_bytes, int config, void* stream);
 
 /* Weight gradient on pair operands: c_slabs[s][n][tap*channels + c] = sum over the rows m of slice s of
  * G[m, n] * X[row(m, tap), c]  (G = gated output gradient [m, n], X = the layer input [m, channels], both pair

@@ -38,18 +38,21 @@ def test_split_pair_layout_and_precision():
         C.split_pair(torch.randn(4, 40, device="cuda"))  # cols % 32 != 0
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+# config: 0 = the launcher's choice, 1 / 2 = one / two LDS stages forced, 8 = no K slices (include/ovis_hip.h)
+@pytest.mark.parametrize("config", [0, 1, 2, 8])
 @pytest.mark.parametrize("m,k,n,bias,res,relu", [(128, 32, 128, False, False, False), (300, 64, 64, False, False, False),
                                                    (1000, 512, 192, True, True, True), (1813, 1024, 512, True, False, True),
-                                                   (513, 2048, 2048, False, True, False), (1, 32, 4, True, False, False)])
-def test_split_gemm_pair_vs_fp64(tile, m, k, n, bias, res, relu):
+                                                   (513, 2048, 2048, False, True, False), (1, 32, 4, True, False, False),
+                                                   (490, 2048, 512, True, True, True), (2100, 160, 64, True, False, True),
+                                                   (777, 1024, 76, True, False, False)])
+def test_split_gemm_pair_vs_fp64(config, m, k, n, bias, res, relu):
     C = _C()
     g = torch.Generator(device="cuda").manual_seed(m * 7 + k + n)
     a = torch.randn(m, k, device="cuda", generator=g)
     b = torch.randn(n, k, device="cuda", generator=g)
     bi = torch.randn(n, device="cuda", generator=g) if bias else None
     r = torch.randn(m, n, device="cuda", generator=g) if res else None
-    c, cp = C.split_gemm_pair(C.split_pair(a), C.split_pair(b), bi, r, relu, True, n % 32 == 0, tile_m=tile)
+    c, cp = C.split_gemm_pair(C.split_pair(a), C.split_pair(b), bi, r, relu, True, n % 32 == 0, config=config)
     ref = a.double() @ b.double().t()
     if bias:
         ref += bi.double()
@@ -63,11 +66,14 @@ def test_split_gemm_pair_vs_fp64(tile, m, k, n, bias, res, relu):
         assert torch.equal(cp, C.split_pair(c))
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+# config: 4 = shifted-row form even where the halo form applies
+@pytest.mark.parametrize("config", [0, 1, 2, 4, 5, 8])
 @pytest.mark.parametrize("r,h,w,c,n,kh,kw,flip", [(5, 7, 7, 64, 64, 3, 3, False), (37, 7, 7, 512, 512, 3, 3, False),
                                                     (3, 5, 9, 32, 128, 3, 3, True), (2, 13, 11, 64, 96, 3, 5, False),
-                                                    (1, 50, 84, 256, 256, 3, 3, True)])
-def test_implicit_conv_vs_fp64(tile, r, h, w, c, n, kh, kw, flip):
+                                                    (1, 50, 84, 256, 256, 3, 3, True), (10, 7, 7, 512, 512, 3, 3, True),
+                                                    (61, 7, 7, 128, 192, 3, 3, False), (4, 9, 6, 64, 128, 3, 3, True),
+                                                    (3, 2, 3, 96, 128, 3, 5, False)])
+def test_implicit_conv_vs_fp64(config, r, h, w, c, n, kh, kw, flip):
     C = _C()
     from cvpr22_cross_modal_pseudo_labeling_amd.layers.pair_bottleneck import conv_weight_matrix
     g = torch.Generator(device="cuda").manual_seed(r + h * 3 + w * 5 + c)
@@ -75,15 +81,53 @@ def test_implicit_conv_vs_fp64(tile, r, h, w, c, n, kh, kw, flip):
     wt = torch.randn(n, c, kh, kw, device="cuda", generator=g)
     xp = C.split_pair(x.view(-1, c))
     wp = C.split_pair(conv_weight_matrix(wt).contiguous())
-    y, _ = C.split_gemm_pair(xp, wp, conv=(h, w, kh, kw, flip), tile_m=tile)
+    y, _ = C.split_gemm_pair(xp, wp, conv=(h, w, kh, kw, flip), config=config)
     wref = wt.flip(2, 3) if flip else wt
     pad = (kh // 2, kw // 2)
     ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wref.double(), padding=pad).permute(0, 2, 3, 1).reshape(-1, n)
     bound = F.conv2d(x.permute(0, 3, 1, 2).abs().double(), wref.abs().double(), padding=pad).permute(0, 2, 3, 1).reshape(-1, n) + 1
     assert ((y.double() - ref).abs() / bound).max().item() < TOL
     if not flip:  # the materialised pair im2col rows give the same product through the plain GEMM
-        y2, _ = C.split_gemm_pair(C.im2col_pair(xp, h, w, kh, kw), wp, tile_m=tile)
+        y2, _ = C.split_gemm_pair(C.im2col_pair(xp, h, w, kh, kw), wp, config=config & 3)
         assert (y - y2).abs().max().item() <= 1e-5 * y.abs().max().item()
+
+
+def test_halo_form_equals_shifted_form_bitwise():
+    """The halo-tile form of the implicit 3x3 (7x7 maps) runs the same products in a different k order than the
+    shifted-row form: same values to fp32 summation order; the K-sliced small-M grid equals the un-sliced one likewise."""
+    C = _C()
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers.pair_bottleneck import conv_weight_matrix
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for r in (10, 300):
+        x = torch.randn(r, 7, 7, 256, device="cuda", generator=g)
+        wt = torch.randn(384, 256, 3, 3, device="cuda", generator=g) * 0.05
+        b = torch.randn(384, device="cuda", generator=g)
+        xp, wp = C.split_pair(x.view(-1, 256)), C.split_pair(conv_weight_matrix(wt).contiguous())
+        outs = [C.split_gemm_pair(xp, wp, b, None, True, True, True, conv=(7, 7, 3, 3, False), config=cfg)
+                for cfg in (0, 4, 8, 12, 5)]
+        ref = outs[3][0]
+        for y, yp in outs:
+            assert (y - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+            assert torch.equal(yp, C.split_pair(y))
+
+
+def test_k_concatenated_second_operand():
+    """a2_pair: [A | A2] x [B | B2]^T as one product == the two products summed (conv3 + projection shortcut)."""
+    C = _C()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for m in (490, 3000):
+        a, a2 = torch.randn(m, 512, device="cuda", generator=g), torch.randn(m, 1024, device="cuda", generator=g)
+        b, b2 = torch.randn(256, 512, device="cuda", generator=g), torch.randn(256, 1024, device="cuda", generator=g)
+        bias = torch.randn(256, device="cuda", generator=g)
+        bcat = C.split_pair(torch.cat([b, b2], 1).contiguous())
+        for cfg in (0, 1, 2, 8):
+            y, yp = C.split_gemm_pair(C.split_pair(a), bcat, bias, None, True, True, True, a2_pair=C.split_pair(a2), config=cfg)
+            ref = (a.double() @ b.double().t() + a2.double() @ b2.double().t() + bias.double()).clamp(min=0)
+            bound = a.abs().double() @ b.abs().double().t() + a2.abs().double() @ b2.abs().double().t() + 1
+            assert ((y.double() - ref).abs() / bound).max().item() < TOL
+            assert torch.equal(yp, C.split_pair(y))
+    with pytest.raises(RuntimeError):
+        C.split_gemm_pair(C.split_pair(a), bcat, a2_pair=C.split_pair(a2[:-1]))
 
 
 def test_im2col_pair_layout():
@@ -381,13 +425,13 @@ def test_split_gemm_pair_gated_epilogue():
     a, b = torch.randn(m, k, device="cuda"), torch.randn(n, k, device="cuda")
     y = torch.randn(m, n, device="cuda").clamp(min=0)
     ap, bp, yp = C.split_pair(a), C.split_pair(b), C.split_pair(y)
-    d, _ = C.split_gemm_pair(ap, bp)
+    d, _ = C.split_gemm_pair(ap, bp, config=8)  # the gated form never cuts K into slices: same summation order
     want_p, want = C.gate_split_pair(d, yp, want_f32=True)
     got, got_p = C.split_gemm_pair_gated(ap, bp, yp, out_f32=True, out_pair=True)
     assert torch.equal(got, want) and torch.equal(got_p, want_p)
     wm = torch.randn(n, 9 * k, device="cuda")
     wp = C.split_pair(wm)
-    d, _ = C.split_gemm_pair(ap, wp, conv=(7, 7, 3, 3, True))
+    d, _ = C.split_gemm_pair(ap, wp, conv=(7, 7, 3, 3, True), config=8)
     want_p, _ = C.gate_split_pair(d, yp)
     _, got_p = C.split_gemm_pair_gated(ap, wp, yp, conv=(7, 7, 3, 3, True))
     assert torch.equal(got_p, want_p)
@@ -408,7 +452,7 @@ def test_split_gemm_full_size_properties():
     full, full_p = C.split_gemm_pair(ap, bp, bias, None, True, True, True)
     assert torch.equal(full_p, C.split_pair(full))
     for r0, r1 in ((0, 128), (50000, 50999), (m - 777, m)):
-        part, _ = C.split_gemm_pair(C.split_pair(a[r0:r1]), bp, bias, None, True, True, False)
+        part, _ = C.split_gemm_pair(C.split_pair(a[r0:r1]), bp, bias, None, True, True, False, config=8)  # same k order: no K slices
         assert torch.equal(part, full[r0:r1]), (r0, r1)
     rows = torch.randint(0, m, (64,), device="cuda", generator=g)
     cols = torch.randint(0, n, (64,), device="cuda", generator=g)
@@ -422,7 +466,7 @@ def test_split_gemm_full_size_properties():
     wm = torch.randn(n2, 9 * c, device="cuda", generator=g) / (9 * c) ** 0.5
     xp, wp = C.split_pair(x), C.split_pair(wm)
     y, _ = C.split_gemm_pair(xp, wp, conv=(h, w, 3, 3, False))
-    sub, _ = C.split_gemm_pair(C.split_pair(x[1000 * 49:1010 * 49]), wp, conv=(h, w, 3, 3, False))
+    sub, _ = C.split_gemm_pair(C.split_pair(x[1000 * 49:1010 * 49]), wp, conv=(h, w, 3, 3, False), config=8)
     assert torch.equal(sub, y[1000 * 49:1010 * 49])
     # weight gradient: all rows == first half + second half (fp32 slab sums: 1e-5 relative), sampled entries vs fp64
     gy = torch.randn(r * h * w, n2, device="cuda", generator=g)
