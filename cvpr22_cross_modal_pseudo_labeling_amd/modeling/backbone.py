@@ -10,8 +10,6 @@ pass after every convolution (layers/batch_norm.py:19-31).  Here each conv+Froze
 MIOpen call with the affine folded into the weights (``w * scale``) and bias (``shift``); the fold
 is a weight-sized op, differentiable w.r.t. the conv weight, and cached for frozen modules.
 """
-import os
-
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -76,10 +74,10 @@ class Bottleneck(nn.Module):
         self._f3 = [ConvBN(self.conv3, self.bn3)]
         self._fd = [ConvBN(self.downsample[0], self.downsample[1])] if self.downsample is not None else None
         self.conv3x3_nchw = None  # None = by autograd mode (see forward_nhwc)
-        self.split_gemm = os.environ.get("OVIS_RES5_FP32_GEMM", "0") != "1"
-        self.split_conv = self.split_gemm and os.environ.get("OVIS_RES5_MIOPEN_3X3", "0") != "1"
-        # pair-layout split GEMM with fused epilogues and implicit 3x3 (csrc/split_gemm.hip): the default NHWC route
-        self.pair_gemm = self.split_conv and os.environ.get("OVIS_RES5_PAIR", "1") != "0"
+        # pair-layout split GEMM with fused epilogues and implicit 3x3 (csrc/split_gemm.hip): the NHWC route.  The other
+        # attribute combinations (K-concatenated split through a library GEMM, fp32 GEMM, per-layer 3x3) are the earlier
+        # forms of the same block, kept as cross-checks: tests/test_heads_gpu.py sets them explicitly
+        self.split_gemm = self.split_conv = self.pair_gemm = True
         self._pair_cache = None
 
     def forward(self, x):
@@ -168,7 +166,7 @@ class Bottleneck(nn.Module):
         res5 FLOPs -- become ONE row-major GEMM over all R*H*W positions each ([R*H*W, Cin] x [Cin, Cout], bias
         = the folded FrozenBN shift) instead of R batched [Cout, Cin] x [Cin, 49] products behind layout
         transposes; a stride-2 1x1 (STRIDE_IN_1X1) first drops the rows it never reads.  By default the GEMMs run as
-        bf16 hi/lo split products on the bf16 matrix pipe (~4e-6 relative error, ``OVIS_RES5_FP32_GEMM=1`` selects
+        bf16 hi/lo split products on the bf16 matrix pipe (~4e-6 relative error, ``split_gemm = False`` selects
         the fp32 GEMM); the 3x3 goes through MIOpen.  Values equal ``forward`` up to that error.
         ``xp``: the pair-layout form of x when the producer already wrote it; ``want_pair``: also return the pair
         form of the result (or None) for the next block -- both only used by the pair-layout route."""
@@ -276,8 +274,7 @@ class Stem(nn.Module):
     def gemm_supported(self, x):
         c = self.conv1
         return (x.is_cuda and not c.weight.requires_grad and not x.requires_grad and c.groups == 1 and c.dilation == (1, 1)
-                and c.stride[0] == c.stride[1] and c.padding[0] == c.padding[1] and c.out_channels % 4 == 0
-                and os.environ.get("OVIS_STEM_MIOPEN", "0") != "1")
+                and c.stride[0] == c.stride[1] and c.padding[0] == c.padding[1] and c.out_channels % 4 == 0)
 
 
 def _make_stage(in_channels, bottleneck_channels, out_channels, block_count, num_groups, stride_in_1x1,
@@ -318,8 +315,7 @@ class ResNetC4(nn.Module):
             self.stages.append(name)
             in_channels = out_channels
         self.out_channels = in_channels
-        self.nhwc = os.environ.get("OVIS_TRUNK_NCHW", "0") != "1"
-        self.train_nhwc = os.environ.get("OVIS_TRUNK_TRAIN_MIOPEN", "0") != "1"
+        self.nhwc = self.train_nhwc = True  # False = per-layer NCHW convolutions (cross-check in the tests)
         self._freeze(cfg.MODEL.BACKBONE.FREEZE_CONV_BODY_AT)
 
     def _freeze(self, freeze_at):
@@ -337,8 +333,8 @@ class ResNetC4(nn.Module):
             # layer1-3 in NHWC with the split-GEMM bottlenecks of the res5 head (1x1 = row-major GEMM, 3x3 = implicit
             # GEMM); one layout copy out (the C4 map, 34 MB).  Frozen trunk (student-teacher configuration): always.
             # Trainable stages (teacher training): through the pair-layout autograd nodes as well -- 39.4 vs 42.2 ms per
-            # step against MIOpen's NCHW kernels (both with a warm MIOpen kernel cache; OVIS_TRUNK_TRAIN_MIOPEN=1 selects
-            # MIOpen).
+            # step against MIOpen's NCHW kernels (both with a warm MIOpen kernel cache; ``train_nhwc = False``
+            # selects MIOpen).
             y, yp = x.permute(0, 2, 3, 1).contiguous(), None
             for i, b in enumerate(blocks):
                 y, yp = b.forward_nhwc(y, xp=yp, want_pair=True) if i + 1 < len(blocks) else (b.forward_nhwc(y, xp=yp), None)
@@ -370,12 +366,11 @@ class ResNetHead(nn.Module):
         self.layer4 = _make_stage(out_channels // 2, r.NUM_GROUPS * r.WIDTH_PER_GROUP * factor, out_channels, 3,
                                   r.NUM_GROUPS, r.STRIDE_IN_1X1, first_stride=2, dilation=r.RES5_DILATION)
         self.out_channels = out_channels
-        self.nhwc = os.environ.get("OVIS_RES5_NCHW", "0") != "1"
-        self.fuse_pooler = os.environ.get("OVIS_RES5_UNFUSED_POOLER", "0") != "1"
+        self.nhwc = self.fuse_pooler = True  # False = per-layer NCHW convolutions / full 14x14 pooling (cross-checks)
 
     def forward(self, x):
         """x [R, C, 14, 14] -> [R, 2048, 7, 7].  On the GPU the stage runs in NHWC with GEMM 1x1s
-        (``Bottleneck.forward_nhwc``) and returns the channels_last view of the result; ``OVIS_RES5_NCHW=1``
+        (``Bottleneck.forward_nhwc``) and returns the channels_last view of the result; ``nhwc = False``
         keeps the plain per-layer convolution path (also taken for grouped / exotic configurations)."""
         if x.is_cuda and self.nhwc and all(b.nhwc_supported() for b in self.layer4):
             y, yp = x.permute(0, 2, 3, 1), None  # the first block's stride-2 slice makes this the only NCHW -> NHWC copy

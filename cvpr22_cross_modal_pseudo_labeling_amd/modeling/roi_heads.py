@@ -18,8 +18,6 @@ projection, no per-mask python loop there), the fg/bg class weights are built on
 device instead of a hard-coded ``.cuda()``, and the mask head handles any number of
 images per process.
 """
-import os
-
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -307,6 +305,8 @@ class ROIBoxHead(nn.Module):
 # mask head
 # ------------------------------------------------------------------------------------------------
 class MaskRCNNC4Predictor(nn.Module):
+    split_gemm = True  # False = the module's plain convolutions (cross-check in tests/test_split_gemm_pair.py)
+
     def __init__(self, cfg, in_channels):
         super().__init__()
         num_classes = 2 if cfg.MODEL.CLS_AGNOSTIC_MASK else cfg.MODEL.ROI_BOX_HEAD.NUM_CLASSES
@@ -329,7 +329,7 @@ class MaskRCNNC4Predictor(nn.Module):
         c = self.conv5_mask
         return (x.is_cuda and x.dim() == 4 and c.kernel_size == (2, 2) and c.stride == (2, 2) and c.padding == (0, 0)
                 and c.output_padding == (0, 0) and c.groups == 1 and c.in_channels % 128 == 0
-                and (4 * c.out_channels) % 128 == 0 and os.environ.get("OVIS_MASK_MIOPEN", "0") != "1")
+                and (4 * c.out_channels) % 128 == 0 and self.split_gemm)
 
     def _upsampled_rows(self, x):
         """relu(conv5_mask(x)) as NHWC rows [P*2H*2W, dim_reduced]: the 2x2 / stride-2 transposed convolution is ONE
@@ -621,6 +621,8 @@ ROIMaskHead.fused_training_loss = _mask_fused_training_loss
 
 
 class CombinedROIHeads(nn.ModuleDict):
+    batch_branches = True  # False = one head pass per branch, the reference's order (cross-check in tests/test_model_gpu.py)
+
     def __init__(self, cfg, in_channels, is_teacher=False):
         heads = [("box", ROIBoxHead(cfg, in_channels, is_teacher))]
         if cfg.MODEL.MASK_ON:
@@ -633,7 +635,7 @@ class CombinedROIHeads(nn.ModuleDict):
 
     def branches_batchable(self, feat):
         return (self.training and feat.is_cuda and (not self.mask_on or (self.mask.share and self.mask.cls_agnostic_mask))
-                and os.environ.get("OVIS_STUDENT_BATCHED", "1") != "0")
+                and self.batch_branches)
 
     def forward_branches(self, feat, branches):
         """Training losses of several independent branches (the student's pseudo-label branch and ground-truth branch,

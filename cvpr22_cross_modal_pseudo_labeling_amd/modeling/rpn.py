@@ -4,8 +4,6 @@ Counterpart of maskrcnn_benchmark/modeling/rpn/anchor_generator.py:34-128,200-29
 rpn/rpn.py:74-197, rpn/inference.py:15-205 and rpn/loss.py:21-131 for the single-level (C4)
 case every shipped config uses.  The proposal path calls the HIP NMS through ``layers.nms``.
 """
-import os
-
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -84,6 +82,8 @@ class AnchorGenerator(nn.Module):
 
 
 class RPNHead(nn.Module):  # rpn.py:74-106
+    split_gemm = True  # False = plain convolutions (cross-check in the tests)
+
     def __init__(self, in_channels, num_anchors):
         super().__init__()
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
@@ -98,7 +98,7 @@ class RPNHead(nn.Module):  # rpn.py:74-106
             return self._forward_gemm(feature)
         c = self.conv
         if (feature.is_cuda and c.in_channels % 128 == 0 and c.out_channels % 128 == 0 and c.kernel_size == (3, 3)
-                and c.padding == (1, 1) and c.stride == (1, 1) and os.environ.get("OVIS_RPN_MIOPEN", "0") != "1"):
+                and c.padding == (1, 1) and c.stride == (1, 1) and self.split_gemm):
             # trainable head (teacher configuration): the 3x3 through the split-GEMM autograd node, the two small
             # predictors stay convolutions on the NCHW view of its NHWC result
             from ..layers.pair_bottleneck import conv_same_pair
@@ -113,8 +113,7 @@ class RPNHead(nn.Module):  # rpn.py:74-106
         c = self.conv
         no_grad = not torch.is_grad_enabled() or not (feature.requires_grad or any(p.requires_grad for p in self.parameters()))
         return (feature.is_cuda and no_grad and c.in_channels % 32 == 0 and c.out_channels % 32 == 0
-                and c.kernel_size == (3, 3) and c.padding == (1, 1) and c.stride == (1, 1)
-                and os.environ.get("OVIS_RPN_MIOPEN", "0") != "1")
+                and c.kernel_size == (3, 3) and c.padding == (1, 1) and c.stride == (1, 1) and self.split_gemm)
 
     def _forward_gemm(self, feature):
         """Frozen head on the split GEMM (csrc/split_gemm.hip): the 3x3 as an implicit GEMM with bias + ReLU in the

@@ -143,18 +143,15 @@ def test_batched_student_branches_match_sequential_branches():
         frozen = model.forward_frozen(images.cuda(), tg)
     res = {}
     for mode in ("0", "1"):
-        os.environ["OVIS_STUDENT_BATCHED"] = mode
-        try:
-            m = copy.deepcopy(model)
-            m.iter = model.iter
-            torch.manual_seed(99)
-            eps = torch.randn(1, 4096, 2, 14, 14, generator=torch.Generator().manual_seed(7))
-            losses = m.forward_student(frozen, tg, eps=eps)
-            sum(losses.values()).backward()
-            res[mode] = ({k: float(v.detach()) for k, v in losses.items()},
-                         {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
-        finally:
-            os.environ.pop("OVIS_STUDENT_BATCHED", None)
+        m = copy.deepcopy(model)
+        m.roi_heads_student.batch_branches = mode == "1"
+        m.iter = model.iter
+        torch.manual_seed(99)
+        eps = torch.randn(1, 4096, 2, 14, 14, generator=torch.Generator().manual_seed(7))
+        losses = m.forward_student(frozen, tg, eps=eps)
+        sum(losses.values()).backward()
+        res[mode] = ({k: float(v.detach()) for k, v in losses.items()},
+                     {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
     (l0, g0), (l1, g1) = res["0"], res["1"]
     assert set(l0) == set(l1)
     for k in l0:

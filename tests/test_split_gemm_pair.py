@@ -397,18 +397,14 @@ def test_mask_predictor_gemm_path_matches_convolutions():
     gs = torch.randn(5, 1, 14, 14, device="cuda")
 
     def run(gemm):
-        os.environ["OVIS_MASK_MIOPEN"] = "0" if gemm else "1"
+        m.split_gemm = gemm
         xx = x.clone().requires_grad_(True)
         m.zero_grad()
         mu, sigma = m.forward_parts(xx)
         ((mu * gm).sum() + (sigma * gs).sum()).backward()
         return [mu.detach(), sigma.detach(), xx.grad] + [p.grad.clone() for p in m.parameters()]
 
-    import os
-    try:
-        ref, got = run(False), run(True)
-    finally:
-        os.environ.pop("OVIS_MASK_MIOPEN", None)
+    ref, got = run(False), run(True)
     assert m._gemm_ok(x)
     for a, b in zip(got, ref):
         assert a.shape == b.shape

@@ -1,5 +1,5 @@
 """Loss trajectory of the student step over N optimisation steps at the config's real learning rate, for the default
-res5 path (NHWC + bf16 hi/lo split GEMMs) or, with OVIS_RES5_NCHW=1, the per-layer fp32 convolution path.
+res5 path (NHWC + bf16 hi/lo split GEMMs) or, with a second argument "nchw", the per-layer fp32 convolution path.
 Same seeds, same synthetic batch: the two trajectories should agree to the fp32 round-off amplification of SGD."""
 import json, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,10 +16,15 @@ model = build_detection_model(cfg).to(dev)
 e_vocab, e_seen = make_embeddings(cfg.MODEL.ROI_BOX_HEAD.EMB_DIM, seed=1234, device=dev)
 model.set_class_embeddings(e_seen); model.set_caption_vocab(e_vocab)
 images, targets = make_batch(2, device=dev, seed=1234); calibrate_stem_bn(model, images)
+nchw = len(sys.argv) > 2 and sys.argv[2] == "nchw"
+if nchw:
+    for m in model.modules():
+        if hasattr(m, "nhwc"):
+            m.nhwc = False
 model.train(); opt = solver.make_optimizer(cfg, model); sch = solver.make_lr_scheduler(cfg, opt); red = comm.BucketedGradReducer(model)
 out = []
 for i in range(steps):
     torch.manual_seed(1000 + i)  # same sampling / noise stream in both runs
     ld = trainer.train_step(model, opt, red, images, targets, sch)
     out.append({k: round(float(v), 6) for k, v in ld.items()})
-print(json.dumps({"path": "nchw_fp32" if os.environ.get("OVIS_RES5_NCHW") == "1" else "nhwc_split", "losses": out}))
+print(json.dumps({"path": "nchw_fp32" if nchw else "nhwc_split", "losses": out}))
