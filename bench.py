@@ -33,6 +33,7 @@ IMS_PER_GPU = 2
 
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 matrix peak (the 2:1-sparsity figure is never used)
+MFMA_F32_PEAK_TFLOPS = 157.3    # same guide: fp32-input matrix peak (= the fp32 vector peak)
 MFMA_SUSTAINED_TFLOPS = 1540.0  # measured: MFMAs + fragment reads of the split GEMM loop without any loads
 
 
@@ -144,6 +145,28 @@ class OpTimer:
             taps = 1 if conv is None else conv[2] * conv[3]
             return (g_pair.shape[0], g_pair.shape[1] // 2, x_pair.shape[1] // 2 * taps, taps)
 
+        def gemm_nt_flops(a, b, bias=None):
+            return 2.0 * a.shape[0] * b.shape[0] * a.shape[1]  # exact-fp32 matrix-core GEMM: 2*M*N*K
+
+        def gemm_nt_bytes(a, b, bias=None):
+            return 4 * (a.numel() + b.numel() + a.shape[0] * b.shape[0])
+
+        def align_bytes(region_emb, noun_emb):
+            return 4 * (region_emb.numel() + noun_emb.numel()) + 12 * noun_emb.shape[0]
+
+        def ce_bytes(logits, labels, bg_weight, need_grad=True):
+            return 4 * logits.numel() * (2 if need_grad else 1) + 8 * labels.numel()
+
+        def bce_bytes(mu, sigma, eps, pos_index, targets, channel, need_grad=True):
+            p = pos_index.numel()
+            px = targets.numel() // max(p, 1)
+            per = 2 + (2 if sigma is not None else 0) + (2 if need_grad else 0)  # mu/eps channels read, gradients written
+            return 4 * p * px * (per + 1) + 8 * p
+
+        self._wrap("gemm_nt", gemm_nt_flops, "mfma_f32", gemm_nt_bytes)
+        self._wrap("region_noun_align", align_bytes)
+        self._wrap("weighted_ce_fwd_bwd", ce_bytes)
+        self._wrap("mask_bce_stochastic_fwd_bwd", bce_bytes)
         self._wrap("split_gemm_pair", split_gemm_flops, "mfma", split_gemm_bytes, nt_shape)
         self._wrap("split_gemm_pair_gated", split_gemm_flops, "mfma", split_gemm_gated_bytes, nt_shape)
         self._wrap("split_gemm_pair_tn", split_gemm_tn_flops, "mfma", split_gemm_tn_bytes, tn_shape)
@@ -154,10 +177,18 @@ class OpTimer:
             ms = sum(r[0].elapsed_time(r[1]) for r in recs)
             work = sum(r[2] for r in recs)
             if self.kind[name] == "mfma":
+                # issued = 3 bf16 hi/lo products x 2*M*N*K; algorithmic = the fp32 product the caller asked for, 2*M*N*K
                 out[name] = {"launches": len(recs), "avg_us": 1e3 * ms / len(recs), "bound": "mfma",
-                             "alg_GFLOP_per_launch": work / len(recs) / 1e9,
+                             "issued_GFLOP_per_launch": work / len(recs) / 1e9,
+                             "alg_GFLOP_per_launch": work / 3.0 / len(recs) / 1e9,
                              "achieved_TFLOPs": work / ms / 1e9 if ms > 0 else 0.0,
                              "fp32_equiv_TFLOPs": work / 3.0 / ms / 1e9 if ms > 0 else 0.0,
+                             "alg_MB_per_launch": self.bytes.get(name, 0.0) / len(recs) / 1e6}
+            elif self.kind[name] == "mfma_f32":
+                out[name] = {"launches": len(recs), "avg_us": 1e3 * ms / len(recs), "bound": "mfma (fp32 inputs)",
+                             "alg_GFLOP_per_launch": work / len(recs) / 1e9,
+                             "achieved_TFLOPs": work / ms / 1e9 if ms > 0 else 0.0,
+                             "frac_of_fp32_mfma_peak": work / ms / 1e9 / MFMA_F32_PEAK_TFLOPS if ms > 0 else 0.0,
                              "alg_MB_per_launch": self.bytes.get(name, 0.0) / len(recs) / 1e6}
             else:
                 out[name] = {"launches": len(recs), "avg_us": 1e3 * ms / len(recs), "bound": "hbm",
@@ -202,7 +233,9 @@ def pmc_traffic(workload, op):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes over this same step (FETCH_SIZE and
     WRITE_SIZE in separate passes, gfx950 correction applied: tools/pmc_step.sh); counters cannot be collected from
     inside the process, so the committed summary of the last pass is reported -- or null when there is none."""
-    path = os.path.join(ROOT, "profiles", f"r1_pmc_step_hbm_traffic_{workload}.json")
+    path = os.path.join(ROOT, "profiles", f"r2_pmc_step_hbm_traffic_{workload}.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", f"r1_pmc_step_hbm_traffic_{workload}.json")
     fam = PMC_KERNEL.get(op)
     try:
         with open(path) as f:
@@ -215,14 +248,35 @@ def pmc_traffic(workload, op):
             f"+ write {k['write_MB_per_launch']} MB, from profiles/{os.path.basename(path)} ({d['correction']})")
 
 
+def _median_ms(fn, reps=5):
+    fn()  # warm-up
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
 def cpu_baseline(workload):
-    """Reference CPU kernels on the native-op work of one image of the step (bounded: ~10-20 s)."""
+    """The reference's own CPU kernels (oracle/_ref; the C port when it was not built) on the native-op work of the step,
+    on the host cores: median of 5 per op on a bounded sample (RoIAlign is linear in the RoI count: 512 RoIs are timed and
+    scaled; NMS at the step's full K), single-threaded as the reference runs them (cpu/ROIAlign_cpu.cpp:133 has its OpenMP
+    pragma commented out), plus an all-cores leg (one image per thread through the bit-identical C port, whose ctypes calls
+    release the interpreter lock) and a torch-CPU timing of the res5 head / trunk convolutions so that a full-step CPU
+    figure exists next to the native-op one.  ~25 s of host time in total."""
+    import concurrent.futures
+
+    import torch.nn.functional as F
+
     import oracle
 
     oracle.build(with_ref=False)
     ref = oracle.ref_module()
     g = torch.Generator().manual_seed(1234)
     feat = torch.randn(1, 1024, 50, 84, generator=g)
+    sample_r = 512
 
     def rois(r):
         xy = torch.rand(r, 2, generator=g) * torch.tensor([1066.0, 640.0])
@@ -236,34 +290,85 @@ def cpu_baseline(workload):
 
     if workload == "student":
         roi_counts, nms_counts = [1000, 5, 512, 512], [6000, 12000]
+        res5_fwd_rois, res5_bwd_rois = 1000 + 5 + 512 + 512, 512 + 512   # per image: frozen teacher passes + student passes
     else:
         roi_counts, nms_counts = [512], [12000]
-    torch.set_num_threads(1)  # the reference kernels are single-threaded (cpu/ROIAlign_cpu.cpp:133)
+        res5_fwd_rois, res5_bwd_rois = 512, 512
+    torch.set_num_threads(1)  # the reference kernels are single-threaded
+    t_start = time.perf_counter()
+    rr = rois(sample_r)
+    roi_fn = (lambda: ref.roi_align_forward(feat, rr, 1 / 16, 14, 14, 0)) if ref is not None else \
+        (lambda: oracle.roi_align_forward(feat, rr, 1 / 16, 14, 14, 0))
+    per_op = {f"roi_align_forward_R{sample_r}": _median_ms(roi_fn)}
+    for k in nms_counts:
+        b, sc = boxes(k)
+        nms_fn = (lambda: ref.nms(b, sc, 0.7)) if ref is not None else (lambda: oracle.nms(b, sc, 0.7))
+        per_op[f"nms_K{k}"] = _median_ms(nms_fn)
+    native_ms = sum(per_op[f"roi_align_forward_R{sample_r}"] * r / sample_r for r in roi_counts) + \
+        sum(per_op[f"nms_K{k}"] for k in nms_counts)
+
+    # all cores: one image's sample per thread through the C port (bit-identical to the reference kernels, tests/test_oracle.py)
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    bk, sk = boxes(nms_counts[0])
+
+    def one_image_sample(_):
+        oracle.roi_align_forward(feat, rr, 1 / 16, 14, 14, 0)
+        oracle.nms(bk, sk, 0.7)
+
+    one_image_sample(0)
     t0 = time.perf_counter()
-    images = 0
-    while True:  # whole images until >= 10 s of CPU work (bounded sample, 10-30 s)
-        for r in roi_counts:
-            rr = rois(r)
-            if ref is not None:
-                ref.roi_align_forward(feat, rr, 1 / 16, 14, 14, 0)
-            else:
-                oracle.roi_align_forward(feat, rr, 1 / 16, 14, 14, 0)
-        for k in nms_counts:
-            b, s = boxes(k)
-            if ref is not None:
-                ref.nms(b, s, 0.7)
-            else:
-                oracle.nms(b, s, 0.7)
-        images += 1
-        dt = time.perf_counter() - t0
-        if dt >= 10.0 or images >= 64:
-            break
-    return {"value": images / dt, "unit": "images/sec", "cores": 1, "kind": "reference" if ref is not None else "port",
-            "sample": (f"native ops of {images} images of the {workload} step only (per image: RoIAlign fwd R={roi_counts} on [1,1024,50,84], "
-                       f"NMS K={nms_counts}, thr .7) with the reference's single-threaded CPU kernels; convolutions, heads "
-                       "and backward excluded because the reference cannot train on CPU (ROIAlign.h:44) -- an UPPER bound "
-                       f"on CPU images/sec; {dt:.1f} s of CPU work"),
-            "host_cpus": os.cpu_count()}
+    one_image_sample(0)
+    t_one = time.perf_counter() - t0
+    with concurrent.futures.ThreadPoolExecutor(threads) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(one_image_sample, range(threads)))
+        t_all = time.perf_counter() - t0
+    speedup = threads * t_one / t_all
+
+    # convolutions: torch CPU (all cores), res5 head forward and forward + backward on 8 RoIs, trunk forward on one image
+    torch.set_num_threads(threads)
+    w1 = torch.randn(512, 1024, 1, 1) * 0.02
+    w2 = torch.randn(512, 512, 3, 3) * 0.02
+    w3 = torch.randn(2048, 512, 1, 1) * 0.02
+    wd = torch.randn(2048, 1024, 1, 1) * 0.02
+    w1b = torch.randn(512, 2048, 1, 1) * 0.02
+    ws = [w1, w2, w3, wd, w1b]
+
+    def res5(x):
+        y = F.relu(F.conv2d(x, w1, stride=2))
+        y = F.relu(F.conv2d(y, w2, padding=1))
+        y = F.relu(F.conv2d(y, w3) + F.conv2d(x, wd, stride=2))
+        for _ in range(2):
+            t = F.relu(F.conv2d(y, w1b))
+            t = F.relu(F.conv2d(t, w2, padding=1))
+            y = F.relu(F.conv2d(t, w3) + y)
+        return y
+
+    xr = torch.randn(8, 1024, 14, 14)
+    with torch.no_grad():
+        per_op["res5_forward_R8_torch_cpu"] = _median_ms(lambda: res5(xr), 3)
+    for w in ws:
+        w.requires_grad_(True)
+    per_op["res5_forward_backward_R8_torch_cpu"] = _median_ms(lambda: res5(xr).sum().backward(), 3)
+    fwd_per_roi = per_op["res5_forward_R8_torch_cpu"] / 8
+    fb_per_roi = per_op["res5_forward_backward_R8_torch_cpu"] / 8
+    conv_ms = fwd_per_roi * (res5_fwd_rois - res5_bwd_rois) + fb_per_roi * res5_bwd_rois
+    full_ms = native_ms / max(speedup, 1.0) + conv_ms  # trunk (65 GFLOP / image) not included: res5 dominates
+    host_s = time.perf_counter() - t_start
+    return {"value": 1e3 / native_ms, "unit": "images/sec", "cores": 1, "kind": "reference" if ref is not None else "port",
+            "sample": (f"native ops of one image of the {workload} step only (RoIAlign fwd R={roi_counts} on [1,1024,50,84] -- timed "
+                       f"at R={sample_r} and scaled linearly -- and NMS K={nms_counts}, thr .7), median of 5 per op, the reference's "
+                       "single-threaded CPU kernels; convolutions, heads and backward excluded because the reference cannot train "
+                       "on CPU (ROIAlign.h:44) -- an UPPER bound on CPU images/sec"),
+            "per_op_median_ms": {k: round(v, 3) for k, v in per_op.items()},
+            "all_cores": {"value": 1e3 / native_ms * speedup, "unit": "images/sec", "cores": threads, "kind": "port",
+                          "sample": f"{threads} threads, one image sample (RoIAlign R={sample_r} + NMS K={nms_counts[0]}) each through "
+                                    f"the C port; measured speed-up x{speedup:.1f} applied to the single-thread figure"},
+            "full_step_estimate": {"value": 1e3 / full_ms, "unit": "images/sec", "cores": threads,
+                                   "method": (f"native ops on all cores + torch-CPU res5 head on all cores: {res5_fwd_rois} RoIs forward of "
+                                              f"which {res5_bwd_rois} also backward per image ({fwd_per_roi:.1f} / {fb_per_roi:.1f} ms per RoI); "
+                                              "trunk and heads not included -- still an upper bound")},
+            "host_cpus": os.cpu_count(), "host_seconds": round(host_s, 1)}
 
 
 def main():
@@ -273,6 +378,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="student", choices=["student", "teacher"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--min-seconds", type=float, default=0.0,
+                    help="extend the timed region to at least this long (steps are added; the JSON reports the count)")
     ap.add_argument("--burn-seconds", type=float, default=3.0, help="GPU clock warm-up before the warm-up steps")
     ap.add_argument("--no-pipeline", action="store_true", help="plain sequential step (no side-stream overlap)")
     ap.add_argument("--per-shape-csv", default="", help="write one row per distinct split-GEMM shape of the step")
@@ -353,11 +460,28 @@ def main():
     sync()
     overlapped = pipe.enabled
     timer.enabled = not overlapped  # sequential workloads: per-kernel HIP-event timing live in the timed region
+    if args.min_seconds > 0:  # calibrate the step count on a short untimed probe (same count on every rank)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            pipe.step(images, targets, nxt)
+        sync()
+        probe = torch.tensor([(time.perf_counter() - t0) / 3], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(probe, op=dist.ReduceOp.MAX)
+        args.steps = max(args.steps, int(args.min_seconds / float(probe.item())) + 1)
+        timer.records.clear()
+    # the K timed steps, bracketed by barrier + synchronize; in between, un-synchronised host timestamps every few
+    # steps give the spread of the step time inside the region (they do not stall the pipeline)
+    chunk = max(1, args.steps // 8)
+    marks = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         loss_dict = pipe.step(images, targets, nxt)
+        if (i + 1) % chunk == 0:
+            marks.append((i + 1, time.perf_counter()))
     sync()
     elapsed = time.perf_counter() - t0
+    chunk_ms = [1e3 * (b[1] - a[1]) / (b[0] - a[0]) for a, b in zip(marks[:-1], marks[1:])]
     pipe.drain()
     timer.enabled = False
     replay_steps = 0
@@ -393,7 +517,13 @@ def main():
         traffic, traffic_note = pmc_traffic(args.workload, dom)
         if k["bound"] == "mfma":
             roofline = {"bound": "mfma", "kernel": dom, "achieved": k["achieved_TFLOPs"], "peak": MFMA_BF16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": k["achieved_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                        "unit": "TFLOP/s", "frac": k["achieved_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS,
+                        # ALGORITHMIC flops of the fp32 convolutions (2*M*N*K) over the same time: against the bf16 matrix
+                        # peak the kernel runs on, and against the fp32 matrix peak an fp32-input kernel would be priced at
+                        "achieved_algorithmic": k["fp32_equiv_TFLOPs"],
+                        "frac_algorithmic": k["fp32_equiv_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS,
+                        "frac_algorithmic_of_fp32_mfma_peak": k["fp32_equiv_TFLOPs"] / MFMA_F32_PEAK_TFLOPS,
+                        "traffic": traffic,
                         "traffic_note": traffic_note,
                         "note": ("bf16 matrix-core flops issued: 3 hi/lo products x 2*M*N*K per fp32-accurate product "
                                  f"({k['fp32_equiv_TFLOPs']:.0f} TFLOP/s fp32-equivalent); `peak` is the dense spec figure -- "
@@ -419,11 +549,15 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (bf16x3 split MFMA, fp32 accum)",
             "data": "synthetic",
+            "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
             "config": {"workload": f"{name}.yaml R-50-C4, {IMS_PER_GPU} img/GPU 3x800x1333, fwd+bwd+allreduce+SGD",
                        "global_batch": global_batch, "parallelism": f"dp{world}", "losses_finite": finite,
                        "pipelined": bool(overlapped)},
+            # host-side step time over chunks of the timed region (issue rate of rank 0; the region total is `ms_per_step`)
+            "ms_per_step_spread": ({"chunk_steps": chunk, "min": round(min(chunk_ms), 3), "median": round(sorted(chunk_ms)[len(chunk_ms) // 2], 3),
+                                    "max": round(max(chunk_ms), 3)} if chunk_ms else None),
             "roofline": roofline,
             "kernels": {n: {kk: round(vv, 3) if isinstance(vv, float) else vv for kk, vv in v.items()}
                         for n, v in kernels.items()},
