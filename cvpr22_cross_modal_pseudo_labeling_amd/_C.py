@@ -179,6 +179,64 @@ def nms(dets, scores, threshold):
     return keep[: int(num.item())]
 
 
+def nms_presorted_batched(boxes, drop, threshold, below=0, ge_mode=False):
+    """NMS of every image's score-sorted candidates in one mask + one reduce launch (``ovis_nms_presorted_batched_f32``):
+    boxes [N, K, 4] in descending score order, drop [N, K] int32 (negative = removed in front of the NMS) or None ->
+    (keep [N, K] int64: per image the survivors' indices ascending, zeros behind them; counts [N, 2] int32 = number of
+    survivors, number of survivors with index < ``below``)."""
+    boxes = _dev(boxes, "boxes")
+    n, k = boxes.shape[0], boxes.shape[1]
+    keep = torch.empty((n, k), dtype=torch.int64, device=boxes.device)
+    counts = torch.zeros((n, 2), dtype=torch.int32, device=boxes.device)
+    if n == 0 or k == 0:
+        return keep, counts
+    if boxes.dim() != 3 or boxes.size(2) != 4:
+        raise RuntimeError("nms_presorted_batched: expected boxes [N,K,4]")
+    if drop is not None:
+        drop = _dev(drop, "drop", torch.int32)
+        if drop.shape != (n, k):
+            raise RuntimeError("nms_presorted_batched: drop must be [N,K] int32")
+    with torch.cuda.device(boxes.device):
+        nbytes = _L.ovis_nms_presorted_workspace_bytes(n, k)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=boxes.device)
+        rc = _L.ovis_nms_presorted_batched_f32(boxes.data_ptr(), 0 if drop is None else drop.data_ptr(), n, k, threshold,
+                                               int(bool(ge_mode)), int(below), ws.data_ptr(), nbytes, keep.data_ptr(),
+                                               counts.data_ptr(), _stream())
+    _lib.check(rc, "nms_presorted_batched")
+    return keep, counts
+
+
+def rpn_decode(box_regression, topk_idx, cell_anchors, image_wh, weights, xform_clip, min_size, anchor_stride):
+    """Decode + clip + small-box flag of the top-k RPN candidates of a batch in one launch (``ovis_rpn_decode_f32``;
+    rpn/inference.py:95-114).  box_regression [N, 4A, H, W] (any strides with stride(2) == W * stride(3): NCHW, or the
+    NCHW view of an NHWC GEMM result), topk_idx [N, K] int64 into the (h, w, a) anchor order, cell_anchors [A, 4],
+    image_wh [N, 2] float32 (width, height) -> (boxes [N, K, 4], drop [N, K] int32: -1 for boxes below min_size)."""
+    if not box_regression.is_cuda or box_regression.dtype != torch.float32:
+        raise RuntimeError("rpn_decode: float32 HIP tensor expected (the product path has no CPU fallback)")
+    n, c4, h, w = box_regression.shape
+    a = cell_anchors.shape[0]
+    if c4 != 4 * a or topk_idx.dtype != torch.int64 or topk_idx.dim() != 2 or topk_idx.shape[0] != n:
+        raise RuntimeError("rpn_decode: expected box_regression [N,4A,H,W], topk_idx [N,K] int64, cell_anchors [A,4]")
+    if h > 1 and box_regression.stride(2) != w * box_regression.stride(3):
+        box_regression = box_regression.contiguous()
+    topk_idx = topk_idx.contiguous()
+    cell_anchors = _dev(cell_anchors, "cell_anchors")
+    image_wh = _dev(image_wh, "image_wh")
+    k = topk_idx.shape[1]
+    boxes = torch.empty((n, k, 4), dtype=torch.float32, device=box_regression.device)
+    drop = torch.empty((n, k), dtype=torch.int32, device=box_regression.device)
+    if n == 0 or k == 0:
+        return boxes, drop
+    wx, wy, ww, wh = weights
+    with torch.cuda.device(box_regression.device):
+        rc = _L.ovis_rpn_decode_f32(box_regression.data_ptr(), box_regression.stride(0), box_regression.stride(3),
+                                    box_regression.stride(1), topk_idx.data_ptr(), cell_anchors.data_ptr(),
+                                    image_wh.data_ptr(), n, k, a, w, float(anchor_stride), wx, wy, ww, wh, xform_clip,
+                                    float(min_size), boxes.data_ptr(), drop.data_ptr(), _stream())
+    _lib.check(rc, "rpn_decode")
+    return boxes, drop
+
+
 # ---- sigmoid focal loss (csrc/SigmoidFocalLoss.h:10-41) ----------------------------------------
 def sigmoid_focalloss_forward(logits, targets, num_classes, gamma, alpha):
     logits, targets = _dev(logits, "logits"), _dev(targets, "targets", torch.int32)

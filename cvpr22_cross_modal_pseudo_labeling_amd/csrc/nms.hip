@@ -63,12 +63,19 @@ __global__ __launch_bounds__(kTile) void nms_mask_kernel(const float4* __restric
                                                          unsigned long long* __restrict__ diag_t) {
   const int row_blk = blockIdx.y, col_blk = blockIdx.x;
   if (row_blk > col_blk) return;
+  {  // batched form: image blockIdx.z of [N, K, ...] inputs; order == nullptr: the boxes come score-sorted already
+    const size_t img = blockIdx.z;
+    boxes += img * K;
+    if (GROUPED) groups += img * K;
+    mask += img * K * nb;
+    diag_t += img * K;
+  }
   __shared__ float4 col_boxes[kTile];
   __shared__ int col_group[kTile];
   const int lane = threadIdx.x;
   const int col = col_blk * kTile + lane;
   if (col < K) {
-    const int o = order[col];
+    const int o = order ? order[col] : col;
     col_boxes[lane] = boxes[o];
     if (GROUPED) col_group[lane] = groups[o];
   }
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(kTile) void nms_mask_kernel(const float4* __restric
   const int row = row_blk * kTile + lane;
   unsigned long long bits = 0;
   if (row < K) {
-    const int orow = order[row];
+    const int orow = order ? order[row] : row;
     const float4 a = boxes[orow];
     const int ga = GROUPED ? groups[orow] : 0;
     const int ncol = min(K - col_blk * kTile, kTile);
@@ -102,9 +109,72 @@ __global__ __launch_bounds__(kTile) void nms_mask_kernel(const float4* __restric
   }
 }
 
+// Tail shared by both reduce kernels: survivors (keepw, by sorted position) -> bitmap by ORIGINAL index -> ascending
+// compaction into keep_out.  groups != nullptr: boxes with a negative group never survive (the RPN's small-box filter,
+// rpn/inference.py:114: they are flagged instead of being removed in front of the NMS).  nk_stride == 2 (batched form):
+// num_keep[1] = survivors with index < `below` (they form a prefix of keep_out) and keep_out is zero-filled past the
+// survivors, so that a padded gather is safe.
+__device__ __forceinline__ void nms_compact(const unsigned long long* keepw, unsigned long long* obits, int* part,
+                                            const int* __restrict__ order, const int* __restrict__ groups, int K, int nb,
+                                            int below, int nk_stride, long long* __restrict__ keep_out,
+                                            int* __restrict__ num_keep) {
+  __shared__ int below_cnt;
+  const int tid = threadIdx.x;
+  if (tid == 0) below_cnt = 0;
+  for (int p = tid; p < K; p += kReduceThreads) {
+    if ((keepw[p >> 6] >> (p & 63)) & 1ull) {
+      const int o = order ? order[p] : p;
+      if (groups == nullptr || groups[o] >= 0) atomicOr(&obits[o >> 6], 1ull << (o & 63));
+    }
+  }
+  __syncthreads();
+  // exclusive scan of per-thread popcounts over contiguous word segments
+  const int seg = (nb + kReduceThreads - 1) / kReduceThreads;
+  const int w0 = tid * seg, w1 = min(nb, w0 + seg);
+  int cnt = 0, cb = 0;
+  for (int w = w0; w < w1; ++w) {
+    const unsigned long long bits = obits[w];
+    cnt += __popcll(bits);
+    const int lim = below - w * 64;  // bits [0, lim) of this word lie below the limit
+    if (lim > 0) cb += __popcll(lim >= 64 ? bits : (bits & ((1ull << lim) - 1ull)));
+  }
+  part[tid] = cnt;
+  if (cb) atomicAdd(&below_cnt, cb);
+  __syncthreads();
+  for (int off = 1; off < kReduceThreads; off <<= 1) {
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int pos = part[tid] - cnt;
+  for (int w = w0; w < w1; ++w) {
+    unsigned long long bits = obits[w];
+    while (bits) {
+      const int i = __builtin_ctzll(bits);
+      bits &= bits - 1;
+      keep_out[pos++] = (long long)w * 64 + i;
+    }
+  }
+  const int total = part[kReduceThreads - 1];
+  if (nk_stride == 2)
+    for (int i = total + tid; i < K; i += kReduceThreads) keep_out[i] = 0;
+  if (tid == kReduceThreads - 1) {
+    num_keep[0] = total;
+    if (nk_stride == 2) num_keep[1] = below_cnt;
+  }
+}
+
 __global__ __launch_bounds__(kReduceThreads) void nms_reduce_kernel(
-    const unsigned long long* __restrict__ mask, const int* __restrict__ order, int K, int nb,
-    long long* __restrict__ keep_out, int* __restrict__ num_keep) {
+    const unsigned long long* __restrict__ mask, const int* __restrict__ order, const int* __restrict__ groups, int K,
+    int nb, int below, int nk_stride, long long* __restrict__ keep_out, int* __restrict__ num_keep) {
+  {
+    const size_t img = blockIdx.x;
+    mask += img * K * nb;
+    if (groups) groups += img * K;
+    keep_out += img * K;
+    num_keep += img * nk_stride;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];
   unsigned long long* removed = sm;        // [nb] suppression bits per sorted position
   unsigned long long* keepw = sm + nb;     // [nb] survivors per sorted position
@@ -150,36 +220,7 @@ __global__ __launch_bounds__(kReduceThreads) void nms_reduce_kernel(
   }
 
   // survivors -> bitmap indexed by original box index (ascending order comes for free)
-  for (int p = tid; p < K; p += kReduceThreads) {
-    if ((keepw[p >> 6] >> (p & 63)) & 1ull) {
-      const int o = order[p];
-      atomicOr(&obits[o >> 6], 1ull << (o & 63));
-    }
-  }
-  __syncthreads();
-  // exclusive scan of per-thread popcounts over contiguous word segments
-  const int seg = (nb + kReduceThreads - 1) / kReduceThreads;
-  const int w0 = tid * seg, w1 = min(nb, w0 + seg);
-  int cnt = 0;
-  for (int w = w0; w < w1; ++w) cnt += __popcll(obits[w]);
-  part[tid] = cnt;
-  __syncthreads();
-  for (int off = 1; off < kReduceThreads; off <<= 1) {
-    const int v = tid >= off ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  int pos = part[tid] - cnt;
-  for (int w = w0; w < w1; ++w) {
-    unsigned long long bits = obits[w];
-    while (bits) {
-      const int i = __builtin_ctzll(bits);
-      bits &= bits - 1;
-      keep_out[pos++] = (long long)w * 64 + i;
-    }
-  }
-  if (tid == kReduceThreads - 1) *num_keep = part[tid];
+  nms_compact(keepw, obits, part, order, groups, K, nb, below, nk_stride, keep_out, num_keep);
 }
 
 
@@ -200,8 +241,16 @@ __device__ __forceinline__ unsigned long long shfl_xor64(unsigned long long v, i
 
 __global__ __launch_bounds__(kReduceThreads) void nms_reduce_pipelined_kernel(
     const unsigned long long* __restrict__ mask, const unsigned long long* __restrict__ diag_t,
-    const int* __restrict__ order, int K, int nb,
+    const int* __restrict__ order, const int* __restrict__ groups, int K, int nb, int below, int nk_stride,
     long long* __restrict__ keep_out, int* __restrict__ num_keep) {
+  {
+    const size_t img = blockIdx.x;
+    mask += img * K * nb;
+    diag_t += img * K;
+    if (groups) groups += img * K;
+    keep_out += img * K;
+    num_keep += img * nk_stride;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];
   unsigned long long* removed = sm;
   unsigned long long* keepw = sm + nb;
@@ -274,35 +323,7 @@ __global__ __launch_bounds__(kReduceThreads) void nms_reduce_pipelined_kernel(
     step(b + 2, buf2, dg2);
   }
 
-  for (int p = tid; p < K; p += kReduceThreads) {
-    if ((keepw[p >> 6] >> (p & 63)) & 1ull) {
-      const int o = order[p];
-      atomicOr(&obits[o >> 6], 1ull << (o & 63));
-    }
-  }
-  __syncthreads();
-  const int seg = (nb + kReduceThreads - 1) / kReduceThreads;
-  const int w0 = tid * seg, w1 = min(nb, w0 + seg);
-  int cnt = 0;
-  for (int w = w0; w < w1; ++w) cnt += __popcll(obits[w]);
-  part[tid] = cnt;
-  __syncthreads();
-  for (int off = 1; off < kReduceThreads; off <<= 1) {
-    const int v = tid >= off ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  int pos = part[tid] - cnt;
-  for (int w = w0; w < w1; ++w) {
-    unsigned long long bits = obits[w];
-    while (bits) {
-      const int i = __builtin_ctzll(bits);
-      bits &= bits - 1;
-      keep_out[pos++] = (long long)w * 64 + i;
-    }
-  }
-  if (tid == kReduceThreads - 1) *num_keep = part[tid];
+  nms_compact(keepw, obits, part, order, groups, K, nb, below, nk_stride, keep_out, num_keep);
 }
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -399,11 +420,58 @@ static int nms_impl(const float* boxes, const float* scores, const int* groups, 
   OVIS_LAUNCH_CHECK();
   const size_t lds = sizeof(unsigned long long) * 3 * (size_t)nb + sizeof(int) * kReduceThreads;
   if (nb <= kFastBlocks)
-    hipLaunchKernelGGL(nms_reduce_pipelined_kernel, dim3(1), dim3(kReduceThreads), lds, s, mask, diag_t, order, K, nb,
-                       (long long*)keep_out, num_keep);
+    hipLaunchKernelGGL(nms_reduce_pipelined_kernel, dim3(1), dim3(kReduceThreads), lds, s, mask, diag_t, order,
+                       (const int*)nullptr, K, nb, 0, 1, (long long*)keep_out, num_keep);
   else
-    hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(kReduceThreads), lds, s, mask, order, K, nb,
-                       (long long*)keep_out, num_keep);
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(kReduceThreads), lds, s, mask, order, (const int*)nullptr, K, nb,
+                       0, 1, (long long*)keep_out, num_keep);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}
+
+// Batched, score-sorted form for the RPN proposal pipeline (rpn/inference.py:95-116): the candidates of every image
+// arrive as the top-k prefix in descending score order, so there is no sort; `drop` flags (negative = the box was
+// removed by the small-box filter in front of the NMS) ride on the group mechanism.
+extern "C" size_t ovis_nms_presorted_workspace_bytes(int num_images, int num_boxes) {
+  if (num_images <= 0 || num_boxes <= 0) return 0;
+  const size_t nb = (size_t)ovis_ceil_div(num_boxes, kTile);
+  return (size_t)num_images * (align256(sizeof(unsigned long long) * (size_t)num_boxes * nb) +
+                               align256(sizeof(unsigned long long) * (size_t)num_boxes));
+}
+
+extern "C" int ovis_nms_presorted_batched_f32(const float* boxes, const int32_t* drop, int num_images, int num_boxes,
+                                              float threshold, int ge_mode, int below, void* workspace,
+                                              size_t workspace_bytes, int64_t* keep_out, int32_t* num_keep,
+                                              void* stream) {
+  if (num_images < 0 || num_boxes < 0 || !num_keep) return OVIS_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (num_images == 0) return OVIS_OK;
+  if (num_boxes == 0) {
+    OVIS_HIP_TRY(hipMemsetAsync(num_keep, 0, sizeof(int32_t) * 2 * (size_t)num_images, s));
+    return OVIS_OK;
+  }
+  if (!boxes || !keep_out || !workspace) return OVIS_EINVAL;
+  const int K = num_boxes, nb = ovis_ceil_div(K, kTile);
+  if (nb > kMaxBlocks || num_images > 65535) return OVIS_ERANGE;
+  if (workspace_bytes < ovis_nms_presorted_workspace_bytes(num_images, K)) return OVIS_ENOSPC;
+  // contiguous [N][K * nb] masks followed by [N][K] transposed diagonal tiles (the kernels index them by image)
+  unsigned long long* mask = (unsigned long long*)workspace;
+  unsigned long long* diag_t = mask + (size_t)num_images * K * nb;
+  dim3 grid(nb, nb, num_images);
+#define OVIS_NMS_MASK(GE_, GR_)                                                                                          \
+  hipLaunchKernelGGL((nms_mask_kernel<GE_, GR_>), grid, dim3(kTile), 0, s, (const float4*)boxes, (const int*)drop,       \
+                     (const int*)nullptr, K, nb, threshold, mask, diag_t)
+  if (drop) { if (ge_mode) OVIS_NMS_MASK(true, true); else OVIS_NMS_MASK(false, true); }
+  else { if (ge_mode) OVIS_NMS_MASK(true, false); else OVIS_NMS_MASK(false, false); }
+#undef OVIS_NMS_MASK
+  OVIS_LAUNCH_CHECK();
+  const size_t lds = sizeof(unsigned long long) * 3 * (size_t)nb + sizeof(int) * kReduceThreads;
+  if (nb <= kFastBlocks)
+    hipLaunchKernelGGL(nms_reduce_pipelined_kernel, dim3(num_images), dim3(kReduceThreads), lds, s, mask, diag_t,
+                       (const int*)nullptr, (const int*)drop, K, nb, below, 2, (long long*)keep_out, num_keep);
+  else
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(num_images), dim3(kReduceThreads), lds, s, mask, (const int*)nullptr,
+                       (const int*)drop, K, nb, below, 2, (long long*)keep_out, num_keep);
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
 }

@@ -63,6 +63,15 @@ class AnchorGenerator(nn.Module):
             self._grid_cache[key] = (shifts.view(-1, 1, 4) + self.cell_anchors.view(1, -1, 4)).reshape(-1, 4)
         return self._grid_cache[key]
 
+    def image_wh(self, sizes, device):
+        """[N, 2] float32 (width, height) of the images (BoxList.size order), cached per size tuple: an operand of the
+        device-side proposal decode."""
+        key = (tuple(sizes), device)
+        if key not in self._grid_cache:
+            self._grid_cache[key] = torch.tensor([[float(w), float(h)] for (w, h) in sizes], dtype=torch.float32,
+                                                 device=device)
+        return self._grid_cache[key]
+
     def visibility(self, anchors, image_w, image_h):
         if self.straddle_thresh < 0:
             return torch.ones(anchors.shape[0], dtype=torch.bool, device=anchors.device)
@@ -151,6 +160,12 @@ def permute_and_flatten(layer, n, a, c, h, w):  # rpn/utils.py
 
 
 class RPNPostProcessor(nn.Module):  # inference.py:15-140 (single feature map)
+    """Proposal selection.  On the device (``anchor_generator`` attached by ``RPNModule``, HIP tensors) the chain after
+    the top-k is three launches for the whole batch: decode + clip + small-box flag (``_C.rpn_decode``), then the NMS
+    mask and reduce kernels on the already score-sorted candidates (``_C.nms_presorted_batched``), then one gather; the
+    host reads back ONE small tensor of survivor counts.  The tensor-op formulation below (``forward_tensor_ops``: the
+    reference's sequence, ~40 launches and 2 host syncs per image) serves CPU tensors and is the cross-check."""
+
     def __init__(self, pre_nms_top_n, post_nms_top_n, nms_thresh, min_size, box_coder):
         super().__init__()
         self.pre_nms_top_n = pre_nms_top_n
@@ -158,8 +173,54 @@ class RPNPostProcessor(nn.Module):  # inference.py:15-140 (single feature map)
         self.nms_thresh = nms_thresh
         self.min_size = min_size
         self.box_coder = box_coder
+        self.device_pipeline = True  # False = tensor ops also on the device (cross-check in the tests)
+
+    def _on_device(self, objectness):
+        return (self.device_pipeline and objectness.is_cuda and self.nms_thresh > 0
+                and self.__dict__.get("anchor_generator") is not None)
+
+    def _candidates(self, anchors, objectness, box_regression, pre):
+        """sigmoid -> top-k (sorted) -> decoded, clipped candidate boxes [N, pre, 4] + drop flags [N, pre]."""
+        from .. import _C
+        n, a, h, w = objectness.shape
+        obj = permute_and_flatten(objectness, n, a, 1, h, w).view(n, -1).sigmoid()
+        scores, topk_idx = obj.topk(pre, dim=1, sorted=True)
+        ag = self.__dict__["anchor_generator"]
+        boxes, drop = _C.rpn_decode(box_regression, topk_idx, ag.cell_anchors, ag.image_wh([b.size for b in anchors], obj.device),
+                                    self.box_coder.weights, self.box_coder.bbox_xform_clip, self.min_size, ag.stride)
+        return scores, boxes, drop
+
+    @staticmethod
+    def _gather(boxes, scores, keep, post):
+        sel = keep[:, :post]
+        return torch.gather(boxes, 1, sel.unsqueeze(-1).expand(-1, -1, 4)), torch.gather(scores, 1, sel)
+
+    @staticmethod
+    def _with_gt(boxlist, target):  # inference.py:51-74
+        gt = BoxList(target.bbox, target.size)
+        gt.add_field("objectness", torch.ones(len(gt), device=gt.bbox.device))
+        return cat_boxlist((boxlist, gt))
 
     def forward(self, anchors, objectness, box_regression, targets=None, add_gt=False):
+        if not self._on_device(objectness):
+            return self.forward_tensor_ops(anchors, objectness, box_regression, targets, add_gt)
+        from .. import _C
+        n, a, h, w = objectness.shape
+        scores, boxes, drop = self._candidates(anchors, objectness, box_regression, min(self.pre_nms_top_n, a * h * w))
+        keep, counts = _C.nms_presorted_batched(boxes, drop, self.nms_thresh)
+        pb, ps = self._gather(boxes, scores, keep, self.post_nms_top_n)
+        cnt = counts[:, 0].tolist()  # the one host read of the selection
+        result = []
+        for i in range(n):
+            m = min(cnt[i], self.post_nms_top_n)
+            boxlist = BoxList(pb[i, :m], anchors[i].size)
+            boxlist.add_field("objectness", ps[i, :m])
+            if add_gt and targets is not None:
+                boxlist = self._with_gt(boxlist, targets[i])
+            result.append(boxlist)
+        return result
+
+    def forward_tensor_ops(self, anchors, objectness, box_regression, targets=None, add_gt=False):
         n, a, h, w = objectness.shape
         objectness = permute_and_flatten(objectness, n, a, 1, h, w).view(n, -1).sigmoid()
         box_regression = permute_and_flatten(box_regression, n, a, 4, h, w)
@@ -177,26 +238,42 @@ class RPNPostProcessor(nn.Module):  # inference.py:15-140 (single feature map)
             boxlist = remove_small_boxes(boxlist, self.min_size)
             boxlist = boxlist_nms(boxlist, self.nms_thresh, max_proposals=self.post_nms_top_n,
                                   score_field="objectness")
-            if add_gt and targets is not None:  # inference.py:51-74
-                gt = BoxList(targets[i].bbox, targets[i].size)
-                gt.add_field("objectness", torch.ones(len(gt), device=gt.bbox.device))
-                boxlist = cat_boxlist((boxlist, gt))
+            if add_gt and targets is not None:
+                boxlist = self._with_gt(boxlist, targets[i])
             result.append(boxlist)
         return result
-
 
     def forward_with(self, other, anchors, objectness, box_regression, targets=None, add_gt=False):
         """Proposals of THIS selector and of ``other`` (same threshold / min size, other.pre_nms_top_n <= ours) from ONE
         decode + NMS pass: candidates are sorted by score and greedy NMS only lets higher-scored boxes suppress, so the
-        survivors among the first ``other.pre_nms_top_n`` candidates ARE ``other``'s NMS result.  Returns
-        (ours, theirs) -- what two separate ``forward`` calls return (ours with the ground truth appended)."""
+        survivors among the first ``other.pre_nms_top_n`` candidates ARE ``other``'s NMS result -- and, survivors being
+        listed by ascending rank, a PREFIX of ours.  Returns (ours, theirs) -- what two separate ``forward`` calls
+        return (ours with the ground truth appended)."""
         assert other.pre_nms_top_n <= self.pre_nms_top_n and other.nms_thresh == self.nms_thresh \
             and other.min_size == self.min_size
         n, a, h, w = objectness.shape
-        objectness = permute_and_flatten(objectness, n, a, 1, h, w).view(n, -1).sigmoid()
-        box_regression = permute_and_flatten(box_regression, n, a, 4, h, w)
         pre = min(self.pre_nms_top_n, a * h * w)
         pre_other = min(other.pre_nms_top_n, a * h * w)
+        if self._on_device(objectness):
+            from .. import _C
+            scores, boxes, drop = self._candidates(anchors, objectness, box_regression, pre)
+            keep, counts = _C.nms_presorted_batched(boxes, drop, self.nms_thresh, below=pre_other)
+            pb, ps = self._gather(boxes, scores, keep, max(self.post_nms_top_n, other.post_nms_top_n))
+            cnt = counts.tolist()  # the one host read: [survivors, survivors among the first pre_other] per image
+            ours, theirs = [], []
+            for i in range(n):
+                m, t = min(cnt[i][0], self.post_nms_top_n), min(cnt[i][1], other.post_nms_top_n)
+                sub = BoxList(pb[i, :t], anchors[i].size)
+                sub.add_field("objectness", ps[i, :t])
+                theirs.append(sub)
+                mine = BoxList(pb[i, :m], anchors[i].size)
+                mine.add_field("objectness", ps[i, :m])
+                if add_gt and targets is not None:
+                    mine = self._with_gt(mine, targets[i])
+                ours.append(mine)
+            return ours, theirs
+        objectness = permute_and_flatten(objectness, n, a, 1, h, w).view(n, -1).sigmoid()
+        box_regression = permute_and_flatten(box_regression, n, a, 4, h, w)
         objectness, topk_idx = objectness.topk(pre, dim=1, sorted=True)
         batch_idx = torch.arange(n, device=objectness.device)[:, None]
         box_regression = box_regression[batch_idx, topk_idx]
@@ -215,9 +292,7 @@ class RPNPostProcessor(nn.Module):  # inference.py:15-140 (single feature map)
             theirs.append(sub.copy_with_fields(["objectness"]))
             mine = kept[:self.post_nms_top_n].copy_with_fields(["objectness"])
             if add_gt and targets is not None:
-                gt = BoxList(targets[i].bbox, targets[i].size)
-                gt.add_field("objectness", torch.ones(len(gt), device=gt.bbox.device))
-                mine = cat_boxlist((mine, gt))
+                mine = self._with_gt(mine, targets[i])
             ours.append(mine)
         return ours, theirs
 
@@ -262,6 +337,8 @@ class RPNModule(nn.Module):  # rpn.py:109-197
                                                    r.MIN_SIZE, coder)
         self.box_selector_test = RPNPostProcessor(r.PRE_NMS_TOP_N_TEST, r.POST_NMS_TOP_N_TEST, r.NMS_THRESH,
                                                   r.MIN_SIZE, coder)
+        for sel in (self.box_selector_train, self.box_selector_test):
+            sel.__dict__["anchor_generator"] = self.anchor_generator  # a reference, not a registered sub-module
         self.loss_evaluator = RPNLossComputation(
             Matcher(r.FG_IOU_THRESHOLD, r.BG_IOU_THRESHOLD, allow_low_quality_matches=True),
             BalancedPositiveNegativeSampler(r.BATCH_SIZE_PER_IMAGE, r.POSITIVE_FRACTION), coder)

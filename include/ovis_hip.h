@@ -135,6 +135,34 @@ int ovis_nms_grouped_f32(const float* boxes, const float* scores, const int32_t*
                          float threshold, int ge_mode, void* workspace, size_t workspace_bytes,
                          int64_t* keep_out, int32_t* num_keep, void* stream);
 
+/* Batched, score-sorted form for the RPN proposal pipeline (mb/modeling/rpn/inference.py:95-116,
+ * mb/structures/boxlist_ops.py:9-49): boxes [num_images, K, 4] are each image's candidates in DESCENDING score order
+ * (the top-k prefix: no sort happens here); `drop` [num_images, K] int32 or NULL: a negative entry marks a box the
+ * small-box filter removed in front of the NMS -- it suppresses nothing and never survives.  Per image: survivors as
+ * ascending indices (= ascending rank) in keep_out[image, 0..n), zero-filled behind them; num_keep[image] = {n, number
+ * of survivors with index < `below`} (those form a prefix of keep_out: the NMS result of the first `below` candidates
+ * alone, i.e. of a selector with a smaller pre-NMS top-n).  One mask launch + one reduce launch for the whole batch. */
+size_t ovis_nms_presorted_workspace_bytes(int num_images, int num_boxes);
+int ovis_nms_presorted_batched_f32(const float* boxes, const int32_t* drop, int num_images, int num_boxes,
+                                   float threshold, int ge_mode, int below, void* workspace, size_t workspace_bytes,
+                                   int64_t* keep_out, int32_t* num_keep, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * RPN proposal decode                        mb/modeling/rpn/inference.py:95-114,
+ *   mb/modeling/box_coder.py:49-95, mb/structures/bounding_box.py:214-225, mb/structures/boxlist_ops.py:34-49
+ * For every image and every candidate k < num_candidates: anchor index topk_idx[image, k] = (y * feature_width + x) *
+ * anchors_per_position + a; its regression deltas are box_regression[image * stride_image + (y * feature_width + x) *
+ * stride_position + (4 * a + c) * stride_channel] (NCHW [N, 4A, H, W]: strides (4A*H*W, 1, H*W); NHWC rows of a GEMM:
+ * (H*W*ld, ld, 1)); its anchor is cell_anchors[a] + (x, y, x, y) * anchor_stride.  Writes the decoded box, clipped to
+ * the image (image_wh [num_images, 2] = width, height), to boxes[image, k] and drop[image, k] = 0, or -1 when the
+ * clipped box is narrower / lower than min_size.  One launch for the batch.
+ * ---------------------------------------------------------------------------------- */
+int ovis_rpn_decode_f32(const float* box_regression, long reg_stride_image, long reg_stride_position,
+                        long reg_stride_channel, const int64_t* topk_idx, const float* cell_anchors,
+                        const float* image_wh, int num_images, int num_candidates, int anchors_per_position,
+                        int feature_width, float anchor_stride, float weight_x, float weight_y, float weight_w,
+                        float weight_h, float xform_clip, float min_size, float* boxes, int32_t* drop, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * ROIPool                                    mb/csrc/ROIPool.h:11-48
  *   kernels: mb/csrc/cuda/ROIPool_cuda.cu:17-77 (fwd), :80-108 (bwd)

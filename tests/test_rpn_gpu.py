@@ -1,0 +1,121 @@
+"""GPU: the RPN proposal chain as device kernels (csrc/rpn.hip decode + clip + small-box flag, csrc/nms.hip batched
+score-sorted NMS with drop flags) against (a) the fixture produced by the reference's RPNPostProcessor
+(tests/golden/heads.npz, rpn/inference.py:76-123), (b) the tensor-op formulation of the same module on the same
+device, and (c) the CPU oracle's NMS on the non-dropped candidates.  Index outputs are compared exactly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def z(golden_dir):
+    return np.load(os.path.join(golden_dir, "heads.npz"))
+
+
+def _module(pre_train, post_train, pre_test, post_test, min_size):
+    from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.rpn import RPNModule
+
+    cfg = get_defaults()
+    cfg.merge_from_list(["MODEL.RPN.PRE_NMS_TOP_N_TRAIN", pre_train, "MODEL.RPN.POST_NMS_TOP_N_TRAIN", post_train,
+                         "MODEL.RPN.PRE_NMS_TOP_N_TEST", pre_test, "MODEL.RPN.POST_NMS_TOP_N_TEST", post_test,
+                         "MODEL.RPN.MIN_SIZE", min_size])
+    cfg.freeze()
+    return RPNModule(cfg, 64).cuda()
+
+
+def test_rpn_device_pipeline_matches_reference_fixture(z):
+    """Same inputs as tests/test_components.py::test_anchors_and_rpn_proposals_match_reference, through the device
+    kernels: the reference module's proposals and scores."""
+    rpn = _module(600, 50, 600, 50, 0)
+    pp = rpn.box_selector_test
+    H, W = 9, 12
+    sizes = [(H * 16, W * 16), (H * 16 - 10, W * 16 - 7)]
+    anchors = rpn.anchor_generator(sizes, torch.zeros(2, 1, H, W, device="cuda"))
+    assert pp._on_device(T(z["rpn_obj"]).cuda())
+    res = pp(anchors, T(z["rpn_obj"]).cuda(), T(z["rpn_reg"]).cuda())
+    for i, r in enumerate(res):
+        want_b, want_s = T(z[f"rpn_boxes{i}"]), T(z[f"rpn_scores{i}"])
+        assert r.bbox.shape == want_b.shape
+        assert torch.allclose(r.bbox.cpu(), want_b, rtol=1e-5, atol=1e-4)
+        assert torch.allclose(r.get_field("objectness").cpu(), want_s)
+
+
+@pytest.mark.parametrize("min_size", [0, 24])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc_view"])
+def test_rpn_device_pipeline_equals_tensor_ops_full_size(min_size, layout):
+    """BASELINE size (two 800x1333 images: 15 x 50 x 84 anchors, 12000 -> 2000 and 6000 -> 1000): the device pipeline
+    returns exactly the boxes and scores of the tensor-op sequence, for one selector and for the shared
+    train + test selection; min_size 24 exercises the drop flags (boxes removed in front of the NMS)."""
+    torch.manual_seed(3)
+    rpn = _module(12000, 2000, 6000, 1000, min_size)
+    n, a, h, w = 2, 15, 50, 84
+    if layout == "nchw":
+        obj = torch.randn(n, a, h, w, device="cuda") * 2
+        reg = torch.randn(n, 4 * a, h, w, device="cuda") * 0.3
+    else:  # what the frozen GEMM head hands over: NCHW views of one NHWC [N, H, W, 76] result
+        y = torch.randn(n, h, w, 76, device="cuda")
+        y[..., :a] *= 2
+        y[..., a:] *= 0.3
+        obj, reg = y[..., :a].permute(0, 3, 1, 2), y[..., a:5 * a].permute(0, 3, 1, 2)
+    sizes = [(800, 1333), (790, 1301)]
+    anchors = rpn.anchor_generator(sizes, obj)
+    gt = []
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.structures import BoxList
+    for s in sizes:
+        gt.append(BoxList(torch.tensor([[10.0, 20.0, 200.0, 300.0], [400.0, 100.0, 700.0, 500.0]], device="cuda"), (s[1], s[0])))
+    tr, te = rpn.box_selector_train, rpn.box_selector_test
+
+    def both(device_pipeline):
+        tr.device_pipeline = te.device_pipeline = device_pipeline
+        single = tr(anchors, obj, reg, gt, add_gt=True)
+        ours, theirs = tr.forward_with(te, anchors, obj, reg, gt, add_gt=True)
+        test_only = te(anchors, obj, reg)
+        return single, ours, theirs, test_only
+
+    got, want = both(True), both(False)
+    for g_list, w_list in zip(got, want):
+        for g, w_ in zip(g_list, w_list):
+            assert len(g) == len(w_) and len(g) > 100
+            assert torch.equal(g.bbox, w_.bbox)
+            assert torch.equal(g.get_field("objectness"), w_.get_field("objectness"))
+    if min_size:
+        ws = got[0][0].bbox[:, 2] - got[0][0].bbox[:, 0] + 1
+        assert float(ws[:-2].min()) >= min_size  # the appended ground truth aside
+
+
+def test_nms_presorted_batched_vs_oracle(oracle_mod):
+    """Score-sorted batched NMS with drop flags == the oracle's NMS on the non-dropped boxes of every image; the second
+    count is the number of survivors among the first `below` candidates, and they are a prefix of the list."""
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+
+    g = torch.Generator().manual_seed(5)
+    n, k = 3, 3000
+    xy = torch.rand(n, k, 2, generator=g) * torch.tensor([900.0, 600.0])
+    wh = torch.rand(n, k, 2, generator=g) * 250 + 4
+    boxes = torch.cat([xy, xy + wh], 2)
+    drop = -(torch.rand(n, k, generator=g) < 0.2).to(torch.int32)
+    scores = torch.sort(torch.rand(n, k, generator=g), dim=1, descending=True).values  # distinct, descending
+    below = 1100
+    keep, counts = _C.nms_presorted_batched(boxes.cuda(), drop.cuda(), 0.6, below=below)
+    keep, counts = keep.cpu(), counts.cpu()
+    for i in range(n):
+        alive = torch.nonzero(drop[i] == 0).squeeze(1)
+        want = alive[oracle_mod.nms(boxes[i][alive], scores[i][alive], 0.6)]
+        c, cb = int(counts[i, 0]), int(counts[i, 1])
+        assert c == want.numel()
+        assert torch.equal(keep[i, :c], want)
+        assert bool((keep[i, c:] == 0).all())
+        assert cb == int((want < below).sum()) and bool((keep[i, :cb] < below).all())
+    keep2, counts2 = _C.nms_presorted_batched(boxes.cuda(), None, 0.6)
+    for i in range(n):
+        want = oracle_mod.nms(boxes[i], scores[i], 0.6)
+        assert torch.equal(keep2[i, : int(counts2[i, 0])].cpu(), want)
