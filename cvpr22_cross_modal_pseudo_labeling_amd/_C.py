@@ -429,6 +429,43 @@ def project_masks(masks, gt_index, boxes, resolution):
     return out
 
 
+def sample_fg_bg(labels, batch_size, max_positives, seed):
+    """fg / bg sampling of one image on the device (``ovis_sample_fg_bg``; balanced_positive_negative_sampler.py:19-68):
+    labels [P] int64 -> (selected [batch_size] int64: chosen indices ascending, zero padded; positive_slots [batch_size]:
+    positions of the positives inside ``selected``; counts [2] int32: number selected, positives among them)."""
+    if not labels.is_cuda or labels.dtype != torch.int64 or labels.dim() != 1:
+        raise RuntimeError("sample_fg_bg: 1-D int64 HIP tensor expected (the product path has no CPU fallback)")
+    labels = labels.contiguous()
+    sel = torch.empty((batch_size,), dtype=torch.int64, device=labels.device)
+    slots = torch.empty((batch_size,), dtype=torch.int64, device=labels.device)
+    counts = torch.empty((2,), dtype=torch.int32, device=labels.device)
+    with torch.cuda.device(labels.device):
+        rc = _L.ovis_sample_fg_bg(labels.data_ptr(), labels.numel(), int(batch_size), int(max_positives),
+                                  int(seed) & 0xFFFFFFFFFFFFFFFF, sel.data_ptr(), slots.data_ptr(), counts.data_ptr(), _stream())
+    _lib.check(rc, "sample_fg_bg")
+    return sel, slots, counts
+
+
+def project_pasted_masks(mask_probs, gt_boxes, gt_index, boxes, image_size, resolution, threshold=0.5):
+    """Mask targets [P, resolution, resolution] for boxes [P, 4] whose ground truth gt_index[p] has its binary mask
+    defined by (mask_probs [G, M, M], gt_boxes [G, 4]) through the Masker paste (``ovis_project_pasted_masks_f32``);
+    image_size = (height, width)."""
+    mask_probs, gt_boxes, boxes = _dev(mask_probs, "mask_probs"), _dev(gt_boxes, "gt_boxes"), _dev(boxes, "boxes")
+    gt_index = _dev(gt_index, "gt_index", torch.int64)
+    p = boxes.shape[0]
+    out = torch.empty((p, resolution, resolution), dtype=torch.float32, device=boxes.device)
+    if p == 0:
+        return out
+    if mask_probs.dim() != 3 or mask_probs.shape[1] != mask_probs.shape[2] or gt_boxes.shape != (mask_probs.shape[0], 4):
+        raise RuntimeError("project_pasted_masks: expected mask_probs [G,M,M] and gt_boxes [G,4]")
+    with torch.cuda.device(boxes.device):
+        rc = _L.ovis_project_pasted_masks_f32(mask_probs.data_ptr(), gt_boxes.data_ptr(), gt_index.data_ptr(),
+                                              boxes.data_ptr(), p, int(image_size[0]), int(image_size[1]),
+                                              mask_probs.shape[1], int(resolution), float(threshold), out.data_ptr(), _stream())
+    _lib.check(rc, "project_pasted_masks")
+    return out
+
+
 def split_pair(x):
     """x [rows, cols] f32 (row-strided view ok, cols % 32 == 0) -> pair layout [rows, 2*cols] bf16: per 32 values
     [hi(32) | lo(32)].  See include/ovis_hip.h."""

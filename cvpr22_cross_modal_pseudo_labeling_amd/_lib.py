@@ -32,6 +32,8 @@ SIGNATURES = {
     "ovis_nms_workspace_bytes": (_sz, [_i]),
     "ovis_nms_f32": (_i, [_vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp]),
     "ovis_nms_grouped_f32": (_i, [_vp, _vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp]),
+    "ovis_sample_fg_bg": (_i, [_vp, _i, _i, _i, ctypes.c_uint64, _vp, _vp, _vp, _vp]),
+    "ovis_project_pasted_masks_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "ovis_nms_presorted_workspace_bytes": (_sz, [_i, _i]),
     "ovis_nms_presorted_batched_f32": (_i, [_vp, _vp, _i, _i, _f, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "ovis_rpn_decode_f32": (_i, [_vp, _l, _l, _l, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp]),

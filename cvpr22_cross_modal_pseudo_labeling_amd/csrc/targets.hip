@@ -10,6 +10,15 @@
 //   project_masks: project_masks_on_boxes (mask_head/loss.py:11-42) for binary 'mask'-mode targets: crop to the
 //                  rounded box (segmentation_mask.py:117-136) and bilinear resize to MxM (F.interpolate,
 //                  align_corners=False; :138-156), cast back to the mask dtype.  One thread per output pixel.
+//   sample_fg_bg : BalancedPositiveNegativeSampler (mb/modeling/balanced_positive_negative_sampler.py:19-68) for one
+//                  image in ONE launch: counts, a uniformly random num_pos-subset of the positives and num_neg-subset of
+//                  the negatives (the reference's randperm()[:k] picks exactly such subsets; the random stream itself
+//                  is torch-version dependent and cannot be matched), compacted in ascending index order like the
+//                  reference's nonzero(pos_mask | neg_mask) -- no nonzero / randperm / host read.
+//   project_pasted_masks: project_masks on masks that exist only as (MxM probability map, box) pairs -- the pseudo
+//                  labels' masks (st_generalized_rcnn.py:266-271).  A pixel of the full-resolution binary mask the
+//                  reference builds with Masker (mask_head/inference.py:100-160: pad by 1, expand the box, bilinear
+//                  resize to the integer box, > 0.5, paste) is evaluated on the fly, so the H x W canvases never exist.
 #include "ovis_common.h"
 
 namespace {
@@ -92,7 +101,236 @@ __global__ __launch_bounds__(256) void project_masks_kernel(const unsigned char*
   const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
   out[i] = is_bool ? (v != 0.f ? 1.f : 0.f) : (float)(unsigned char)v;
 }
+// ---- fg / bg sampler ------------------------------------------------------------------------------------------------
+constexpr int kSampThreads = 1024;
+
+__device__ __forceinline__ unsigned sample_key(unsigned long long seed, unsigned i) {  // splitmix64 of (seed, index)
+  unsigned long long z = seed + ((unsigned long long)i + 1ull) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+
+// class of a matched label: 1 positive (label >= 1), 0 negative (label == 0), 2 ignored (< 0)
+__device__ __forceinline__ int sample_class(long lab) { return lab >= 1 ? 1 : (lab == 0 ? 0 : 2); }
+
+// exclusive block scan of one int per thread (kSampThreads threads); returns the prefix, *total = the sum
+__device__ __forceinline__ int block_exscan(int v, int* sh, int* total) {
+  const int tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+  for (int off = 1; off < kSampThreads; off <<= 1) {
+    const int t = tid >= off ? sh[tid - off] : 0;
+    __syncthreads();
+    sh[tid] += t;
+    __syncthreads();
+  }
+  const int incl = sh[tid];
+  *total = sh[kSampThreads - 1];
+  __syncthreads();
+  return incl - v;
+}
+
+__global__ __launch_bounds__(kSampThreads) void sample_fg_bg_kernel(const long* __restrict__ labels, int P, int batch_size,
+                                                                    int max_pos, unsigned long long seed,
+                                                                    long* __restrict__ sel_idx, long* __restrict__ pos_slot,
+                                                                    int* __restrict__ counts) {
+  __shared__ int sh[kSampThreads];
+  __shared__ unsigned hist[2][256];
+  __shared__ unsigned prefix[2], want[2];  // per class: key prefix fixed so far, how many keys below it are still wanted
+  const int tid = threadIdx.x;
+  const int chunk = (P + kSampThreads - 1) / kSampThreads;
+  const int i0 = min(tid * chunk, P), i1 = min(i0 + chunk, P);  // contiguous slice: the scans below are in index order
+  // class counts
+  int c1 = 0, c0 = 0;
+  for (int i = i0; i < i1; ++i) {
+    const int c = sample_class(labels[i]);
+    c1 += c == 1;
+    c0 += c == 0;
+  }
+  int npos, nneg;
+  block_exscan(c1, sh, &npos);
+  block_exscan(c0, sh, &nneg);
+  const int k_pos = min(npos, max_pos);
+  const int k_neg = min(nneg, batch_size - k_pos);
+  // radix select (4 passes of 8 bits, most significant first) of the k-th smallest key of each class: afterwards every
+  // key below thr[c] is selected and `want[c]` of the keys equal to it (lowest indices first)
+  const int kk[2] = {k_neg, k_pos}, nn[2] = {nneg, npos};
+  if (tid < 2) {
+    prefix[tid] = 0;
+    want[tid] = (unsigned)kk[tid];
+  }
+  __syncthreads();
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    for (int b = tid; b < 512; b += kSampThreads) hist[b >> 8][b & 255] = 0;
+    __syncthreads();
+    const unsigned pf0 = prefix[0], pf1 = prefix[1];
+    for (int i = i0; i < i1; ++i) {
+      const int c = sample_class(labels[i]);
+      if (c == 2 || kk[c] >= nn[c]) continue;  // everything of the class is taken: no threshold needed
+      const unsigned key = sample_key(seed, (unsigned)i);
+      const unsigned pf = c ? pf1 : pf0;
+      if (pass == 0 || (key >> (shift + 8)) == (pf >> (shift + 8))) atomicAdd(&hist[c][(key >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    if (tid < 2 && kk[tid] < nn[tid]) {
+      unsigned acc = 0, w = want[tid];
+      int d = 0;
+      for (; d < 256; ++d) {  // first digit whose bucket crosses the number of keys still wanted
+        const unsigned h = hist[tid][d];
+        if (acc + h > w) break;
+        acc += h;
+      }
+      d = min(d, 255);
+      prefix[tid] |= (unsigned)d << shift;
+      want[tid] = w - acc;
+    }
+    __syncthreads();
+  }
+  const unsigned thr[2] = {prefix[0], prefix[1]};
+  const unsigned ties_wanted[2] = {want[0], want[1]};
+  // ties (key == thr[c]) are granted in index order: exclusive count of the thread's preceding ties, per class
+  int t0 = 0, t1 = 0;
+  for (int i = i0; i < i1; ++i) {
+    const int c = sample_class(labels[i]);
+    if (c == 2 || kk[c] >= nn[c]) continue;
+    if (sample_key(seed, (unsigned)i) == thr[c]) (c ? t1 : t0) += 1;
+  }
+  int tot;
+  int tie_before[2];
+  tie_before[0] = block_exscan(t0, sh, &tot);
+  tie_before[1] = block_exscan(t1, sh, &tot);
+  // selection flags -> ascending compaction (and the positives' slots inside the compacted list)
+  int n_sel = 0, n_ps = 0;
+  int seen[2] = {tie_before[0], tie_before[1]};
+  for (int i = i0; i < i1; ++i) {
+    const int c = sample_class(labels[i]);
+    if (c == 2) continue;
+    bool take;
+    if (kk[c] >= nn[c]) take = true;
+    else {
+      const unsigned key = sample_key(seed, (unsigned)i);
+      take = key < thr[c] || (key == thr[c] && (unsigned)(seen[c]++) < ties_wanted[c]);
+    }
+    n_sel += take;
+    n_ps += take && c == 1;
+  }
+  int total_sel, total_pos;
+  int at = block_exscan(n_sel, sh, &total_sel);
+  int pat = block_exscan(n_ps, sh, &total_pos);
+  seen[0] = tie_before[0];
+  seen[1] = tie_before[1];
+  for (int i = i0; i < i1; ++i) {
+    const int c = sample_class(labels[i]);
+    if (c == 2) continue;
+    bool take;
+    if (kk[c] >= nn[c]) take = true;
+    else {
+      const unsigned key = sample_key(seed, (unsigned)i);
+      take = key < thr[c] || (key == thr[c] && (unsigned)(seen[c]++) < ties_wanted[c]);
+    }
+    if (take) {
+      if (c == 1) pos_slot[pat++] = at;
+      sel_idx[at++] = i;
+    }
+  }
+  for (int j = total_sel + tid; j < batch_size; j += kSampThreads) sel_idx[j] = 0;
+  for (int j = total_pos + tid; j < batch_size; j += kSampThreads) pos_slot[j] = 0;
+  if (tid == 0) {
+    counts[0] = total_sel;
+    counts[1] = total_pos;
+  }
+}
+
+// ---- mask targets from (probability map, box) pairs ---------------------------------------------------------------------
+// Pixel (Y, X) of the binary image mask Masker would paste for ground truth g (mask_head/inference.py:100-160 with
+// padding 1): the M x M map, zero-padded to (M+2)^2, is resized bilinearly (align_corners=False) to the integer box
+// obtained by expanding the box by (M+2)/M about its centre and truncating, thresholded, and pasted clipped to the image.
+__device__ __forceinline__ float pasted_pixel(const float* __restrict__ prob, int M, int4 bx, int bw, int bh, float thr,
+                                              int im_h, int im_w, int Y, int X) {
+  if (Y < 0 || X < 0 || Y >= im_h || X >= im_w || Y < bx.y || Y > bx.w || X < bx.x || X > bx.z) return 0.f;
+  const int S = M + 2;
+  // upsample_bilinear2d, align_corners=False: src = scale * (dst + 0.5) - 0.5 clamped at 0, scale = in / out
+  const float scale_y = (float)S / (float)bh, scale_x = (float)S / (float)bw;
+  const float sy = fmaxf(scale_y * ((float)(Y - bx.y) + 0.5f) - 0.5f, 0.f);
+  const float sx = fmaxf(scale_x * ((float)(X - bx.x) + 0.5f) - 0.5f, 0.f);
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = y0 + (y0 < S - 1), x1 = x0 + (x0 < S - 1);
+  const float ly = sy - (float)y0, lx = sx - (float)x0;
+  auto at = [&](int y, int x) {  // the padded map: a zero border of one pixel
+    return (y >= 1 && y <= M && x >= 1 && x <= M) ? prob[(y - 1) * M + (x - 1)] : 0.f;
+  };
+  const float v = (1.f - ly) * ((1.f - lx) * at(y0, x0) + lx * at(y0, x1)) + ly * ((1.f - lx) * at(y1, x0) + lx * at(y1, x1));
+  return v > thr ? 1.f : 0.f;
+}
+
+__global__ __launch_bounds__(256) void project_pasted_masks_kernel(const float* __restrict__ probs,
+                                                                  const float* __restrict__ gt_boxes,
+                                                                  const long* __restrict__ gt_index,
+                                                                  const float* __restrict__ boxes, int P, int H, int W,
+                                                                  int Mp, int M, float thr, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)P * M * M;
+  if (i >= total) return;
+  const int dx = (int)(i % M), dy = (int)((i / M) % M), p = (int)(i / ((long)M * M));
+  // the crop window and the resize taps: project_masks_kernel, expression by expression
+  const float4 bb = *(const float4*)(boxes + 4 * p);
+  const float b0 = rintf(bb.x), b1 = rintf(bb.y), b2 = rintf(bb.z), b3 = rintf(bb.w);
+  const float xmin = fminf(fmaxf(b0, 0.f), (float)(W - 1)), ymin = fminf(fmaxf(b1, 0.f), (float)(H - 1));
+  const float xmax = fmaxf(fminf(fmaxf(b2, 0.f), (float)W), xmin + 1.f);
+  const float ymax = fmaxf(fminf(fmaxf(b3, 0.f), (float)H), ymin + 1.f);
+  const float w = xmax - xmin, h = ymax - ymin;
+  const float inv_m = 1.f / (float)M;
+  const float sy = fmaxf(((float)dy + 0.5f) * (h * inv_m) - 0.5f, 0.f);
+  const float sx = fmaxf(((float)dx + 0.5f) * (w * inv_m) - 0.5f, 0.f);
+  float y0 = floorf(sy), x0 = floorf(sx);
+  const float ly = sy - y0, lx = sx - x0;
+  y0 = fminf(y0, h - 1.f);
+  x0 = fminf(x0, w - 1.f);
+  const float y1 = fminf(y0 + 1.f, h - 1.f), x1 = fminf(x0 + 1.f, w - 1.f);
+  // the ground truth's pasted mask: integer box of the expanded pseudo box (Masker: scale (M+2)/M, truncation)
+  const long g = gt_index[p];
+  const float4 gb = *(const float4*)(gt_boxes + 4 * g);
+  const float scale = (float)(Mp + 2) / (float)Mp;
+  const float w_half = (gb.z - gb.x) * 0.5f * scale, h_half = (gb.w - gb.y) * 0.5f * scale;
+  const float x_c = (gb.z + gb.x) * 0.5f, y_c = (gb.w + gb.y) * 0.5f;
+  const int4 bx = make_int4((int)(x_c - w_half), (int)(y_c - h_half), (int)(x_c + w_half), (int)(y_c + h_half));
+  const int bw = max(bx.z - bx.x + 1, 1), bh = max(bx.w - bx.y + 1, 1);
+  const float* pr = probs + g * Mp * Mp;
+  const int Y0 = (int)(y0 + ymin), Y1 = (int)(y1 + ymin), X0 = (int)(x0 + xmin), X1 = (int)(x1 + xmin);
+  const float v00 = pasted_pixel(pr, Mp, bx, bw, bh, thr, H, W, Y0, X0), v01 = pasted_pixel(pr, Mp, bx, bw, bh, thr, H, W, Y0, X1);
+  const float v10 = pasted_pixel(pr, Mp, bx, bw, bh, thr, H, W, Y1, X0), v11 = pasted_pixel(pr, Mp, bx, bw, bh, thr, H, W, Y1, X1);
+  const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+  out[i] = v != 0.f ? 1.f : 0.f;
+}
 }  // namespace
+
+extern "C" int ovis_sample_fg_bg(const int64_t* labels, int num, int batch_size, int max_positives, uint64_t seed,
+                                 int64_t* selected, int64_t* positive_slots, int32_t* counts, void* stream) {
+  if (num < 0 || batch_size <= 0 || max_positives < 0 || max_positives > batch_size) return OVIS_EINVAL;
+  if (!selected || !positive_slots || !counts || (num > 0 && !labels)) return OVIS_EINVAL;
+  hipLaunchKernelGGL(sample_fg_bg_kernel, dim3(1), dim3(kSampThreads), 0, (hipStream_t)stream, (const long*)labels, num,
+                     batch_size, max_positives, (unsigned long long)seed, (long*)selected, (long*)positive_slots, counts);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}
+
+extern "C" int ovis_project_pasted_masks_f32(const float* mask_probs, const float* gt_boxes, const int64_t* gt_index,
+                                             const float* boxes, int num, int image_height, int image_width,
+                                             int prob_resolution, int resolution, float threshold, float* out,
+                                             void* stream) {
+  if (num < 0 || image_height <= 0 || image_width <= 0 || prob_resolution <= 0 || resolution <= 0) return OVIS_EINVAL;
+  if (num == 0) return OVIS_OK;
+  if (!mask_probs || !gt_boxes || !gt_index || !boxes || !out) return OVIS_EINVAL;
+  if (((uintptr_t)boxes & 15) || ((uintptr_t)gt_boxes & 15)) return OVIS_ERANGE;
+  const long total = (long)num * resolution * resolution;
+  hipLaunchKernelGGL(project_pasted_masks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     mask_probs, gt_boxes, (const long*)gt_index, boxes, num, image_height, image_width, prob_resolution,
+                     resolution, threshold, out);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}
 
 extern "C" int ovis_match_encode_f32(const float* gt_boxes, const int64_t* gt_labels, const float* proposals,
                                      int num_gt, int num_proposals, float high_threshold, float low_threshold,

@@ -28,7 +28,7 @@ from .. import _C
 from .backbone import Backbone
 from .roi_heads import CombinedROIHeads, Masker
 from .rpn import RPNModule
-from .structures import BoxList, to_image_list
+from .structures import BoxList, PastedMasks, to_image_list
 
 
 class GeneralizedRCNN(nn.Module):
@@ -147,8 +147,15 @@ class STGeneralizedRCNN(nn.Module):
         if self.mask_on:
             _, results, _ = teacher(features, pseudo_labels, None, bbox_only=False)
             for res, pl in zip(results, pseudo_labels):
-                masks = self.masker(res.get_field("mask"), pl)[:, 0]  # [W,H,W] bool
-                pl.add_field("masks", masks)
+                if pl.bbox.is_cuda:
+                    # the pasted image-size masks (Masker, mask_head/inference.py:124-205) are only ever cropped and
+                    # resized back to 14x14 by the student's mask loss: keep (probability map, box) and let
+                    # _C.project_pasted_masks evaluate the pixels it needs -- same targets, no H x W canvases
+                    w, h = pl.size
+                    pl.add_field("masks", PastedMasks(res.get_field("mask")[:, 0], pl.bbox, (h, w),
+                                                      self.masker.threshold, self.masker.padding))
+                else:
+                    pl.add_field("masks", self.masker(res.get_field("mask"), pl)[:, 0])  # [W,H,W] bool
         teacher["box"].predictor.set_class_embeddings(class_embs)
         return pseudo_labels
 

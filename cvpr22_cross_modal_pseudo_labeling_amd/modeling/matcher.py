@@ -39,6 +39,19 @@ class BalancedPositiveNegativeSampler:
     def __init__(self, batch_size_per_image, positive_fraction):
         self.batch_size_per_image = batch_size_per_image
         self.positive_fraction = positive_fraction
+        self._calls = 0
+
+    def sample_device(self, labels, generator=None):
+        """One image on the device (``_C.sample_fg_bg``): -> (selected [B] ascending indices, zero padded; positive_slots
+        [B]: where the positives sit inside ``selected``; counts [2] int32 device tensor = selected, positives).  The
+        subsets are uniformly random like the reference's randperm()[:k]; the key stream is seeded from torch's seed
+        (or the given generator) and a per-sampler call counter, so runs with the same seeds repeat."""
+        from .. import _C
+        base = generator.initial_seed() if generator is not None else torch.initial_seed()
+        self._calls += 1
+        seed = (base * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        return _C.sample_fg_bg(labels, self.batch_size_per_image,
+                               int(self.batch_size_per_image * self.positive_fraction), seed)
 
     def __call__(self, matched_idxs, generator=None):
         pos_idx, neg_idx = [], []

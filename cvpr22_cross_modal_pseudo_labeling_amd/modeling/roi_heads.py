@@ -28,7 +28,7 @@ from ..layers import (Conv2d, ConvTranspose2d, ROIAlign, linear_mfma, smooth_l1_
 from .backbone import ResNetHead
 from .box_coder import BoxCoder
 from .matcher import BalancedPositiveNegativeSampler, Matcher
-from .structures import BoxList, box_iou, boxlist_nms, cat_boxlist
+from .structures import BoxList, PastedMasks, box_iou, boxlist_nms, cat_boxlist
 
 
 def _cat(tensors, dim=0):
@@ -153,8 +153,48 @@ class FastRCNNLossComputation:
         self.cls_agnostic_bbox_reg = cfg.MODEL.CLS_AGNOSTIC_BBOX_REG
         self.bg_weight = cfg.MODEL.ROI_BOX_HEAD.LOSS_WEIGHT_BACKGROUND
         self.generator = None  # optional torch.Generator for reproducible sampling in tests
+        self.device_sampler = True  # False = the tensor-op sampler also on the device (cross-check in the tests)
 
     def subsample(self, proposals, targets):
+        return self.subsample_many([(proposals, targets)])[0]
+
+    def subsample_many(self, groups):
+        """``subsample`` for several (proposals, targets) groups -- the student's pseudo-label and ground-truth branches --
+        at once.  On the device every image costs two launches (IoU match + labels + delta targets, csrc/targets.hip
+        ``match_encode``; fg / bg sampling, ``sample_fg_bg``) and the host reads the survivor counts of ALL images back in
+        ONE copy; the sampled lists carry ``pos_index`` (where the positives sit), so neither the box loss nor the mask
+        head runs a ``nonzero``.  The reference's sequence (box_head/loss.py:89-123: IoU matrix, Matcher, randperm
+        sampler, boolean indexing: ~60 launches and 3 host syncs per image) serves CPU tensors."""
+        if not all(p.bbox.is_cuda for props, _ in groups for p in props) or self.matcher.allow_low_quality_matches \
+                or not self.device_sampler:
+            return [self._subsample_tensor_ops(props, tgts) for props, tgts in groups]
+        pending = []
+        for props, tgts in groups:
+            for prop, tgt in zip(props, tgts):
+                idx, labels, reg = _C.match_encode(tgt.bbox, tgt.get_field("labels"), prop.bbox, self.matcher.high_threshold,
+                                                   self.matcher.low_threshold, self.box_coder.weights)
+                sel, slots, counts = self.sampler.sample_device(labels, self.generator)
+                pending.append((prop, idx, labels, reg, sel, slots, counts))
+        cnt = torch.stack([p[-1] for p in pending]).tolist() if pending else []  # the one host read
+        out, k = [], 0
+        for props, _ in groups:
+            group = []
+            for _p in props:
+                prop, idx, labels, reg, sel, slots, _c = pending[k]
+                n, npos = cnt[k]
+                k += 1
+                s = sel[:n]
+                b = BoxList(prop.bbox.index_select(0, s), prop.size)
+                b.add_field("labels", labels.index_select(0, s))
+                b.add_field("regression_targets", reg.index_select(0, s))
+                b.add_field("matched_gt", idx.index_select(0, s))
+                b.pos_index = slots[:npos]
+                group.append(b)
+            out.append(group)
+        self._proposals = out[-1]
+        return out
+
+    def _subsample_tensor_ops(self, proposals, targets):
         out = []
         labels_all = []
         for prop, tgt in zip(proposals, targets):
@@ -184,15 +224,41 @@ class FastRCNNLossComputation:
         proposals = self._proposals
         labels = _cat([p.get_field("labels") for p in proposals], 0)
         reg_targets = _cat([p.get_field("regression_targets") for p in proposals], 0)
-        pos = torch.nonzero(labels > 0).squeeze(1)
+        pos = positives_index(proposals)
+        if pos is None:
+            pos = torch.nonzero(labels > 0).squeeze(1)
         if self.cls_agnostic_bbox_reg:
-            map_inds = torch.tensor([4, 5, 6, 7], device=class_logits.device)
+            picked = box_regression.index_select(0, pos)[:, 4:8]
         else:
             map_inds = 4 * labels[pos][:, None] + torch.tensor([0, 1, 2, 3], device=class_logits.device)
-        box_loss = smooth_l1_loss(box_regression[pos[:, None], map_inds], reg_targets[pos], size_average=False,
-                                  beta=1) / labels.numel()
+            picked = box_regression[pos[:, None], map_inds]
+        box_loss = smooth_l1_loss(picked, reg_targets.index_select(0, pos), size_average=False, beta=1) / labels.numel()
         cls_loss = weighted_cross_entropy(class_logits, labels, self.bg_weight)
         return cls_loss, box_loss
+
+
+def positives_index(proposals):
+    """Row indices of the positives in the concatenation of sampled proposal lists, from the ``pos_index`` the device
+    sampler attached to every list (None when a list has none: the caller falls back to ``nonzero``)."""
+    parts, off = [], 0
+    for p in proposals:
+        pi = getattr(p, "pos_index", None)
+        if pi is None:
+            return None
+        parts.append(pi + off if off else pi)
+        off += len(p)
+    return _cat(parts, 0) if parts else None
+
+
+def positive_proposals(p):
+    """The positives of a sampled list as a light BoxList (boxes, labels, matched ground-truth index), flagged
+    ``all_positive`` so that the mask loss neither re-matches them nor searches them again."""
+    pi = p.pos_index
+    out = BoxList(p.bbox.index_select(0, pi), p.size)
+    out.add_field("labels", p.get_field("labels").index_select(0, pi))
+    out.add_field("matched_gt", p.get_field("matched_gt").index_select(0, pi))
+    out.all_positive = True
+    return out
 
 
 class PostProcessor(nn.Module):
@@ -443,6 +509,13 @@ class MaskRCNNLossComputation:
                 masks.append(torch.empty(0, dtype=torch.float32, device=prop.bbox.device))
                 continue
             gt_masks = tgt.get_field("masks")
+            if getattr(prop, "all_positive", False) and prop.has_field("matched_gt") and prop.bbox.is_cuda:
+                # sampled positives of the box head: same thresholds, so the match is the one already made
+                labels.append(prop.get_field("labels"))
+                masks.append(self._project(gt_masks, prop.get_field("matched_gt"), prop.bbox))
+                continue
+            if isinstance(gt_masks, PastedMasks):
+                gt_masks = gt_masks.materialize()
             fused = (prop.bbox.is_cuda and not self.matcher.allow_low_quality_matches and gt_masks.dim() == 3
                      and gt_masks.dtype in (torch.bool, torch.uint8))
             if fused:
@@ -461,13 +534,25 @@ class MaskRCNNLossComputation:
             labels.append(lab)
         return labels, masks
 
+    def _project(self, gt_masks, gt_index, boxes):
+        m = self.discretization_size
+        if isinstance(gt_masks, PastedMasks):  # pseudo labels: targets straight from the probability maps
+            return _C.project_pasted_masks(gt_masks.probs, gt_masks.boxes, gt_index, boxes, gt_masks.image_size, m,
+                                           gt_masks.threshold)
+        if gt_masks.dim() == 3 and gt_masks.dtype in (torch.bool, torch.uint8):
+            return _C.project_masks(gt_masks, gt_index, boxes, m)
+        return project_masks_on_boxes(gt_masks, gt_index, boxes, m)
+
     def fused(self, proposals, mu, sigma, eps, targets):
         """Same value as ``__call__`` on ``mu[None] + eps * sigma`` (one noise sample), through the fused HIP
         forward+backward kernel; ``sigma`` / ``eps`` None = deterministic logits."""
         labels, mask_targets = self.prepare_targets(list(proposals), list(targets))
         labels = _cat(labels, 0)
         mask_targets = _cat([m for m in mask_targets if m.numel() > 0] or mask_targets[:1], 0)
-        pos = torch.nonzero(labels > 0).squeeze(1)
+        if all(getattr(p, "all_positive", False) for p in proposals):
+            pos = torch.arange(labels.numel(), device=labels.device)
+        else:
+            pos = torch.nonzero(labels > 0).squeeze(1)
         if mask_targets.numel() == 0:
             return mu.sum() * 0
         if not self.cls_agnostic_mask:
@@ -564,10 +649,14 @@ class ROIMaskHead(nn.Module):
 
     def forward(self, features, proposals, targets=None, compute_uncertain=False, eps=None):
         if self.training:
-            positive_inds = [p.get_field("labels") > 0 for p in proposals]
-            proposals = [p[i] for p, i in zip(proposals, positive_inds)]
+            sel = positives_index(proposals)
+            if sel is not None:  # device sampler: the positives are known by index
+                proposals = [positive_proposals(p) for p in proposals]
+            else:
+                positive_inds = [p.get_field("labels") > 0 for p in proposals]
+                proposals = [p[i] for p, i in zip(proposals, positive_inds)]
+                sel = _cat(positive_inds, 0)
         if self.training and self.share:
-            sel = _cat(positive_inds, 0)
             fl = features.permute(0, 2, 3, 1) if features.dim() == 4 else None
             if fl is not None and fl.is_contiguous() and not features.is_contiguous():
                 # box-head features arrive as an NCHW view of NHWC memory: select the positives in that layout, so the
@@ -647,7 +736,7 @@ class CombinedROIHeads(nn.ModuleDict):
         the height."""
         box = self.box
         with torch.no_grad():
-            sampled = [box.loss_evaluator.subsample(br["proposals"], br["targets"]) for br in branches]
+            sampled = box.loss_evaluator.subsample_many([(br["proposals"], br["targets"]) for br in branches])
         parts = []
         for br, props in zip(branches, sampled):
             for img, p in zip(br["image_ids"], props):
@@ -666,13 +755,17 @@ class CombinedROIHeads(nn.ModuleDict):
             off += cnt
         if self.mask_on:
             mask = self.mask
-            pos_masks = [[p.get_field("labels") > 0 for p in props] for props in sampled]
-            sel = _cat([m for ms in pos_masks for m in ms], 0)
+            sel = positives_index([p for props in sampled for p in props])
+            if sel is not None:
+                pos_all = [[positive_proposals(p) for p in props] for props in sampled]
+            else:
+                pos_masks = [[p.get_field("labels") > 0 for p in props] for props in sampled]
+                sel = _cat([m for ms in pos_masks for m in ms], 0)
+                pos_all = [[p[m] for p, m in zip(props, ms)] for props, ms in zip(sampled, pos_masks)]
             fl = x.permute(0, 2, 3, 1)
             xs = fl[sel].permute(0, 3, 1, 2) if (fl.is_contiguous() and not x.is_contiguous()) else x[sel]  # ONE index op
             off = 0
-            for br, props, ms, losses in zip(branches, sampled, pos_masks, out):
-                pos_props = [p[m] for p, m in zip(props, ms)]
+            for br, pos_props, losses in zip(branches, pos_all, out):
                 k = sum(len(p) for p in pos_props)
                 losses["loss_mask"] = mask.fused_training_loss(xs[off:off + k], pos_props, br["targets"],
                                                                br.get("compute_uncertain", False), br.get("eps"))

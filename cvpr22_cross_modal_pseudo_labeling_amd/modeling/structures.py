@@ -57,6 +57,8 @@ class BoxList:
         return self.bbox.shape[0]
 
     def __getitem__(self, item):
+        if torch.is_tensor(item) and item.dtype == torch.bool:
+            item = torch.nonzero(item).squeeze(1)  # ONE nonzero instead of one per indexed field
         out = BoxList(self.bbox[item], self.size)
         for k, v in self.extra_fields.items():
             out.add_field(k, v[item] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == len(self) else v)
@@ -86,6 +88,30 @@ class BoxList:
 
     def __repr__(self):
         return f"BoxList(num_boxes={len(self)}, image_width={self.size[0]}, image_height={self.size[1]})"
+
+
+class PastedMasks:
+    """Binary instance masks of one image that are DEFINED by per-instance probability maps and boxes through the
+    Masker paste (mask_head/inference.py:100-160) -- the pseudo labels' masks (st_generalized_rcnn.py:266-271) -- kept in
+    that form: the student's mask targets are computed from the maps directly (``_C.project_pasted_masks``), so the
+    H x W canvases are only built when something asks for them (``materialize``).  probs [G, M, M], boxes [G, 4],
+    image_size = (height, width)."""
+
+    def __init__(self, probs, boxes, image_size, threshold=0.5, padding=1):
+        assert padding == 1, "the device kernel implements the reference's Masker(padding=1)"
+        self.probs, self.boxes, self.image_size, self.threshold, self.padding = probs, boxes, tuple(image_size), threshold, padding
+
+    def __len__(self):
+        return self.probs.shape[0]
+
+    def to(self, device):
+        return PastedMasks(self.probs.to(device), self.boxes.to(device), self.image_size, self.threshold, self.padding)
+
+    def materialize(self):
+        """bool [G, H, W]: what Masker(threshold, padding) pastes."""
+        from .roi_heads import Masker
+        h, w = self.image_size
+        return Masker(self.threshold, self.padding)(self.probs[:, None], BoxList(self.boxes, (w, h)))[:, 0]
 
 
 def cat_boxlist(boxlists):  # boxlist_ops.py:107-129

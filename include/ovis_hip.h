@@ -363,6 +363,25 @@ int ovis_match_encode_f32(const float* gt_boxes, const int64_t* gt_labels, const
                           float* regression_targets, void* stream);
 int ovis_project_masks_f32(const uint8_t* masks, const int64_t* gt_index, const float* boxes, int num, int height,
                            int width, int resolution, int masks_are_bool, float* out, void* stream);
+/* ovis_sample_fg_bg: BalancedPositiveNegativeSampler of one image (mb/modeling/balanced_positive_negative_sampler.py:
+ * 19-68) in one launch.  labels [num] int64 (>= 1 positive, 0 negative, < 0 ignored).  num_pos = min(#positives,
+ * max_positives), num_neg = min(#negatives, batch_size - num_pos); a uniformly random subset of each size (keys =
+ * splitmix64(seed, index): the reference draws torch.randperm()[:k], whose stream is version dependent) -> selected
+ * [batch_size] int64: the chosen indices ASCENDING (the order of the reference's nonzero(pos_mask | neg_mask)), zeros
+ * behind them; positive_slots [batch_size]: positions of the positives inside `selected`; counts[0] = number selected,
+ * counts[1] = positives among them.  No host round trip.
+ *
+ * ovis_project_pasted_masks_f32: ovis_project_masks_f32 for ground truths whose binary image mask is DEFINED by a
+ * prob_resolution^2 probability map and a box -- Masker.forward_single_image (mb/modeling/roi_heads/mask_head/
+ * inference.py:100-160, padding 1: pad, expand the box by (M+2)/M, truncate to integers, bilinear resize, > threshold,
+ * paste clipped to the image) -- as the pseudo labels' masks are (st_generalized_rcnn.py:266-271).  Every mask pixel
+ * the crop + resize reads is evaluated from the map on the fly: same targets as pasting first, no H x W canvas.
+ * mask_probs [G, prob_resolution, prob_resolution] f32, gt_boxes [G, 4], gt_index [num], boxes [num, 4]. */
+int ovis_sample_fg_bg(const int64_t* labels, int num, int batch_size, int max_positives, uint64_t seed,
+                      int64_t* selected, int64_t* positive_slots, int32_t* counts, void* stream);
+int ovis_project_pasted_masks_f32(const float* mask_probs, const float* gt_boxes, const int64_t* gt_index,
+                                  const float* boxes, int num, int image_height, int image_width, int prob_resolution,
+                                  int resolution, float threshold, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Cross-modal head: fp32 GEMM on the matrix cores

@@ -269,6 +269,20 @@ def gen_heads():
         out[f"paste_box{i}"] = np.array(box, dtype=np.float32)
         out[f"paste_out{i}"] = paste_mask_in_image(m, torch.tensor(box), 120, 160).numpy()
     out["paste_mask"] = m.numpy()
+
+    # ---- fg / bg sampler (balanced_positive_negative_sampler.py:19-68): the masks when the quotas cover every candidate
+    # (deterministic) and the COUNTS when they do not (the subsets themselves are random)
+    from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+    lab = torch.zeros(900, dtype=torch.int64)
+    perm = torch.randperm(900, generator=g)
+    lab[perm[:130]] = torch.randint(1, 49, (130,), generator=g)
+    lab[perm[130:200]] = -1
+    pos_all, neg_all = BalancedPositiveNegativeSampler(4096, 0.25)([lab])
+    pos_q, neg_q = BalancedPositiveNegativeSampler(512, 0.25)([lab])
+    pos_f, neg_f = BalancedPositiveNegativeSampler(256, 1.0)([lab])
+    out.update(sampler_labels=lab.numpy(), sampler_pos_all=pos_all[0].numpy(), sampler_neg_all=neg_all[0].numpy(),
+               sampler_counts_512_025=np.array([int(pos_q[0].sum()), int(neg_q[0].sum())]),
+               sampler_counts_256_100=np.array([int(pos_f[0].sum()), int(neg_f[0].sum())]))
     np.savez_compressed(os.path.join(HERE, "heads.npz"), **out)
 
 

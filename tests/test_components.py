@@ -136,6 +136,19 @@ def test_anchors_and_rpn_proposals_match_reference(z):
         assert torch.allclose(r.get_field("objectness"), T(z[f"rpn_scores{i}"]))
 
 
+def test_sampler_matches_reference_fixture(z):
+    """BalancedPositiveNegativeSampler (tensor-op form): the reference's masks when every candidate is taken, its counts
+    otherwise (balanced_positive_negative_sampler.py:39-47)."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.matcher import BalancedPositiveNegativeSampler
+    lab = T(z["sampler_labels"])
+    pos, neg = BalancedPositiveNegativeSampler(4096, 0.25)([lab])
+    assert torch.equal(pos[0], T(z["sampler_pos_all"])) and torch.equal(neg[0], T(z["sampler_neg_all"]))
+    for batch, frac, key in ((512, 0.25, "sampler_counts_512_025"), (256, 1.0, "sampler_counts_256_100")):
+        pos, neg = BalancedPositiveNegativeSampler(batch, frac)([lab])
+        assert [int(pos[0].sum()), int(neg[0].sum())] == z[key].tolist()
+        assert not bool((pos[0] & neg[0]).any()) and bool((lab[pos[0]] >= 1).all()) and bool((lab[neg[0]] == 0).all())
+
+
 def test_paste_mask_matches_reference(z):
     m = T(z["paste_mask"])
     for i in range(3):

@@ -67,3 +67,104 @@ def test_project_masks_vs_tensor_ops(dtype):
     assert got.shape == (P, 14, 14)
     assert torch.equal(got, ref)
     assert _C.project_masks(masks, idx[:0].cuda(), boxes[:0].cuda(), 14).shape == (0, 14, 14)
+
+
+# ---- device fg / bg sampler (csrc/targets.hip::sample_fg_bg_kernel) ------------------------------------------------------
+def _labels(p, n_pos, n_ign, g):
+    lab = torch.zeros(p, dtype=torch.int64)
+    perm = torch.randperm(p, generator=g)
+    lab[perm[:n_pos]] = torch.randint(1, 49, (n_pos,), generator=g)
+    lab[perm[n_pos:n_pos + n_ign]] = -1
+    return lab
+
+
+@pytest.mark.parametrize("p,n_pos,n_ign,batch,frac", [(2007, 300, 40, 512, 0.25), (2007, 900, 0, 512, 1.0), (1007, 3, 5, 512, 0.25),
+                                                      (300, 20, 10, 512, 0.25), (63000, 700, 30000, 256, 0.5), (5, 0, 5, 512, 0.25)])
+def test_sample_fg_bg_counts_and_membership(p, n_pos, n_ign, batch, frac):
+    """Counts follow balanced_positive_negative_sampler.py:39-47; the selection is a subset of the right classes, ascending,
+    zero padded; positive_slots point at the positives; the same seed repeats, another seed differs when there is a choice."""
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+    g = torch.Generator().manual_seed(p + n_pos)
+    lab = _labels(p, n_pos, n_ign, g)
+    n_neg = p - n_pos - n_ign
+    want_pos = min(n_pos, int(batch * frac))
+    want_neg = min(n_neg, batch - want_pos)
+    sel, slots, counts = _C.sample_fg_bg(lab.cuda(), batch, int(batch * frac), 12345)
+    sel, slots, (n, npos) = sel.cpu(), slots.cpu(), counts.tolist()
+    assert (n, npos) == (want_pos + want_neg, want_pos)
+    s = sel[:n]
+    assert bool((s[1:] > s[:-1]).all()) and bool((sel[n:] == 0).all())
+    assert int((lab[s] >= 1).sum()) == want_pos and int((lab[s] == 0).sum()) == want_neg
+    assert torch.equal(torch.nonzero(lab[s] >= 1).squeeze(1), slots[:npos])
+    sel2, _, c2 = _C.sample_fg_bg(lab.cuda(), batch, int(batch * frac), 12345)
+    assert torch.equal(sel2.cpu(), sel) and c2.tolist() == [n, npos]
+    if want_neg < n_neg or want_pos < n_pos:
+        sel3, _, _ = _C.sample_fg_bg(lab.cuda(), batch, int(batch * frac), 999)
+        assert not torch.equal(sel3.cpu(), sel)
+
+
+def test_sample_fg_bg_vs_reference_fixture(golden_dir):
+    """Fixture made by the reference's BalancedPositiveNegativeSampler (tests/golden/make_golden.py): the masks when the
+    quotas cover every candidate (deterministic), the counts when they do not."""
+    import os
+
+    import numpy as np
+
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+    z = np.load(os.path.join(golden_dir, "heads.npz"))
+    lab = torch.from_numpy(z["sampler_labels"]).to(torch.int64)
+    sel, slots, counts = _C.sample_fg_bg(lab.cuda(), 4096, int(4096 * 0.25), 7)
+    n, npos = counts.tolist()
+    want = torch.from_numpy(z["sampler_pos_all"] | z["sampler_neg_all"])
+    assert torch.equal(sel[:n].cpu(), torch.nonzero(want).squeeze(1))
+    assert torch.equal(sel[:n].cpu()[slots[:npos].cpu()], torch.nonzero(torch.from_numpy(z["sampler_pos_all"])).squeeze(1))
+    for batch, frac, key in ((512, 0.25, "sampler_counts_512_025"), (256, 1.0, "sampler_counts_256_100")):
+        _, _, c = _C.sample_fg_bg(lab.cuda(), batch, int(batch * frac), 11)
+        n, npos = c.tolist()
+        assert [npos, n - npos] == z[key].tolist()
+
+
+def test_sample_fg_bg_is_uniform():
+    """Every negative is picked with probability k / n: over 400 seeds the per-element pick counts of 64-of-256 stay
+    inside 5 sigma of the binomial, and so do the counts of pairs of neighbours (no index-correlated keys)."""
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+    lab = torch.zeros(256, dtype=torch.int64).cuda()
+    hits = torch.zeros(256)
+    pair = torch.zeros(255)
+    trials = 400
+    for seed in range(trials):
+        sel, _, counts = _C.sample_fg_bg(lab, 64, 0, seed * 7919 + 1)
+        m = torch.zeros(256)
+        m[sel[: counts.tolist()[0]].cpu()] = 1
+        hits += m
+        pair += m[1:] * m[:-1]
+    pr = 64 / 256
+    sd = (trials * pr * (1 - pr)) ** 0.5
+    assert float((hits - trials * pr).abs().max()) < 5 * sd
+    pp = pr * 63 / 255
+    assert float((pair - trials * pp).abs().max()) < 5 * (trials * pp * (1 - pp)) ** 0.5 + 1
+
+
+# ---- mask targets straight from (probability map, box) pairs -----------------------------------------------------------
+@pytest.mark.parametrize("G,P,size", [(6, 300, (800, 1333)), (1, 7, (160, 192)), (3, 50, (97, 61))])
+def test_project_pasted_masks_equals_paste_then_project(G, P, size):
+    """_C.project_pasted_masks == Masker paste (mask_head/inference.py:124-205) followed by _C.project_masks, bit for bit,
+    including pseudo boxes and proposals that stick out of the image."""
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.structures import PastedMasks
+    h, w = size
+    g = torch.Generator().manual_seed(G * 100 + P)
+    gt = _boxes(G, g, float(w), float(h))
+    gt[0] = torch.tensor([-7.3, -4.1, w * 0.6, h * 0.7])           # sticks out at the top left
+    gt[-1] = torch.tensor([w * 0.5, h * 0.4, w + 9.0, h + 5.5])     # ... and at the bottom right
+    probs = torch.rand(G, 14, 14, generator=g)
+    idx = torch.randint(0, G, (P,), generator=g)
+    prop = gt[idx] + torch.randn(P, 4, generator=g) * 9
+    pm = PastedMasks(probs.cuda(), gt.cuda(), (h, w))
+    full = pm.materialize()
+    assert full.shape == (G, h, w) and full.dtype == torch.bool and bool(full.any())
+    want = _C.project_masks(full, idx.cuda(), prop.cuda(), 14)
+    got = _C.project_pasted_masks(probs.cuda(), gt.cuda(), idx.cuda(), prop.cuda(), (h, w), 14)
+    assert got.shape == want.shape == (P, 14, 14)
+    assert torch.equal(got, want), int((got != want).sum())
+    assert 0.05 < float(got.mean()) < 0.95
