@@ -1,7 +1,8 @@
 """GPU parity of the whole step: the same tiny student-teacher (and teacher) step run (a) on the MI355X
 through the HIP ops and (b) on CPU tensors with the native ops routed to the oracle, same weights, same
 inputs, same injected noise, deterministic sampling (batch sizes large enough that the fg/bg samplers
-take everything).  Tolerance 1e-3 relative (north_star) on every loss; gradients compared by norm."""
+take everything).  Tolerance 1e-3 relative (north_star) on every loss; gradients compared element-wise (relative L2
+distance per parameter tensor <= 5e-3)."""
 import os
 
 import pytest
@@ -31,8 +32,8 @@ def _run(model, e_vocab, e_seen, images, targets, device, ctx):
     with ctx:
         losses = model(images.to(device), tg, eps=eps) if is_student else model(images.to(device), tg)
         sum(losses.values()).backward()
-    grads = {n: p.grad.detach().float().norm().item() for n, p in model.named_parameters() if p.grad is not None}
-    return {k: float(v) for k, v in losses.items()}, grads
+    grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}
+    return {k: float(v.detach()) for k, v in losses.items()}, grads
 
 
 @pytest.mark.parametrize("name", ["student_teacher_mask_rcnn_uncertainty", "zeroshot_mask"])
@@ -52,10 +53,15 @@ def test_step_matches_oracle_backed_cpu_step(name):
     assert set(l_gpu) == set(l_cpu)
     for k in l_cpu:
         assert abs(l_gpu[k] - l_cpu[k]) <= 1e-3 * max(abs(l_cpu[k]), 1e-3), (k, l_gpu[k], l_cpu[k])
+    # gradients element-wise: relative L2 distance per parameter tensor (a permuted or sign-flipped gradient has the
+    # right norm and a distance of O(1)).  5e-3: a ReLU pre-activation within rounding of zero may flip its gate
+    # between the two arithmetics, which moves isolated entries.
     checked = 0
     for n, v in g_cpu.items():
-        if v > 1e-6 and n in g_gpu:
-            assert abs(g_gpu[n] - v) <= 5e-3 * v + 1e-6, (n, g_gpu[n], v)
+        nv = v.norm().item()
+        if nv > 1e-6 and n in g_gpu:
+            d = (g_gpu[n] - v).norm().item()
+            assert d <= 5e-3 * nv + 1e-7, (n, d, nv)
             checked += 1
     assert checked >= 10
 

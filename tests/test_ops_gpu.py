@@ -195,6 +195,46 @@ def test_roi_align_full_size_properties(C):
     assert torch.allclose(gi.double().sum(), go.double().sum(), rtol=1e-4)
 
 
+def _rpn_like_rois(g, r, n_img):
+    """RoIs with the size mix of RPN proposals (log-uniform areas 32^2..600^2, ratios 1:2..2:1, a few near-full-image)."""
+    area = torch.exp(torch.rand(r, generator=g) * (2 * torch.log(torch.tensor(600.0 / 32))) + 2 * torch.log(torch.tensor(32.0)))
+    ratio = torch.exp((torch.rand(r, generator=g) - 0.5) * 2 * torch.log(torch.tensor(2.0)))
+    w, h = torch.sqrt(area / ratio).clamp(max=1332), torch.sqrt(area * ratio).clamp(max=799)
+    x1 = torch.rand(r, generator=g) * (1333 - w)
+    y1 = torch.rand(r, generator=g) * (800 - h)
+    b = torch.randint(0, n_img, (r,), generator=g).float()
+    rois = torch.stack([b, x1, y1, x1 + w - 1, y1 + h - 1], 1)
+    rois[:4, 1:] = torch.tensor([[0.0, 0.0, 1332.0, 799.0], [3.5, 2.25, 1320.0, 790.0], [600.0, 0.0, 1332.0, 799.0], [0.0, 300.0, 1332.0, 799.0]])
+    return rois
+
+
+def test_roi_align_step_poolers_full_size_vs_oracle(C, oracle_mod):
+    """BASELINE size ([2,1024,50,84], 2000 RPN-like RoIs): the poolers the training step actually runs -- the default
+    exact kernel, the strided NHWC form (teacher step) and the strided pair form (student step: small / large window
+    launches, bins written as bf16 hi | lo) -- against the oracle (== the reference CPU kernel) on sampled
+    (RoI, channel-block) tiles: the oracle pools 8 channels of 96 RoIs, the kernels pool everything.  Bit-exact; the
+    pair form is compared as hi + lo with the split's own error bound."""
+    g = torch.Generator().manual_seed(77)
+    n, c, h, w = 2, 1024, 50, 84
+    x = torch.randn(n, c, h, w, generator=g)
+    rois = _rpn_like_rois(g, 2000, n)
+    xd, rd = x.cuda(), rois.cuda()
+    full = C.roi_align_forward(xd, rd, 1 / 16, 14, 14, 0)                              # [R, C, 14, 14]
+    nhwc = C.roi_align_forward_strided_nhwc(xd, rd, 1 / 16, 14, 14, 0, 2)              # [R, 7, 7, C]
+    pair, (oh, ow) = C.roi_align_forward_strided_pair(xd, rd, 1 / 16, 14, 14, 0, 2)   # [R*49, 2C] bf16
+    assert (oh, ow) == (7, 7) and nhwc.shape == (2000, 7, 7, c)
+    assert torch.equal(nhwc, full[:, :, ::2, ::2].permute(0, 2, 3, 1))                # strided bins == the exact kernel's
+    sel_r = torch.cat([torch.arange(4), torch.randperm(2000, generator=g)[:92]])
+    for c0 in (0, 504, 1016):
+        want = oracle_mod.roi_align_forward(x[:, c0:c0 + 8].contiguous(), rois[sel_r], 1 / 16, 14, 14, 0)
+        assert torch.equal(full[sel_r.cuda(), c0:c0 + 8].cpu(), want), c0
+    # pair layout: per 32 channels [hi x32 | lo x32] bf16; hi + lo reproduces the fp32 bin to the split's 2^-17
+    pr = pair.view(2000, 49, c // 32, 2, 32).float()
+    rec = (pr[:, :, :, 0] + pr[:, :, :, 1]).reshape(2000, 7, 7, c)
+    assert torch.equal(pr[:, :, :, 0].reshape(2000, 7, 7, c), nhwc.to(torch.bfloat16).float())
+    assert float((rec - nhwc).abs().max()) <= 2.0 ** -16 * float(nhwc.abs().max())
+
+
 # ---------------------------------------------------------------- NMS
 @pytest.mark.parametrize("name", ["rpn_like", "dense", "tiny", "one"])
 def test_nms_golden_exact(C, golden_dir, name):
