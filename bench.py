@@ -132,6 +132,17 @@ class OpTimer:
         self._wrap("roi_align_forward_strided_pair", roi_fwd_strided_bytes)
         self._wrap("roi_align_backward", roi_bwd_bytes)
         self._wrap("nms_padded", nms_bytes)
+
+        def nms_batched_bytes(boxes, drop, threshold, below=0, ge_mode=False):
+            n, k = boxes.shape[0], boxes.shape[1]
+            nb = (k + 63) // 64
+            return n * (16 * k + (4 * k if drop is not None else 0) + 8 * k * (nb + 1) // 2 * 2 + 8 * k)  # boxes, flags, upper-triangle mask written + read, keep
+
+        def rpn_decode_bytes(box_regression, topk_idx, cell_anchors, image_wh, weights, xform_clip, min_size, anchor_stride):
+            return topk_idx.numel() * (8 + 16 + 16 + 4)  # index + 4 deltas read, box + flag written
+
+        self._wrap("nms_presorted_batched", nms_batched_bytes)
+        self._wrap("rpn_decode", rpn_decode_bytes)
         self._wrap("split_bf16x3", split_bytes)
         self._wrap("im2col_split_bf16x3", im2col_bytes)
         self._wrap("bias_act_", bias_act_bytes)

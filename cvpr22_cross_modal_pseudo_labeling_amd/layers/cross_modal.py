@@ -32,8 +32,86 @@ class _LinearMFMA(Function):
         return dx, dw, db
 
 
+_PAIR_WEIGHT_CACHE = {}
+
+
+def _pair_weight_padded(weight, n_pad):
+    """[N, K] f32 -> pair layout [n_pad, 2K] (zero rows behind N); cached for tensors that do not require grad (the class /
+    vocabulary matrices, frozen emb_pred), keyed on identity + version."""
+    import torch.nn.functional as F
+    frozen = not weight.requires_grad
+    key = (id(weight), weight._version, weight.device, n_pad)
+    if frozen:
+        hit = _PAIR_WEIGHT_CACHE.get(id(weight))
+        if hit is not None and hit[0] == key and hit[1]() is weight:
+            return hit[2]
+    w = weight.detach()
+    if w.shape[0] != n_pad:
+        w = F.pad(w, (0, 0, 0, n_pad - w.shape[0]))
+    wp = _C.split_pair(w.contiguous())
+    if frozen:
+        import weakref
+        if len(_PAIR_WEIGHT_CACHE) > 64:
+            _PAIR_WEIGHT_CACHE.clear()
+        _PAIR_WEIGHT_CACHE[id(weight)] = (key, weakref.ref(weight), wp)
+    return wp
+
+
+class _LinearPair(Function):
+    """y = x @ weight^T + bias on the pair-layout split GEMM (csrc/split_gemm.hip): the region x text products of the
+    cross-modal head (roi_box_predictors.py:62-81) as fp32-accurate three-term bf16 hi/lo products on the bf16 matrix
+    cores -- several times the rate of the fp32-input MFMA GEMM they replace, and deterministic (small-M problems are cut
+    into K slices whose slabs one kernel reduces; no atomics).  N is padded to a multiple of 128 with zero rows."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        import torch.nn.functional as F
+        n = weight.shape[0]
+        n_pad = -(-n // 128) * 128
+        xp = _C.split_pair(x.detach().contiguous())
+        wp = _pair_weight_padded(weight, n_pad)
+        b = None
+        if bias is not None:
+            b = bias.detach() if n == n_pad else F.pad(bias.detach(), (0, n_pad - n))
+        y, _ = _C.split_gemm_pair(xp, wp, b)
+        ctx.save_for_backward(xp, weight)
+        ctx.has_bias = bias is not None
+        ctx.n_pad = n_pad
+        return y if n == n_pad else y[:, :n].contiguous()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        import torch.nn.functional as F
+        xp, weight = ctx.saved_tensors
+        n, n_pad = weight.shape[0], ctx.n_pad
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = dw = db = None
+        if need_x or need_w:
+            g = dy if n == n_pad else F.pad(dy, (0, n_pad - n))
+            gp = _C.split_pair(g.contiguous())                                  # [M, 2 n_pad]
+            if need_x:
+                wt = weight.detach().t()
+                wt = wt if n == n_pad else F.pad(wt, (0, n_pad - n))            # [K, n_pad]
+                dx, _ = _C.split_gemm_pair(gp, _C.split_pair(wt.contiguous()))  # dY W
+            if need_w:
+                dw = _C.split_gemm_pair_tn(gp, xp)[:n]                          # dY^T X over the rows
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db
+
+
+def _pair_ok(x, weight):
+    return (x.is_cuda and x.dim() == 2 and weight.dim() == 2 and x.dtype == torch.float32 and weight.shape[1] % 128 == 0
+            and weight.shape[0] >= 32 and x.shape[0] > 0)
+
+
 def linear_mfma(x, weight, bias=None):
-    """y = x @ weight^T + bias with x [M,K], weight [N,K] (nn.Linear layout)."""
+    """y = x @ weight^T + bias with x [M,K], weight [N,K] (nn.Linear layout): split GEMM on the bf16 matrix cores when
+    the shape allows (K % 128 == 0, N >= 32), else the exact-fp32 MFMA GEMM (``_C.gemm_nt``: the mask predictor's
+    1- and 2-channel 1x1 heads)."""
+    if _pair_ok(x, weight):
+        return _LinearPair.apply(x, weight, bias)
     return _LinearMFMA.apply(x, weight, bias)
 
 
@@ -170,7 +248,7 @@ def split_linear(x, *weights_and_biases):
 
 def text_logits(region_emb, class_emb):
     """einsum('pe,ce->pc'): region embeddings [P,E] against the class / vocabulary matrix [C,E]."""
-    return _LinearMFMA.apply(region_emb, class_emb, None)
+    return linear_mfma(region_emb, class_emb, None)
 
 
 class _WeightedCE(Function):

@@ -91,6 +91,36 @@ def test_gemm_and_linear_autograd_vs_torch(m, n, k):
         assert (got_g.cpu().double() - want_g).abs().max().item() <= 1e-5 * scale * max(1.0, (m + n + k) ** 0.5 / 8)
 
 
+@pytest.mark.parametrize("m,n,k", [(1024, 776, 2048), (2000, 768, 2048), (1024, 1203, 768), (1024, 49, 768), (3, 776, 2048)])
+def test_linear_pair_split_gemm_vs_fp64_and_deterministic(m, n, k):
+    """The cross-modal head's products through the pair-layout split GEMM (layers.cross_modal._LinearPair): inside the
+    three-term bf16 split's bound 3e-5 * sum|a||b| of the fp64 product (a single product can reach 2^-17 + 2^-17 + 2^-18 =
+    1.9e-5 plus the fp32 accumulation; long sums measure ~1e-6), forward and both gradients,
+    and bit-identical run to run (K slices are reduced in a fixed order, no atomics)."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers import cross_modal
+
+    g = torch.Generator().manual_seed(m + n + k)
+    a, b, bias = torch.randn(m, k, generator=g) * 0.5, torch.randn(n, k, generator=g) * 0.05, torch.randn(n, generator=g)
+    gy = torch.randn(m, n, generator=g)
+    assert cross_modal._pair_ok(a.cuda(), b.cuda())
+
+    def run():
+        ad, bd, biasd = a.cuda().requires_grad_(True), b.cuda().requires_grad_(True), bias.cuda().requires_grad_(True)
+        y = cross_modal.linear_mfma(ad, bd, biasd)
+        y.backward(gy.cuda())
+        return y.detach(), ad.grad, bd.grad, biasd.grad
+
+    y, da, db, dbias = run()
+    a64, b64, g64 = a.double(), b.double(), gy.double()
+    for got, want, bound in ((y, a64 @ b64.t() + bias.double(), a64.abs() @ b64.abs().t() + bias.double().abs()),
+                             (da, g64 @ b64, g64.abs() @ b64.abs()), (db, g64.t() @ a64, g64.abs().t() @ a64.abs())):
+        assert got.shape == want.shape
+        assert bool(((got.cpu().double() - want).abs() <= 3e-5 * bound + 1e-30).all())
+    assert torch.allclose(dbias.cpu().double(), g64.sum(0), rtol=1e-5, atol=1e-5)
+    for t1, t2 in zip(run(), (y, da, db, dbias)):
+        assert torch.equal(t1, t2)
+
+
 def test_region_noun_align_vs_torch():
     from cvpr22_cross_modal_pseudo_labeling_amd import _C
 

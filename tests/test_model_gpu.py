@@ -106,8 +106,8 @@ def test_pipelined_trainer_matches_plain_steps():
         got = run(kind)
         for a, b in zip(got, plain):
             for k in b:
-                # not bit-identical run to run: split-K slices of the head GEMM add with fp32 atomics (~1e-5)
-                assert abs(a[k] - b[k]) <= 2e-4 * max(abs(b[k]), 1e-3), (kind, k, a[k], b[k])
+                # the head GEMMs run on the split GEMM (fixed-order K slices): the step repeats to fp32 round-off
+                assert abs(a[k] - b[k]) <= 1e-6 * max(abs(b[k]), 1e-3), (kind, k, a[k], b[k])
 
 
 def test_rpn_shared_selection_matches_two_selections():
