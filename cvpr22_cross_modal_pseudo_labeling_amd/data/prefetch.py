@@ -56,15 +56,27 @@ class DevicePrefetcher:
             ev.record(self.stream)
         return moved, ev
 
+    def _put(self, item):
+        """Blocking put that gives up when the consumer has closed the prefetcher (a full queue nobody reads)."""
+        while not self.stop:
+            try:
+                self.q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
     def _run(self, it):
         try:
             for batch in it:
-                if self.stop:
-                    return
-                self.q.put(self._stage(batch))
-            self.q.put((self._END, None))
+                if self.stop or not self._put(self._stage(batch)):
+                    break
+            else:
+                self._put((self._END, None))
         except BaseException as e:  # handed to the consumer
-            self.q.put((e, None))
+            self._put((e, None))
+        finally:
+            del it  # lets a DataLoader iterator shut its worker processes down
 
     def __iter__(self):
         return self
@@ -82,10 +94,16 @@ class DevicePrefetcher:
             _map(item, lambda t: (t.record_stream(cur), t)[1] if t.is_cuda else t)  # allocated on the copy stream
         return item
 
-    def close(self):
+    def close(self, timeout=10.0):
+        """Stop the staging thread and wait for it: no copy is issued on the copy stream after this returns (the caller
+        may tear the process group / the device context down)."""
         self.stop = True
         try:
             while True:
                 self.q.get_nowait()
         except queue.Empty:
             pass
+        if self.thread.is_alive() and threading.current_thread() is not self.thread:
+            self.thread.join(timeout)
+        if self.stream is not None:
+            self.stream.synchronize()

@@ -75,5 +75,4 @@ def calibrate_stem_bn(model, images):
     stem = model.backbone.body.stem
     y = torch.nn.functional.conv2d(images[:1], stem.conv1.weight, None, stem.conv1.stride, stem.conv1.padding)
     stem.bn1.running_mean.copy_(y.mean((0, 2, 3)))
-    stem.bn1.running_var.copy_(y.var((0, 2, 3)))
-    stem._f[0]._cache = None
+    stem.bn1.running_var.copy_(y.var((0, 2, 3)))  # in-place: bumps the buffer versions every folded-weight cache keys on

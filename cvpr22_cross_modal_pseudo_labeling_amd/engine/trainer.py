@@ -128,11 +128,14 @@ class PipelinedTrainer:
             self._launch_frozen(next_batch[0], next_batch[1], inputs_ready)
         return loss_dict
 
-    def drain(self):
+    def drain(self, discard=False):
+        """Wait for the look-ahead frozen half.  Its outputs depend on frozen weights only, so they stay valid across a
+        checkpoint save and are kept for the next step unless ``discard``."""
         self._check_worker()
         if self.pending is not None:
             self.pending[2].synchronize()
-            self.pending = None
+            if discard:
+                self.pending = None
 
 
 def do_train(cfg, model, data_iter, optimizer, scheduler, max_iter, start_iter=0, log_period=None, logger=None,
@@ -153,6 +156,7 @@ def do_train(cfg, model, data_iter, optimizer, scheduler, max_iter, start_iter=0
             return None
 
     batch = fetch()
+    completed = start_iter
     for iteration in range(start_iter, max_iter):
         if batch is None:
             break
@@ -164,6 +168,7 @@ def do_train(cfg, model, data_iter, optimizer, scheduler, max_iter, start_iter=0
             continue
         ok_next = nxt is not None and not any(len(t) < 1 for t in nxt[1])
         loss_dict = pipe.step(images, targets, nxt if ok_next else None)
+        completed = iteration + 1
         batch = nxt
         if (iteration + 1) % log_period == 0 or iteration + 1 == max_iter:
             reduced = comm.reduce_loss_dict(loss_dict)  # the only host sync of the loop
@@ -178,10 +183,12 @@ def do_train(cfg, model, data_iter, optimizer, scheduler, max_iter, start_iter=0
         if checkpointer is not None and checkpoint_period and (iteration + 1) % checkpoint_period == 0:
             pipe.drain()  # the look-ahead half holds no state, but the weights must be quiescent while they are read
             checkpointer.save("model_{:07d}".format(iteration + 1), iteration=iteration + 1)
-    pipe.drain()
+    pipe.drain(discard=True)
     reducer.remove()
-    if checkpointer is not None and max_iter > start_iter:
-        checkpointer.save("model_final", iteration=max_iter)
+    if checkpointer is not None and completed > start_iter:
+        if completed < max_iter:
+            logger.warning("the data stream ended after %d of %d iterations", completed, max_iter)
+        checkpointer.save("model_final", iteration=completed)
     total = time.time() - start
     logger.info("Total training time: %.1f s (%.4f s / it)", total, total / max(max_iter - start_iter, 1))
     return history

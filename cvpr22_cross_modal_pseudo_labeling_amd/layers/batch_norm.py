@@ -16,11 +16,14 @@ class FrozenBatchNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(n))
         self.register_buffer("running_var", torch.ones(n))
 
+    def fold_key(self):
+        """Identity + version of the four buffers: what any cache of a value derived from ``fold()`` must be keyed on."""
+        return tuple((id(b), b._version) for b in (self.weight, self.bias, self.running_mean, self.running_var))
+
     def fold(self):
         # the four buffers are constants of the step: the pair is computed once per buffer state (in-place updates such
         # as load_state_dict bump the version counters, .to() replaces the tensors)
-        bufs = (self.weight, self.bias, self.running_mean, self.running_var)
-        key = tuple((id(b), b._version) for b in bufs)
+        key = self.fold_key()
         cached = getattr(self, "_fold_cache", None)
         if cached is not None and cached[0] == key:
             return cached[1], cached[2]

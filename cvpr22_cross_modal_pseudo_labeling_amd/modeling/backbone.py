@@ -30,13 +30,13 @@ class ConvBN(nn.Module):
     def folded(self):
         w = self.conv.weight
         frozen = not w.requires_grad
-        if (frozen and self._cache is not None and self._cache[0] is w and self._cache[1] == w._version
-                and self._cache[2].device == w.device):
-            return self._cache[2], self._cache[3]
+        key = (id(w), w._version, w.device) + self.bn.fold_key()  # the FrozenBN buffers are part of the folded weight
+        if frozen and self._cache is not None and self._cache[0] == key:
+            return self._cache[1], self._cache[2]
         scale, shift = self.bn.fold()
         fw = w * scale.reshape(-1, 1, 1, 1)
         if frozen:
-            self._cache = (w, w._version, fw.detach(), shift.detach())
+            self._cache = (key, fw.detach(), shift.detach())
         return fw, shift
 
     def forward(self, x):
@@ -142,7 +142,7 @@ class Bottleneck(nn.Module):
         wpairs = None
         if not any(t.requires_grad for t in ws_all):
             # frozen block: the pair forms of the folded weights (and the summed shift) are computed once
-            key = tuple((id(t), t._version, t.device) for t in ws_all) + tuple(id(bn._fold_cache[1]) for bn in bns)
+            key = tuple((id(t), t._version, t.device) for t in ws_all) + tuple(k for bn in bns for k in bn.fold_key())
             if self._pair_cache is None or self._pair_cache[0] != key:
                 wp = {"w1": _C.weight_prep_pair(w1, s1)[0], "w2": _C.weight_prep_pair(w2, s2)[0],
                       "w3": _C.weight_prep_pair(w3, s3)[0],
@@ -259,7 +259,7 @@ class Stem(nn.Module):
         from .. import _C
         w, b = self._f[0].folded()
         c = self.conv1
-        key = (id(w), w._version)
+        key = (id(w), w._version) + self.bn1.fold_key()
         if getattr(self, "_wp", None) is None or self._wp[0] != key:
             k = w.shape[1] * w.shape[2] * w.shape[3]
             kp = -(-k // 32) * 32

@@ -172,6 +172,18 @@ def main():
             ms = timeit(lambda: _C.gemm_nt(a, b), args.iters)
             res.append({"op": "gemm_f32_mfma", "shape": f"{m}x{n}x{k}", "what": what, "ms": ms,
                         "TFLOPs": 2.0 * m * n * k / ms / 1e9, "frac_fp32_mfma_peak": 2.0 * m * n * k / ms / 1e9 / 157.3})
+            # the route the cross-modal head takes (layers/cross_modal.py::_LinearPair): operand split + pair-layout split
+            # GEMM on the bf16 matrix cores; "gemm only" = operands already in pair layout (cached class matrix)
+            from cvpr22_cross_modal_pseudo_labeling_amd.layers import linear_mfma
+            with torch.no_grad():
+                ms = timeit(lambda: linear_mfma(a, b), args.iters)
+                n_pad = -(-n // 128) * 128
+                ap = _C.split_pair(a)
+                bp = _C.split_pair(torch.nn.functional.pad(b, (0, 0, 0, n_pad - n)))
+                ms_g = timeit(lambda: _C.split_gemm_pair(ap, bp), args.iters)
+            res.append({"op": "linear_pair(split GEMM)", "shape": f"{m}x{n}x{k}", "what": what, "ms": ms, "ms_gemm_only": ms_g,
+                        "TFLOPs_fp32_equiv": 2.0 * m * n * k / ms / 1e9, "TFLOPs_fp32_equiv_gemm_only": 2.0 * m * n * k / ms_g / 1e9,
+                        "TFLOPs_bf16_issued_gemm_only": 6.0 * m * n_pad * k / ms_g / 1e9})
     if "dcn" in ops:
         from cvpr22_cross_modal_pseudo_labeling_amd.layers import deform_conv
         x = torch.randn(2, 512, 100, 168, generator=g).to(dev)

@@ -5,7 +5,8 @@
 One process per GPU (RCCL via torch.distributed, env:// rendezvous), config = defaults <- yaml <- trailing overrides,
 frozen before use.  There is no dataset access in this build, so the data stream is the synthetic COCO-shaped generator
 (cvpr22_cross_modal_pseudo_labeling_amd/data/synthetic.py).  MODEL.WEIGHT (a ``.pth`` in the reference's wire format),
-OUTPUT_DIR resume and SOLVER.CHECKPOINT_PERIOD behave as in the reference (utils/checkpoint.py); evaluation and
+OUTPUT_DIR resume and SOLVER.CHECKPOINT_PERIOD behave as in the reference (utils/checkpoint.py: checkpoints are written and
+resumed from whenever OUTPUT_DIR is set; ``--no-checkpoints`` opts out); evaluation and
 TensorBoard are outside the hot-path scope.
 """
 import argparse
@@ -43,8 +44,14 @@ def train(cfg, local_rank, distributed, max_iter, ims_per_gpu, save_checkpoints=
         backbone_prefix=cfg.MODEL.BACKBONE_PREFIX,
         load_emb_pred_from=(cfg.MODEL.MMSS_HEAD.DEFAULT_HEAD if cfg.MODEL.LOAD_EMB_PRED_FROM_MMSS_HEAD else None),
         load_classifier=cfg.MODEL.LOAD_CLASSIFIER)
+    resumed = checkpointer.has_checkpoint()
     extra = checkpointer.load(cfg.MODEL.WEIGHT, load_trainer_state=cfg.MODEL.LOAD_TRAINER_STATE)
     start_iter = int(extra.get("iteration", 0)) if cfg.MODEL.LOAD_TRAINER_STATE else 0
+    if resumed and hasattr(model, "roi_heads_student") and not cfg.MODEL.RESUME:
+        # st_generalized_rcnn.py:197-200 copies the teacher heads over the student at iteration 0 unless MODEL.RESUME
+        logging.getLogger("ovis.trainer").warning(
+            "resuming from %s with MODEL.RESUME False: the student heads in the checkpoint will be overwritten by the "
+            "teacher's at the first iteration (set MODEL.RESUME True to keep them)", cfg.OUTPUT_DIR)
     if distributed:
         comm.broadcast_parameters(model)
 
@@ -72,8 +79,10 @@ def main():
     parser.add_argument("--local_rank", type=int, default=int(os.environ.get("LOCAL_RANK", 0)))
     parser.add_argument("--skip-test", dest="skip_test", action="store_true", help="accepted for compatibility")
     parser.add_argument("--max-iter", type=int, default=None, help="override SOLVER.MAX_ITER for a short run")
-    parser.add_argument("--save-checkpoints", action="store_true",
-                        help="write model_<iter>.pth / model_final.pth / last_checkpoint under OUTPUT_DIR and resume from them")
+    parser.add_argument("--no-checkpoints", action="store_true",
+                        help="do not write model_<iter>.pth / model_final.pth / last_checkpoint under OUTPUT_DIR and do not "
+                             "resume from them (the reference always does both, tools/train_net.py:76-88)")
+    parser.add_argument("--save-checkpoints", action="store_true", help="accepted for compatibility: saving is the default")
     parser.add_argument("opts", default=None, nargs=argparse.REMAINDER, help="KEY VALUE overrides")
     args = parser.parse_args()
 
@@ -96,7 +105,8 @@ def main():
     ims_per_gpu = max(cfg.SOLVER.IMS_PER_BATCH // num_gpus, 1)
     logging.getLogger("ovis.trainer").info("%d images per GPU and iteration (SOLVER.IMS_PER_BATCH %d / %d GPUs)", ims_per_gpu,
                                            cfg.SOLVER.IMS_PER_BATCH, num_gpus)
-    train(cfg, args.local_rank, distributed, args.max_iter or cfg.SOLVER.MAX_ITER, ims_per_gpu, args.save_checkpoints)
+    train(cfg, args.local_rank, distributed, args.max_iter or cfg.SOLVER.MAX_ITER, ims_per_gpu,
+          save_checkpoints=bool(cfg.OUTPUT_DIR) and not args.no_checkpoints)
     if distributed:
         dist.destroy_process_group()
 
