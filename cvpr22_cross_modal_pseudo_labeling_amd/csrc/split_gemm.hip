@@ -428,10 +428,19 @@ __global__ __launch_bounds__(256, 2) void split_gemm_tn_kernel(SplitGemmTnArgs p
   constexpr int TILE_BYTES = 32 * 512, STAGE = 2 * TILE_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // XCD-aware renumbering INSIDE chunks of one resident round (2 workgroups x 256 CUs): every XCD gets a contiguous
+  // run of a chunk's ids (neighbouring tiles share G / X blocks in its L2), while the chunks follow each other in
+  // dispatch order -- so the workgroups resident at one time cover ~half of the row slices (ids are slice-major) and
+  // their G / X working set (~200 MB on the res5 shapes) stays inside the 256 MB Infinity Cache.  Renumbering the whole
+  // grid at once spread the resident set over ALL slices (410 MB) and the kernel fetched 2.3x its algorithmic bytes
+  // from HBM (profiles/r1_pmc_step_hbm_traffic_student.json).
   int id;
   {
-    const int b = blockIdx.x, q = nblocks >> 3, r = nblocks & 7, xcd = b & 7, loc = b >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    constexpr int kChunk = 2 * OVIS_NUM_CU;
+    const int b = blockIdx.x, base = b / kChunk * kChunk;
+    const int nb = min(nblocks - base, kChunk), bl = b - base;
+    const int q = nb >> 3, r = nb & 7, xcd = bl & 7, loc = bl >> 3;
+    id = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
   const int per_slice = tiles_i * tiles_j;
   const int slice = id / per_slice;
