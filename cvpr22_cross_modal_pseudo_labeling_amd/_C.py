@@ -123,6 +123,28 @@ def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, b
     return gin
 
 
+def roi_align_backward_strided(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels, height,
+                               width, sampling_ratio, bin_stride):
+    """Backward of ``roi_align_forward_strided_nhwc``: ``grad`` [R, C, ceil(PH/s), ceil(PW/s)] (the gradient of the bins
+    the strided pooler produced) -> grad_input [N, C, H, W].  Returns None when the plane-owner kernel does not cover the
+    shape (the caller scatters into a full tile and uses ``roi_align_backward``)."""
+    grad, rois = _dev(grad, "grad"), _dev(rois, "rois")
+    r = rois.size(0)
+    gin = torch.empty((batch_size, channels, height, width), dtype=grad.dtype, device=grad.device)
+    if gin.numel() == 0:
+        return gin
+    with torch.cuda.device(grad.device):
+        nbytes = _L.ovis_roi_align_backward_workspace_bytes(r, batch_size, height, width)
+        ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=grad.device)
+        rc = _L.ovis_roi_align_backward_strided_ws_f32(grad.data_ptr(), rois.data_ptr(), gin.data_ptr(), r, batch_size,
+                                                       channels, height, width, pooled_height, pooled_width, bin_stride,
+                                                       spatial_scale, sampling_ratio, ws.data_ptr(), nbytes, _stream())
+    if rc == -3:  # OVIS_ERANGE
+        return None
+    _lib.check(rc, "roi_align_backward_strided")
+    return gin
+
+
 # ---- NMS (csrc/nms.h:10-28) -------------------------------------------------------------------
 def nms_padded(dets, scores, threshold, ge_mode=False):
     """Sync-free form: returns (keep[K] int64 -- first n entries valid, ascending; n as a

@@ -25,6 +25,7 @@ SIGNATURES = {
     "ovis_roi_align_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ovis_roi_align_backward_plane_supported": (_i, [_i, _i, _i, _i]),
     "ovis_roi_align_backward_ws_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
+    "ovis_roi_align_backward_strided_ws_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "ovis_roi_pool_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "ovis_roi_pool_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ovis_deform_psroi_pool_forward_f32": (_i, [_vp] * 5 + [_i] * 7 + [_f] + [_i] * 5 + [_f, _vp]),

@@ -643,8 +643,8 @@ extern "C" int ovis_roi_align_forward_mfma_supported(int height, int width, int 
 // roi_align_bwd_plane.hip
 int ovis_roi_align_backward_plane_launch(const float* grad_output, const float* rois, float* grad_input,
                                          int num_rois, int batch, int channels, int height, int width,
-                                         int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
-                                         void* workspace, size_t workspace_bytes, hipStream_t s);
+                                         int pooled_h, int pooled_w, int bin_stride, float spatial_scale,
+                                         int sampling_ratio, void* workspace, size_t workspace_bytes, hipStream_t s);
 extern "C" int ovis_roi_align_backward_plane_supported(int height, int width, int pooled_h, int pooled_w);
 
 extern "C" int ovis_roi_align_backward_f32(const float* grad_output, const float* rois,
@@ -695,13 +695,38 @@ extern "C" int ovis_roi_align_backward_ws_f32(const float* grad_output, const fl
   if (num_rois > 0 && ovis_roi_align_backward_plane_supported(height, width, pooled_h, pooled_w)) {
     if (!grad_output || !rois || !grad_input) return OVIS_EINVAL;
     const int rc = ovis_roi_align_backward_plane_launch(grad_output, rois, grad_input, num_rois, batch, channels,
-                                                        height, width, pooled_h, pooled_w, spatial_scale,
+                                                        height, width, pooled_h, pooled_w, 1, spatial_scale,
                                                         sampling_ratio, workspace, workspace_bytes,
                                                         (hipStream_t)stream);
     if (rc != -100) return rc;  // -100: offsets would not fit 32 bits -> atomic path below
   }
   return ovis_roi_align_backward_f32(grad_output, rois, grad_input, num_rois, batch, channels, height, width,
                                      pooled_h, pooled_w, spatial_scale, sampling_ratio, stream);
+}
+
+// Backward of the strided pooler (ovis_roi_align_forward_strided_nhwc_f32): grad_output holds only the bins
+// (bin_stride * i, bin_stride * j) as [num_rois, channels, ceil(pooled_h / bin_stride), ceil(pooled_w / bin_stride)]
+// tiles -- a quarter of the bytes of the zero-scattered full tile at bin_stride 2.  Plane-owner kernel only: shapes it
+// does not cover return OVIS_ERANGE (the caller scatters into a full tile and uses ovis_roi_align_backward_ws_f32).
+extern "C" int ovis_roi_align_backward_strided_ws_f32(const float* grad_output, const float* rois, float* grad_input,
+                                                      int num_rois, int batch, int channels, int height, int width,
+                                                      int pooled_h, int pooled_w, int bin_stride, float spatial_scale,
+                                                      int sampling_ratio, void* workspace, size_t workspace_bytes,
+                                                      void* stream) {
+  if (num_rois < 0 || batch < 0 || channels < 0 || height <= 0 || width <= 0 || pooled_h <= 0 || pooled_w <= 0 ||
+      bin_stride <= 0)
+    return OVIS_EINVAL;
+  if ((size_t)batch * channels == 0) return OVIS_OK;
+  if (!grad_input) return OVIS_EINVAL;
+  if (num_rois == 0)
+    return (int)hipMemsetAsync(grad_input, 0, (size_t)batch * channels * height * width * sizeof(float), (hipStream_t)stream);
+  const int th = (pooled_h + bin_stride - 1) / bin_stride, tw = (pooled_w + bin_stride - 1) / bin_stride;
+  if (!ovis_roi_align_backward_plane_supported(height, width, th, tw)) return OVIS_ERANGE;
+  if (!grad_output || !rois) return OVIS_EINVAL;
+  const int rc = ovis_roi_align_backward_plane_launch(grad_output, rois, grad_input, num_rois, batch, channels, height,
+                                                      width, pooled_h, pooled_w, bin_stride, spatial_scale,
+                                                      sampling_ratio, workspace, workspace_bytes, (hipStream_t)stream);
+  return rc == -100 ? OVIS_ERANGE : rc;
 }
 
 extern "C" int ovis_roi_align_forward_ws_f32(const float* input, const float* rois, float* output, int num_rois,

@@ -60,9 +60,13 @@ constexpr int kPlanThreads = 256;
 __host__ __device__ inline long list_stride(int R, int NXB, int NYB) { return (long)R * NXB * NYB + kListPad + kGDepth; }
 
 __global__ __launch_bounds__(kPlanThreads) void roi_bwd_plan_kernel(
-    const float* __restrict__ rois, int R, int batch, int C, int H, int W, int PH, int PW, float scale,
+    const float* __restrict__ rois, int R, int batch, int C, int H, int W, int PH, int PW, int bin_stride, float scale,
     int sampling_ratio, u4* __restrict__ list, int* __restrict__ counts, u4* __restrict__ tx,
     u4* __restrict__ ty, int NXB, int NYB) {
+  // bin_stride > 1: grad_output holds only the bins (bin_stride * i, bin_stride * j) the strided pooler produced
+  // (roi_align_fwd_strided_nhwc_kernel), as [R, C, TH, TW] tiles; the tables carry those bins' weights, every other
+  // bin's gradient is zero by construction and is never read.
+  const int TH = (PH + bin_stride - 1) / bin_stride, TW = (PW + bin_stride - 1) / bin_stride;
   __shared__ int wave_total[kPlanThreads / 64];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(kPlanThreads) void roi_bwd_plan_kernel(
       int o = base + before + incl - nb;
       for (int xb = 0; xb < nbx; ++xb)
         for (int yb = 0; yb < nby; ++yb)
-          my[o++] = (u4){(unsigned)r * (unsigned)(C * PH * PW) * 4u,
+          my[o++] = (u4){(unsigned)r * (unsigned)(C * TH * TW) * 4u,
                          (unsigned)(block_origin(g.wy0, yb, H) * W + block_origin(g.wx0, xb, W)) * 4u,
                          (unsigned)(r * NXB + xb) * 1024u, (unsigned)(r * NYB + yb) * 1024u};
       base += all;
@@ -128,8 +132,8 @@ __global__ __launch_bounds__(kPlanThreads) void roi_bwd_plan_kernel(
     if (col >= g.wx0 + xb * kT && col <= min(g.wx0 + xb * kT + kT - 1, g.wx1)) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int j = min(4 * s, PW - 4) + e;  // the main kernel's k-slot -> bin-column map (pulled-back last group)
-        if (j >= 4 * s) v[e] = axis_weight(g.start_w, g.bin_w, g.gw, j, W, col);
+        const int j = min(4 * s, TW - 4) + e;  // the main kernel's k-slot -> bin-column map (pulled-back last group)
+        if (j >= 4 * s) v[e] = axis_weight(g.start_w, g.bin_w, g.gw, j * bin_stride, W, col);
       }
     }
     tx[((long)r * NXB + xb) * 64 + lane] = split_bf16(v);
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(kPlanThreads) void roi_bwd_plan_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int i = 4 * s + e;
-        if (i < PH) v[e] = axis_weight(g.start_h, g.bin_h, g.gh, i, H, row) / g.count;
+        if (i < TH) v[e] = axis_weight(g.start_h, g.bin_h, g.gh, i * bin_stride, H, row) / g.count;
       }
     }
     ty[((long)r * NYB + yb) * 64 + lane] = split_bf16(v);
@@ -380,10 +384,11 @@ extern "C" int ovis_roi_align_backward_plane_supported(int height, int width, in
 
 int ovis_roi_align_backward_plane_launch(const float* grad_output, const float* rois, float* grad_input,
                                          int num_rois, int batch, int channels, int height, int width,
-                                         int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
-                                         void* workspace, size_t workspace_bytes, hipStream_t s) {
+                                         int pooled_h, int pooled_w, int bin_stride, float spatial_scale,
+                                         int sampling_ratio, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  const int tile_h = (pooled_h + bin_stride - 1) / bin_stride, tile_w = (pooled_w + bin_stride - 1) / bin_stride;
   // item byte offsets are 32-bit: grad_output and the tables must each stay below 4 GiB (else: atomic path)
-  if ((double)num_rois * channels * pooled_h * pooled_w * 4.0 >= 4294967296.0 ||
+  if ((double)num_rois * channels * tile_h * tile_w * 4.0 >= 4294967296.0 ||
       ((double)num_rois * ovis_ceil_div(width, kT) + 1) * 1024.0 >= 4294967296.0 ||
       ((double)num_rois * ovis_ceil_div(height, kT) + 1) * 1024.0 >= 4294967296.0)
     return OVIS_PLANE_TOO_BIG;
@@ -406,8 +411,8 @@ int ovis_roi_align_backward_plane_launch(const float* grad_output, const float* 
   const long blocks = (long)batch * ovis_ceil_div(channels, nw);
   if (plan_blocks > 0x7fffffffL || blocks > 0x7fffffffL) return OVIS_ERANGE;
   hipLaunchKernelGGL(roi_bwd_plan_kernel, dim3((unsigned)plan_blocks), dim3(kPlanThreads), 0, s, rois, num_rois,
-                     batch, channels, height, width, pooled_h, pooled_w, spatial_scale, sampling_ratio, list, counts, tx, ty,
-                     NXB, NYB);
+                     batch, channels, height, width, pooled_h, pooled_w, bin_stride, spatial_scale, sampling_ratio, list,
+                     counts, tx, ty, NXB, NYB);
   OVIS_LAUNCH_CHECK();
   static bool attr_set = false;
   if (!attr_set) {
@@ -421,7 +426,7 @@ int ovis_roi_align_backward_plane_launch(const float* grad_output, const float* 
   const bool fit = height >= kT && width >= kT;
 #define OVIS_BWD_LAUNCH(NW_, FIT_, WC_)                                                                                  \
   hipLaunchKernelGGL((roi_bwd_mfma_kernel<NW_, FIT_, WC_>), dim3((unsigned)blocks), dim3(NW_ * 64), lds, s, grad_output, \
-                     list, counts, tx, ty, grad_input, num_rois, batch, channels, height, width, pooled_h, pooled_w,      \
+                     list, counts, tx, ty, grad_input, num_rois, batch, channels, height, width, tile_h, tile_w,          \
                      NXB, NYB, stride)
   if (nw == 8) {
     if (fit && width == 84) OVIS_BWD_LAUNCH(8, true, 84);  // the C4 map of an 800 x 1333 batch

@@ -35,7 +35,9 @@ roi_align = _ROIAlign.apply
 class _ROIAlignStridedNHWC(Function):
     """RoIAlign fused with the stride of the layer that consumes it: only bins (s*i, s*j), NHWC output
     [R, ceil(PH/s), ceil(PW/s), C] (``_C.roi_align_forward_strided_nhwc``).  Backward: the gradient of the
-    skipped bins is zero, so it is scattered into a zero [R, C, PH, PW] tile and handed to ``roi_align_backward``."""
+    skipped bins is zero; the plane-owner kernel reads the computed bins' tiles directly (tables built for the strided
+    bins, ``_C.roi_align_backward_strided``) -- for maps it does not cover the tile is scattered into a zero
+    [R, C, PH, PW] one and handed to ``roi_align_backward``."""
 
     @staticmethod
     def forward(ctx, input, roi, output_size, spatial_scale, sampling_ratio, bin_stride):
@@ -55,6 +57,11 @@ class _ROIAlignStridedNHWC(Function):
         bs, ch, h, w = ctx.input_shape
         ph, pw = ctx.output_size
         s = ctx.bin_stride
+        # [R, oh, ow, C] -> [R, C, oh, ow] tiles of the computed bins only: a quarter of the bytes of the full tile
+        grad_input = _C.roi_align_backward_strided(grad_output.permute(0, 3, 1, 2).contiguous(), rois, ctx.spatial_scale, ph, pw,
+                                                   bs, ch, h, w, ctx.sampling_ratio, s)
+        if grad_input is not None:
+            return grad_input, None, None, None, None, None
         full = grad_output.new_zeros((grad_output.shape[0], ch, ph, pw))
         full[:, :, ::s, ::s] = grad_output.permute(0, 3, 1, 2)
         grad_input = _C.roi_align_backward(full, rois, ctx.spatial_scale, ph, pw, bs, ch, h, w, ctx.sampling_ratio)

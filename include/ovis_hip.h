@@ -111,6 +111,15 @@ int ovis_roi_align_backward_ws_f32(const float* grad_output, const float* rois,
                                    int height, int width, int pooled_h, int pooled_w,
                                    float spatial_scale, int sampling_ratio, void* workspace,
                                    size_t workspace_bytes, void* stream);
+/* Backward of ovis_roi_align_forward_strided_nhwc_f32 (the pooler fused with the stride of the res5 head's first
+ * convolution): grad_output [num_rois, channels, ceil(pooled_h / bin_stride), ceil(pooled_w / bin_stride)] holds the
+ * gradient of the bins (bin_stride * i, bin_stride * j) only -- the other bins were never computed, their gradient is
+ * zero -- so a quarter of the bytes of the full tile are read at bin_stride 2.  Same workspace as the form above.
+ * Plane-owner kernel only: OVIS_ERANGE for shapes it does not cover (scatter into a full tile and use the form above). */
+int ovis_roi_align_backward_strided_ws_f32(const float* grad_output, const float* rois, float* grad_input,
+                                           int num_rois, int batch, int channels, int height, int width,
+                                           int pooled_h, int pooled_w, int bin_stride, float spatial_scale,
+                                           int sampling_ratio, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * NMS                                        mb/csrc/nms.h:10-28, mb/csrc/cuda/nms.cu:13-131
