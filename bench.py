@@ -131,6 +131,11 @@ class OpTimer:
         self._wrap("roi_align_forward_strided_nhwc", roi_fwd_strided_bytes)
         self._wrap("roi_align_forward_strided_pair", roi_fwd_strided_bytes)
         self._wrap("roi_align_backward", roi_bwd_bytes)
+
+        def roi_bwd_strided_bytes(grad, rois, scale, ph, pw, n, c, h, w, sr, bs):
+            return 4 * grad.numel() + 4 * n * c * h * w + 20 * rois.shape[0]  # the computed bins' tiles + the planes
+
+        self._wrap("roi_align_backward_strided", roi_bwd_strided_bytes)
         self._wrap("nms_padded", nms_bytes)
 
         def nms_batched_bytes(boxes, drop, threshold, below=0, ge_mode=False):
@@ -237,7 +242,8 @@ def per_shape_rows(timer, steps):
 PMC_KERNEL = {"split_gemm_pair": "split_gemm_kernel", "split_gemm_pair_gated": "split_gemm_kernel",
               "split_gemm_pair_tn": "split_gemm_tn_kernel", "gate_split_pair": "gate_split_pair_kernel",
               "split_pair": "split_pair_kernel", "roi_align_forward_strided_pair": "roi_align_fwd_strided_nhwc_kernel",
-              "roi_align_forward_strided_nhwc": "roi_align_fwd_strided_nhwc_kernel"}
+              "roi_align_forward_strided_nhwc": "roi_align_fwd_strided_nhwc_kernel",
+              "roi_align_backward_strided": "roi_bwd_mfma_kernel", "roi_align_backward": "roi_bwd_mfma_kernel"}
 
 
 def pmc_traffic(workload, op):
