@@ -35,25 +35,31 @@ class _LinearMFMA(Function):
 _PAIR_WEIGHT_CACHE = {}
 
 
-def _pair_weight_padded(weight, n_pad):
-    """[N, K] f32 -> pair layout [n_pad, 2K] (zero rows behind N); cached for tensors that do not require grad (the class /
-    vocabulary matrices, frozen emb_pred), keyed on identity + version."""
+def _pair_weight_padded(weight, n_pad, transposed=False):
+    """[N, K] f32 -> pair layout [n_pad, 2K] (zero rows behind N), or of its transpose [K, 2 * n_pad] (the data-gradient
+    operand); cached for tensors that do not require grad (the class / vocabulary matrices, frozen emb_pred), keyed on
+    identity + version."""
     import torch.nn.functional as F
     frozen = not weight.requires_grad
-    key = (id(weight), weight._version, weight.device, n_pad)
+    slot = (id(weight), transposed)
+    key = (id(weight), weight._version, weight.device, n_pad, transposed)
     if frozen:
-        hit = _PAIR_WEIGHT_CACHE.get(id(weight))
+        hit = _PAIR_WEIGHT_CACHE.get(slot)
         if hit is not None and hit[0] == key and hit[1]() is weight:
             return hit[2]
     w = weight.detach()
-    if w.shape[0] != n_pad:
+    if transposed:
+        w = w.t()
+        if w.shape[1] != n_pad:
+            w = F.pad(w, (0, n_pad - w.shape[1]))
+    elif w.shape[0] != n_pad:
         w = F.pad(w, (0, 0, 0, n_pad - w.shape[0]))
     wp = _C.split_pair(w.contiguous())
     if frozen:
         import weakref
         if len(_PAIR_WEIGHT_CACHE) > 64:
             _PAIR_WEIGHT_CACHE.clear()
-        _PAIR_WEIGHT_CACHE[id(weight)] = (key, weakref.ref(weight), wp)
+        _PAIR_WEIGHT_CACHE[slot] = (key, weakref.ref(weight), wp)
     return wp
 
 
@@ -65,10 +71,12 @@ class _LinearPair(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
+        """Returns [M, N] -- a column slice (view) of the padded [M, n_pad] product when N is not a multiple of 128; a
+        caller that can build its weight already padded (zero rows) avoids the pad launches."""
         import torch.nn.functional as F
         n = weight.shape[0]
         n_pad = -(-n // 128) * 128
-        xp = _C.split_pair(x.detach().contiguous())
+        xp = _C.split_pair(x.detach())   # row-strided views (column slices of a padded product) are read in place
         wp = _pair_weight_padded(weight, n_pad)
         b = None
         if bias is not None:
@@ -77,7 +85,7 @@ class _LinearPair(Function):
         ctx.save_for_backward(xp, weight)
         ctx.has_bias = bias is not None
         ctx.n_pad = n_pad
-        return y if n == n_pad else y[:, :n].contiguous()
+        return y if n == n_pad else y[:, :n]
 
     @staticmethod
     @once_differentiable
@@ -91,9 +99,7 @@ class _LinearPair(Function):
             g = dy if n == n_pad else F.pad(dy, (0, n_pad - n))
             gp = _C.split_pair(g.contiguous())                                  # [M, 2 n_pad]
             if need_x:
-                wt = weight.detach().t()
-                wt = wt if n == n_pad else F.pad(wt, (0, n_pad - n))            # [K, n_pad]
-                dx, _ = _C.split_gemm_pair(gp, _C.split_pair(wt.contiguous()))  # dY W
+                dx, _ = _C.split_gemm_pair(gp, _pair_weight_padded(weight, n_pad, transposed=True))  # dY W
             if need_w:
                 dw = _C.split_gemm_pair_tn(gp, xp)[:n]                          # dY^T X over the rows
         if ctx.has_bias and ctx.needs_input_grad[2]:

@@ -102,8 +102,17 @@ class STGeneralizedRCNN(nn.Module):
         self._seen_cls = self.roi_heads["box"].predictor.cls_score
 
     def combine_embs(self, embs):
-        # exemplar bank is empty (see module docstring) -> st_generalized_rcnn.py:165-166
-        return F.normalize(embs, dim=-1)
+        # exemplar bank is empty (see module docstring) -> st_generalized_rcnn.py:165-166.  The matrices are constants of
+        # the run: the normalised form is computed once per (tensor, version), so the predictor's operand caches hit
+        key = (id(embs), embs._version, embs.device)
+        cache = self.__dict__.setdefault("_combined", {})
+        hit = cache.get(id(embs))
+        if hit is None or hit[0] != key or hit[1] is not embs:
+            if len(cache) > 8:
+                cache.clear()
+            hit = (key, embs, F.normalize(embs, dim=-1))
+            cache[id(embs)] = hit
+        return hit[2]
 
     def prepare_model(self):
         student = self.roi_heads_student["box"].predictor

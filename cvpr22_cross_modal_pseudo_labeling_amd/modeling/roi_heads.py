@@ -127,13 +127,24 @@ class FastRCNNPredictor(nn.Module):
 
     def forward(self, x):
         x = self.pooled(x)
-        # both Linear layers share the pooled operand: one MFMA GEMM over the concatenated [768+8, 2048] weight
-        w = torch.cat([self.emb_pred.weight, self.bbox_pred.weight], 0)
-        b = torch.cat([self.emb_pred.bias, self.bbox_pred.bias], 0)
+        # both Linear layers share the pooled operand: one GEMM over the concatenated [768 + 8, 2048] weight, built
+        # already padded with zero rows to the split GEMM's 128-column tiles (one cat, no separate pad)
+        n = self.emb_dim + self.bbox_pred.out_features
+        pad = (-n) % 128 if x.is_cuda else 0
+        zw, zb = self._zero_rows(pad, x)
+        w = torch.cat([self.emb_pred.weight, self.bbox_pred.weight] + ([zw] if pad else []), 0)
+        b = torch.cat([self.emb_pred.bias, self.bbox_pred.bias] + ([zb] if pad else []), 0)
         y = linear_mfma(x, w, b)
-        cls_emb, bbox = y[:, : self.emb_dim], y[:, self.emb_dim:]
+        cls_emb, bbox = y[:, : self.emb_dim], y[:, self.emb_dim:n]
         cls_logit = text_logits(cls_emb, self.cls_score)  # einsum('pe,ce->pc')
         return cls_logit, bbox
+
+    def _zero_rows(self, pad, x):
+        z = getattr(self, "_zero_pad", None)
+        if pad and (z is None or z[0].shape[0] != pad or z[0].device != x.device):
+            z = (x.new_zeros((pad, self.emb_pred.in_features)), x.new_zeros((pad,)))
+            self._zero_pad = z
+        return z if pad else (None, None)
 
     def embed(self, x):
         """region embeddings only (teacher alignment pass)"""
