@@ -13,34 +13,52 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// Everything an element needs comes from ONE exponential, one reciprocal and one logarithm (hardware v_exp_f32 /
+// v_rcp_f32 / v_log_f32, ~1 ulp): e = exp(-|x|), r = 1 / (1 + e), L = log(1 + e) give
+//   p = sigmoid(x) = x >= 0 ? r : e r,   1 - p = x >= 0 ? e r : r,   log p = min(x, 0) - L,
+//   log(1 - p) = -max(x, 0) - L  (the reference's stable form, SigmoidFocalLoss_cuda.cu:44-46),
+// and only the term of the element's own case (positive class / negative class / ignored row) is evaluated.  The
+// reference evaluates expf twice, powf twice and logf twice per element for both terms (~6 software transcendental
+// sequences): this op was VALU-bound at 9-13 % of the HBM rate.
+struct FocalParts {
+  float p, q, logp, log1mp;
+};
+
+__device__ __forceinline__ FocalParts focal_parts(float x) {
+  const float e = __builtin_amdgcn_exp2f(-fabsf(x) * 1.44269504088896341f);
+  const float r = __builtin_amdgcn_rcpf(1.f + e);
+  const float L = __builtin_amdgcn_logf(1.f + e) * 0.693147180559945309f;  // v_log_f32 is log2
+  FocalParts f;
+  const float er = e * r;
+  f.p = x >= 0.f ? r : er;
+  f.q = x >= 0.f ? er : r;
+  // log(max(p, FLT_MIN)) of the reference: p underflows for x < -87.3, where the clamp takes over
+  f.logp = fmaxf(fminf(x, 0.f) - L, -87.33654475055310898657f);
+  f.log1mp = -fmaxf(x, 0.f) - L;
+  return f;
+}
+
+__device__ __forceinline__ float focal_pow(float a, float gamma) {  // a in [0, 1]
+  if (gamma == 2.f) return a * a;   // RetinaNet's gamma (config/defaults.py:433)
+  if (gamma == 0.f) return 1.f;
+  if (gamma == 1.f) return a;
+  return __builtin_amdgcn_exp2f(gamma * __builtin_amdgcn_logf(a));  // 0 -> exp2(-inf) = 0 for gamma > 0
+}
+
 __device__ __forceinline__ float focal_fwd_elem(float x, int t, int d, float gamma, float alpha) {
-  const float c1 = (t == d + 1) ? 1.f : 0.f;
-  const float c2 = (t >= 0 && t != d + 1) ? 1.f : 0.f;
-  const float zn = 1.f - alpha, zp = alpha;
-  const float p = 1.f / (1.f + expf(-x));
-  const float term1 = powf(1.f - p, gamma) * logf(fmaxf(p, FLT_MIN));
-  const float pos = x >= 0.f ? 1.f : 0.f;
-  const float term2 = powf(p, gamma) * (-1.f * x * pos - logf(1.f + expf(x - 2.f * x * pos)));
-  float loss = 0.f;
-  loss += -c1 * term1 * zp;
-  loss += -c2 * term2 * zn;
-  return loss;
+  if (t < 0) return 0.f;
+  const FocalParts f = focal_parts(x);
+  if (t == d + 1) return -alpha * (focal_pow(f.q, gamma) * f.logp);
+  return -(1.f - alpha) * (focal_pow(f.p, gamma) * f.log1mp);
 }
 
 __device__ __forceinline__ float focal_bwd_elem(float x, int t, int d, float gamma, float alpha,
                                                 float up) {
-  const float c1 = (t == d + 1) ? 1.f : 0.f;
-  const float c2 = (t >= 0 && t != d + 1) ? 1.f : 0.f;
-  const float zn = 1.f - alpha, zp = alpha;
-  const float p = 1.f / (1.f + expf(-x));
-  const float term1 = powf(1.f - p, gamma) * (1.f - p - (p * gamma * logf(fmaxf(p, FLT_MIN))));
-  const float pos = x >= 0.f ? 1.f : 0.f;
-  const float term2 =
-      powf(p, gamma) *
-      ((-1.f * x * pos - logf(1.f + expf(x - 2.f * x * pos))) * (1.f - p) * gamma - p);
-  float g = 0.f;
-  g += -c1 * term1 * zp;
-  g += -c2 * term2 * zn;
+  if (t < 0) return 0.f;
+  const FocalParts f = focal_parts(x);
+  float g;
+  if (t == d + 1) g = -alpha * (focal_pow(f.q, gamma) * (f.q - f.p * gamma * f.logp));
+  else g = -(1.f - alpha) * (focal_pow(f.p, gamma) * (f.log1mp * f.q * gamma - f.p));
   return g * up;
 }
 

@@ -404,6 +404,26 @@ def test_focal_vs_oracle_and_module(C, oracle_mod, num, c):
     assert abs(total.item() - want.double().sum().item()) <= 1e-4 * max(1.0, want.double().sum().item())
 
 
+@pytest.mark.parametrize("gamma", [2.0, 1.5, 1.0, 0.0, 3.0])
+def test_focal_extreme_logits_and_gammas_vs_oracle(C, oracle_mod, gamma):
+    """Saturated logits (|x| up to 120: p underflows, the reference's log(max(p, FLT_MIN)) clamp takes over), x = 0,
+    every gamma branch of the kernel, positive / negative / ignored rows -- against the C restatement of the CUDA formula
+    (SigmoidFocalLoss_cuda.cu:21-101), forward and backward."""
+    vals = torch.tensor([-120.0, -95.0, -88.0, -87.0, -60.0, -20.0, -3.0, -1e-3, 0.0, 1e-3, 2.5, 17.0, 40.0, 89.0, 110.0, 0.7])
+    num = vals.numel()
+    logits = vals[:, None].repeat(1, 4).contiguous()              # [16, 4]: column 1 is the positive class where t == 2
+    for t in (2, 0, -1):
+        targets = torch.full((num,), t, dtype=torch.int32)
+        up = torch.linspace(0.5, 1.5, num * 4).view(num, 4)
+        want = oracle_mod.sigmoid_focal_loss_forward(logits, targets, gamma, 0.25)
+        wgrad = oracle_mod.sigmoid_focal_loss_backward(logits, targets, up, gamma, 0.25)
+        got = C.sigmoid_focalloss_forward(logits.cuda(), targets.cuda(), 4, gamma, 0.25).cpu()
+        grad = C.sigmoid_focalloss_backward(logits.cuda(), targets.cuda(), up.cuda(), 4, gamma, 0.25).cpu()
+        assert bool(torch.isfinite(got).all()) and bool(torch.isfinite(grad).all())
+        assert torch.allclose(got, want, rtol=2e-5, atol=1e-7), (t, (got - want).abs().max())
+        assert torch.allclose(grad, wgrad, rtol=2e-5, atol=1e-7), (t, (grad - wgrad).abs().max())
+
+
 def test_roi_align_backward_plane_kernel_reproducible(C, oracle_mod):
     """The plane-owner matrix-core kernel (default for maps whose plane fits LDS) issues no atomics: two runs are
     bit-identical; RoIs up to 500 px exercise multi-block windows (several 16-cell blocks per axis)."""
