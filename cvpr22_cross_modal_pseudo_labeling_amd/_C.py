@@ -65,9 +65,33 @@ def roi_align_forward_mfma(input, rois, spatial_scale, pooled_height, pooled_wid
     return _roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio, False)
 
 
+def _channels_last_map(input, channel_multiple):
+    """An [N, C, H, W] HIP tensor whose MEMORY is NHWC-contiguous (the NCHW view of the trunk's NHWC result) with a channel
+    count the NHWC-input pooler takes: no layout copy is needed."""
+    return (input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and input.shape[1] % channel_multiple == 0
+            and not input.is_contiguous() and input.permute(0, 2, 3, 1).is_contiguous() and input.data_ptr() % 16 == 0)
+
+
+def _strided_from_nhwc(input, rois, out, spatial_scale, pooled_height, pooled_width, sampling_ratio, bin_stride, pair):
+    n, c, h, w = input.shape
+    with torch.cuda.device(input.device):
+        rc = _L.ovis_roi_align_forward_strided_from_nhwc_f32(input.data_ptr(), rois.data_ptr(), out.data_ptr(), rois.size(0), n, c,
+                                                             h, w, pooled_height, pooled_width, bin_stride, spatial_scale,
+                                                             sampling_ratio, int(pair), _stream())
+    _lib.check(rc, "roi_align_forward_strided_from_nhwc")
+
+
 def roi_align_forward_strided_nhwc(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio, bin_stride):
     """Extension: bins (bin_stride*i, bin_stride*j) only, as [R, ceil(PH/s), ceil(PW/s), C] (NHWC); bit-identical to
-    ``roi_align_forward(...)[:, :, ::s, ::s].permute(0, 2, 3, 1)``."""
+    ``roi_align_forward(...)[:, :, ::s, ::s].permute(0, 2, 3, 1)``.  A channels-last ``input`` is pooled in place (no
+    window staging: ``ovis_roi_align_forward_strided_from_nhwc_f32``), an NCHW one through the window-staging kernel."""
+    if _channels_last_map(input, 4):
+        rois = _dev(rois, "rois")
+        oh, ow = -(-pooled_height // bin_stride), -(-pooled_width // bin_stride)
+        out = torch.empty((rois.size(0), oh, ow, input.shape[1]), dtype=input.dtype, device=input.device)
+        if out.numel():
+            _strided_from_nhwc(input, rois, out, spatial_scale, pooled_height, pooled_width, sampling_ratio, bin_stride, False)
+        return out
     input, rois = _dev(input, "input"), _dev(rois, "rois")
     if rois.dim() != 2 or rois.size(1) != 5 or input.dim() != 4:
         raise RuntimeError("roi_align_forward_strided_nhwc: expected input [N,C,H,W] and rois [R,5]")
@@ -87,7 +111,15 @@ def roi_align_forward_strided_nhwc(input, rois, spatial_scale, pooled_height, po
 
 def roi_align_forward_strided_pair(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio, bin_stride):
     """``roi_align_forward_strided_nhwc`` written in pair layout: [R*oh*ow, 2*C] bf16 (exactly ``split_pair`` of the fp32
-    bins), the operand of the res5 head's first split GEMM.  Returns (pair rows, (oh, ow))."""
+    bins), the operand of the res5 head's first split GEMM.  Returns (pair rows, (oh, ow)).  Channels-last inputs are
+    pooled in place (see ``roi_align_forward_strided_nhwc``)."""
+    if _channels_last_map(input, 32):
+        rois = _dev(rois, "rois")
+        oh, ow = -(-pooled_height // bin_stride), -(-pooled_width // bin_stride)
+        out = torch.empty((rois.size(0) * oh * ow, 2 * input.shape[1]), dtype=torch.bfloat16, device=input.device)
+        if out.numel():
+            _strided_from_nhwc(input, rois, out, spatial_scale, pooled_height, pooled_width, sampling_ratio, bin_stride, True)
+        return out, (oh, ow)
     input, rois = _dev(input, "input"), _dev(rois, "rois")
     if rois.dim() != 2 or rois.size(1) != 5 or input.dim() != 4:
         raise RuntimeError("roi_align_forward_strided_pair: expected input [N,C,H,W] and rois [R,5]")

@@ -21,6 +21,7 @@ SIGNATURES = {
     "ovis_roi_align_forward_ws_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "ovis_roi_align_forward_strided_nhwc_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "ovis_roi_align_forward_strided_pair_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "ovis_roi_align_forward_strided_from_nhwc_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "ovis_roi_align_backward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "ovis_roi_align_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ovis_roi_align_backward_plane_supported": (_i, [_i, _i, _i, _i]),

@@ -449,6 +449,68 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_strided_nhwc_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// Strided pooler on an NHWC (channels-last) map.  The trunk computes in NHWC; read in that layout every bilinear tap
+// of a sample is one contiguous C-vector, so the pooler needs no LDS window staging at all: lanes run over channel
+// groups of 4 (one 16-byte load per tap, a whole 4 KB line per wave-pair at C = 1024), the 256 threads of a workgroup
+// own one RoI and walk its OH x OW bins together.  Per (bin, channel) the samples are visited in the reference's order
+// with the reference's expressions (fwd_pool4_strided above, the exact kernel's arithmetic), so the result is
+// BIT-IDENTICAL to the NCHW kernels; neighbouring samples' taps are served by L1 / L2 (the map is 17 MB per image).
+// ---------------------------------------------------------------------------------------
+template <bool FAST>
+__device__ __forceinline__ void pool_nhwc_strided(const f4* __restrict__ img4, const RoiGeom& g, int H, int W, int C4,
+                                                  int bs, int OH, int OW, float* __restrict__ out_r, char* pair_r) {
+  const int items = OH * OW * C4;
+  const int C = C4 * 4;
+  for (int item = threadIdx.x; item < items; item += kThreads) {
+    const int k = item % C4, obin = item / C4;
+    const int oh = obin / OW;
+    const int ph = oh * bs, pw = (obin - oh * OW) * bs;
+    const f4* base = img4 + k;
+    f4 acc = (f4)(0.f);
+    for (int iy = 0; iy < g.gh; ++iy) {
+      const float y = sample_coord_t<FAST>(g.start_h, ph, g.bin_h, iy, g.gh, g.inv_gh);
+      int yl, yh;
+      float ly, hy;
+      if (!axis_sample(y, H, yl, yh, ly, hy)) continue;
+      const long ryl = (long)yl * W * C4, ryh = (long)yh * W * C4;
+      for (int ix = 0; ix < g.gw; ++ix) {
+        const float x = sample_coord_t<FAST>(g.start_w, pw, g.bin_w, ix, g.gw, g.inv_gw);
+        int xl, xh;
+        float lx, hx;
+        if (!axis_sample(x, W, xl, xh, lx, hx)) continue;
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        const long cl = (long)xl * C4, ch = (long)xh * C4;
+        acc += w1 * base[ryl + cl] + w2 * base[ryl + ch] + w3 * base[ryh + cl] + w4 * base[ryh + ch];
+      }
+    }
+    const f4 o = FAST ? acc * g.inv_count : acc / g.count;
+    if (pair_r) pool_store4_pair(pair_r, obin, 4 * k, C, o);
+    else *(f4*)(out_r + (long)obin * C + 4 * k) = o;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc_in_strided_kernel(
+    const float* __restrict__ in, const float* __restrict__ rois, float* __restrict__ out, int R, int batch, int C,
+    int H, int W, int PH, int PW, int bs, int OH, int OW, float scale, int sampling_ratio, int pair_out) {
+  const int r = blockIdx.x;
+  const RoiGeom g = make_geom(rois + (long)r * 5, scale, H, W, PH, PW, sampling_ratio, batch);
+  float* out_r = out + (long)r * OH * OW * C;   // both layouts take 4*C bytes per bin
+  char* pair_r = pair_out ? (char*)out_r : nullptr;
+  const int C4 = C >> 2;
+  if (g.empty) {
+    for (int item = threadIdx.x; item < OH * OW * C4; item += kThreads) {
+      const int k = item % C4, obin = item / C4;
+      if (pair_r) pool_store4_pair(pair_r, obin, 4 * k, C, (f4)(0.f));
+      else *(f4*)(out_r + (long)obin * C + 4 * k) = (f4)(0.f);
+    }
+    return;
+  }
+  const f4* img4 = (const f4*)(in + (long)g.b * H * W * C);
+  if (g.pow2) pool_nhwc_strided<true>(img4, g, H, W, C4, bs, OH, OW, out_r, pair_r);
+  else pool_nhwc_strided<false>(img4, g, H, W, C4, bs, OH, OW, out_r, pair_r);
+}
+
+// ---------------------------------------------------------------------------------------
 // Backward
 //
 // Bilinear average pooling is separable: out = Ay * win * Ax^T with Ay[ph][y] the summed row
@@ -764,6 +826,27 @@ extern "C" int ovis_roi_align_forward_strided_pair_f32(const float* input, const
   if (channels % 32 != 0 || ((uintptr_t)output_pair & 15)) return OVIS_ERANGE;
   return strided_nhwc_launch(input, rois, (float*)output_pair, num_rois, batch, channels, height, width, pooled_h,
                              pooled_w, bin_stride, spatial_scale, sampling_ratio, 1, stream);
+}
+
+// input in NHWC ([batch, height, width, channels] contiguous); output NHWC fp32 (pair_out == 0) or pair rows
+extern "C" int ovis_roi_align_forward_strided_from_nhwc_f32(const float* input_nhwc, const float* rois, void* output,
+                                                            int num_rois, int batch, int channels, int height,
+                                                            int width, int pooled_h, int pooled_w, int bin_stride,
+                                                            float spatial_scale, int sampling_ratio, int pair_out,
+                                                            void* stream) {
+  if (num_rois < 0 || batch < 0 || channels < 0 || height <= 0 || width <= 0 || pooled_h <= 0 || pooled_w <= 0 ||
+      bin_stride <= 0)
+    return OVIS_EINVAL;
+  if (num_rois == 0 || channels == 0) return OVIS_OK;
+  if (!input_nhwc || !rois || !output) return OVIS_EINVAL;
+  if (channels % 4 != 0 || (pair_out && channels % 32 != 0) || ((uintptr_t)input_nhwc & 15) || ((uintptr_t)output & 15))
+    return OVIS_ERANGE;
+  const int oh = (pooled_h + bin_stride - 1) / bin_stride, ow = (pooled_w + bin_stride - 1) / bin_stride;
+  hipLaunchKernelGGL(roi_align_fwd_nhwc_in_strided_kernel, dim3((unsigned)num_rois), dim3(kThreads), 0, (hipStream_t)stream,
+                     input_nhwc, rois, (float*)output, num_rois, batch, channels, height, width, pooled_h, pooled_w,
+                     bin_stride, oh, ow, spatial_scale, sampling_ratio, pair_out);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
 }
 
 static int strided_nhwc_launch(const float* input, const float* rois, float* output, int num_rois, int batch,

@@ -331,14 +331,16 @@ class ResNetC4(nn.Module):
         if (x.is_cuda and self.nhwc and all(b.nhwc_supported() for b in blocks)
                 and (frozen or (self.train_nhwc and all(b.pair_gemm and b.pair_supported() for b in blocks)))):
             # layer1-3 in NHWC with the split-GEMM bottlenecks of the res5 head (1x1 = row-major GEMM, 3x3 = implicit
-            # GEMM); one layout copy out (the C4 map, 34 MB).  Frozen trunk (student-teacher configuration): always.
+            # GEMM).  Frozen trunk (student-teacher configuration): always.
             # Trainable stages (teacher training): through the pair-layout autograd nodes as well -- 39.4 vs 42.2 ms per
             # step against MIOpen's NCHW kernels (both with a warm MIOpen kernel cache; ``train_nhwc = False``
             # selects MIOpen).
             y, yp = x.permute(0, 2, 3, 1).contiguous(), None
             for i, b in enumerate(blocks):
                 y, yp = b.forward_nhwc(y, xp=yp, want_pair=True) if i + 1 < len(blocks) else (b.forward_nhwc(y, xp=yp), None)
-            return [y.permute(0, 3, 1, 2).contiguous()]
+            # the C4 map stays in NHWC memory (an NCHW-shaped view of it): the poolers read channels-last maps in place
+            # (csrc/roi_align.hip::roi_align_fwd_nhwc_in_strided_kernel) and the RPN head wants NHWC rows anyway
+            return [y.permute(0, 3, 1, 2)]
         x = x.contiguous()  # the GEMM stem hands over channels_last memory; MIOpen's NCHW kernels are the faster ones here
         for name in self.stages:
             x = getattr(self, name)(x)

@@ -85,6 +85,14 @@ int ovis_roi_align_forward_strided_pair_f32(const float* input, const float* roi
                                             int num_rois, int batch, int channels, int height, int width,
                                             int pooled_h, int pooled_w, int bin_stride,
                                             float spatial_scale, int sampling_ratio, void* stream);
+/* The same two poolers for a feature map that is already NHWC ([batch, height, width, channels] contiguous: what the
+ * trunk of this library computes in): no window staging, every bilinear tap is one contiguous channel vector; samples
+ * are visited in the reference's order, so the bins are bit-identical to the forms above.  pair_out != 0: pair rows
+ * (channels % 32 == 0), else NHWC fp32 (channels % 4 == 0). */
+int ovis_roi_align_forward_strided_from_nhwc_f32(const float* input_nhwc, const float* rois, void* output, int num_rois,
+                                                 int batch, int channels, int height, int width, int pooled_h,
+                                                 int pooled_w, int bin_stride, float spatial_scale, int sampling_ratio,
+                                                 int pair_out, void* stream);
 
 /* grad_input [batch, channels, height, width] is fully overwritten (zero-filled, then
  * accumulated into) by this call; the caller does not need to clear it. */

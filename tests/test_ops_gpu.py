@@ -109,6 +109,33 @@ def test_roi_align_forward_strided_nhwc_bit_exact(C, golden_dir):
     assert (xa.grad - xc.grad).abs().max().item() <= 1e-5 * xc.grad.abs().max().item()
 
 
+@pytest.mark.parametrize("c", [64, 100, 1024])
+def test_roi_align_strided_poolers_on_channels_last_map_bit_exact(C, c):
+    """A channels-last feature map (NCHW view of NHWC memory: what the trunk hands over) is pooled in place by the
+    NHWC-input kernel; bins bit-identical to the NCHW window-staging kernel and to the exact kernel's, fp32 and pair output,
+    RoIs of every size incl. one outside the map and non-power-of-two sampling grids."""
+    g = torch.Generator().manual_seed(c)
+    n, h, w = 2, 50, 84
+    x = torch.randn(n, c, h, w, generator=g).cuda()
+    x_cl = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)          # same values, NHWC memory
+    assert not x_cl.is_contiguous()
+    rois = torch.cat([_rois(g, 60, n, 1333, 800, 8, 1200), torch.tensor([[0, 0.0, 0.0, 1332.0, 799.0], [1, 5000.0, 5000.0, 5100.0, 5100.0],
+                                                                        [1, 100.0, 50.0, 820.0, 700.0]])]).cuda()
+    want = C.roi_align_forward(x, rois, 1 / 16, 14, 14, 0)[:, :, ::2, ::2].permute(0, 2, 3, 1)
+    got = C.roi_align_forward_strided_nhwc(x_cl, rois, 1 / 16, 14, 14, 0, 2)
+    assert torch.equal(got, want)
+    assert torch.equal(got, C.roi_align_forward_strided_nhwc(x, rois, 1 / 16, 14, 14, 0, 2))
+    if c % 32 == 0:
+        p_cl, shp = C.roi_align_forward_strided_pair(x_cl, rois, 1 / 16, 14, 14, 0, 2)
+        p_nc, _ = C.roi_align_forward_strided_pair(x, rois, 1 / 16, 14, 14, 0, 2)
+        assert shp == (7, 7) and torch.equal(p_cl, p_nc)
+        assert torch.equal(p_cl, C.split_pair(got.reshape(-1, c)))
+    for sr, s in ((2, 2), (0, 3), (3, 1)):
+        a = C.roi_align_forward_strided_nhwc(x_cl, rois, 1 / 16, 14, 14, sr, s)
+        b = C.roi_align_forward(x, rois, 1 / 16, 14, 14, sr)[:, :, ::s, ::s].permute(0, 2, 3, 1)
+        assert torch.equal(a, b), (sr, s)
+
+
 def test_roi_align_forward_large_map_global_path(C, oracle_mod):
     # 120x160 = 19200-cell window for the whole-image RoI: exceeds the LDS window budget
     g = torch.Generator().manual_seed(3)

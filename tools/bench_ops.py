@@ -74,6 +74,11 @@ def main():
                 alg_s = 4 * r * c * 49 + 4 * n * c * h * w + 20 * r
                 res.append({"op": "roi_align_forward_strided_nhwc(s=2)", "rois": kind, "ms": ms, "alg_MB": alg_s / 1e6,
                             "GBps": alg_s / ms / 1e6, "frac_hbm": alg_s / ms / 1e6 / HBM_PEAK_GBS})
+                x_cl = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)  # channels-last map: pooled in place
+                ms = timeit(lambda: _C.roi_align_forward_strided_pair(x_cl, rois, 1 / 16, 14, 14, 0, 2), args.iters)
+                res.append({"op": "roi_align_forward_strided_pair(s=2, channels-last map)", "rois": kind, "ms": ms,
+                            "alg_MB": alg_s / 1e6, "GBps": alg_s / ms / 1e6, "frac_hbm": alg_s / ms / 1e6 / HBM_PEAK_GBS})
+                del x_cl
             if "roi_bwd" in ops:
                 go = torch.randn(r, c, 14, 14, generator=g).to(dev)
                 ms = timeit(lambda: _C.roi_align_backward(go, rois, 1 / 16, 14, 14, n, c, h, w, 0), args.iters)
