@@ -612,7 +612,7 @@ def im2col_nchw_pair(x, kh, kw, stride, pad):
 
 
 def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f32=True, out_pair=False, conv=None,
-                    config=0, a2_pair=None):
+                    config=0, a2_pair=None, residual_pair=None):
     """act(A @ B^T + bias + residual) with A [M, 2*ch] / B [N, 2*K] in pair layout (``split_pair``); fp32-accurate
     three-term bf16 hi/lo product on the matrix cores (csrc/split_gemm.hip).  conv = (h, w, kh, kw, flip): A is an
     NHWC tensor [M/(h*w), h, w, ch] and B holds [N, kh*kw*ch] tap-major weights -- stride-1 "same" convolution as an
@@ -645,6 +645,22 @@ def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f3
         return c, cp
     if bias is not None:
         bias = _dev(bias, "bias")
+    if residual_pair is not None:
+        # shortcut in pair layout (hi + lo, exact in fp32): plain 1x1 products only
+        if residual is not None or conv is not None or a2_pair is not None or n % 32 or not (
+                residual_pair.is_cuda and residual_pair.dtype == torch.bfloat16 and residual_pair.dim() == 2
+                and residual_pair.stride(1) == 1 and residual_pair.shape == (m, 2 * n)):
+            raise RuntimeError("split_gemm_pair: residual_pair must be [M, 2N] bfloat16 pair rows of a plain product")
+        with torch.cuda.device(dev):
+            nbytes = _L.ovis_split_gemm_pair_workspace_bytes(m, n, ch, 0, 1, 1, 0) if not (config & 8) else 0
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
+            rc = _L.ovis_split_gemm_pair_rp(a_pair.data_ptr(), 2 * a_pair.stride(0), b_pair.data_ptr(), 2 * b_pair.stride(0),
+                                            0 if c is None else c.data_ptr(), n, 0 if cp is None else cp.data_ptr(), 4 * n,
+                                            0 if bias is None else bias.data_ptr(), residual_pair.data_ptr(),
+                                            2 * residual_pair.stride(0), m, n, ch, int(bool(relu)),
+                                            0 if ws is None else ws.data_ptr(), nbytes, config, _stream())
+        _lib.check(rc, "split_gemm_pair_rp")
+        return c, cp
     if residual is not None and not (residual.is_cuda and residual.dtype == torch.float32 and residual.dim() == 2
                                      and residual.stride(1) == 1 and residual.shape == (m, n)):
         raise RuntimeError("split_gemm_pair: residual must be a float32 [M, N] HIP tensor with unit column stride")

@@ -60,6 +60,8 @@ struct SplitGemmArgs {
   float* C; long ldc;                // fp32 result (may be null)
   char* Cp; long cp_rs;              // pair result (may be null), bytes per row
   const float* bias; const float* res; long ldr;
+  const char* resp; long resp_rs;    // shortcut given in PAIR layout (hi + lo is exact in fp32): the block input a bottleneck
+                                     // already holds as its conv1 operand -- no fp32 copy of it has to exist
   const char* gate; long gate_rs;    // optional ReLU gate of a backward pass: pair rows of the forward activation (hi > 0)
   float* slab;                       // split-K: raw partial sums [kslices][M][N] (then C / Cp / bias / ... are unused here)
   long M; int N; int ch; int ch2; int T; int H; int W; int KH; int KW; int flip; int relu; int gw;
@@ -80,10 +82,18 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 __device__ __forceinline__ void epilogue_store4(const SplitGemmArgs& p, long m, int n, f32x4 v) {
   if (p.bias) v += *(const f32x4*)(p.bias + n);
   if (p.res) v += *(const f32x4*)(p.res + m * p.ldr + n);
+  const long poff = (long)(n >> 5) * 128 + (n & 31) * 2;
+  if (p.resp) {
+    const char* sp = p.resp + m * p.resp_rs + poff;
+    const uint2 h = *(const uint2*)sp, l = *(const uint2*)(sp + 64);
+    v.x += __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
+    v.y += __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
+    v.z += __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
+    v.w += __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u);
+  }
   if (p.relu) {
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
   }
-  const long poff = (long)(n >> 5) * 128 + (n & 31) * 2;
   if (p.gate) {  // data gradient of a layer whose input went through a ReLU: zero where that activation was <= 0
     const uint2 h = *(const uint2*)(p.gate + m * p.gate_rs + poff);
     const unsigned a0 = h.x & 0xffffu, a1 = h.x >> 16, a2 = h.y & 0xffffu, a3 = h.y >> 16;
@@ -1065,6 +1075,7 @@ extern "C" size_t ovis_split_gemm_pair_workspace_bytes(long m, int n, int channe
 static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void* a2_pair, long a2_row_bytes,
                                 const void* b_pair, long b_row_bytes, float* c, long ldc, void* c_pair,
                                 long c_pair_row_bytes, const float* bias, const float* residual, long ldr,
+                                const void* residual_pair, long residual_pair_row_bytes,
                                 const void* gate_pair, long gate_row_bytes, long m, int n, int channels, int channels2,
                                 int taps_h, int taps_w, int height, int width, int flip, int relu, void* workspace,
                                 size_t workspace_bytes, int config, void* stream) {
@@ -1093,6 +1104,7 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
   p.B = (const char*)b_pair; p.b_rs = b_row_bytes;
   p.C = c; p.ldc = ldc; p.Cp = (char*)c_pair; p.cp_rs = c_pair_row_bytes;
   p.bias = bias; p.res = residual; p.ldr = ldr;
+  p.resp = (const char*)residual_pair; p.resp_rs = residual_pair_row_bytes;
   p.gate = (const char*)gate_pair; p.gate_rs = gate_row_bytes;
   p.slab = q.kslices > 1 ? (float*)workspace : nullptr;
   p.M = m; p.N = n; p.ch = channels; p.ch2 = channels2; p.T = T; p.H = height; p.W = width; p.KH = taps_h; p.KW = taps_w;
@@ -1145,8 +1157,22 @@ extern "C" int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const 
                                     int flip, int relu, void* workspace, size_t workspace_bytes, int config,
                                     void* stream) {
   return split_gemm_pair_impl(a_pair, a_row_bytes, a2_pair, a2_row_bytes, b_pair, b_row_bytes, c, ldc, c_pair,
-                              c_pair_row_bytes, bias, residual, ldr, nullptr, 0, m, n, channels, channels2, taps_h,
-                              taps_w, height, width, flip, relu, workspace, workspace_bytes, config, stream);
+                              c_pair_row_bytes, bias, residual, ldr, nullptr, 0, nullptr, 0, m, n, channels, channels2,
+                              taps_h, taps_w, height, width, flip, relu, workspace, workspace_bytes, config, stream);
+}
+
+// The same with the shortcut operand given in pair layout ([m, n] pair rows, n % 32 == 0): residual = hi + lo, exact in
+// fp32.  A bottleneck holds its input as the pair operand of conv1 anyway, so the identity shortcut needs no fp32 copy of
+// the block input -- the producing block writes its result in pair layout only (4 instead of 8 bytes per element).
+extern "C" int ovis_split_gemm_pair_rp(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
+                                       float* c, long ldc, void* c_pair, long c_pair_row_bytes, const float* bias,
+                                       const void* residual_pair, long residual_pair_row_bytes, long m, int n,
+                                       int channels, int relu, void* workspace, size_t workspace_bytes, int config,
+                                       void* stream) {
+  if (!residual_pair || n % 32 != 0 || residual_pair_row_bytes % 16 != 0 || ((uintptr_t)residual_pair & 15)) return OVIS_ERANGE;
+  return split_gemm_pair_impl(a_pair, a_row_bytes, nullptr, 0, b_pair, b_row_bytes, c, ldc, c_pair, c_pair_row_bytes, bias,
+                              nullptr, 0, residual_pair, residual_pair_row_bytes, nullptr, 0, m, n, channels, 0, 1, 1, 0, 0,
+                              0, relu, workspace, workspace_bytes, config, stream);
 }
 
 extern "C" int ovis_split_gemm_pair_gated(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
@@ -1156,6 +1182,6 @@ extern "C" int ovis_split_gemm_pair_gated(const void* a_pair, long a_row_bytes, 
                                           void* stream) {
   if (!gate_pair || gate_row_bytes % 16 != 0 || ((uintptr_t)gate_pair & 15) || n % 32 != 0) return OVIS_ERANGE;
   return split_gemm_pair_impl(a_pair, a_row_bytes, nullptr, 0, b_pair, b_row_bytes, c, ldc, c_pair, c_pair_row_bytes,
-                              nullptr, nullptr, 0, gate_pair, gate_row_bytes, m, n, channels, 0, taps_h, taps_w, height,
-                              width, flip, 0, nullptr, 0, config | 8, stream);
+                              nullptr, nullptr, 0, nullptr, 0, gate_pair, gate_row_bytes, m, n, channels, 0, taps_h, taps_w,
+                              height, width, flip, 0, nullptr, 0, config | 8, stream);
 }

@@ -65,13 +65,23 @@ def _dw(gp, xp, w, scale, conv=None):
     return d if scale is None else d * scale.view(-1, 1, 1, 1)
 
 
+def is_placeholder(t):
+    """A zero-stride stand-in for a block output that exists only in pair layout (see ``_BottleneckPair.forward``)."""
+    return t is not None and t.numel() > 1 and all(st == 0 for st in t.stride())
+
+
 class _BottleneckPair(Function):
     @staticmethod
-    def forward(ctx, x, xp, geom, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, want_pair, wpairs, pool):
+    def forward(ctx, x, xp, geom, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, want_pair, wpairs, pool, want_f32=True):
         """x [M, Cin] f32 rows conv1 reads (may be None when wd is given and no input gradient is wanted), xp its pair
         form or None; geom = (h, w) of the map the rows tile; w1/w2/w3/wd RAW convolution weights (wd None = identity
         shortcut) with their folded FrozenBN scales s1/s2/s3/sd (per output channel, no gradient) and shifts b1/b2,
-        b3 = the conv3 (+ shortcut) shift; wpairs: optional cached pair weights of a frozen block."""
+        b3 = the conv3 (+ shortcut) shift; wpairs: optional cached pair weights of a frozen block.
+        want_f32 False (with want_pair): the result is written in PAIR layout only -- the next block reads it as its conv1
+        operand AND as its identity shortcut (hi + lo, exact in fp32; ``split_gemm_pair(residual_pair=...)``), so the 4
+        bytes per element of the fp32 copy are neither written nor re-read.  The fp32 output slot then carries a
+        zero-stride placeholder (never read: it carries the shape and routes the gradient between the autograd nodes of a
+        chain)."""
         h, w = geom
         if xp is None:
             xp = _C.split_pair(x)
@@ -86,6 +96,8 @@ class _BottleneckPair(Function):
             pd, td = _C.weight_prep_pair(wd, sd, need_bwd) if wd is not None else (None, None)
             wpairs = {"w1": p1, "w2": p2, "w3": p3, "wd": pd}
             wts = (t1, t2, t3, td)
+        f32 = bool(want_f32 or pool or not want_pair)
+        x_real = x is not None and not is_placeholder(x)
         _, o1p = _C.split_gemm_pair(xp, wpairs["w1"], b1, None, True, False, True)
         _, o2p = _C.split_gemm_pair(o1p, wpairs["w2"], b2, None, True, False, True, conv=(h, w, kh, kw, False))
         if wd is not None:
@@ -94,14 +106,19 @@ class _BottleneckPair(Function):
             w3d = wpairs.get("w3d")
             if w3d is None:
                 w3d = torch.cat([wpairs["w3"], wpairs["wd"]], 1)
-            out, outp = _C.split_gemm_pair(o2p, w3d, b3, None, True, True, want_pair, a2_pair=xp)
-        else:
-            out, outp = _C.split_gemm_pair(o2p, wpairs["w3"], b3, x, True, True, want_pair)
+            out, outp = _C.split_gemm_pair(o2p, w3d, b3, None, True, f32, want_pair, a2_pair=xp)
+        elif x_real:
+            out, outp = _C.split_gemm_pair(o2p, wpairs["w3"], b3, x, True, f32, want_pair)
+        else:  # the block input exists only as its pair form: shortcut = hi + lo
+            out, outp = _C.split_gemm_pair(o2p, wpairs["w3"], b3, None, True, f32, want_pair, residual_pair=xp)
         # pool: also return the mean over the h*w rows of every map (the head's average pooling) as an output of THIS
         # node, so that its gradient is broadcast inside the fused gate + split kernel of the backward instead of
         # being materialised ([rows, C] expand) and added to the dense gradient by two tensor ops
         pooled = out.view(-1, h * w, out.shape[1]).mean(dim=1) if pool else None
-        ctx.save_for_backward(xp, o1p, o2p, out, w1, w2, w3, wd, s1, s2, s3, sd)
+        gate_src = out if out is not None else outp  # the last ReLU's gate: the fp32 result or the hi halves of its pair form
+        if out is None:
+            out = outp.new_empty((1,), dtype=torch.float32).expand(outp.shape[0], outp.shape[1] // 2)
+        ctx.save_for_backward(xp, o1p, o2p, gate_src, w1, w2, w3, wd, s1, s2, s3, sd)
         ctx.wts = wts
         ctx.geom = (h, w, kh, kw)
         ctx.set_materialize_grads(False)  # no zero tensors for absent / non-differentiable gradient slots
@@ -113,8 +130,8 @@ class _BottleneckPair(Function):
     @once_differentiable
     def backward(ctx, dout, _dpair, dpooled):
         if dout is None and dpooled is None:
-            return (None,) * 17
-        xp, o1p, o2p, out, w1, w2, w3, wd, s1, s2, s3, sd = ctx.saved_tensors
+            return (None,) * 18
+        xp, o1p, o2p, out, w1, w2, w3, wd, s1, s2, s3, sd = ctx.saved_tensors   # out: fp32 result or its pair form (gate)
         h, w, kh, kw = ctx.geom
         need = ctx.needs_input_grad
         need_x, need_w1, need_w2, need_w3, need_wd = need[0], need[3], need[6], need[9], need[12]
@@ -143,17 +160,17 @@ class _BottleneckPair(Function):
                 dx, _ = _C.split_gemm_pair(g1p, t1, None, res)
         if wd is not None and need_wd:
             dwd = _dw(g3p, xp, wd, sd)
-        return dx, None, None, dw1, None, None, dw2, None, None, dw3, None, None, dwd, None, None, None, None
+        return dx, None, None, dw1, None, None, dw2, None, None, dw3, None, None, dwd, None, None, None, None, None
 
 
 def bottleneck_pair(x, xp, geom, w1, b1, w2, b2, w3, b3, wd=None, want_pair=False, wpairs=None, pool=False,
-                    scales=(None, None, None, None)):
+                    scales=(None, None, None, None), want_f32=True):
     """(out f32 [M, Cout], out in pair layout or None[, mean of out over the h*w rows of every map when ``pool``]) of
     one bottleneck on the rows x [M, Cin] of an (h, w) map.  w1/w2/w3/wd are the convolution weights as the model
     stores them; ``scales`` = their folded FrozenBN scales (None = weights already folded)."""
     s1, s2, s3, sd = scales
     out, outp, pooled = _BottleneckPair.apply(x, xp, geom, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, want_pair, wpairs,
-                                              pool)
+                                              pool, want_f32)
     return (out, outp, pooled) if pool else (out, outp)
 
 

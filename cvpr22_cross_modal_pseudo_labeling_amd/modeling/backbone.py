@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..layers import Conv2d, FrozenBatchNorm2d, bias_relu_, split_conv_same, split_linear
-from ..layers.pair_bottleneck import bottleneck_pair, pair_weight
+from ..layers.pair_bottleneck import bottleneck_pair, is_placeholder, pair_weight
 
 
 class ConvBN(nn.Module):
@@ -78,6 +78,9 @@ class Bottleneck(nn.Module):
         # attribute combinations (K-concatenated split through a library GEMM, fp32 GEMM, per-layer 3x3) are the earlier
         # forms of the same block, kept as cross-checks: tests/test_heads_gpu.py sets them explicitly
         self.split_gemm = self.split_conv = self.pair_gemm = True
+        # a block that hands its result on in pair layout (want_pair) does not also write it as fp32: the next block
+        # takes its identity shortcut from the pair form (hi + lo).  False = fp32 + pair (cross-check in the tests)
+        self.pair_only_chain = True
         self._pair_cache = None
 
     def forward(self, x):
@@ -116,10 +119,10 @@ class Bottleneck(nn.Module):
             keep = self._fd is None or (torch.is_grad_enabled() and x.requires_grad) or xp is None
             x = x[:, ::sy, ::sx, :]
             hs, ws = x.shape[1], x.shape[2]
-            x2d = x.contiguous().view(-1, c) if keep else None
+            x2d = (x.reshape(-1, c) if is_placeholder(x) else x.contiguous().view(-1, c)) if keep else None
         else:
             hs, ws = h, w
-            x2d = x.view(-1, c)
+            x2d = x.reshape(-1, c)
         return self._pair_node(x2d, xp, r, hs, ws, want_pair, pool)
 
     def forward_pair_rows(self, xp, r, hs, ws, want_pair=False, pool=False):
@@ -154,7 +157,7 @@ class Bottleneck(nn.Module):
         else:
             b3s = b3 if bd is None else b3 + bd
         res = bottleneck_pair(x2d, xp, (hs, ws), w1, b1, w2, b2, w3, b3s, wd, want_pair, wpairs, pool,
-                              scales=(s1, s2, s3, sd))
+                              scales=(s1, s2, s3, sd), want_f32=not (want_pair and self.pair_only_chain))
         out = res[0].view(r, hs, ws, res[0].shape[-1])
         if pool:
             out._ovis_pooled = res[2]  # [R, C] mean over the map, an output of the same autograd node (see pooled())

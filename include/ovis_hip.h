@@ -349,6 +349,14 @@ int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const void* a2_pa
                          long c_pair_row_bytes, const float* bias, const float* residual, long ldr, long m,
                          int n, int channels, int channels2, int taps_h, int taps_w, int height, int width,
                          int flip, int relu, void* workspace, size_t workspace_bytes, int config, void* stream);
+/* The plain (1x1) form with the shortcut operand in PAIR layout: residual_pair [m, n] pair rows (n % 32 == 0), added as
+ * hi + lo (exact in fp32; 2^-17 relative to the value the pair was split from).  A bottleneck
+ * (mb/modeling/backbone/resnet.py:323-344) holds its input as the pair operand of conv1 anyway: with this form the
+ * identity shortcut needs no fp32 copy of the block input, so the producing block writes its result in pair layout only. */
+int ovis_split_gemm_pair_rp(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes, float* c, long ldc,
+                            void* c_pair, long c_pair_row_bytes, const float* bias, const void* residual_pair,
+                            long residual_pair_row_bytes, long m, int n, int channels, int relu, void* workspace,
+                            size_t workspace_bytes, int config, void* stream);
 
 /* Weight gradient on pair operands: c_slabs[s][n][tap*channels + c] = sum over the rows m of slice s of
  * G[m, n] * X[row(m, tap), c]  (G = gated output gradient [m, n], X = the layer input [m, channels], both pair

@@ -233,6 +233,74 @@ def test_bottleneck_pair_node_vs_fp64_autograd(proj):
         assert (a.double() - b).norm().item() <= 1e-4 * b.norm().item(), gname
 
 
+@pytest.mark.parametrize("m,k,n", [(777, 128, 256), (3000, 512, 2048), (64, 64, 32)])
+def test_split_gemm_pair_residual_in_pair_layout(m, k, n):
+    """The shortcut operand given as pair rows: act(A B^T + bias + (hi + lo)) -- bit-identical to passing the fp32 tensor
+    hi + lo as the residual, for fp32 and pair outputs, with and without K slices."""
+    C = _C()
+    g = torch.Generator(device="cuda").manual_seed(m + n)
+    a = C.split_pair(torch.randn(m, k, device="cuda", generator=g))
+    b = C.split_pair(torch.randn(n, k, device="cuda", generator=g) * 0.1)
+    bias = torch.randn(n, device="cuda", generator=g)
+    r = torch.randn(m, n, device="cuda", generator=g)
+    rp = C.split_pair(r)
+    pr = rp.view(m, n // 32, 2, 32).float()
+    r_rec = (pr[:, :, 0] + pr[:, :, 1]).reshape(m, n).contiguous()   # hi + lo: exact in fp32
+    for config in (0, 8):
+        want, want_p = C.split_gemm_pair(a, b, bias, r_rec, True, True, True, config=config)
+        got, got_p = C.split_gemm_pair(a, b, bias, None, True, True, True, config=config, residual_pair=rp)
+        assert torch.equal(got, want) and torch.equal(got_p, want_p)
+        none, only_p = C.split_gemm_pair(a, b, bias, None, True, False, True, config=config, residual_pair=rp)
+        assert none is None and torch.equal(only_p, want_p)
+    assert float((r_rec - r).abs().max()) <= 2.0 ** -16 * float(r.abs().max())
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_bottleneck_chain_pair_only_vs_fp32_chain(train):
+    """A res5-like chain (projection block + two identity blocks) with the intermediate results carried in PAIR layout
+    only (identity shortcut = hi + lo of the block input, zero-stride placeholders as fp32 handles) against the same chain
+    with fp32 + pair intermediates: outputs within 3e-5 of the maximum, every gradient within 5e-3 in the L2 norm (a
+    pre-activation within rounding of zero may flip its ReLU gate between the two arithmetics, which moves isolated
+    entries by O(1): the bound of the other cross-path gradient tests)."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers.pair_bottleneck import is_placeholder
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.backbone import ResNetHead
+    cfg = get_defaults()
+    cfg.freeze()
+    torch.manual_seed(11)
+    head = ResNetHead(cfg).cuda()
+    for m in head.modules():
+        if hasattr(m, "running_var"):
+            m.weight.uniform_(0.5, 1.5)
+            m.bias.uniform_(-0.2, 0.2)
+    for p in head.parameters():
+        p.requires_grad_(train)
+    x = torch.randn(20, 7, 7, 1024, device="cuda")
+    gy = torch.randn(20, 2048, 7, 7, device="cuda")
+
+    def run(pair_only):
+        for b in head.layer4:
+            b.pair_only_chain = pair_only
+        xx = x.clone().requires_grad_(train)
+        with torch.set_grad_enabled(train):
+            y = head.forward_pooled_nhwc(xx)
+            if train:
+                head.zero_grad()
+                y.backward(gy)
+        return [y.detach()] + ([xx.grad] + [p.grad.clone() for p in head.parameters()] if train else [])
+
+    # the chained blocks really exchange placeholders
+    b0 = head.layer4[0]
+    b0.pair_only_chain = True
+    with torch.no_grad():
+        mid, midp = b0.forward_nhwc(x, prestrided=True, want_pair=True)
+    assert is_placeholder(mid) and midp.shape == (20 * 49, 2 * 2048)
+    ref, got = run(False), run(True)
+    assert (got[0] - ref[0]).abs().max().item() <= 3e-5 * ref[0].abs().max().item()
+    for a, b in zip(got[1:], ref[1:]):
+        assert (a - b).norm().item() <= 5e-3 * b.norm().item() + 1e-12
+
+
 def test_stem_gemm_matches_convolution():
     """7x7 / stride-2 stem as im2col-pair + split GEMM (+ folded FrozenBN, ReLU, max-pool) vs the fp64 convolution."""
     from cvpr22_cross_modal_pseudo_labeling_amd.modeling.backbone import Stem
