@@ -1045,6 +1045,19 @@ SplitGemmPlan split_gemm_plan(long m, int n, int channels, int channels2, int ta
       q.steps_per_slice = (int)((units + s - 1) / s);
       q.kslices = (units + q.steps_per_slice - 1) / q.steps_per_slice;
     }
+  } else if (!(config & 8) && !q.narrow && q.mode != HALO) {
+    // Grids of one or two workgroups per CU that walk a long K (the 50 x 84 maps of layer3 and the RPN head: 66 row
+    // tiles): the CUs with one workgroup more than the others set the kernel's duration.  Cutting K in 2 / 4 makes the
+    // work items smaller, so they spread evenly (8400 x 256 x 2304: 132 workgroups on 256 CUs -> 528; the RPN head's
+    // 528 x 288 k-steps -> 1056 x 144); the slabs are small next to the K walk.
+    int sl = 1;
+    if (nb <= OVIS_NUM_CU && units >= 64) sl = 4;
+    else if (nb <= OVIS_NUM_CU && units >= 32) sl = 2;
+    else if (nb < 3L * OVIS_NUM_CU && units >= 128) sl = 2;
+    if (sl > 1) {
+      q.steps_per_slice = (units + sl - 1) / sl;
+      q.kslices = (units + q.steps_per_slice - 1) / q.steps_per_slice;
+    }
   }
   // Large grids: ONE LDS stage and three / four workgroups per CU instead of two double-buffered ones -- nothing
   // overlaps inside a workgroup, but more independent workgroups hide each other's load phases better (measured on
