@@ -8,12 +8,13 @@ cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python bench.py --workload $WL --no-pipeline --no-cpu-baseline --steps 8 --warmup 3 --burn-seconds 1 > $OUT/bench.log 2>&1
 f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 python tools/gap_report.py $f -250 -50 | cut -c1-170
-python - $f $OUT/bench.log <<PY
-import csv, json, sys
-rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(sys.argv[1])))
-t1 = max(e for _, e in rows)
-sel = [r for r in rows if t1 - 250e6 < r[0] < t1 - 50e6]
-ms = json.loads([l for l in open(sys.argv[2]) if l.startswith('{"metric')][-1])["ms_per_step"]
-print(f"launches per step: {len(sel) * ms / 200:.0f} ({len(sel)} kernels in 200 ms of steady state, {ms:.1f} ms per step under the profiler)")
+python - $f <<PY
+import csv, sys
+rows = sorted((int(r["Start_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[1])))
+t1 = rows[-1][0]
+sel = [n for t, n in rows if t1 - 250e6 < t < t1 - 50e6]
+# the batched NMS reduce runs exactly once per training step: its count = the number of steps inside the window
+steps = sum(1 for n in sel if "nms_reduce" in n)
+print(f"launches per step: {len(sel) / max(steps, 1):.0f} ({len(sel)} kernels and {steps} steps in 200 ms of steady state)")
 PY
 rm -rf $OUT/trace
