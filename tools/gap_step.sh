@@ -11,10 +11,10 @@ python tools/gap_report.py $f -250 -50 | cut -c1-170
 python - $f <<PY
 import csv, sys
 rows = sorted((int(r["Start_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[1])))
-t1 = rows[-1][0]
-sel = [n for t, n in rows if t1 - 250e6 < t < t1 - 50e6]
-# the batched NMS reduce runs exactly once per training step: its count = the number of steps inside the window
-steps = sum(1 for n in sel if "nms_reduce" in n)
-print(f"launches per step: {len(sel) / max(steps, 1):.0f} ({len(sel)} kernels and {steps} steps in 200 ms of steady state)")
+# the batched NMS reduce runs exactly once per training step: the kernels between two consecutive ones are one step
+marks = [i for i, (t, n) in enumerate(rows) if "nms_reduce" in n]
+per_step = sorted(b - a for a, b in zip(marks[:-1], marks[1:]))[: max(len(marks) - 1, 1)]
+steady = per_step[: max(1, len(per_step) // 2)]  # the smaller half: steps without warm-up / calibration extras
+print(f"launches per step: {steady[len(steady) // 2]} (median over the steady steps; {len(marks)} steps in the trace)")
 PY
 rm -rf $OUT/trace
