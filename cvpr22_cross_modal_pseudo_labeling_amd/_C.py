@@ -5,6 +5,8 @@ is a thin tensor<->pointer shim over the C ABI in ``include/ovis_hip.h``.  Devic
 only: CPU tensors raise ``RuntimeError`` (the reference itself raises "Not implemented on the
 CPU" for most of these, csrc/ROIAlign.h:44, csrc/SigmoidFocalLoss.h:23,40).
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -291,6 +293,83 @@ def rpn_decode(box_regression, topk_idx, cell_anchors, image_wh, weights, xform_
     return boxes, drop
 
 
+def box_decode(rel_codes, boxes, weights, xform_clip, rows_per_image=None, image_sizes=None):
+    """``BoxCoder.decode`` (modeling/box_coder.py:49-95) in one launch (``ovis_box_decode_f32``): rel_codes [R, 4K] (any row
+    stride), boxes [R, 4] -> [R, 4K].  With ``rows_per_image`` (ints, image-major rows) and ``image_sizes`` ((width, height)
+    per image) every row is also clipped to its image (``BoxList.clip_to_image``, structures/bounding_box.py:214-225)."""
+    if not rel_codes.is_cuda or rel_codes.dtype != torch.float32 or rel_codes.dim() != 2 or rel_codes.shape[1] % 4:
+        raise RuntimeError("box_decode: rel_codes must be a float32 HIP tensor [R, 4K] (the product path has no CPU fallback)")
+    if boxes.shape != (rel_codes.shape[0], 4):
+        raise RuntimeError("box_decode: boxes must be [R, 4]")
+    boxes = boxes.to(torch.float32)
+    if rel_codes.stride(1) != 1:
+        rel_codes = rel_codes.contiguous()
+    if boxes.stride(1) != 1:
+        boxes = boxes.contiguous()
+    r, k = rel_codes.shape[0], rel_codes.shape[1] // 4
+    out = torch.empty((r, 4 * k), dtype=torch.float32, device=rel_codes.device)
+    if r == 0:
+        return out
+    n = 0 if rows_per_image is None else len(rows_per_image)
+    counts = wh = None
+    if n:
+        counts = (ctypes.c_int32 * n)(*[int(c) for c in rows_per_image])
+        wh = (ctypes.c_float * (2 * n))(*[float(v) for size in image_sizes for v in size])
+    wx, wy, ww, wh_ = weights
+    with torch.cuda.device(rel_codes.device):
+        rc = _L.ovis_box_decode_f32(rel_codes.data_ptr(), rel_codes.stride(0), boxes.data_ptr(), boxes.stride(0), r, k, wx, wy,
+                                    ww, wh_, xform_clip, n, counts, wh, out.data_ptr(), _stream())
+    _lib.check(rc, "box_decode")
+    return out
+
+
+def rois_from_boxes(boxes, image_ids=None):
+    """``Pooler.convert_to_roi_format`` (modeling/poolers.py:73-86) in one launch (``ovis_rois_from_boxes_f32``): a list of
+    per-image [n_i, 4] float32 HIP tensors -> [sum n_i, 5] rows (image index, x1, y1, x2, y2); the image index of list
+    entry i is ``image_ids[i]`` (default i)."""
+    if not boxes:
+        raise RuntimeError("rois_from_boxes: at least one image expected")
+    boxes = [_dev(b, "boxes") for b in boxes]
+    if any(b.dim() != 2 or b.shape[1] != 4 for b in boxes):
+        raise RuntimeError("rois_from_boxes: [n, 4] tensors expected")
+    n = len(boxes)
+    rois = torch.empty((sum(b.shape[0] for b in boxes), 5), dtype=torch.float32, device=boxes[0].device)
+    if rois.shape[0]:
+        ptrs = (ctypes.c_void_p * n)(*[b.data_ptr() if b.shape[0] else None for b in boxes])
+        counts = (ctypes.c_int32 * n)(*[b.shape[0] for b in boxes])
+        ids = None if image_ids is None else (ctypes.c_int32 * n)(*[int(i) for i in image_ids])
+        with torch.cuda.device(rois.device):
+            rc = _L.ovis_rois_from_boxes_f32(ptrs, counts, ids, n, rois.data_ptr(), _stream())
+        _lib.check(rc, "rois_from_boxes")
+    return rois
+
+
+def smooth_l1_picked_fwd_bwd(box_regression, regression_targets, positives, labels, column0, beta, denominator,
+                             need_grad=True):
+    """Box-regression loss of the box head (roi_heads/box_head/loss.py:147-170) with its gradient in one pass
+    (``ovis_smooth_l1_picked_fwd_bwd_f32``): sum over the positives of smooth_l1(box_regression[p, col0 + c] -
+    regression_targets[p, c]) / denominator, col0 = 4 * labels[p] (``labels`` given) or ``column0``.
+    -> (loss scalar tensor, d loss / d box_regression [R, C] or None)."""
+    if not box_regression.is_cuda or box_regression.dtype != torch.float32 or box_regression.dim() != 2:
+        raise RuntimeError("smooth_l1_picked: float32 HIP tensor [R, C] expected (the product path has no CPU fallback)")
+    if box_regression.stride(1) != 1:
+        box_regression = box_regression.contiguous()
+    regression_targets = _dev(regression_targets, "regression_targets")
+    positives = _dev(positives, "positives", torch.int64)
+    labels = None if labels is None else _dev(labels, "labels", torch.int64)
+    r, c = box_regression.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=box_regression.device)
+    grad = torch.empty((r, c), dtype=torch.float32, device=box_regression.device) if need_grad else None
+    with torch.cuda.device(box_regression.device):
+        rc = _L.ovis_smooth_l1_picked_fwd_bwd_f32(box_regression.data_ptr(), box_regression.stride(0), r, c,
+                                                  regression_targets.data_ptr(), regression_targets.stride(0),
+                                                  positives.data_ptr(), 0 if labels is None else labels.data_ptr(),
+                                                  positives.numel(), column0, beta, float(denominator), loss.data_ptr(),
+                                                  0 if grad is None else grad.data_ptr(), _stream())
+    _lib.check(rc, "smooth_l1_picked_fwd_bwd")
+    return loss[0], grad
+
+
 # ---- sigmoid focal loss (csrc/SigmoidFocalLoss.h:10-41) ----------------------------------------
 def sigmoid_focalloss_forward(logits, targets, num_classes, gamma, alpha):
     logits, targets = _dev(logits, "logits"), _dev(targets, "targets", torch.int32)
@@ -498,6 +577,29 @@ def sample_fg_bg(labels, batch_size, max_positives, seed):
                                   int(seed) & 0xFFFFFFFFFFFFFFFF, sel.data_ptr(), slots.data_ptr(), counts.data_ptr(), _stream())
     _lib.check(rc, "sample_fg_bg")
     return sel, slots, counts
+
+
+def gather_rows(index, boxes_a=None, boxes_b=None, ints_a=None, ints_b=None):
+    """``x.index_select(0, index)`` for up to two [P, 4] float32 and two [P] int64 tensors in one launch
+    (``ovis_gather_rows``) -> tuple of the gathered tensors (None where the source is None)."""
+    index = _dev(index, "index", torch.int64)
+    n = index.numel()
+    srcs = [None if t is None else _dev(t, "boxes", torch.float32) for t in (boxes_a, boxes_b)] + \
+           [None if t is None else _dev(t, "ints", torch.int64) for t in (ints_a, ints_b)]
+    for t in srcs[:2]:
+        if t is not None and (t.dim() != 2 or t.shape[1] != 4):
+            raise RuntimeError("gather_rows: float sources must be [P, 4]")
+    for t in srcs[2:]:
+        if t is not None and t.dim() != 1:
+            raise RuntimeError("gather_rows: int64 sources must be [P]")
+    outs = [None if t is None else torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in srcs]
+    if n:
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        with torch.cuda.device(index.device):
+            rc = _L.ovis_gather_rows(index.data_ptr(), n, ptr(srcs[0]), ptr(outs[0]), ptr(srcs[1]), ptr(outs[1]), ptr(srcs[2]),
+                                     ptr(outs[2]), ptr(srcs[3]), ptr(outs[3]), _stream())
+        _lib.check(rc, "gather_rows")
+    return tuple(outs)
 
 
 def project_pasted_masks(mask_probs, gt_boxes, gt_index, boxes, image_size, resolution, threshold=0.5):

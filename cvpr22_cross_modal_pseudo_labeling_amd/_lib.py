@@ -38,6 +38,10 @@ SIGNATURES = {
     "ovis_project_pasted_masks_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "ovis_nms_presorted_workspace_bytes": (_sz, [_i, _i]),
     "ovis_nms_presorted_batched_f32": (_i, [_vp, _vp, _i, _i, _f, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+    "ovis_box_decode_f32": (_i, [_vp, _l, _vp, _l, _l, _i, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "ovis_smooth_l1_picked_fwd_bwd_f32": (_i, [_vp, _l, _i, _i, _vp, _l, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "ovis_gather_rows": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ovis_rois_from_boxes_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "ovis_rpn_decode_f32": (_i, [_vp, _l, _l, _l, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp]),
     "ovis_sigmoid_focal_loss_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "ovis_sigmoid_focal_loss_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),

@@ -304,6 +304,22 @@ __global__ __launch_bounds__(256) void project_pasted_masks_kernel(const float* 
   const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
   out[i] = v != 0.f ? 1.f : 0.f;
 }
+// rows `index[0..n)` of up to two [P, 4] f32 arrays and two [P] int64 arrays in one launch: the sampled proposals'
+// boxes / regression targets / labels / matched ground truths (box_head/loss.py:112-121: proposals_per_image[img_sampled_inds])
+__global__ __launch_bounds__(256) void gather_rows_kernel(const long long* __restrict__ index, int n,
+                                                         const float4* __restrict__ fa, float4* __restrict__ fa_out,
+                                                         const float4* __restrict__ fb, float4* __restrict__ fb_out,
+                                                         const long long* __restrict__ ia, long long* __restrict__ ia_out,
+                                                         const long long* __restrict__ ib, long long* __restrict__ ib_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long r = index[i];
+  if (fa) fa_out[i] = fa[r];
+  if (fb) fb_out[i] = fb[r];
+  if (ia) ia_out[i] = ia[r];
+  if (ib) ib_out[i] = ib[r];
+}
+
 }  // namespace
 
 extern "C" int ovis_sample_fg_bg(const int64_t* labels, int num, int batch_size, int max_positives, uint64_t seed,
@@ -357,6 +373,22 @@ extern "C" int ovis_project_masks_f32(const uint8_t* masks, const int64_t* gt_in
   const long total = (long)num * resolution * resolution;
   hipLaunchKernelGGL(project_masks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, masks,
                      (const long*)gt_index, boxes, num, height, width, resolution, masks_are_bool, out);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}
+
+extern "C" int ovis_gather_rows(const int64_t* index, int num, const float* boxes_a, float* boxes_a_out,
+                                const float* boxes_b, float* boxes_b_out, const int64_t* ints_a, int64_t* ints_a_out,
+                                const int64_t* ints_b, int64_t* ints_b_out, void* stream) {
+  if (num < 0) return OVIS_EINVAL;
+  if (num == 0) return OVIS_OK;
+  if (!index || (boxes_a && !boxes_a_out) || (boxes_b && !boxes_b_out) || (ints_a && !ints_a_out) || (ints_b && !ints_b_out))
+    return OVIS_EINVAL;
+  if ((((uintptr_t)boxes_a | (uintptr_t)boxes_a_out | (uintptr_t)boxes_b | (uintptr_t)boxes_b_out) & 15) != 0) return OVIS_EINVAL;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ovis_ceil_div(num, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)index, num, (const float4*)boxes_a, (float4*)boxes_a_out, (const float4*)boxes_b,
+                     (float4*)boxes_b_out, (const long long*)ints_a, (long long*)ints_a_out, (const long long*)ints_b,
+                     (long long*)ints_b_out);
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
 }

@@ -14,11 +14,20 @@ import torch
 from . import comm
 
 
+def total_loss(loss_dict):
+    """Sum of the loss terms (trainer.py:96 ``sum(loss for loss in loss_dict.values())``) as one stack + one reduction
+    instead of a chain of scalar adds."""
+    terms = [v if torch.is_tensor(v) else torch.as_tensor(float(v)) for v in loss_dict.values()]
+    if len(terms) < 3 or not all(t.is_cuda for t in terms):
+        return sum(terms)
+    return torch.stack([t.reshape(()) for t in terms]).sum()
+
+
 def train_step(model, optimizer, reducer, images, targets, scheduler=None):
     """One optimisation step; returns the (un-reduced) loss dict of this rank."""
     reducer.zero_grad()
     loss_dict = model(images, targets)
-    losses = sum(loss for loss in loss_dict.values())
+    losses = total_loss(loss_dict)
     losses.backward()
     reducer.finish()
     optimizer.step()
@@ -117,7 +126,7 @@ class PipelinedTrainer:
             self._launch_frozen(next_batch[0], next_batch[1], inputs_ready, threaded=True)
         self.reducer.zero_grad()
         loss_dict = self.model.forward_student(frozen, targets)
-        losses = sum(loss for loss in loss_dict.values())
+        losses = total_loss(loss_dict)
         losses.backward()
         self.reducer.finish()
         self.optimizer.step()

@@ -1,6 +1,6 @@
 """Operator API of ``maskrcnn_benchmark.layers`` (maskrcnn_benchmark/layers/__init__.py:23-46)."""
 from .batch_norm import FrozenBatchNorm2d
-from .cross_modal import bias_relu_, linear_mfma, split_conv_same, split_linear, stochastic_mask_bce, text_logits, weighted_cross_entropy
+from .cross_modal import bias_relu_, linear_mfma, smooth_l1_picked, split_conv_same, split_linear, stochastic_mask_bce, text_logits, weighted_cross_entropy
 from .dcn import DeformConv, ModulatedDeformConv, ModulatedDeformConvPack, deform_conv, modulated_deform_conv
 from .dcn import DeformRoIPooling, DeformRoIPoolingPack, ModulatedDeformRoIPoolingPack, deform_roi_pooling
 from .misc import BatchNorm2d, Conv2d, ConvTranspose2d, DFConv2d, interpolate
@@ -39,6 +39,7 @@ __all__ = [
     "split_conv_same",
     "bias_relu_",
     "text_logits",
+    "smooth_l1_picked",
     "weighted_cross_entropy",
     "stochastic_mask_bce",
 ]

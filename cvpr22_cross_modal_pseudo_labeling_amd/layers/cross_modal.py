@@ -276,6 +276,27 @@ def weighted_cross_entropy(logits, labels, bg_weight):
     return _WeightedCE.apply(logits, labels, bg_weight)
 
 
+class _SmoothL1Picked(Function):
+    @staticmethod
+    def forward(ctx, box_regression, regression_targets, positives, labels, column0, beta, denominator):
+        loss, grad = _C.smooth_l1_picked_fwd_bwd(box_regression, regression_targets, positives, labels, column0, beta,
+                                                 denominator, need_grad=box_regression.requires_grad)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None, None, None
+
+
+def smooth_l1_picked(box_regression, regression_targets, positives, labels, column0, beta, denominator):
+    """sum over the rows ``positives`` of smooth_l1(box_regression[p, col0:col0 + 4] - regression_targets[p]; beta) /
+    denominator, col0 = 4 * labels[p] or ``column0`` (labels None) -- box_head/loss.py:147-170 as one fused op."""
+    return _SmoothL1Picked.apply(box_regression, regression_targets, positives, labels, column0, beta, denominator)
+
+
 class _StochasticMaskBCE(Function):
     @staticmethod
     def forward(ctx, mu, sigma, eps, pos_index, targets, channel):

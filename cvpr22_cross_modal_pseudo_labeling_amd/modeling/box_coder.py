@@ -24,7 +24,25 @@ class BoxCoder:
         return torch.stack((wx * (gt_cx - ex_cx) / ex_w, wy * (gt_cy - ex_cy) / ex_h,
                             ww * torch.log(gt_w / ex_w), wh * torch.log(gt_h / ex_h)), dim=1)
 
-    def decode(self, rel_codes, boxes):
+    def decode(self, rel_codes, boxes, rows_per_image=None, image_sizes=None):
+        """``rows_per_image`` / ``image_sizes`` ((width, height) per image; extension): also clip every row to its image, as
+        ``BoxList.clip_to_image`` would afterwards.  Device tensors: one launch (``_C.box_decode``)."""
+        if rel_codes.is_cuda and rel_codes.dtype == torch.float32:
+            from .. import _C
+            return _C.box_decode(rel_codes, boxes, self.weights, self.bbox_xform_clip, rows_per_image, image_sizes)
+        pred = self._decode_tensor_ops(rel_codes, boxes)
+        if rows_per_image is not None:
+            at = 0
+            for n, (w, h) in zip(rows_per_image, image_sizes):
+                rows = pred[at:at + n]
+                rows[:, 0::4].clamp_(min=0, max=w - TO_REMOVE)
+                rows[:, 1::4].clamp_(min=0, max=h - TO_REMOVE)
+                rows[:, 2::4].clamp_(min=0, max=w - TO_REMOVE)
+                rows[:, 3::4].clamp_(min=0, max=h - TO_REMOVE)
+                at += n
+        return pred
+
+    def _decode_tensor_ops(self, rel_codes, boxes):
         boxes = boxes.to(rel_codes.dtype)
         widths = boxes[:, 2] - boxes[:, 0] + TO_REMOVE
         heights = boxes[:, 3] - boxes[:, 1] + TO_REMOVE

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import _C
-from ..layers import (Conv2d, ConvTranspose2d, ROIAlign, linear_mfma, smooth_l1_loss, stochastic_mask_bce,
+from ..layers import (Conv2d, ConvTranspose2d, ROIAlign, linear_mfma, smooth_l1_loss, smooth_l1_picked, stochastic_mask_bce,
                       text_logits, weighted_cross_entropy)
 from .backbone import ResNetHead
 from .box_coder import BoxCoder
@@ -45,6 +45,8 @@ class Pooler(nn.Module):
 
     @staticmethod
     def convert_to_roi_format(boxes):
+        if boxes and all(b.bbox.is_cuda and b.bbox.dtype == torch.float32 for b in boxes):
+            return _C.rois_from_boxes([b.bbox for b in boxes])  # one launch
         parts = []
         for i, b in enumerate(boxes):
             ids = torch.full((len(b), 1), float(i), dtype=b.bbox.dtype, device=b.bbox.device)
@@ -194,11 +196,11 @@ class FastRCNNLossComputation:
                 prop, idx, labels, reg, sel, slots, _c = pending[k]
                 n, npos = cnt[k]
                 k += 1
-                s = sel[:n]
-                b = BoxList(prop.bbox.index_select(0, s), prop.size)
-                b.add_field("labels", labels.index_select(0, s))
-                b.add_field("regression_targets", reg.index_select(0, s))
-                b.add_field("matched_gt", idx.index_select(0, s))
+                bbox_s, reg_s, labels_s, idx_s = _C.gather_rows(sel[:n], prop.bbox, reg, labels, idx)  # one launch
+                b = BoxList(bbox_s, prop.size)
+                b.add_field("labels", labels_s)
+                b.add_field("regression_targets", reg_s)
+                b.add_field("matched_gt", idx_s)
                 b.pos_index = slots[:npos]
                 group.append(b)
             out.append(group)
@@ -238,12 +240,17 @@ class FastRCNNLossComputation:
         pos = positives_index(proposals)
         if pos is None:
             pos = torch.nonzero(labels > 0).squeeze(1)
-        if self.cls_agnostic_bbox_reg:
-            picked = box_regression.index_select(0, pos)[:, 4:8]
+        if box_regression.is_cuda and labels.numel():
+            # gather + smooth L1 + its gradient in one pass (csrc/boxes.hip)
+            box_loss = smooth_l1_picked(box_regression, reg_targets, pos, None if self.cls_agnostic_bbox_reg else labels, 4,
+                                        1.0, labels.numel())
         else:
-            map_inds = 4 * labels[pos][:, None] + torch.tensor([0, 1, 2, 3], device=class_logits.device)
-            picked = box_regression[pos[:, None], map_inds]
-        box_loss = smooth_l1_loss(picked, reg_targets.index_select(0, pos), size_average=False, beta=1) / labels.numel()
+            if self.cls_agnostic_bbox_reg:
+                picked = box_regression.index_select(0, pos)[:, 4:8]
+            else:
+                map_inds = 4 * labels[pos][:, None] + torch.tensor([0, 1, 2, 3], device=class_logits.device)
+                picked = box_regression[pos[:, None], map_inds]
+            box_loss = smooth_l1_loss(picked, reg_targets.index_select(0, pos), size_average=False, beta=1) / labels.numel()
         cls_loss = weighted_cross_entropy(class_logits, labels, self.bg_weight)
         return cls_loss, box_loss
 
@@ -265,9 +272,13 @@ def positive_proposals(p):
     """The positives of a sampled list as a light BoxList (boxes, labels, matched ground-truth index), flagged
     ``all_positive`` so that the mask loss neither re-matches them nor searches them again."""
     pi = p.pos_index
-    out = BoxList(p.bbox.index_select(0, pi), p.size)
-    out.add_field("labels", p.get_field("labels").index_select(0, pi))
-    out.add_field("matched_gt", p.get_field("matched_gt").index_select(0, pi))
+    if p.bbox.is_cuda:
+        bbox, _, labels, matched = _C.gather_rows(pi, p.bbox, None, p.get_field("labels"), p.get_field("matched_gt"))
+    else:
+        bbox, labels, matched = (t.index_select(0, pi) for t in (p.bbox, p.get_field("labels"), p.get_field("matched_gt")))
+    out = BoxList(bbox, p.size)
+    out.add_field("labels", labels)
+    out.add_field("matched_gt", matched)
     out.all_positive = True
     return out
 
@@ -288,15 +299,15 @@ class PostProcessor(nn.Module):
         concat = _cat([b.bbox for b in boxes], 0)
         if self.cls_agnostic_bbox_reg:
             box_regression = box_regression[:, -4:]
-        proposals = self.box_coder.decode(box_regression.reshape(sum(per_img), -1), concat)
+        # decode + clip_to_image in one launch on the device (BoxCoder.decode with the image sizes)
+        proposals = self.box_coder.decode(box_regression.reshape(sum(per_img), -1), concat, per_img, [b.size for b in boxes])
         num_classes = class_prob.shape[1]
         if self.cls_agnostic_bbox_reg:
             proposals = proposals.repeat(1, num_classes)
         results = []
         for prob, prop, b in zip(class_prob.split(per_img, 0), proposals.split(per_img, 0), boxes):
-            boxlist = BoxList(prop.reshape(-1, 4), b.size)
+            boxlist = BoxList(prop.reshape(-1, 4), b.size)  # already clipped (remove_empty=False: nothing else to do)
             boxlist.add_field("scores", prob.reshape(-1))
-            boxlist = boxlist.clip_to_image(remove_empty=False)
             if not self.is_teacher:
                 boxlist = self.filter_results(boxlist, num_classes)
             results.append(boxlist)
@@ -748,12 +759,9 @@ class CombinedROIHeads(nn.ModuleDict):
         box = self.box
         with torch.no_grad():
             sampled = box.loss_evaluator.subsample_many([(br["proposals"], br["targets"]) for br in branches])
-        parts = []
-        for br, props in zip(branches, sampled):
-            for img, p in zip(br["image_ids"], props):
-                ids = torch.full((len(p), 1), float(img), dtype=p.bbox.dtype, device=p.bbox.device)
-                parts.append(torch.cat([ids, p.bbox], dim=1))
-        x = box.feature_extractor.forward_rois([feat], _cat(parts, 0))
+        rois = _C.rois_from_boxes([p.bbox for props in sampled for p in props],
+                                  [img for br in branches for img in br["image_ids"]])  # RoIs of every branch, one launch
+        x = box.feature_extractor.forward_rois([feat], rois)
         pooled = box.predictor.pooled(x)
         counts = [sum(len(p) for p in props) for props in sampled]
         out, off = [], 0

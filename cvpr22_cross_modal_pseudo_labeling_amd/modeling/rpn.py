@@ -85,7 +85,10 @@ class AnchorGenerator(nn.Module):
         out = []
         for (h, w) in image_sizes:
             b = BoxList(anchors, (w, h))
-            b.add_field("visibility", self.visibility(anchors, w, h))
+            key = ("visibility", int(w), int(h), feature.shape[-2], feature.shape[-1], anchors.device)
+            if key not in self._grid_cache:  # a function of the image size and the grid only
+                self._grid_cache[key] = self.visibility(anchors, w, h)
+            b.add_field("visibility", self._grid_cache[key])
             out.append(b)
         return out
 

@@ -181,6 +181,42 @@ int ovis_rpn_decode_f32(const float* box_regression, long reg_stride_image, long
                         float weight_h, float xform_clip, float min_size, float* boxes, int32_t* drop, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Box decode of the box post-processor       mb/modeling/roi_heads/box_head/inference.py:40-88,
+ *   mb/modeling/box_coder.py:49-95, mb/structures/bounding_box.py:214-225
+ * rel_codes [num_rows, 4 * boxes_per_row] (row stride codes_row_stride, in floats), boxes [num_rows, 4] (row stride
+ * boxes_row_stride) -> decoded [num_rows, 4 * boxes_per_row] dense: BoxCoder.decode with the given weights and
+ * bbox_xform_clip, expression by expression as the reference writes it.  num_images > 0 also clips every row to its image
+ * (clip_to_image): rows_per_image [num_images] int32 and image_wh [num_images, 2] float (width, height) are HOST arrays
+ * (at most OVIS_BOX_DECODE_MAX_IMAGES images: they travel as kernel arguments), rows are image-major and
+ * sum(rows_per_image) == num_rows.  One launch.
+ * ---------------------------------------------------------------------------------- */
+#define OVIS_BOX_DECODE_MAX_IMAGES 16
+int ovis_box_decode_f32(const float* rel_codes, long codes_row_stride, const float* boxes, long boxes_row_stride,
+                        long num_rows, int boxes_per_row, float weight_x, float weight_y, float weight_w,
+                        float weight_h, float xform_clip, int num_images, const int32_t* rows_per_image,
+                        const float* image_wh, float* decoded, void* stream);
+
+/* Pooler.convert_to_roi_format (mb/modeling/poolers.py:73-86): boxes[i] (HOST array of device pointers) holds image i's
+ * [boxes_per_image[i], 4] boxes (boxes_per_image: HOST array); rois [sum, 5] receives (id_i, x1, y1, x2, y2) rows in list
+ * order, id_i = image_ids[i] (HOST array) or i when image_ids is NULL.  One launch per OVIS_BOX_DECODE_MAX_IMAGES images. */
+int ovis_rois_from_boxes_f32(const float* const* boxes, const int32_t* boxes_per_image, const int32_t* image_ids,
+                             int num_images, float* rois, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Box-regression loss of the box head, forward + backward fused
+ *   mb/modeling/roi_heads/box_head/loss.py:147-170, mb/layers/smooth_l1_loss.py:6-16
+ * loss[0] = sum over the positives p = positives[0..num_positives) and c < 4 of
+ *   smooth_l1(box_regression[p, col0(p) + c] - regression_targets[p, c]; beta) / denominator,
+ * col0(p) = 4 * labels[p] (labels != NULL: class-specific regression) or column0 (class-agnostic: 4).
+ * grad_regression (may be NULL) [num_rows, num_columns] dense is fully written (zero outside the picked entries).
+ * Single workgroup, fixed summation order: deterministic.
+ * ---------------------------------------------------------------------------------- */
+int ovis_smooth_l1_picked_fwd_bwd_f32(const float* box_regression, long regression_row_stride, int num_rows,
+                                      int num_columns, const float* regression_targets, long targets_row_stride,
+                                      const int64_t* positives, const int64_t* labels, int num_positives, int column0,
+                                      float beta, float denominator, float* loss, float* grad_regression, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * ROIPool                                    mb/csrc/ROIPool.h:11-48
  *   kernels: mb/csrc/cuda/ROIPool_cuda.cu:17-77 (fwd), :80-108 (bwd)
  * input [batch, channels, height, width] f32, rois [num_rois, 5] (batch index, x1, y1, x2, y2);
@@ -407,6 +443,12 @@ int ovis_sample_fg_bg(const int64_t* labels, int num, int batch_size, int max_po
 int ovis_project_pasted_masks_f32(const float* mask_probs, const float* gt_boxes, const int64_t* gt_index,
                                   const float* boxes, int num, int image_height, int image_width, int prob_resolution,
                                   int resolution, float threshold, float* out, void* stream);
+/* ovis_gather_rows: out[i] = src[index[i]] for up to two [P, 4] f32 arrays and two [P] int64 arrays at once (a NULL source
+ * is skipped) -- the sampled proposals' boxes, regression targets, labels and matched ground truths
+ * (mb/modeling/roi_heads/box_head/loss.py:112-121 indexes every field of the BoxList separately).  One launch. */
+int ovis_gather_rows(const int64_t* index, int num, const float* boxes_a, float* boxes_a_out, const float* boxes_b,
+                     float* boxes_b_out, const int64_t* ints_a, int64_t* ints_a_out, const int64_t* ints_b,
+                     int64_t* ints_b_out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Cross-modal head: fp32 GEMM on the matrix cores

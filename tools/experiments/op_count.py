@@ -21,10 +21,27 @@ opnames = collections.defaultdict(collections.Counter)
 wall = collections.Counter()
 
 
+NO_LAUNCH = ("view", "reshape", "permute", "expand", "slice", "select", "as_strided", "t.", "transpose", "unsqueeze", "squeeze",
+             "detach", "alias", "_unsafe_view", "empty", "new_empty", "unbind", "split", "_local_scalar_dense", "sym_", "stride",
+             "size", "is_", "_to_copy_noop", "lift_fresh", "chunk", "narrow", "unfold", "resize_", "set_", "record_stream")
+sites = collections.Counter()
+site_ops = collections.defaultdict(collections.Counter)
+
+
 class Counter(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         counts[stack[-1]] += 1
         opnames[stack[-1]][func.__name__] += 1
+        if not func.__name__.startswith(NO_LAUNCH):
+            try:
+                f = sys._getframe(1)
+            except ValueError:  # an op the autograd thread runs without any Python frame
+                f = None
+            while f is not None and "cvpr22_cross_modal_pseudo_labeling_amd" not in f.f_code.co_filename:
+                f = f.f_back
+            where = f"<autograd thread> {func.__name__}" if f is None else f"{f.f_code.co_filename.split('_amd/')[-1]}:{f.f_lineno} {f.f_code.co_name}"
+            sites[where] += 1
+            site_ops[where][func.__name__] += 1
         return func(*args, **(kwargs or {}))
 
 
@@ -107,3 +124,7 @@ print(f"step wall {1e3 * (time.perf_counter() - t0):.1f} ms, {sum(counts.values(
 for k, v in counts.most_common():
     print(f"{v:6d} ops  {1e3 * wall[k]:8.2f} ms host wall  {k}")
     print("         " + ", ".join(f"{n}:{c}" for n, c in opnames[k].most_common(8)))
+print("--- ops that launch device work, by source line (forward thread only)")
+print(sum(sites.values()), "ops")
+for k, v in sites.most_common(150):
+    print(f"{v:5d}  {k}   " + ", ".join(f"{n}:{c}" for n, c in site_ops[k].most_common(4)))

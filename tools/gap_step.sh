@@ -17,4 +17,5 @@ per_step = sorted(b - a for a, b in zip(marks[:-1], marks[1:]))[: max(len(marks)
 steady = per_step[: max(1, len(per_step) // 2)]  # the smaller half: steps without warm-up / calibration extras
 print(f"launches per step: {steady[len(steady) // 2]} (median over the steady steps; {len(marks)} steps in the trace)")
 PY
+python tools/step_launch_histogram.py $f 45
 rm -rf $OUT/trace
