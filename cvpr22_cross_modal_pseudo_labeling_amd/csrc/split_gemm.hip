@@ -78,25 +78,58 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));
 }
 
-// bias + shortcut + ReLU + gate + fp32 / pair stores of 4 consecutive columns n..n+3 of row m
-__device__ __forceinline__ void epilogue_store4(const SplitGemmArgs& p, long m, int n, f32x4 v) {
-  if (p.bias) v += *(const f32x4*)(p.bias + n);
-  if (p.res) v += *(const f32x4*)(p.res + m * p.ldr + n);
-  const long poff = (long)(n >> 5) * 128 + (n & 31) * 2;
-  if (p.resp) {
-    const char* sp = p.resp + m * p.resp_rs + poff;
-    const uint2 h = *(const uint2*)sp, l = *(const uint2*)(sp + 64);
-    v.x += __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
-    v.y += __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
-    v.z += __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
-    v.w += __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u);
+// Epilogue operand of 4 consecutive columns of one row, loaded ahead of its use.  A launch has at most ONE kind (the
+// launcher checks): the fp32 shortcut (a | b = its 16 bytes); a shortcut given in pair layout (a = hi halves, b = lo
+// halves, 64 bytes further); the hi halves of a ReLU gate (a).  All three are fetched by the same two 8-byte loads from
+// a base / row stride / column offset / second-load offset chosen once per kernel (EpilogueSource), so that the loads
+// are straight-line code whose results nothing touches before epilogue_apply4 -- a per-kind branch around them made the
+// compiler wait for every load where it was issued.
+struct EpilogueOperands {
+  uint2 a, b;
+};
+
+struct EpilogueSource {
+  const char* base;   // null: no operand
+  long row_bytes;
+  int second;         // byte offset of the second 8-byte load
+};
+
+__device__ __forceinline__ EpilogueSource epilogue_source(const SplitGemmArgs& p) {
+  EpilogueSource s;
+  s.base = p.res ? (const char*)p.res : (p.resp ? p.resp : p.gate);
+  s.row_bytes = p.res ? p.ldr * 4 : (p.resp ? p.resp_rs : p.gate_rs);
+  s.second = p.res ? 8 : (p.resp ? 64 : 0);
+  return s;
+}
+
+// column byte offset of columns n..n+3 inside an operand row
+__device__ __forceinline__ long epilogue_column_bytes(const SplitGemmArgs& p, int n, long poff) { return p.res ? (long)n * 4 : poff; }
+
+__device__ __forceinline__ void epilogue_fetch4(const EpilogueSource& s, long m, long column_bytes, EpilogueOperands& o) {
+  const char* q = s.base + m * s.row_bytes + column_bytes;
+  o.a = *(const uint2*)q;
+  o.b = *(const uint2*)(q + s.second);
+}
+
+// bias + shortcut + ReLU + gate + fp32 / pair stores of 4 consecutive columns n..n+3 of row m (operands already loaded)
+__device__ __forceinline__ void epilogue_apply4(const SplitGemmArgs& p, long m, int n, long poff, f32x4 v, const f32x4& bias4,
+                                                const EpilogueOperands& o) {
+  if (p.bias) v += bias4;
+  if (p.res) {
+    v.x += __uint_as_float(o.a.x); v.y += __uint_as_float(o.a.y); v.z += __uint_as_float(o.b.x); v.w += __uint_as_float(o.b.y);
+  } else if (p.resp) {
+    const unsigned hx = o.a.x, hy = o.a.y, lx = o.b.x, ly = o.b.y;
+    v.x += __uint_as_float(hx << 16) + __uint_as_float(lx << 16);
+    v.y += __uint_as_float(hx & 0xffff0000u) + __uint_as_float(lx & 0xffff0000u);
+    v.z += __uint_as_float(hy << 16) + __uint_as_float(ly << 16);
+    v.w += __uint_as_float(hy & 0xffff0000u) + __uint_as_float(ly & 0xffff0000u);
   }
   if (p.relu) {
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
   }
   if (p.gate) {  // data gradient of a layer whose input went through a ReLU: zero where that activation was <= 0
-    const uint2 h = *(const uint2*)(p.gate + m * p.gate_rs + poff);
-    const unsigned a0 = h.x & 0xffffu, a1 = h.x >> 16, a2 = h.y & 0xffffu, a3 = h.y >> 16;
+    const unsigned gx = o.a.x, gy = o.a.y;
+    const unsigned a0 = gx & 0xffffu, a1 = gx >> 16, a2 = gy & 0xffffu, a3 = gy >> 16;
     if (a0 == 0u || a0 >= 0x8000u) v.x = 0.f;
     if (a1 == 0u || a1 >= 0x8000u) v.y = 0.f;
     if (a2 == 0u || a2 >= 0x8000u) v.z = 0.f;
@@ -111,6 +144,16 @@ __device__ __forceinline__ void epilogue_store4(const SplitGemmArgs& p, long m, 
     *(uint2*)d = make_uint2(h01, h23);
     *(uint2*)(d + 64) = make_uint2(l01, l23);
   }
+}
+
+__device__ __forceinline__ void epilogue_store4(const SplitGemmArgs& p, long m, int n, f32x4 v) {
+  const long poff = (long)(n >> 5) * 128 + (n & 31) * 2;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias4 = *(const f32x4*)(p.bias + n);
+  const EpilogueSource src = epilogue_source(p);
+  EpilogueOperands o;
+  if (src.base) epilogue_fetch4(src, m, epilogue_column_bytes(p, n, poff), o);
+  epilogue_apply4(p, m, n, poff, v, bias4, o);
 }
 
 template <int WM, int WN, int MODE, int NS, int OCC>
@@ -366,18 +409,57 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
   const int er = lane >> 4, es = lane & 15;   // row within a group of 4, 4-column slot
   const int n = n0 + wn * 64 + es * 4;
   float* slab = p.slab ? p.slab + (long)slice * p.M * p.N : nullptr;
+  // The shortcut / gate operands of row group f + 1 are requested before group f is stored and those of group 0 before
+  // anything else: a lane's 16 (row, 4 columns) pieces would otherwise be 16 load -> wait -> store round trips in a row
+  // (vmcnt also counts the stores), ~30 us per tile against ~10 us of matrix work for a K = 512 product.
+  const bool col_ok = n < p.N;
+  const long poff = (long)(n >> 5) * 128 + (n & 31) * 2;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (!slab && p.bias && col_ok) bias4 = *(const f32x4*)(p.bias + n);
+  // pieces of 2 rows, double-buffered: 8 pieces per lane
+  // NBUF - 1 pieces are in flight ahead of the one being stored; with two ahead the wait for a piece's operands no longer
+  // includes the previous piece's stores (vmcnt retires in order).  The single-stage SHIFTED form has no registers for it.
+  constexpr int NBUF = (MODE == SHIFTED && NS == 1) ? 2 : 3;
+  EpilogueOperands ops[NBUF][2];
+  // The fetches are UNCONDITIONAL straight-line loads (rows / columns outside the problem re-read its last row / first
+  // column; a launch without an operand, or a split-K slice, reads the first bytes of B with a zero row stride and
+  // ignores them): a load under a branch makes the wait-count pass assume "nothing was issued since", i.e. vmcnt(0)
+  // in front of every use, which also drains the prefetch for the next piece.
+  EpilogueSource src = epilogue_source(p);
+  long src_col = epilogue_column_bytes(p, col_ok ? n : 0, col_ok ? poff : 0);
+  if (slab || !src.base) {
+    src.base = p.B;
+    src.row_bytes = 0;
+    src.second = 8;
+    src_col = 0;
+  }
+  const long m_last = p.M - 1;
+  auto fetch = [&](int piece, EpilogueOperands (&o)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long m = m0 + wm * 64 + (piece >> 1) * 16 + ((piece & 1) * 2 + j) * 4 + er;
+      epilogue_fetch4(src, m < m_last ? m : m_last, src_col, o[j]);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; ++i) fetch(i, ops[i]);
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) *(f32x4*)(stg + frow * 256 + (((g * 4 + fc) ^ frow) << 4)) = acc[f][g];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int r = it * 4 + er;
-      const f32x4 v = *(const f32x4*)(stg + r * 256 + ((es ^ r) << 4));
-      const long m = m0 + wm * 64 + f * 16 + r;
-      if (m < p.M && n < p.N) {
-        if (slab) *(f32x4*)(slab + m * p.N + n) = v;
-        else epilogue_store4(p, m, n, v);
+    for (int h = 0; h < 2; ++h) {
+      const int piece = f * 2 + h;
+      if (piece + NBUF - 1 < 8) fetch(piece + NBUF - 1, ops[(piece + NBUF - 1) % NBUF]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = (h * 2 + j) * 4 + er;
+        const f32x4 v = *(const f32x4*)(stg + r * 256 + ((es ^ r) << 4));
+        const long m = m0 + wm * 64 + f * 16 + r;
+        if (m < p.M && col_ok) {
+          if (slab) *(f32x4*)(slab + m * p.N + n) = v;
+          else epilogue_apply4(p, m, n, poff, v, bias4, ops[piece % NBUF][j]);
+        }
       }
     }
   }
@@ -1099,6 +1181,7 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
   const int T = taps_h * taps_w;
   if (T > 1 && (height <= 0 || width <= 0 || height > 32767 || width > 32767 || channels2 != 0)) return OVIS_EINVAL;
   if (channels2 != 0 && !a2_pair) return OVIS_EINVAL;
+  if ((residual != nullptr) + (residual_pair != nullptr) + (gate_pair != nullptr) > 1) return OVIS_EINVAL;  // one epilogue operand
   if (channels % 32 != 0 || channels2 % 32 != 0 || n % 4 != 0 || (c_pair && n % 32 != 0) || a_row_bytes % 16 != 0 ||
       a2_row_bytes % 16 != 0 || b_row_bytes % 16 != 0 || ((uintptr_t)a_pair & 15) || ((uintptr_t)a2_pair & 15) ||
       ((uintptr_t)b_pair & 15) || ((uintptr_t)c & 15) || ((uintptr_t)c_pair & 15) || ((uintptr_t)bias & 15) ||
