@@ -112,11 +112,16 @@ class OpTimer:
             # every operand once: A and B pair rows (4 B / value), the fp32 and / or pair result, the shortcut
             m, n = a_pair.shape[0], b_pair.shape[0]
             return (2 * a_pair.numel() + 2 * b_pair.numel() + 4 * m * n * (int(bool(out_f32)) + int(bool(out_pair)))
-                    + (4 * m * n if residual is not None else 0))
+                    + (4 * m * n if (residual is not None or kwargs.get("residual_pair") is not None) else 0))
 
         def split_gemm_gated_bytes(a_pair, b_pair, gate_pair, conv=None, out_f32=False, out_pair=True):
             m, n = a_pair.shape[0], b_pair.shape[0]
             return 2 * a_pair.numel() + 2 * b_pair.numel() + 4 * m * n * (int(bool(out_f32)) + int(bool(out_pair))) + 2 * m * n
+
+        def split_gemm_rp_gated_bytes(a_pair, b_pair, residual_pair, gate_pair, out_f32=False, out_pair=True):
+            m, n = a_pair.shape[0], b_pair.shape[0]  # operands, the pair shortcut (4 B / value), the gate's hi halves (2 B), results
+            return (2 * a_pair.numel() + 2 * b_pair.numel() + 4 * m * n * (int(bool(out_f32)) + int(bool(out_pair))) + 4 * m * n
+                    + 2 * m * n)
 
         def split_gemm_tn_bytes(g_pair, x_pair, conv=None, scale=None, weight_shape=None):
             taps = 1 if conv is None else conv[2] * conv[3]
@@ -185,6 +190,7 @@ class OpTimer:
         self._wrap("mask_bce_stochastic_fwd_bwd", bce_bytes)
         self._wrap("split_gemm_pair", split_gemm_flops, "mfma", split_gemm_bytes, nt_shape)
         self._wrap("split_gemm_pair_gated", split_gemm_flops, "mfma", split_gemm_gated_bytes, nt_shape)
+        self._wrap("split_gemm_pair_rp_gated", split_gemm_flops, "mfma", split_gemm_rp_gated_bytes, nt_shape)
         self._wrap("split_gemm_pair_tn", split_gemm_tn_flops, "mfma", split_gemm_tn_bytes, tn_shape)
 
     def summary(self):
@@ -240,6 +246,7 @@ def per_shape_rows(timer, steps):
 
 # bench.py op name -> kernel family of the committed PMC summary (profiles/r1_pmc_step_hbm_traffic_<workload>.json)
 PMC_KERNEL = {"split_gemm_pair": "split_gemm_kernel", "split_gemm_pair_gated": "split_gemm_kernel",
+              "split_gemm_pair_rp_gated": "split_gemm_kernel",
               "split_gemm_pair_tn": "split_gemm_tn_kernel", "gate_split_pair": "gate_split_pair_kernel",
               "split_pair": "split_pair_kernel", "roi_align_forward_strided_pair": "roi_align_fwd_strided_nhwc_kernel",
               "roi_align_forward_strided_nhwc": "roi_align_fwd_strided_nhwc_kernel",

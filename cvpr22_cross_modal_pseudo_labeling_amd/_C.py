@@ -831,6 +831,32 @@ def split_gemm_pair_gated(a_pair, b_pair, gate_pair, conv=None, out_f32=False, o
     return c, cp
 
 
+def split_gemm_pair_rp_gated(a_pair, b_pair, residual_pair, gate_pair, out_f32=False, out_pair=True, config=0):
+    """(A @ B^T + r) * (x > 0) with r (``residual_pair``) and x (``gate_pair``) [M, 2N] in pair layout: the input gradient
+    of an identity bottleneck, gated by the ReLU of the block below and split for its backward GEMMs in the epilogue
+    (``ovis_split_gemm_pair_rp_gated``).  Returns (f32 or None, pair or None)."""
+    for t, name in ((a_pair, "a_pair"), (b_pair, "b_pair"), (residual_pair, "residual_pair"), (gate_pair, "gate_pair")):
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1):
+            raise RuntimeError(f"split_gemm_pair_rp_gated: {name} must be a 2-D bfloat16 HIP tensor in pair layout")
+    m, ch = a_pair.shape[0], a_pair.shape[1] // 2
+    n, k = b_pair.shape[0], b_pair.shape[1] // 2
+    if k != ch or gate_pair.shape != (m, 2 * n) or residual_pair.shape != (m, 2 * n):
+        raise RuntimeError("split_gemm_pair_rp_gated: shape mismatch")
+    dev = a_pair.device
+    c = torch.empty((m, n), dtype=torch.float32, device=dev) if out_f32 else None
+    cp = torch.empty((m, 2 * n), dtype=torch.bfloat16, device=dev) if out_pair else None
+    if m == 0 or n == 0:
+        return c, cp
+    with torch.cuda.device(dev):
+        rc = _L.ovis_split_gemm_pair_rp_gated(a_pair.data_ptr(), 2 * a_pair.stride(0), b_pair.data_ptr(),
+                                              2 * b_pair.stride(0), 0 if c is None else c.data_ptr(), n,
+                                              0 if cp is None else cp.data_ptr(), 4 * n, residual_pair.data_ptr(),
+                                              2 * residual_pair.stride(0), gate_pair.data_ptr(), 2 * gate_pair.stride(0), m, n,
+                                              ch, config, _stream())
+    _lib.check(rc, "split_gemm_pair_rp_gated")
+    return c, cp
+
+
 def split_gemm_pair_tn_supported(n, ch, conv=None):
     if n % 128 or ch % 128:
         return False

@@ -112,8 +112,11 @@ __device__ __forceinline__ void epilogue_fetch4(const EpilogueSource& s, long m,
 }
 
 // bias + shortcut + ReLU + gate + fp32 / pair stores of 4 consecutive columns n..n+3 of row m (operands already loaded)
+// DUAL: a pair-layout shortcut (in `o`) AND a ReLU gate (hi halves in `gate2`) -- the input gradient of an identity
+// bottleneck handed to the block below already gated and split.
+template <bool DUAL = false>
 __device__ __forceinline__ void epilogue_apply4(const SplitGemmArgs& p, long m, int n, long poff, f32x4 v, const f32x4& bias4,
-                                                const EpilogueOperands& o) {
+                                                const EpilogueOperands& o, uint2 gate2 = make_uint2(0u, 0u)) {
   if (p.bias) v += bias4;
   if (p.res) {
     v.x += __uint_as_float(o.a.x); v.y += __uint_as_float(o.a.y); v.z += __uint_as_float(o.b.x); v.w += __uint_as_float(o.b.y);
@@ -128,7 +131,7 @@ __device__ __forceinline__ void epilogue_apply4(const SplitGemmArgs& p, long m, 
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
   }
   if (p.gate) {  // data gradient of a layer whose input went through a ReLU: zero where that activation was <= 0
-    const unsigned gx = o.a.x, gy = o.a.y;
+    const unsigned gx = DUAL ? gate2.x : o.a.x, gy = DUAL ? gate2.y : o.a.y;
     const unsigned a0 = gx & 0xffffu, a1 = gx >> 16, a2 = gy & 0xffffu, a3 = gy >> 16;
     if (a0 == 0u || a0 >= 0x8000u) v.x = 0.f;
     if (a1 == 0u || a1 >= 0x8000u) v.y = 0.f;
@@ -156,7 +159,7 @@ __device__ __forceinline__ void epilogue_store4(const SplitGemmArgs& p, long m, 
   epilogue_apply4(p, m, n, poff, v, bias4, o);
 }
 
-template <int WM, int WN, int MODE, int NS, int OCC>
+template <int WM, int WN, int MODE, int NS, int OCC, bool DUAL = false>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemmArgs p, int tiles_n, int ntiles) {
   constexpr int BM = WM * 64, BN = WN * 64, NW = WM * WN;
   constexpr int A_ROWS = MODE == HALO ? BM + 2 * kHalo + 1 : BM;  // HALO: + one row of zeros
@@ -419,8 +422,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
   // pieces of 2 rows, double-buffered: 8 pieces per lane
   // NBUF - 1 pieces are in flight ahead of the one being stored; with two ahead the wait for a piece's operands no longer
   // includes the previous piece's stores (vmcnt retires in order).  The single-stage SHIFTED form has no registers for it.
-  constexpr int NBUF = (MODE == SHIFTED && NS == 1) ? 2 : 3;
+  constexpr int NBUF = (DUAL || (MODE == SHIFTED && NS == 1)) ? 2 : 3;
   EpilogueOperands ops[NBUF][2];
+  uint2 gates[NBUF][2];  // DUAL only
   // The fetches are UNCONDITIONAL straight-line loads (rows / columns outside the problem re-read its last row / first
   // column; a launch without an operand, or a split-K slice, reads the first bytes of B with a zero row stride and
   // ignores them): a load under a branch makes the wait-count pass assume "nothing was issued since", i.e. vmcnt(0)
@@ -434,15 +438,18 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
     src_col = 0;
   }
   const long m_last = p.M - 1;
-  auto fetch = [&](int piece, EpilogueOperands (&o)[2]) {
+  const char* gate_col = DUAL ? p.gate + (col_ok ? poff : 0) : nullptr;
+  auto fetch = [&](int piece, EpilogueOperands (&o)[2], uint2 (&g)[2]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const long m = m0 + wm * 64 + (piece >> 1) * 16 + ((piece & 1) * 2 + j) * 4 + er;
-      epilogue_fetch4(src, m < m_last ? m : m_last, src_col, o[j]);
+      const long mc = m < m_last ? m : m_last;
+      epilogue_fetch4(src, mc, src_col, o[j]);
+      if constexpr (DUAL) g[j] = *(const uint2*)(gate_col + mc * p.gate_rs);
     }
   };
 #pragma unroll
-  for (int i = 0; i < NBUF - 1; ++i) fetch(i, ops[i]);
+  for (int i = 0; i < NBUF - 1; ++i) fetch(i, ops[i], gates[i]);
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
 #pragma unroll
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int piece = f * 2 + h;
-      if (piece + NBUF - 1 < 8) fetch(piece + NBUF - 1, ops[(piece + NBUF - 1) % NBUF]);
+      if (piece + NBUF - 1 < 8) fetch(piece + NBUF - 1, ops[(piece + NBUF - 1) % NBUF], gates[(piece + NBUF - 1) % NBUF]);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int r = (h * 2 + j) * 4 + er;
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
         const long m = m0 + wm * 64 + f * 16 + r;
         if (m < p.M && col_ok) {
           if (slab) *(f32x4*)(slab + m * p.N + n) = v;
-          else epilogue_apply4(p, m, n, poff, v, bias4, ops[piece % NBUF][j]);
+          else epilogue_apply4<DUAL>(p, m, n, poff, v, bias4, ops[piece % NBUF][j], gates[piece % NBUF][j]);
         }
       }
     }
@@ -1181,7 +1188,10 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
   const int T = taps_h * taps_w;
   if (T > 1 && (height <= 0 || width <= 0 || height > 32767 || width > 32767 || channels2 != 0)) return OVIS_EINVAL;
   if (channels2 != 0 && !a2_pair) return OVIS_EINVAL;
-  if ((residual != nullptr) + (residual_pair != nullptr) + (gate_pair != nullptr) > 1) return OVIS_EINVAL;  // one epilogue operand
+  // one epilogue operand -- or the pair shortcut together with a gate (the DUAL kernels, plain products only)
+  const bool dual = residual_pair && gate_pair && !residual;
+  if (!dual && (residual != nullptr) + (residual_pair != nullptr) + (gate_pair != nullptr) > 1) return OVIS_EINVAL;
+  if (dual && T > 1) return OVIS_ERANGE;
   if (channels % 32 != 0 || channels2 % 32 != 0 || n % 4 != 0 || (c_pair && n % 32 != 0) || a_row_bytes % 16 != 0 ||
       a2_row_bytes % 16 != 0 || b_row_bytes % 16 != 0 || ((uintptr_t)a_pair & 15) || ((uintptr_t)a2_pair & 15) ||
       ((uintptr_t)b_pair & 15) || ((uintptr_t)c & 15) || ((uintptr_t)c_pair & 15) || ((uintptr_t)bias & 15) ||
@@ -1211,20 +1221,24 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
   const long nblocks = ntiles * q.kslices;
   if (nblocks > 0x7fffffffL) return OVIS_ERANGE;
   hipStream_t s = (hipStream_t)stream;
-#define OVIS_SG_LAUNCH(WM_, WN_, MODE_, NS_, OCC_)                                                                  \
+#define OVIS_SG_LAUNCH_(WM_, WN_, MODE_, NS_, OCC_, DUAL_)                                                           \
   do {                                                                                                              \
     constexpr int a_rows = MODE_ == HALO ? WM_ * 64 + 2 * kHalo + 1 : WM_ * 64;                                      \
     constexpr int lds = NS_ * (a_rows * 128 + WN_ * 64 * 128);                                                       \
     static bool attr_set = false;                                                                                   \
     if (!attr_set) {                                                                                                \
-      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<WM_, WN_, MODE_, NS_, OCC_>,                  \
+      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<WM_, WN_, MODE_, NS_, OCC_, DUAL_>,           \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));                           \
       attr_set = true;                                                                                              \
     }                                                                                                               \
-    hipLaunchKernelGGL((split_gemm_kernel<WM_, WN_, MODE_, NS_, OCC_>), dim3((unsigned)nblocks),                    \
+    hipLaunchKernelGGL((split_gemm_kernel<WM_, WN_, MODE_, NS_, OCC_, DUAL_>), dim3((unsigned)nblocks),             \
                        dim3(WM_ * WN_ * 64), lds, s, p, q.tiles_n, (int)ntiles);                                    \
   } while (0)
-  if (q.narrow) {
+#define OVIS_SG_LAUNCH(WM_, WN_, MODE_, NS_, OCC_) OVIS_SG_LAUNCH_(WM_, WN_, MODE_, NS_, OCC_, false)
+  if (dual) {
+    if (q.narrow || q.mode != PLAIN || q.kslices > 1) return OVIS_ERANGE;
+    if (q.stages == 1) OVIS_SG_LAUNCH_(2, 2, PLAIN, 1, 4, true); else OVIS_SG_LAUNCH_(2, 2, PLAIN, 2, 2, true);
+  } else if (q.narrow) {
     if (q.mode == PLAIN) OVIS_SG_LAUNCH(2, 1, PLAIN, 1, 2); else OVIS_SG_LAUNCH(2, 1, SHIFTED, 1, 2);
   } else if (q.mode == HALO) {
     OVIS_SG_LAUNCH(2, 2, HALO, 1, 4);
@@ -1233,6 +1247,7 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
   } else {
     if (q.stages == 1) OVIS_SG_LAUNCH(2, 2, PLAIN, 1, 4); else OVIS_SG_LAUNCH(2, 2, PLAIN, 2, 2);
   }
+#undef OVIS_SG_LAUNCH_
 #undef OVIS_SG_LAUNCH
   OVIS_LAUNCH_CHECK();
   if (q.kslices > 1) {
@@ -1280,4 +1295,20 @@ extern "C" int ovis_split_gemm_pair_gated(const void* a_pair, long a_row_bytes, 
   return split_gemm_pair_impl(a_pair, a_row_bytes, nullptr, 0, b_pair, b_row_bytes, c, ldc, c_pair, c_pair_row_bytes,
                               nullptr, nullptr, 0, nullptr, 0, gate_pair, gate_row_bytes, m, n, channels, 0, taps_h, taps_w,
                               height, width, flip, 0, nullptr, 0, config | 8, stream);
+}
+
+// The input gradient of an identity bottleneck, ready for the block below: (A @ B^T + shortcut gradient given in pair
+// layout) * (block input > 0), written in pair layout (and / or fp32).  See include/ovis_hip.h.
+extern "C" int ovis_split_gemm_pair_rp_gated(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
+                                             float* c, long ldc, void* c_pair, long c_pair_row_bytes,
+                                             const void* residual_pair, long residual_pair_row_bytes,
+                                             const void* gate_pair, long gate_row_bytes, long m, int n, int channels,
+                                             int config, void* stream) {
+  if (!residual_pair || !gate_pair || n % 32 != 0 || residual_pair_row_bytes % 16 != 0 || gate_row_bytes % 16 != 0 ||
+      ((uintptr_t)residual_pair & 15) || ((uintptr_t)gate_pair & 15))
+    return OVIS_ERANGE;
+  if (n < 128) return OVIS_ERANGE;  // the narrow-tile kernels have no DUAL form
+  return split_gemm_pair_impl(a_pair, a_row_bytes, nullptr, 0, b_pair, b_row_bytes, c, ldc, c_pair, c_pair_row_bytes,
+                              nullptr, nullptr, 0, residual_pair, residual_pair_row_bytes, gate_pair, gate_row_bytes, m, n,
+                              channels, 0, 1, 1, 0, 0, 0, 0, nullptr, 0, config | 8, stream);
 }

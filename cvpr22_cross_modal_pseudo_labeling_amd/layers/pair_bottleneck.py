@@ -70,9 +70,23 @@ def is_placeholder(t):
     return t is not None and t.numel() > 1 and all(st == 0 for st in t.stride())
 
 
+class GradLink:
+    """Side channel between two consecutive ``_BottleneckPair`` nodes of a pair-only chain: the block above leaves the
+    gradient w.r.t. the block below's output here, in pair layout and ALREADY gated by that output's ReLU
+    (``_C.split_gemm_pair_rp_gated``); the fp32 gradient autograd routes between the nodes is then a zero-stride
+    placeholder, as the activation was in the forward.  The block below takes it (once) instead of gating and
+    splitting an fp32 gradient."""
+
+    __slots__ = ("grad_pair",)
+
+    def __init__(self):
+        self.grad_pair = None
+
+
 class _BottleneckPair(Function):
     @staticmethod
-    def forward(ctx, x, xp, geom, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, want_pair, wpairs, pool, want_f32=True):
+    def forward(ctx, x, xp, geom, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, want_pair, wpairs, pool, want_f32=True,
+                link_in=None, link_out=None):
         """x [M, Cin] f32 rows conv1 reads (may be None when wd is given and no input gradient is wanted), xp its pair
         form or None; geom = (h, w) of the map the rows tile; w1/w2/w3/wd RAW convolution weights (wd None = identity
         shortcut) with their folded FrozenBN scales s1/s2/s3/sd (per output channel, no gradient) and shifts b1/b2,
@@ -121,6 +135,10 @@ class _BottleneckPair(Function):
         ctx.save_for_backward(xp, o1p, o2p, gate_src, w1, w2, w3, wd, s1, s2, s3, sd)
         ctx.wts = wts
         ctx.geom = (h, w, kh, kw)
+        # link_in: this block's input exists only in pair layout and comes from a block that reads its gradient from the
+        # link; link_out: this block's own output is pair-only and the block above may leave its gradient there
+        ctx.link_in = link_in if (wd is None and not x_real) else None
+        ctx.link_out = link_out if not f32 else None
         ctx.set_materialize_grads(False)  # no zero tensors for absent / non-differentiable gradient slots
         if outp is not None:
             ctx.mark_non_differentiable(outp)
@@ -129,8 +147,12 @@ class _BottleneckPair(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dout, _dpair, dpooled):
-        if dout is None and dpooled is None:
-            return (None,) * 18
+        link_out, link_in = ctx.link_out, ctx.link_in
+        linked = link_out.grad_pair if link_out is not None else None
+        if link_out is not None:
+            link_out.grad_pair = None
+        if dout is None and dpooled is None and linked is None:
+            return (None,) * 20
         xp, o1p, o2p, out, w1, w2, w3, wd, s1, s2, s3, sd = ctx.saved_tensors   # out: fp32 result or its pair form (gate)
         h, w, kh, kw = ctx.geom
         need = ctx.needs_input_grad
@@ -141,9 +163,15 @@ class _BottleneckPair(Function):
                         for t, sc in ((w1, s1), (w2, s2), (w3, s3), (wd, sd)))
         t1, t2, t3, td = wts
         n3 = w3.shape[0]
-        # gate of the block's last ReLU, fused with the split; the identity shortcut also needs the gated gradient in fp32
-        g3p, g3 = _C.gate_split_pair(None if dout is None else dout.reshape(-1, n3), out, want_f32=(wd is None and need_x),
-                                     pooled=dpooled, pool_rows=h * w)
+        # the input gradient goes to the block below through the link when that block left one and the fused form applies
+        to_link = (need_x and wd is None and link_in is not None and xp.shape[1] // 2 >= 128)
+        if linked is not None:
+            g3p, g3 = linked, None  # gated and split by the block above (dout is only a placeholder)
+        else:
+            # gate of the block's last ReLU, fused with the split; the identity shortcut needs the gated gradient too: in
+            # fp32, or (linked form) in the pair layout just written
+            g3p, g3 = _C.gate_split_pair(None if dout is None else dout.reshape(-1, n3), out,
+                                         want_f32=(wd is None and need_x and not to_link), pooled=dpooled, pool_rows=h * w)
         dw3 = _dw(g3p, o2p, w3, s3) if need_w3 else None
         _, g2p = _C.split_gemm_pair_gated(g3p, t3, o2p)                  # (dY W3) gated by relu(o2), split: one kernel
         dw2 = _dw(g2p, o1p, w2, s2, (h, w, kh, kw)) if need_w2 else None
@@ -153,14 +181,23 @@ class _BottleneckPair(Function):
             if need_w1:
                 dw1 = _dw(g1p, xp, w1, s1)
             if need_x:
-                if wd is not None:
-                    res, _ = _C.split_gemm_pair(g3p, td)
+                if to_link:
+                    # (dY1 W1 + shortcut gradient) gated by the block input's ReLU, in pair layout only: what the block
+                    # below would compute from an fp32 gradient with one more pass over it
+                    _, link_in.grad_pair = _C.split_gemm_pair_rp_gated(g1p, t1, g3p, xp)
+                    dx = g1p.new_empty((1,), dtype=torch.float32).expand(xp.shape[0], xp.shape[1] // 2)
                 else:
-                    res = g3
-                dx, _ = _C.split_gemm_pair(g1p, t1, None, res)
+                    if wd is not None:
+                        res, _ = _C.split_gemm_pair(g3p, td)
+                        dx, _ = _C.split_gemm_pair(g1p, t1, None, res)
+                    elif g3 is not None:
+                        dx, _ = _C.split_gemm_pair(g1p, t1, None, g3)
+                    else:  # linked gradient from above, fp32 gradient wanted below: the shortcut term from its pair form
+                        dx, _ = _C.split_gemm_pair(g1p, t1, None, None, False, True, False, residual_pair=g3p)
         if wd is not None and need_wd:
             dwd = _dw(g3p, xp, wd, sd)
-        return dx, None, None, dw1, None, None, dw2, None, None, dw3, None, None, dwd, None, None, None, None, None
+        return (dx, None, None, dw1, None, None, dw2, None, None, dw3, None, None, dwd, None, None, None, None, None, None,
+                None)
 
 
 def bottleneck_pair(x, xp, geom, w1, b1, w2, b2, w3, b3, wd=None, want_pair=False, wpairs=None, pool=False,
@@ -169,8 +206,13 @@ def bottleneck_pair(x, xp, geom, w1, b1, w2, b2, w3, b3, wd=None, want_pair=Fals
     one bottleneck on the rows x [M, Cin] of an (h, w) map.  w1/w2/w3/wd are the convolution weights as the model
     stores them; ``scales`` = their folded FrozenBN scales (None = weights already folded)."""
     s1, s2, s3, sd = scales
+    pair_only = want_pair and not want_f32 and not pool
+    link_in = getattr(xp, "_ovis_grad_link", None) if (xp is not None and (x is None or is_placeholder(x))) else None
+    link_out = GradLink() if pair_only else None
     out, outp, pooled = _BottleneckPair.apply(x, xp, geom, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, want_pair, wpairs,
-                                              pool, want_f32)
+                                              pool, want_f32, link_in, link_out)
+    if link_out is not None and outp is not None:
+        outp._ovis_grad_link = link_out  # travels with the pair tensor to the block that consumes it
     return (out, outp, pooled) if pool else (out, outp)
 
 

@@ -348,6 +348,16 @@ int ovis_split_gemm_pair_gated(const void* a_pair, long a_row_bytes, const void*
                                long gate_row_bytes, long m, int n, int channels, int taps_h, int taps_w,
                                int height, int width, int flip, int config, void* stream);
 
+/* The input gradient of an identity bottleneck (mb/modeling/backbone/resnet.py:290-342: out = relu(conv3(..) + x)), handed
+ * to the block below ready for use: C = (A B^T + r) * (x > 0) -- r the gradient arriving through the shortcut, given in
+ * pair layout (residual_pair: hi + lo), x the block input in pair layout (gate_pair: the block below's ReLU output, only
+ * the hi halves are read) -- written in pair layout (c_pair) and / or fp32 (c).  The block below then needs neither a
+ * gate + split pass nor an fp32 gradient tensor.  Plain products only (1x1); n % 32 == 0, n >= 128 (else OVIS_ERANGE). */
+int ovis_split_gemm_pair_rp_gated(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes, float* c,
+                                  long ldc, void* c_pair, long c_pair_row_bytes, const void* residual_pair,
+                                  long residual_pair_row_bytes, const void* gate_pair, long gate_row_bytes, long m, int n,
+                                  int channels, int config, void* stream);
+
 /* im2col of a strided convolution on an NCHW f32 image [num, channels, height, width] into pair rows
  * [num*ho*wo, k_padded]: k = (ky*kw + kx)*channels + c, columns >= kh*kw*channels are zero (k_padded % 32 == 0).
  * The 7x7 stride-2 stem (mb/modeling/backbone/resnet.py:347-366) then is one ovis_split_gemm_pair. */

@@ -255,6 +255,35 @@ def test_split_gemm_pair_residual_in_pair_layout(m, k, n):
     assert float((r_rec - r).abs().max()) <= 2.0 ** -16 * float(r.abs().max())
 
 
+@pytest.mark.parametrize("m,k,n", [(1000, 512, 2048), (77, 128, 128), (4100, 2048, 512)])
+def test_split_gemm_pair_rp_gated_equals_two_step_form(m, k, n):
+    """(A B^T + (hi + lo of the pair shortcut)) * (x > 0), pair and fp32 outputs, in ONE launch -- bit-identical to the
+    two-step form it replaces (product with the fp32 shortcut hi + lo, then gate_split_pair with the gate's pair form),
+    and within the split product's error of the fp64 value."""
+    C = _C()
+    g = torch.Generator(device="cuda").manual_seed(m + k)
+    a32, b32 = torch.randn(m, k, device="cuda", generator=g), torch.randn(n, k, device="cuda", generator=g) * 0.1
+    a, b = C.split_pair(a32), C.split_pair(b32)
+    r = torch.randn(m, n, device="cuda", generator=g)
+    rp = C.split_pair(r)
+    pr = rp.view(m, n // 32, 2, 32).float()
+    r_rec = (pr[:, :, 0] + pr[:, :, 1]).reshape(m, n).contiguous()
+    x = torch.randn(m, n, device="cuda", generator=g)
+    x[::3] = 0.0  # exact zeros gate off (relu'(0) = 0)
+    xp = C.split_pair(x)
+    full, _ = C.split_gemm_pair(a, b, None, r_rec, False, True, False, config=8)
+    want_p, want = C.gate_split_pair(full, xp, want_f32=True)
+    got, got_p = C.split_gemm_pair_rp_gated(a, b, rp, xp, out_f32=True, out_pair=True)
+    assert torch.equal(got, want) and torch.equal(got_p, want_p)
+    none, only_p = C.split_gemm_pair_rp_gated(a, b, rp, xp)
+    assert none is None and torch.equal(only_p, want_p)
+    ref = (a32.double() @ b32.double().t() + r_rec.double()) * (x > 0)
+    assert float((got.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+    with pytest.raises(RuntimeError):  # the narrow-tile kernels have no such form
+        C.split_gemm_pair_rp_gated(a, C.split_pair(b32[:64]), C.split_pair(r[:, :64].contiguous()),
+                                   C.split_pair(x[:, :64].contiguous()))
+
+
 @pytest.mark.parametrize("train", [False, True])
 def test_bottleneck_chain_pair_only_vs_fp32_chain(train):
     """A res5-like chain (projection block + two identity blocks) with the intermediate results carried in PAIR layout
@@ -295,7 +324,26 @@ def test_bottleneck_chain_pair_only_vs_fp32_chain(train):
     with torch.no_grad():
         mid, midp = b0.forward_nhwc(x, prestrided=True, want_pair=True)
     assert is_placeholder(mid) and midp.shape == (20 * 49, 2 * 2048)
-    ref, got = run(False), run(True)
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C as C
+    calls = {"rp_gated": 0, "gate_split": 0}
+    rp_gated, gate_split = C.split_gemm_pair_rp_gated, C.gate_split_pair
+
+    def count(name, fn):
+        def wrapped(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return wrapped
+
+    ref = run(False)
+    C.split_gemm_pair_rp_gated, C.gate_split_pair = count("rp_gated", rp_gated), count("gate_split", gate_split)
+    try:
+        got = run(True)
+    finally:
+        C.split_gemm_pair_rp_gated, C.gate_split_pair = rp_gated, gate_split
+    if train:
+        # the two identity blocks hand their input gradient down gated and split (GradLink): one gate + split pass (the
+        # gradient entering the chain) instead of three
+        assert calls == {"rp_gated": 2, "gate_split": 1}
     assert (got[0] - ref[0]).abs().max().item() <= 3e-5 * ref[0].abs().max().item()
     for a, b in zip(got[1:], ref[1:]):
         assert (a - b).norm().item() <= 5e-3 * b.norm().item() + 1e-12
