@@ -521,7 +521,11 @@ struct SplitGemmTnArgs {
                : "n"(N)                                                                                            \
                : "memory")
 
-template <bool CONV>
+// SMALL (with CONV): maps of at most 64 pixels (the 7x7 maps of the res5 head).  Which rows of a map a tap reads inside the
+// map is then one 64-bit mask (built by a ballot at kernel start) and a DMA row only tracks its pixel index -- ~10 vector
+// instructions per row and step instead of ~45 for the (y, x) bookkeeping of the general form, which at 181 VALU + 73
+// SALU per 48 MFMAs had the 3x3 weight gradient issue-bound (1000 TFLOP/s against 1260-1360 for the 1x1 forms).
+template <bool CONV, bool SMALL = false>
 __global__ __launch_bounds__(256, 2) void split_gemm_tn_kernel(SplitGemmTnArgs p, int tiles_i, int tiles_j,
                                                               int nblocks) {
   constexpr int TILE_BYTES = 32 * 512, STAGE = 2 * TILE_BYTES;
@@ -566,8 +570,14 @@ __global__ __launch_bounds__(256, 2) void split_gemm_tn_kernel(SplitGemmTnArgs p
   const int prow = lane >> 5, pseg = (lane & 31) >> 1, phalf = lane & 1;
   int rows[4];          // tile row of the lane in its 4 pieces
   long g_off[4], x_off[4];
-  int x_y[4], x_x[4];   // map position of the X row, kept incrementally
+  int x_y[4], x_x[4];   // map position of the X row, kept incrementally (SMALL: x_x = pixel index y * W + x)
   int m_row[4];
+  const int HW = CONV ? p.H * p.W : 1;
+  unsigned long long tap_mask = 0;  // SMALL: bit q set <=> pixel q of a map, shifted by this tap, is inside the map
+  if (CONV && SMALL) {
+    const int qy = lane / p.W, qx = lane - qy * p.W;
+    tap_mask = __ballot(lane < HW && (unsigned)(qy + tdy) < (unsigned)p.H && (unsigned)(qx + tdx) < (unsigned)p.W);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int piece = wave * 4 + i;
@@ -579,9 +589,10 @@ __global__ __launch_bounds__(256, 2) void split_gemm_tn_kernel(SplitGemmTnArgs p
     m_row[i] = m;
     g_off[i] = (long)m * p.g_rs + (long)i0 * 4 + seg * 32 + phalf * 16;
     x_off[i] = ((long)m + off_rows) * p.x_rs + (long)c0 * 4 + seg * 32 + phalf * 16;
-    x_x[i] = CONV ? m % p.W : 0;
-    x_y[i] = CONV ? (m / p.W) % p.H : 0;
+    x_x[i] = CONV ? (SMALL ? m % HW : m % p.W) : 0;
+    x_y[i] = (CONV && !SMALL) ? (m / p.W) % p.H : 0;
   }
+  const int step_q = (CONV && SMALL) ? 32 % HW : 0;
   const int step_dx = CONV ? 32 % p.W : 0, step_dy = CONV ? 32 / p.W : 0;
   const bool y_single = step_dy + 1 <= p.H;  // one conditional subtraction brings y back into [0, H)
   const char* zero_src = g_zero_line + (lane & 7) * 16;
@@ -593,7 +604,12 @@ __global__ __launch_bounds__(256, 2) void split_gemm_tn_kernel(SplitGemmTnArgs p
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       x_ok[i] = m_row[i] < Mi;
-      if (CONV) {
+      if (CONV && SMALL) {
+        x_ok[i] = x_ok[i] && ((tap_mask >> x_x[i]) & 1ull) != 0ull;
+        int q = x_x[i] + step_q;
+        if (q >= HW) q -= HW;
+        x_x[i] = q;
+      } else if (CONV) {
         x_ok[i] = x_ok[i] && (unsigned)(x_y[i] + tdy) < (unsigned)p.H && (unsigned)(x_x[i] + tdx) < (unsigned)p.W;
         int x = x_x[i] + step_dx, y = x_y[i] + step_dy;
         if (x >= p.W) { x -= p.W; ++y; }
@@ -1082,7 +1098,14 @@ extern "C" int ovis_split_gemm_pair_tn(const void* g_pair, long g_row_bytes, con
   if (nblocks > 0x7fffffffL) return OVIS_ERANGE;
   hipStream_t s = (hipStream_t)stream;
   const int lds = 2 * 2 * 32 * 512;
-  if (T > 1) {
+  if (T > 1 && (long)height * width <= 64) {
+    static bool attr_set_s = false;
+    if (!attr_set_s) {
+      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_tn_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr_set_s = true;
+    }
+    hipLaunchKernelGGL((split_gemm_tn_kernel<true, true>), dim3((unsigned)nblocks), dim3(256), lds, s, p, tiles_i, tiles_j, (int)nblocks);
+  } else if (T > 1) {
     static bool attr_set_c = false;
     if (!attr_set_c) {
       OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
