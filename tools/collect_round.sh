@@ -14,5 +14,6 @@ bash tools/prof_step.sh teacher $OUT/prof_teacher > $OUT/prof_teacher.txt 2>&1
 bash tools/gap_step.sh student $OUT/gap_student > $OUT/gap_student.txt 2>&1
 bash tools/prof_op.sh roi_bwd $OUT/prof_roi_bwd > $OUT/prof_roi_bwd.txt 2>&1
 bash tools/pmc_step.sh $OUT/pmc_teacher teacher > $OUT/pmc_teacher.log 2>&1
+bash tools/pmc_step.sh $OUT/pmc_student student > $OUT/pmc_student.log 2>&1
 find $OUT -name "*kernel_trace.csv" -delete
 ls $OUT
