@@ -407,8 +407,6 @@ def main():
     ap.add_argument("--burn-seconds", type=float, default=3.0, help="GPU clock warm-up before the warm-up steps")
     ap.add_argument("--no-pipeline", action="store_true", help="plain sequential step (no side-stream overlap)")
     ap.add_argument("--per-shape-csv", default="", help="write one row per distinct split-GEMM shape of the step")
-    ap.add_argument("--channels-last", action="store_true", help="experiment: run the trunk / heads in NHWC")
-    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen exhaustive find)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -418,8 +416,6 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if args.miopen_find:
-        torch.backends.cudnn.benchmark = True
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
@@ -445,11 +441,6 @@ def main():
         model.set_caption_vocab(e_vocab)
     images, targets = make_batch(IMS_PER_GPU, device=dev, seed=1234 + rank)
     calibrate_stem_bn(model, images)
-    if args.channels_last:
-        model = model.to(memory_format=torch.channels_last)
-        images = images.contiguous(memory_format=torch.channels_last)
-        _orig_fwd = _C.roi_align_forward
-        _C.roi_align_forward = lambda *a: _orig_fwd(*a).contiguous(memory_format=torch.channels_last)
     comm.broadcast_parameters(model)
     model.train()
     optimizer = solver.make_optimizer(cfg, model)

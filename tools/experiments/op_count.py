@@ -114,6 +114,26 @@ tag_fn(model, "forward_frozen", "forward_frozen(other)")
 tag_fn(model, "forward_student", "forward_student(other)")
 tag_fn(optimizer, "step", "optimizer.step")
 
+class _CountingLib:
+    """Proxy of the ctypes library handle: counts the native-library calls (each launches 1-3 kernels)."""
+
+    def __init__(self, lib):
+        self._lib, self.calls = lib, collections.Counter()
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.startswith("ovis_"):
+            return fn
+
+        def call(*a):
+            self.calls[name] += 1
+            return fn(*a)
+        return call
+
+
+from cvpr22_cross_modal_pseudo_labeling_amd import _C as _ops
+_ops._L = native = _CountingLib(_ops._L)
+
 t0 = time.perf_counter()
 with Counter():
     stack.append("step(other: backward, reducer, ...)")
@@ -124,7 +144,11 @@ print(f"step wall {1e3 * (time.perf_counter() - t0):.1f} ms, {sum(counts.values(
 for k, v in counts.most_common():
     print(f"{v:6d} ops  {1e3 * wall[k]:8.2f} ms host wall  {k}")
     print("         " + ", ".join(f"{n}:{c}" for n, c in opnames[k].most_common(8)))
-print("--- ops that launch device work, by source line (forward thread only)")
+launching_native = {k: v for k, v in native.calls.items() if not k.endswith(("_bytes", "_slices", "_supported", "_version"))}
+print(f"--- device work of the step: {sum(sites.values())} launching aten ops (both threads) + {sum(launching_native.values())} "
+      "native-library calls; the kernel-trace count of launches per step is in profiles/r2_gap_report_student_nopipe.txt")
+print("    native calls: " + ", ".join(f"{n[5:]}:{c}" for n, c in sorted(launching_native.items(), key=lambda kv: -kv[1])))
+print("--- launching aten ops by source line (ops of the autograd thread have no Python frame)")
 print(sum(sites.values()), "ops")
 for k, v in sites.most_common(150):
     print(f"{v:5d}  {k}   " + ", ".join(f"{n}:{c}" for n, c in site_ops[k].most_common(4)))
