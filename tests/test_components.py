@@ -389,3 +389,33 @@ def test_synthetic_batches_through_worker_processes_keep_their_order():
         assert torch.equal(images, want_images)
         assert all(torch.equal(a.bbox, b.bbox) for a, b in zip(targets, want_targets))
     pre.close()
+
+
+def test_box_decode_with_image_clip_equals_decode_then_clip_to_image(z):
+    """``BoxCoder.decode(..., rows_per_image, image_sizes)`` (the form the box post-processor calls; on the device one
+    kernel) on CPU tensors: the reference's decode (fixture) followed by ``BoxList.clip_to_image`` per image."""
+    coder = BoxCoder(weights=(10.0, 10.0, 5.0, 5.0))
+    codes, boxes = T(z["coder_codes"]).clone(), T(z["coder_prop"]).clone()
+    codes[::3] *= 40.0  # push some boxes outside the images
+    n = codes.shape[0]
+    per_img, sizes = [n // 3, 0, n - n // 3], [(60, 40), (10, 10), (35, 55)]
+    want = coder.decode(codes, boxes)
+    at = 0
+    for cnt, size in zip(per_img, sizes):
+        for j in range(want.shape[1] // 4):  # clip_to_image clamps in place through the column-slice views
+            BoxList(want[at:at + cnt, 4 * j:4 * j + 4], size).clip_to_image(remove_empty=False)
+        at += cnt
+    got = coder.decode(codes, boxes, per_img, sizes)
+    assert torch.equal(got, want)
+    assert float(got[:, 0::2].max()) <= 59.0 and float(got.min()) >= 0.0
+
+
+def test_total_loss_is_the_sum_of_the_terms():
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine.trainer import total_loss
+
+    terms = {"a": torch.tensor(1.5, requires_grad=True), "b": torch.tensor(2.25, requires_grad=True),
+             "c": torch.tensor(-0.5, requires_grad=True), "d": 0.0}
+    t = total_loss(terms)
+    assert float(t) == 3.25
+    t.backward()
+    assert all(float(v.grad) == 1.0 for v in terms.values() if torch.is_tensor(v))
