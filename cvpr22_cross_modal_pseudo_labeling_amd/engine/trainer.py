@@ -50,6 +50,10 @@ def _record_stream(obj, stream):
     elif hasattr(obj, "bbox") and hasattr(obj, "extra_fields"):  # BoxList
         _record_stream(obj.bbox, stream)
         _record_stream(obj.extra_fields, stream)
+        _record_stream(getattr(obj, "pos_index", None), stream)  # sampled lists: where their positives sit
+    elif hasattr(obj, "probs") and hasattr(obj, "boxes"):  # PastedMasks
+        _record_stream(obj.probs, stream)
+        _record_stream(obj.boxes, stream)
 
 
 class PipelinedTrainer:
