@@ -15,7 +15,27 @@ _L = _lib.load()
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # the raw handle of the current stream of the current device (the `with _on(...)` around every launch makes that
+    # the operands' device); ~10x cheaper than building a torch.cuda.Stream object per launch
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+
+
+class _Same:
+    """No-op context: the operands already live on the current device (every launch of a one-GPU-per-process run)."""
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_SAME = _Same()
+
+
+def _on(device):
+    """``torch.cuda.device(device)`` only when it would change the current device."""
+    return _SAME if device.index == torch.cuda.current_device() else torch.cuda.device(device)
 
 
 def _dev(t, name, dtype=torch.float32):
@@ -39,7 +59,7 @@ def _roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, 
     out = torch.empty((r, c, pooled_height, pooled_width), dtype=input.dtype, device=input.device)
     if out.numel() == 0:
         return out
-    with torch.cuda.device(input.device):
+    with _on(input.device):
         if exact:
             rc = _L.ovis_roi_align_forward_f32(input.data_ptr(), rois.data_ptr(), out.data_ptr(), r, n, c, h, w,
                                                pooled_height, pooled_width, spatial_scale, sampling_ratio, _stream())
@@ -76,7 +96,7 @@ def _channels_last_map(input, channel_multiple):
 
 def _strided_from_nhwc(input, rois, out, spatial_scale, pooled_height, pooled_width, sampling_ratio, bin_stride, pair):
     n, c, h, w = input.shape
-    with torch.cuda.device(input.device):
+    with _on(input.device):
         rc = _L.ovis_roi_align_forward_strided_from_nhwc_f32(input.data_ptr(), rois.data_ptr(), out.data_ptr(), rois.size(0), n, c,
                                                              h, w, pooled_height, pooled_width, bin_stride, spatial_scale,
                                                              sampling_ratio, int(pair), _stream())
@@ -103,7 +123,7 @@ def roi_align_forward_strided_nhwc(input, rois, spatial_scale, pooled_height, po
     out = torch.empty((r, oh, ow, c), dtype=input.dtype, device=input.device)
     if out.numel() == 0:
         return out
-    with torch.cuda.device(input.device):
+    with _on(input.device):
         rc = _L.ovis_roi_align_forward_strided_nhwc_f32(input.data_ptr(), rois.data_ptr(), out.data_ptr(), r, n, c, h,
                                                         w, pooled_height, pooled_width, bin_stride, spatial_scale,
                                                         sampling_ratio, _stream())
@@ -130,7 +150,7 @@ def roi_align_forward_strided_pair(input, rois, spatial_scale, pooled_height, po
     oh, ow = -(-pooled_height // bin_stride), -(-pooled_width // bin_stride)
     out = torch.empty((r * oh * ow, 2 * c), dtype=torch.bfloat16, device=input.device)
     if out.numel():
-        with torch.cuda.device(input.device):
+        with _on(input.device):
             rc = _L.ovis_roi_align_forward_strided_pair_f32(input.data_ptr(), rois.data_ptr(), out.data_ptr(), r, n, c, h, w,
                                                             pooled_height, pooled_width, bin_stride, spatial_scale,
                                                             sampling_ratio, _stream())
@@ -145,7 +165,7 @@ def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, b
     gin = torch.empty((batch_size, channels, height, width), dtype=grad.dtype, device=grad.device)
     if gin.numel() == 0:
         return gin
-    with torch.cuda.device(grad.device):
+    with _on(grad.device):
         # plane-owner MFMA kernel when the H x W plane fits LDS (needs a per-call table workspace); the
         # library falls back to the window-gather + atomic kernel for larger maps
         nbytes = _L.ovis_roi_align_backward_workspace_bytes(r, batch_size, height, width)
@@ -167,7 +187,7 @@ def roi_align_backward_strided(grad, rois, spatial_scale, pooled_height, pooled_
     gin = torch.empty((batch_size, channels, height, width), dtype=grad.dtype, device=grad.device)
     if gin.numel() == 0:
         return gin
-    with torch.cuda.device(grad.device):
+    with _on(grad.device):
         nbytes = _L.ovis_roi_align_backward_workspace_bytes(r, batch_size, height, width)
         ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=grad.device)
         rc = _L.ovis_roi_align_backward_strided_ws_f32(grad.data_ptr(), rois.data_ptr(), gin.data_ptr(), r, batch_size,
@@ -191,7 +211,7 @@ def nms_padded(dets, scores, threshold, ge_mode=False):
         return keep, num
     if dets.dim() != 2 or dets.size(1) != 4 or scores.numel() != k:
         raise RuntimeError("nms: expected dets [K,4] and scores [K]")
-    with torch.cuda.device(dets.device):
+    with _on(dets.device):
         nbytes = _L.ovis_nms_workspace_bytes(k)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dets.device)
         rc = _L.ovis_nms_f32(dets.data_ptr(), scores.data_ptr(), k, threshold, int(bool(ge_mode)), ws.data_ptr(),
@@ -213,7 +233,7 @@ def nms_grouped_padded(dets, scores, groups, threshold, ge_mode=False):
         return keep, num
     if dets.dim() != 2 or dets.size(1) != 4 or scores.numel() != k or groups.numel() != k:
         raise RuntimeError("nms_grouped: expected dets [K,4], scores [K] and groups [K]")
-    with torch.cuda.device(dets.device):
+    with _on(dets.device):
         nbytes = _L.ovis_nms_workspace_bytes(k)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dets.device)
         rc = _L.ovis_nms_grouped_f32(dets.data_ptr(), scores.data_ptr(), groups.data_ptr(), k, threshold,
@@ -252,7 +272,7 @@ def nms_presorted_batched(boxes, drop, threshold, below=0, ge_mode=False):
         drop = _dev(drop, "drop", torch.int32)
         if drop.shape != (n, k):
             raise RuntimeError("nms_presorted_batched: drop must be [N,K] int32")
-    with torch.cuda.device(boxes.device):
+    with _on(boxes.device):
         nbytes = _L.ovis_nms_presorted_workspace_bytes(n, k)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=boxes.device)
         rc = _L.ovis_nms_presorted_batched_f32(boxes.data_ptr(), 0 if drop is None else drop.data_ptr(), n, k, threshold,
@@ -284,7 +304,7 @@ def rpn_decode(box_regression, topk_idx, cell_anchors, image_wh, weights, xform_
     if n == 0 or k == 0:
         return boxes, drop
     wx, wy, ww, wh = weights
-    with torch.cuda.device(box_regression.device):
+    with _on(box_regression.device):
         rc = _L.ovis_rpn_decode_f32(box_regression.data_ptr(), box_regression.stride(0), box_regression.stride(3),
                                     box_regression.stride(1), topk_idx.data_ptr(), cell_anchors.data_ptr(),
                                     image_wh.data_ptr(), n, k, a, w, float(anchor_stride), wx, wy, ww, wh, xform_clip,
@@ -316,7 +336,7 @@ def box_decode(rel_codes, boxes, weights, xform_clip, rows_per_image=None, image
         counts = (ctypes.c_int32 * n)(*[int(c) for c in rows_per_image])
         wh = (ctypes.c_float * (2 * n))(*[float(v) for size in image_sizes for v in size])
     wx, wy, ww, wh_ = weights
-    with torch.cuda.device(rel_codes.device):
+    with _on(rel_codes.device):
         rc = _L.ovis_box_decode_f32(rel_codes.data_ptr(), rel_codes.stride(0), boxes.data_ptr(), boxes.stride(0), r, k, wx, wy,
                                     ww, wh_, xform_clip, n, counts, wh, out.data_ptr(), _stream())
     _lib.check(rc, "box_decode")
@@ -338,7 +358,7 @@ def rois_from_boxes(boxes, image_ids=None):
         ptrs = (ctypes.c_void_p * n)(*[b.data_ptr() if b.shape[0] else None for b in boxes])
         counts = (ctypes.c_int32 * n)(*[b.shape[0] for b in boxes])
         ids = None if image_ids is None else (ctypes.c_int32 * n)(*[int(i) for i in image_ids])
-        with torch.cuda.device(rois.device):
+        with _on(rois.device):
             rc = _L.ovis_rois_from_boxes_f32(ptrs, counts, ids, n, rois.data_ptr(), _stream())
         _lib.check(rc, "rois_from_boxes")
     return rois
@@ -360,7 +380,7 @@ def smooth_l1_picked_fwd_bwd(box_regression, regression_targets, positives, labe
     r, c = box_regression.shape
     loss = torch.empty((1,), dtype=torch.float32, device=box_regression.device)
     grad = torch.empty((r, c), dtype=torch.float32, device=box_regression.device) if need_grad else None
-    with torch.cuda.device(box_regression.device):
+    with _on(box_regression.device):
         rc = _L.ovis_smooth_l1_picked_fwd_bwd_f32(box_regression.data_ptr(), box_regression.stride(0), r, c,
                                                   regression_targets.data_ptr(), regression_targets.stride(0),
                                                   positives.data_ptr(), 0 if labels is None else labels.data_ptr(),
@@ -378,7 +398,7 @@ def sigmoid_focalloss_forward(logits, targets, num_classes, gamma, alpha):
     losses = torch.empty_like(logits)
     if losses.numel() == 0:
         return losses
-    with torch.cuda.device(logits.device):
+    with _on(logits.device):
         rc = _L.ovis_sigmoid_focal_loss_forward_f32(logits.data_ptr(), targets.data_ptr(), losses.data_ptr(),
                                                     logits.size(0), logits.size(1), gamma, alpha, _stream())
     _lib.check(rc, "sigmoid_focalloss_forward")
@@ -393,7 +413,7 @@ def sigmoid_focalloss_backward(logits, targets, d_losses, num_classes, gamma, al
     d_logits = torch.zeros_like(logits)
     if d_logits.numel() == 0:
         return d_logits
-    with torch.cuda.device(logits.device):
+    with _on(logits.device):
         rc = _L.ovis_sigmoid_focal_loss_backward_f32(logits.data_ptr(), targets.data_ptr(), d_losses.data_ptr(),
                                                      d_logits.data_ptr(), logits.size(0), num_classes, gamma,
                                                      alpha, _stream())
@@ -412,7 +432,7 @@ def roi_pool_forward(input, rois, spatial_scale, pooled_height, pooled_width):
     out = torch.empty((r, c, pooled_height, pooled_width), dtype=input.dtype, device=input.device)
     argmax = torch.zeros((r, c, pooled_height, pooled_width), dtype=torch.int32, device=input.device)
     if out.numel():
-        with torch.cuda.device(input.device):
+        with _on(input.device):
             rc = _L.ovis_roi_pool_forward_f32(input.data_ptr(), rois.data_ptr(), out.data_ptr(), argmax.data_ptr(), r, n, c, h,
                                               w, pooled_height, pooled_width, spatial_scale, _stream())
         _lib.check(rc, "roi_pool_forward")
@@ -427,7 +447,7 @@ def roi_pool_backward(grad, input, rois, argmax, spatial_scale, pooled_height, p
     argmax = argmax.to(torch.int32).contiguous()
     gin = torch.empty((batch_size, channels, height, width), dtype=grad.dtype, device=grad.device)
     if gin.numel():
-        with torch.cuda.device(grad.device):
+        with _on(grad.device):
             rc = _L.ovis_roi_pool_backward_f32(grad.data_ptr(), argmax.data_ptr(), rois.data_ptr(), gin.data_ptr(),
                                                rois.size(0), batch_size, channels, height, width, pooled_height,
                                                pooled_width, _stream())
@@ -456,7 +476,7 @@ def deform_psroi_pooling_forward(input, bbox, trans, out, top_count, no_trans, s
     tr = 0 if no_trans else _dev(trans, "trans").data_ptr()
     if not (out.is_contiguous() and top_count.is_contiguous() and top_count.dtype == torch.float32):
         raise RuntimeError("deform_psroi_pooling_forward: out / top_count must be contiguous float32")
-    with torch.cuda.device(input.device):
+    with _on(input.device):
         rc = _L.ovis_deform_psroi_pool_forward_f32(input.data_ptr(), bbox.data_ptr(), tr, out.data_ptr(),
                                                    top_count.data_ptr(), n, batch, channels, height, width, channels_trans,
                                                    int(bool(no_trans)), spatial_scale, output_dim, group_size,
@@ -481,7 +501,7 @@ def deform_psroi_pooling_backward(out_grad, input, bbox, trans, top_count, input
         if not (trans_grad.is_cuda and trans_grad.is_contiguous() and trans_grad.shape == trans.shape):
             raise RuntimeError("deform_psroi_pooling_backward: trans_grad must be a contiguous HIP tensor shaped like trans")
         tg = trans_grad.data_ptr()
-    with torch.cuda.device(input.device):
+    with _on(input.device):
         rc = _L.ovis_deform_psroi_pool_backward_f32(out_grad.data_ptr(), top_count.data_ptr(), input.data_ptr(),
                                                     bbox.data_ptr(), tr, input_grad.data_ptr(), tg, n, batch, channels,
                                                     height, width, channels_trans, int(bool(no_trans)), spatial_scale,
@@ -502,7 +522,7 @@ def split_bf16x3(x, mode):
     out = torch.empty((rows, 3 * cols), dtype=torch.bfloat16, device=x.device)
     if out.numel() == 0:
         return out
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = _L.ovis_split_bf16x3_f32(x.data_ptr(), x.stride(0), out.data_ptr(), rows, cols, mode, _stream())
     _lib.check(rc, "split_bf16x3")
     return out
@@ -517,7 +537,7 @@ def im2col_split_bf16x3(x, kh, kw, flip=False):
     out = torch.empty((r * h * w, 3 * kh * kw * c), dtype=torch.bfloat16, device=x.device)
     if out.numel() == 0:
         return out
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = _L.ovis_im2col_split_bf16x3_f32(x.data_ptr(), out.data_ptr(), r, h, w, c, kh, kw, int(bool(flip)), _stream())
     _lib.check(rc, "im2col_split_bf16x3")
     return out
@@ -536,7 +556,7 @@ def match_encode(gt_boxes, gt_labels, proposals, high, low, weights=None, betwee
     reg = torch.empty((p, 4), dtype=torch.float32, device=proposals.device) if weights is not None else None
     if p:
         wx, wy, ww, wh = weights if weights is not None else (1.0, 1.0, 1.0, 1.0)
-        with torch.cuda.device(proposals.device):
+        with _on(proposals.device):
             rc = _L.ovis_match_encode_f32(gt_boxes.data_ptr(), gt_labels.data_ptr(), proposals.data_ptr(), g, p, high, low,
                                           int(bool(between_keeps_label)), wx, wy, ww, wh, idx.data_ptr(), lab.data_ptr(),
                                           0 if reg is None else reg.data_ptr(), _stream())
@@ -554,7 +574,7 @@ def project_masks(masks, gt_index, boxes, resolution):
     p = boxes.shape[0]
     out = torch.empty((p, resolution, resolution), dtype=torch.float32, device=boxes.device)
     if p:
-        with torch.cuda.device(boxes.device):
+        with _on(boxes.device):
             rc = _L.ovis_project_masks_f32(masks.data_ptr(), gt_index.data_ptr(), boxes.data_ptr(), p, masks.shape[1],
                                            masks.shape[2], resolution, int(masks.dtype == torch.bool), out.data_ptr(),
                                            _stream())
@@ -572,7 +592,7 @@ def sample_fg_bg(labels, batch_size, max_positives, seed):
     sel = torch.empty((batch_size,), dtype=torch.int64, device=labels.device)
     slots = torch.empty((batch_size,), dtype=torch.int64, device=labels.device)
     counts = torch.empty((2,), dtype=torch.int32, device=labels.device)
-    with torch.cuda.device(labels.device):
+    with _on(labels.device):
         rc = _L.ovis_sample_fg_bg(labels.data_ptr(), labels.numel(), int(batch_size), int(max_positives),
                                   int(seed) & 0xFFFFFFFFFFFFFFFF, sel.data_ptr(), slots.data_ptr(), counts.data_ptr(), _stream())
     _lib.check(rc, "sample_fg_bg")
@@ -595,7 +615,7 @@ def gather_rows(index, boxes_a=None, boxes_b=None, ints_a=None, ints_b=None):
     outs = [None if t is None else torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in srcs]
     if n:
         ptr = lambda t: 0 if t is None else t.data_ptr()
-        with torch.cuda.device(index.device):
+        with _on(index.device):
             rc = _L.ovis_gather_rows(index.data_ptr(), n, ptr(srcs[0]), ptr(outs[0]), ptr(srcs[1]), ptr(outs[1]), ptr(srcs[2]),
                                      ptr(outs[2]), ptr(srcs[3]), ptr(outs[3]), _stream())
         _lib.check(rc, "gather_rows")
@@ -614,7 +634,7 @@ def project_pasted_masks(mask_probs, gt_boxes, gt_index, boxes, image_size, reso
         return out
     if mask_probs.dim() != 3 or mask_probs.shape[1] != mask_probs.shape[2] or gt_boxes.shape != (mask_probs.shape[0], 4):
         raise RuntimeError("project_pasted_masks: expected mask_probs [G,M,M] and gt_boxes [G,4]")
-    with torch.cuda.device(boxes.device):
+    with _on(boxes.device):
         rc = _L.ovis_project_pasted_masks_f32(mask_probs.data_ptr(), gt_boxes.data_ptr(), gt_index.data_ptr(),
                                               boxes.data_ptr(), p, int(image_size[0]), int(image_size[1]),
                                               mask_probs.shape[1], int(resolution), float(threshold), out.data_ptr(), _stream())
@@ -633,7 +653,7 @@ def split_pair(x):
     out = torch.empty((rows, 2 * cols), dtype=torch.bfloat16, device=x.device)
     if out.numel() == 0:
         return out
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = _L.ovis_split_pair_f32(x.data_ptr(), x.stride(0), out.data_ptr(), rows, cols, _stream())
     _lib.check(rc, "split_pair")
     return out
@@ -671,7 +691,7 @@ def gate_split_pair(dy, gate=None, want_f32=False, pooled=None, pool_rows=0):
     g32 = torch.empty((rows, cols), dtype=torch.float32, device=dev) if want_f32 else None
     if out.numel() == 0:
         return out, g32
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = _L.ovis_gate_split_pair_f32(0 if dy is None else dy.data_ptr(), 0 if dy is None else dy.stride(0),
                                          0 if gate is None else gate.data_ptr(), is_pair, out.data_ptr(),
                                          0 if g32 is None else g32.data_ptr(), rows, cols,
@@ -691,7 +711,7 @@ def im2col_pair(xp, h, w, kh, kw):
     out = torch.empty((m, kh * kw * c2), dtype=torch.bfloat16, device=xp.device)
     if out.numel() == 0:
         return out
-    with torch.cuda.device(xp.device):
+    with _on(xp.device):
         rc = _L.ovis_im2col_pair(xp.data_ptr(), out.data_ptr(), m // (h * w), h, w, c2 // 2, kh, kw, _stream())
     _lib.check(rc, "im2col_pair")
     return out
@@ -707,7 +727,7 @@ def im2col_nchw_pair(x, kh, kw, stride, pad):
     kp = -(-(kh * kw * c) // 32) * 32
     out = torch.empty((n * ho * wo, 2 * kp), dtype=torch.bfloat16, device=x.device)
     if out.numel():
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             rc = _L.ovis_im2col_nchw_pair_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, kh, kw, stride, pad, kp, _stream())
         _lib.check(rc, "im2col_nchw_pair")
     return out, (ho, wo)
@@ -753,7 +773,7 @@ def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f3
                 residual_pair.is_cuda and residual_pair.dtype == torch.bfloat16 and residual_pair.dim() == 2
                 and residual_pair.stride(1) == 1 and residual_pair.shape == (m, 2 * n)):
             raise RuntimeError("split_gemm_pair: residual_pair must be [M, 2N] bfloat16 pair rows of a plain product")
-        with torch.cuda.device(dev):
+        with _on(dev):
             nbytes = _L.ovis_split_gemm_pair_workspace_bytes(m, n, ch, 0, 1, 1, 0) if not (config & 8) else 0
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
             rc = _L.ovis_split_gemm_pair_rp(a_pair.data_ptr(), 2 * a_pair.stride(0), b_pair.data_ptr(), 2 * b_pair.stride(0),
@@ -766,7 +786,7 @@ def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f3
     if residual is not None and not (residual.is_cuda and residual.dtype == torch.float32 and residual.dim() == 2
                                      and residual.stride(1) == 1 and residual.shape == (m, n)):
         raise RuntimeError("split_gemm_pair: residual must be a float32 [M, N] HIP tensor with unit column stride")
-    with torch.cuda.device(dev):
+    with _on(dev):
         nbytes = _L.ovis_split_gemm_pair_workspace_bytes(m, n, ch, ch2, kh, kw, w) if not (config & 8) else 0
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
         rc = _L.ovis_split_gemm_pair(a_pair.data_ptr(), 2 * a_pair.stride(0),
@@ -795,7 +815,7 @@ def weight_prep_pair(w, scale=None, want_transposed=False):
     bwd = torch.empty((c, 2 * t * n), dtype=torch.bfloat16, device=w.device) if want_transposed else None
     if scale is not None:
         scale = _dev(scale.detach(), "scale")
-    with torch.cuda.device(w.device):
+    with _on(w.device):
         rc = _L.ovis_weight_prep_pair_f32(w.data_ptr(), 0 if scale is None else scale.data_ptr(), fwd.data_ptr(),
                                           0 if bwd is None else bwd.data_ptr(), n, c, t, _stream())
     _lib.check(rc, "weight_prep_pair")
@@ -822,7 +842,7 @@ def split_gemm_pair_gated(a_pair, b_pair, gate_pair, conv=None, out_f32=False, o
     cp = torch.empty((m, 2 * n), dtype=torch.bfloat16, device=dev) if out_pair else None
     if m == 0 or n == 0:
         return c, cp
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = _L.ovis_split_gemm_pair_gated(a_pair.data_ptr(), 2 * a_pair.stride(0), b_pair.data_ptr(), 2 * b_pair.stride(0),
                                            0 if c is None else c.data_ptr(), n, 0 if cp is None else cp.data_ptr(), 4 * n,
                                            gate_pair.data_ptr(), 2 * gate_pair.stride(0), m, n, ch, kh, kw, h, w,
@@ -847,7 +867,7 @@ def split_gemm_pair_rp_gated(a_pair, b_pair, residual_pair, gate_pair, out_f32=F
     cp = torch.empty((m, 2 * n), dtype=torch.bfloat16, device=dev) if out_pair else None
     if m == 0 or n == 0:
         return c, cp
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = _L.ovis_split_gemm_pair_rp_gated(a_pair.data_ptr(), 2 * a_pair.stride(0), b_pair.data_ptr(),
                                               2 * b_pair.stride(0), 0 if c is None else c.data_ptr(), n,
                                               0 if cp is None else cp.data_ptr(), 4 * n, residual_pair.data_ptr(),
@@ -889,7 +909,7 @@ def split_gemm_pair_tn(g_pair, x_pair, conv=None, scale=None, weight_shape=None)
         return z if weight_shape is None else z.new_zeros(weight_shape)
     slices = _L.ovis_split_gemm_tn_slices(m, n, ch, kh * kw)
     slabs = torch.empty((slices, n, kh * kw * ch), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = _L.ovis_split_gemm_pair_tn(g_pair.data_ptr(), 2 * g_pair.stride(0), x_pair.data_ptr(), 2 * x_pair.stride(0),
                                         slabs.data_ptr(), slices, m, n, ch, kh, kw, h, w, _stream())
         _lib.check(rc, "split_gemm_pair_tn")
@@ -914,7 +934,7 @@ def bias_act_(y, bias=None, residual=None, relu=True):
         raise RuntimeError("bias_act_: residual must be contiguous with y's shape")
     if y.numel() == 0:
         return y
-    with torch.cuda.device(y.device):
+    with _on(y.device):
         rc = _L.ovis_bias_act_f32(y.data_ptr(), 0 if bias is None else bias.data_ptr(),
                                   0 if residual is None else residual.data_ptr(), y.shape[0], y.shape[1],
                                   int(bool(relu)), _stream())
@@ -939,7 +959,7 @@ def gemm_nt(a, b, bias=None):
         return out.zero_() if bias is None else out.copy_(bias.expand(m, n))
     if bias is not None:
         bias = _dev(bias, "bias")
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         rc = _L.ovis_gemm_f32(a.data_ptr(), a.stride(0), a.stride(1), b.data_ptr(), b.stride(0), b.stride(1),
                               0 if bias is None else bias.data_ptr(), out.data_ptr(), n, m, n, k, _stream())
     _lib.check(rc, "gemm_f32")
@@ -956,7 +976,7 @@ def region_noun_align(region_emb, noun_emb):
     idx = torch.empty((w,), dtype=torch.int64, device=region_emb.device)
     if w == 0:
         return raw, prob, idx
-    with torch.cuda.device(region_emb.device):
+    with _on(region_emb.device):
         rc = _L.ovis_region_noun_align_f32(region_emb.data_ptr(), noun_emb.data_ptr(), raw.data_ptr(),
                                            prob.data_ptr(), idx.data_ptr(), p, w, d, _stream())
     _lib.check(rc, "region_noun_align")
@@ -970,7 +990,7 @@ def weighted_ce_fwd_bwd(logits, labels, bg_weight, need_grad=True):
     loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty_like(logits) if need_grad else None
     scratch = torch.empty((max(p, 1),), dtype=torch.float32, device=logits.device)
-    with torch.cuda.device(logits.device):
+    with _on(logits.device):
         rc = _L.ovis_weighted_ce_fwd_bwd_f32(logits.data_ptr(), labels.data_ptr(), bg_weight, loss.data_ptr(),
                                              0 if dlogits is None else dlogits.data_ptr(), scratch.data_ptr(), p, c,
                                              _stream())
@@ -994,7 +1014,7 @@ def mask_bce_stochastic_fwd_bwd(mu, sigma, eps, pos_index, targets, channel, nee
         if (need_grad and sigma is not None) else None
     scratch = torch.empty((max(npos, 1),), dtype=torch.float32, device=mu.device)
     ptr = lambda t: 0 if t is None else t.data_ptr()
-    with torch.cuda.device(mu.device):
+    with _on(mu.device):
         rc = _L.ovis_mask_bce_stochastic_fwd_bwd_f32(mu.data_ptr(), ptr(sigma), ptr(eps), pos_index.data_ptr(),
                                                      targets.data_ptr(), loss.data_ptr(), ptr(dmu), ptr(dsigma),
                                                      scratch.data_ptr(), p, npos, c, mm, channel, _stream())
@@ -1043,7 +1063,7 @@ def _dcn_forward(input, weight, bias, offset, mask, output, kH, kW, dH, dW, padH
     cin_g, cout_g = cin // group, cout // group
     step = max(1, min(step, b))
     col = torch.empty((cin * K, step, plane), dtype=torch.float32, device=input.device)
-    with torch.cuda.device(input.device):
+    with _on(input.device):
         for s0 in range(0, b, step):
             nb = min(step, b - s0)
             rc = _L.ovis_deform_im2col_f32(input[s0].data_ptr(), offset[s0].data_ptr(),
@@ -1082,7 +1102,7 @@ def _dcn_backward(input, weight, offset, mask, grad_output, grad_input, grad_off
         if t is not None and not t.is_contiguous():
             raise RuntimeError("deform_conv backward: gradient buffers must be contiguous")
     col = torch.empty((cin * K, step, plane), dtype=torch.float32, device=input.device)
-    with torch.cuda.device(input.device):
+    with _on(input.device):
         for s0 in range(0, b, step):
             nb = min(step, b - s0)
             if grad_input is not None or grad_offset is not None:
