@@ -184,6 +184,23 @@ class OpTimer:
             per = 2 + (2 if sigma is not None else 0) + (2 if need_grad else 0)  # mu/eps channels read, gradients written
             return 4 * p * px * (per + 1) + 8 * p
 
+        def box_decode_bytes(rel_codes, boxes, weights, xform_clip, rows_per_image=None, image_sizes=None):
+            return 4 * (2 * rel_codes.numel() + boxes.numel())  # deltas + boxes read, decoded boxes written
+
+        def smooth_l1_bytes(box_regression, regression_targets, positives, labels, column0, beta, denominator, need_grad=True):
+            return positives.numel() * (8 + 32) + (4 * box_regression.numel() if need_grad else 0)
+
+        def rois_bytes(boxes, image_ids=None):
+            return 36 * sum(b.shape[0] for b in boxes)
+
+        def gather_rows_bytes(index, boxes_a=None, boxes_b=None, ints_a=None, ints_b=None):
+            per_row = 8 + 32 * (boxes_a is not None) + 32 * (boxes_b is not None) + 16 * (ints_a is not None) + 16 * (ints_b is not None)
+            return index.numel() * per_row
+
+        self._wrap("box_decode", box_decode_bytes)
+        self._wrap("smooth_l1_picked_fwd_bwd", smooth_l1_bytes)
+        self._wrap("rois_from_boxes", rois_bytes)
+        self._wrap("gather_rows", gather_rows_bytes)
         self._wrap("gemm_nt", gemm_nt_flops, "mfma_f32", gemm_nt_bytes)
         self._wrap("region_noun_align", align_bytes)
         self._wrap("weighted_ce_fwd_bwd", ce_bytes)
