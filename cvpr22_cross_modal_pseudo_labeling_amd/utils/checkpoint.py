@@ -3,12 +3,14 @@
 Counterparts: maskrcnn_benchmark/utils/model_serialization.py:10-89 (suffix alignment of state-dict keys, ``module.``
 prefix of DistributedDataParallel) and utils/checkpoint.py:14-154 (``Checkpointer`` file layout: ``model_<iter>.pth``
 holding ``{"model", "optimizer", "scheduler", **extras}`` + a ``last_checkpoint`` tag file; ``DetectronCheckpointer``
-key-rewrite rules).  Catalog / URL / Caffe2 ``.pkl`` sources are out of scope here (no network).
+key-rewrite rules).  ``catalog://`` names, URLs and Caffe2 ``.pkl`` files go through ``utils/weight_sources.py``.
 """
 import logging
 import os
 
 import torch
+
+from . import weight_sources
 
 
 def strip_prefix_if_present(state_dict, prefix):
@@ -129,6 +131,7 @@ class DetectronCheckpointer(Checkpointer):
         self.cfg = cfg
 
     def _load_file(self, f):
-        if f.startswith(("catalog://", "http")) or f.endswith(".pkl"):
-            raise NotImplementedError("catalog / URL / Caffe2 .pkl sources are not available in this build: pass a .pth file")
+        # catalog:// name -> URL -> model cache; Caffe2 / Detectron .pkl -> translated blob names (utils/checkpoint.py:132-154)
+        if weight_sources.is_foreign(f):
+            return weight_sources.resolve(f, self.cfg, is_main_process=self.save_to_disk)
         return super()._load_file(f)

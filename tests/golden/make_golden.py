@@ -286,6 +286,56 @@ def gen_heads():
     np.savez_compressed(os.path.join(HERE, "heads.npz"), **out)
 
 
+def c2_blob_names():
+    """Blob names of a Detectron R-50-C4 Mask R-CNN checkpoint / an ImageNet-pretrained R-50 (the checkpoints the
+    reference's configs name), incl. solver momentum blobs."""
+    names = ["conv1_w", "res_conv1_bn_s", "res_conv1_bn_b", "fc1000_w", "fc1000_b", "pred_w", "pred_b",
+             "conv_rpn_w", "conv_rpn_b", "rpn_cls_logits_w", "rpn_cls_logits_b", "rpn_bbox_pred_w", "rpn_bbox_pred_b",
+             "cls_score_w", "cls_score_b", "bbox_pred_w", "bbox_pred_b", "conv5_mask_w", "conv5_mask_b",
+             "mask_fcn_logits_w", "mask_fcn_logits_b", "conv1_w_momentum", "res2_0_branch2a_w_momentum"]
+    for stage, blocks in ((2, 3), (3, 4), (4, 6), (5, 3)):
+        for b in range(blocks):
+            for br in ("2a", "2b", "2c") + (("1",) if b == 0 else ()):
+                names += [f"res{stage}_{b}_branch{br}_w", f"res{stage}_{b}_branch{br}_bn_s", f"res{stage}_{b}_branch{br}_bn_b"]
+    return names
+
+
+def gen_c2_names():
+    """Name pairs (C2 blob -> torch parameter) produced by the reference's own translation, catalog URLs and cache file
+    names: tests/golden/c2_names.json (data only)."""
+    import json
+
+    six = types.ModuleType("torch._six")
+    six.PY3 = True
+    sys.modules["torch._six"] = six
+    torch._six = six
+    import importlib.util
+
+    # config/__init__ needs yacs (absent here); paths_catalog.py itself only imports os / copy
+    spec = importlib.util.spec_from_file_location("ref_paths_catalog",
+                                                  os.path.join(REF, "maskrcnn_benchmark/config/paths_catalog.py"))
+    catalog_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(catalog_mod)
+    ModelCatalog = catalog_mod.ModelCatalog
+    from maskrcnn_benchmark.utils import c2_model_loading as c2
+
+    names = [n for n in c2_blob_names() if n not in ("pred_w", "pred_b")]  # pred_* and fc1000_* collide in one file
+    mapped = c2._rename_weights_for_resnet({n: np.zeros(1, np.float32) for n in names}, c2._C2_STAGE_NAMES["R-50"])
+    # the function returns an OrderedDict in sorted-original-key order without the momentum blobs
+    kept = [n for n in sorted(names) if "_momentum" not in n]
+    pairs = dict(zip(kept, mapped.keys()))
+    alt = c2._rename_weights_for_resnet({"pred_w": np.zeros(1, np.float32), "pred_b": np.zeros(1, np.float32)},
+                                        c2._C2_STAGE_NAMES["R-50"])
+    pairs.update(dict(zip(["pred_b", "pred_w"], alt.keys())))
+    catalog = {n: ModelCatalog.get(n) for n in ("ImageNetPretrained/MSRA/R-50", "ImageNetPretrained/MSRA/R-101",
+                                                "ImageNetPretrained/FAIR/20171220/X-101-32x8d",
+                                                "Caffe2Detectron/COCO/35858791/e2e_mask_rcnn_R-50-C4_1x",
+                                                "Caffe2Detectron/COCO/37697547/e2e_keypoint_rcnn_R-50-FPN_1x")}
+    with open(os.path.join(HERE, "c2_names.json"), "w") as f:
+        json.dump({"names": pairs, "momentum": [n for n in names if "_momentum" in n], "catalog": catalog}, f, indent=1,
+                  sort_keys=True)
+
+
 def main():
     torch.set_num_threads(1)
     ref_c = import_reference()
@@ -293,6 +343,7 @@ def main():
     gen_nms(ref_c)
     gen_focal()
     gen_heads()
+    gen_c2_names()
     print("fixtures written to", HERE)
 
 

@@ -325,8 +325,8 @@ def test_checkpoint_suffix_alignment_and_roundtrip(tmp_path):
     assert extra == {"iteration": 7}
     for k, v in fresh.state_dict().items():
         assert torch.equal(v, sd[k]), k
-    with pytest.raises(NotImplementedError):
-        ck._load_file("catalog://ImageNetPretrained/MSRA/R-50")
+    with pytest.raises(RuntimeError, match="not present in the catalog"):  # other sources: utils/weight_sources.py
+        ck._load_file("catalog://ImageNetPretrained/MSRA/R-18")
 
 
 def test_masker_batched_host_read_equals_per_mask_paste():
@@ -419,3 +419,97 @@ def test_total_loss_is_the_sum_of_the_terms():
     assert float(t) == 3.25
     t.backward()
     assert all(float(v.grad) == 1.0 for v in terms.values() if torch.is_tensor(v))
+
+
+def test_c2_names_catalog_and_cache_paths_match_reference(golden_dir, tmp_path, monkeypatch):
+    """utils/weight_sources.py against name pairs / URLs produced by the reference's own functions
+    (tests/golden/c2_names.json, written by make_golden.py::gen_c2_names): every blob of an R-50-C4 Detectron / ImageNet
+    checkpoint, the momentum blobs dropped, catalog names, and cache_url's file naming (model_zoo.py:40-48)."""
+    import json
+
+    from cvpr22_cross_modal_pseudo_labeling_amd.utils import weight_sources as ws
+
+    with open(os.path.join(golden_dir, "c2_names.json")) as f:
+        gold = json.load(f)
+    assert len(gold["names"]) >= 170
+    for blob, want in gold["names"].items():
+        assert ws.c2_name_to_torch(blob) == want, blob
+    assert all(ws.c2_name_to_torch(b) is None for b in gold["momentum"])
+    with pytest.raises(RuntimeError):
+        ws.c2_name_to_torch("fpn_inner_res5_2_sum_lateral_w")
+    for name, url in gold["catalog"].items():
+        assert ws.catalog_url(name) == url
+    with pytest.raises(RuntimeError):
+        ws.catalog_url("ImageNetPretrained/MSRA/R-18")
+    monkeypatch.setenv("TORCH_MODEL_ZOO", str(tmp_path))
+    assert ws.cache_path(gold["catalog"]["ImageNetPretrained/MSRA/R-50"]) == str(tmp_path / "R-50.pkl")
+    det = ws.cache_path(gold["catalog"]["Caffe2Detectron/COCO/35858791/e2e_mask_rcnn_R-50-C4_1x"])
+    assert os.path.dirname(det) == str(tmp_path) and os.path.basename(det).startswith("_detectron_35858791_12_2017_baselines_")
+    assert det.endswith("_generalized_rcnn_model_final.pkl")
+
+
+def test_detectron_checkpointer_loads_c2_pickle_and_catalog_names(tmp_path, monkeypatch):
+    """A Caffe2-format pickle (``blobs`` of numpy arrays under C2 names, incl. momentum blobs) of the ResNet-C4 trunk +
+    res5 head round-trips into the model through ``DetectronCheckpointer`` -- by path and by ``catalog://`` name served
+    from the model cache (no network) -- and a missing cache file fails with the path it belongs at."""
+    import pickle
+
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.detector import build_detection_model
+    from cvpr22_cross_modal_pseudo_labeling_amd.utils.checkpoint import DetectronCheckpointer
+
+    cfg = get_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, "configs/coco_cap_det/zeroshot_mask.yaml"))
+    cfg.freeze()
+    torch.manual_seed(7)
+    model = build_detection_model(cfg)
+    inv_branch = {"conv1": "2a", "conv2": "2b", "conv3": "2c", "bn1": "2a_bn", "bn2": "2b_bn", "bn3": "2c_bn"}
+
+    def c2_name(key):  # torch name -> C2 blob name, for the tensors a C2 checkpoint holds
+        p = key.split(".")
+        kind = {"weight": "w", "bias": "b"}.get(p[-1])
+        if kind is None:
+            return None
+        if p[0] == "conv1":
+            return f"conv1_{kind}"
+        if p[0] == "bn1":
+            return f"res_conv1_bn_{'s' if kind == 'w' else 'b'}"
+        if p[0].startswith("layer"):
+            stage, block, mod = int(p[0][5:]) + 1, p[1], p[2]
+            if mod == "downsample":
+                bn = p[3] == "1"
+                return f"res{stage}_{block}_branch1{'_bn' if bn else ''}_{('s' if kind == 'w' else 'b') if bn else kind}"
+            bn = mod.startswith("bn")
+            return f"res{stage}_{block}_branch{inv_branch[mod]}_{('s' if kind == 'w' else 'b') if bn else kind}"
+        return None
+
+    blobs, expect = {}, {}
+    g = torch.Generator().manual_seed(1)
+    for scope, prefix in ((model.backbone.body, "backbone.body."), (model.roi_heads["box"].feature_extractor.head,
+                                                                     "roi_heads.box.feature_extractor.head.")):
+        for key, t in scope.state_dict().items():
+            key = key.replace("stem.", "")
+            blob = c2_name(key)
+            if blob is None or not torch.is_floating_point(t):
+                continue
+            v = torch.randn(t.shape, generator=g)
+            blobs[blob] = v.numpy()
+            expect[prefix + ("stem." if key.split(".")[0] in ("conv1", "bn1") else "") + key] = v
+    blobs["conv1_w_momentum"] = np.zeros(3, np.float32)
+    assert len(blobs) > 150
+    path = tmp_path / "R-50.pkl"
+    with open(path, "wb") as f:
+        pickle.dump({"blobs": blobs}, f)
+
+    def check(m):
+        sd = m.state_dict()
+        for k, v in expect.items():
+            assert torch.equal(sd[k], v), k
+
+    DetectronCheckpointer(cfg, model).load(str(path))
+    check(model)
+    monkeypatch.setenv("TORCH_MODEL_ZOO", str(tmp_path))
+    model2 = build_detection_model(cfg)
+    DetectronCheckpointer(cfg, model2).load("catalog://ImageNetPretrained/MSRA/R-50")
+    check(model2)
+    with pytest.raises(RuntimeError, match="R-101.pkl"):
+        DetectronCheckpointer(cfg, model2).load("catalog://ImageNetPretrained/MSRA/R-101")
