@@ -1030,6 +1030,9 @@ def _gemm_raw(a_ptr, a_rs, a_ks, b_ptr, b_rs, b_ks, c_ptr, c_rs, m, n, k, bias_p
     _lib.check(rc, "gemm_ex_f32")
 
 
+dcn_implicit = True  # False: the column route (im2col + GEMM) also where the implicit GEMM applies (cross-check in the tests)
+
+
 def _dcn_dims(input, weight, kH, kW, dH, dW, padH, padW, dilH, dilW):
     b, cin, h, w = input.shape
     ho = (h + 2 * padH - (dilH * (kH - 1) + 1)) // dH + 1
@@ -1061,6 +1064,20 @@ def _dcn_forward(input, weight, bias, offset, mask, output, kH, kW, dH, dW, padH
         raise RuntimeError("deform_conv: output must be a contiguous [B, C_out, H_out, W_out] tensor")
     K, plane = kH * kW, ho * wo
     cin_g, cout_g = cin // group, cout // group
+    if dcn_implicit and group == 1 and (cin // dg) % 32 == 0 and cout % 4 == 0 and b * plane > 0:
+        # no column buffer: one implicit GEMM on the pair-layout split GEMM, the A tiles sampled in the kernel
+        x_nhwc = input.permute(0, 2, 3, 1).contiguous()
+        wp, _ = weight_prep_pair(weight, None)
+        rows = torch.empty((b * plane, cout), dtype=torch.float32, device=input.device)
+        with _on(input.device):
+            rc = _L.ovis_deform_conv_implicit_f32(x_nhwc.data_ptr(), offset.data_ptr(),
+                                                  0 if mask is None else mask.data_ptr(), wp.data_ptr(), 2 * wp.stride(0),
+                                                  0 if bias is None else _dev(bias, "bias").data_ptr(), rows.data_ptr(),
+                                                  cout, b, cin, h, w, cout, ho, wo, kH, kW, dH, dW, padH, padW, dilH, dilW,
+                                                  dg, _stream())
+        _lib.check(rc, "deform_conv_implicit")
+        output.copy_(rows.view(b, ho, wo, cout).permute(0, 3, 1, 2))
+        return 1
     step = max(1, min(step, b))
     col = torch.empty((cin * K, step, plane), dtype=torch.float32, device=input.device)
     with _on(input.device):

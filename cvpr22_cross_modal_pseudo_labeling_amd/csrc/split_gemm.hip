@@ -50,7 +50,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ char g_zero_line[128];  // zero-initialised: the line an out-of-map tap reads
 
-enum { PLAIN = 0, SHIFTED = 1, HALO = 2 };
+enum { PLAIN = 0, SHIFTED = 1, HALO = 2, DEFORM = 3 };
 constexpr int kHalo = 8;  // rows staged on either side of a HALO tile
 
 struct SplitGemmArgs {
@@ -66,6 +66,10 @@ struct SplitGemmArgs {
   float* slab;                       // split-K: raw partial sums [kslices][M][N] (then C / Cp / bias / ... are unused here)
   long M; int N; int ch; int ch2; int T; int H; int W; int KH; int KW; int flip; int relu; int gw;
   int kslices; int steps_per_slice;  // k-steps (PLAIN / SHIFTED) or channel blocks (HALO) per slice
+  // DEFORM (deformable convolution as an implicit GEMM, no column buffer): A is produced by bilinear sampling of an
+  // NHWC fp32 image [B, H, W, ch] at (ho * stride - pad + ky * dil + offset) instead of being read; rows = B * Ho * Wo
+  const float* dimg; const float* doff; const float* dmask;  // offsets [B, dg*2*T, Ho, Wo], mask [B, dg*T, Ho, Wo] or null
+  int Ho; int Wo; int sh; int sw; int ph; int pw; int dlh; int dlw; int dg;
 };
 
 __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
@@ -269,6 +273,80 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
     }
   };
 
+  // ---- DEFORM: the A tile of a k-step = (tap, 32-channel block) is SAMPLED, not loaded: the deformable-convolution
+  // sample of modulated / plain DCN (deform_conv_kernel_cuda.cu:198-250, 578-644: bilinear with zero padding, the four
+  // terms in the reference's order, times the mask) is split into bf16 hi / lo and written where the LDS-DMA of the
+  // other modes would have put it.  The cells of step kb + 1 are fetched into registers under the MFMAs of step kb.
+  // Thread t of the 256 samples rows (t >> 3) + 32 j, j < 4, and the four channels 4 (t & 7) .. + 3 of the 32-channel
+  // block: eight neighbouring lanes read one whole 128-byte line of a cell (a lane owning 16 channels of one row had
+  // every load instruction touch 32 different lines for 32 bytes each, and the kernel sat on the texture-address rate).
+  // Per-(tap, deformable group) state of the thread's four rows, recomputed only when the tap or the group changes (a
+  // tap spans ch / 32 k-steps): bilinear weights, element offsets of the four cells (-1: outside the image) and mask.
+  constexpr int DR = MODE == DEFORM ? 4 : 1;
+  float d_w[DR][4], d_mask[DR];
+  int d_o[DR][4];
+  int d_tap = -1, d_grp = -1;
+  f32x4 d_v[DR][4];  // [row][cell]: the 4 channels of the k-step fetched ahead
+  auto deform_fetch = [&](int tap, int cb) {
+    if constexpr (MODE == DEFORM) {
+      const int prow0 = threadIdx.x >> 3, pch = (threadIdx.x & 7) * 4;
+      const int grp = (cb * 32) / (p.ch / p.dg);
+      if (tap != d_tap || grp != d_grp) {  // wave-uniform
+        d_tap = tap;
+        d_grp = grp;
+        const long plane_o = (long)p.Ho * p.Wo;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gm = clamp_row((int)m0 + prow0 + 32 * j);
+          const int wo = gm % p.Wo, t1 = gm / p.Wo;
+          const int ho = t1 % p.Ho, bimg = t1 / p.Ho;
+          const long pix = (long)ho * p.Wo + wo;
+          const float* off = p.doff + (((long)bimg * p.dg + grp) * 2 * p.T + 2 * tap) * plane_o + pix;
+          const float h = (float)(ho * p.sh - p.ph + ky * p.dlh) + off[0];
+          const float w = (float)(wo * p.sw - p.pw + kx * p.dlw) + off[plane_o];
+          d_o[j][0] = d_o[j][1] = d_o[j][2] = d_o[j][3] = -1;
+          d_w[j][0] = d_w[j][1] = d_w[j][2] = d_w[j][3] = 0.f;
+          if (h > -1.f && w > -1.f && h < (float)p.H && w < (float)p.W) {
+            const int hl = (int)floorf(h), wl = (int)floorf(w);
+            const int hh = hl + 1, wh = wl + 1;
+            const float lh = h - hl, lw = w - wl, uh = 1.f - lh, uw = 1.f - lw;
+            d_w[j][0] = uh * uw; d_w[j][1] = uh * lw; d_w[j][2] = lh * uw; d_w[j][3] = lh * lw;
+            const int img = bimg * p.H * p.W;  // the image has fewer than 2^31 elements (checked by the launcher)
+            if (hl >= 0 && wl >= 0) d_o[j][0] = (img + hl * p.W + wl) * p.ch;
+            if (hl >= 0 && wh <= p.W - 1) d_o[j][1] = (img + hl * p.W + wh) * p.ch;
+            if (hh <= p.H - 1 && wl >= 0) d_o[j][2] = (img + hh * p.W + wl) * p.ch;
+            if (hh <= p.H - 1 && wh <= p.W - 1) d_o[j][3] = (img + hh * p.W + wh) * p.ch;
+          }
+          d_mask[j] = p.dmask ? p.dmask[(((long)bimg * p.dg + grp) * p.T + tap) * plane_o + pix] : 1.f;
+        }
+      }
+      const float* base = p.dimg + cb * 32 + pch;
+      const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d_v[j][c] = d_o[j][c] >= 0 ? *(const f32x4*)(base + d_o[j][c]) : z;
+    }
+  };
+  // bilinear combination (the reference's four-term order), mask, bf16 hi / lo split and the LDS writes of the fetched step
+  auto deform_commit = [&]() {
+    if constexpr (MODE == DEFORM) {
+      const int prow0 = threadIdx.x >> 3, chunk = (threadIdx.x & 7) >> 1, sub = (threadIdx.x & 1) * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v = d_w[j][0] * d_v[j][0] + d_w[j][1] * d_v[j][1] + d_w[j][2] * d_v[j][2] + d_w[j][3] * d_v[j][3];
+        if (p.dmask) v *= d_mask[j];
+        const unsigned h0 = pack_bf16(v.x, v.y), h1 = pack_bf16(v.z, v.w);
+        const unsigned l0 = pack_bf16(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u));
+        const unsigned l1 = pack_bf16(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u));
+        const int prow = prow0 + 32 * j, sw = (prow >> 1) & 7;
+        *(uint2*)(smem + prow * 128 + ((chunk ^ sw) << 4) + sub) = make_uint2(h0, h1);
+        *(uint2*)(smem + prow * 128 + (((4 + chunk) ^ sw) << 4) + sub) = make_uint2(l0, l1);
+      }
+    }
+  };
+
   // ---- fragment read addresses.  Fragment f of a wave covers tile rows .. + f*16 + frow: the swizzle term
   // ((row >> 1) & 7) does not depend on f, so the four fragments of an operand sit 2048 bytes apart. ----
   const int wm = wave / WN, wn = wave % WN;
@@ -365,14 +443,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
     const int kb0 = slice * p.steps_per_slice;
     int kb1 = kb0 + p.steps_per_slice;
     if (kb1 > nk) kb1 = nk;
-    int ld_tap = 0, ld_cb = kb0;       // (tap, channel block) of the next stage to load (SHIFTED)
-    if (MODE == SHIFTED) {
+    int ld_tap = 0, ld_cb = kb0;       // (tap, channel block) of the next stage to load (SHIFTED / DEFORM)
+    if (MODE == SHIFTED || MODE == DEFORM) {
       ld_tap = kb0 / cpb;
       ld_cb = kb0 - ld_tap * cpb;
       set_tap(ld_tap);
     }
     auto issue = [&](int stage, int kb, const LaneGeom& g) {
-      if (MODE == SHIFTED) {
+      if (MODE == DEFORM) {
+        // the A tile is written by deform_commit (its operands were fetched a k-step ahead): only B is loaded here
+      } else if (MODE == SHIFTED) {
         issue_a_shifted(stage, ld_cb, g);
         if (++ld_cb == cpb) {
           ld_cb = 0;
@@ -383,7 +463,25 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
       }
       issue_b(stage, kb, g);
     };
-    if (NS == 1) {
+    if (MODE == DEFORM) {
+      // sampled A tile: the cell loads of step kb + 1 are in flight under the MFMAs of step kb
+      auto advance = [&]() {
+        if (++ld_cb == cpb) {
+          ld_cb = 0;
+          ++ld_tap;
+        }
+      };
+      if (kb0 < kb1) deform_fetch(ld_tap, ld_cb);
+      for (int kb = kb0; kb < kb1; ++kb) {
+        issue(0, kb, lane_geom(lane));  // the weight tile's DMA first: it lands under the sampling arithmetic
+        deform_commit();
+        __syncthreads();
+        advance();
+        if (kb + 1 < kb1) deform_fetch(ld_tap, ld_cb);
+        compute_static(smem);
+        __syncthreads();
+      }
+    } else if (NS == 1) {
       for (int kb = kb0; kb < kb1; ++kb) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
@@ -1334,4 +1432,50 @@ extern "C" int ovis_split_gemm_pair_rp_gated(const void* a_pair, long a_row_byte
   return split_gemm_pair_impl(a_pair, a_row_bytes, nullptr, 0, b_pair, b_row_bytes, c, ldc, c_pair, c_pair_row_bytes,
                               nullptr, nullptr, 0, residual_pair, residual_pair_row_bytes, gate_pair, gate_row_bytes, m, n,
                               channels, 0, 1, 1, 0, 0, 0, 0, nullptr, 0, config | 8, stream);
+}
+
+// Deformable convolution (v1 / modulated v2) forward as ONE implicit GEMM: rows = output pixels, K = (tap, channel), the
+// A tile of every k-step sampled in the kernel (split_gemm_kernel<.., DEFORM, ..>) -- no column buffer.
+// See include/ovis_hip.h.
+extern "C" int ovis_deform_conv_implicit_f32(const float* input_nhwc, const float* offset, const float* mask,
+                                             const void* weight_pair, long weight_row_bytes, const float* bias,
+                                             float* output, long ldc, int batch, int channels, int height, int width,
+                                             int out_channels, int out_h, int out_w, int kernel_h, int kernel_w,
+                                             int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                                             int deformable_group, void* stream) {
+  if (batch < 0 || channels <= 0 || height <= 0 || width <= 0 || out_channels <= 0 || out_h <= 0 || out_w <= 0 ||
+      kernel_h <= 0 || kernel_w <= 0 || stride_h <= 0 || stride_w <= 0 || dil_h <= 0 || dil_w <= 0 || deformable_group <= 0)
+    return OVIS_EINVAL;
+  const long m = (long)batch * out_h * out_w;
+  if (m == 0) return OVIS_OK;
+  if (!input_nhwc || !offset || !weight_pair || !output) return OVIS_EINVAL;
+  if ((long)batch * height * width * channels > 0x7fffffffL) return OVIS_ERANGE;
+  if (channels % deformable_group != 0 || (channels / deformable_group) % 32 != 0 || out_channels % 4 != 0 || ldc % 4 != 0 ||
+      weight_row_bytes % 16 != 0 || m > 0x7fffff00L || ((uintptr_t)input_nhwc & 15) || ((uintptr_t)weight_pair & 15) ||
+      ((uintptr_t)output & 15) || ((uintptr_t)bias & 15))
+    return OVIS_ERANGE;
+  SplitGemmArgs p = {};
+  p.B = (const char*)weight_pair; p.b_rs = weight_row_bytes;
+  p.C = output; p.ldc = ldc; p.bias = bias;
+  p.M = m; p.N = out_channels; p.ch = channels; p.ch2 = 0; p.T = kernel_h * kernel_w; p.H = height; p.W = width;
+  p.KH = kernel_h; p.KW = kernel_w; p.flip = 0; p.relu = 0;
+  p.kslices = 1; p.steps_per_slice = p.T * (channels / 32);
+  p.dimg = input_nhwc; p.doff = offset; p.dmask = mask;
+  p.Ho = out_h; p.Wo = out_w; p.sh = stride_h; p.sw = stride_w; p.ph = pad_h; p.pw = pad_w; p.dlh = dil_h; p.dlw = dil_w;
+  p.dg = deformable_group;
+  const int tiles_m = (int)((m + 127) / 128), tiles_n = (out_channels + 127) / 128;
+  p.gw = (tiles_n % 4 == 0) ? 4 : tiles_n;
+  const long ntiles = (long)tiles_m * tiles_n;
+  if (ntiles > 0x7fffffffL) return OVIS_ERANGE;
+  constexpr int lds = 128 * 128 + 128 * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<2, 2, DEFORM, 1, 2>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((split_gemm_kernel<2, 2, DEFORM, 1, 2>), dim3((unsigned)ntiles), dim3(256), lds, (hipStream_t)stream, p,
+                     tiles_n, (int)ntiles);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
 }

@@ -534,6 +534,21 @@ int ovis_deform_col2im_coord_f32(const float* columns, const float* input, const
                                  int kernel_w, int pad_h, int pad_w, int stride_h, int stride_w,
                                  int dilation_h, int dilation_w, int deformable_group, void* stream);
 
+/* Deformable convolution forward WITHOUT the column buffer (mb/csrc/cuda/deform_conv_cuda.cu:161-260, :491-560;
+ * sampling: deform_conv_kernel_cuda.cu:198-250, 578-644): one implicit GEMM over rows = output pixels (batch, out_h,
+ * out_w) and K = (tap, channel) on the pair-layout split GEMM of the res5 head -- the A tile of every k-step is bilinear-
+ * sampled in the kernel (zero padding, the reference's four-term order, times the mask when given) from input_nhwc
+ * [batch, height, width, channels] fp32, split into bf16 hi / lo and multiplied with weight_pair [out_channels,
+ * taps * channels] (tap-major pair rows: ovis_weight_prep_pair_f32).  offset [batch, dg*2*taps, out_h, out_w], mask
+ * [batch, dg*taps, out_h, out_w] or NULL (v1), bias [out_channels] or NULL; output [batch*out_h*out_w, out_channels]
+ * fp32 rows (NHWC), row stride ldc.  Convolution groups = 1; (channels / deformable_group) % 32 == 0,
+ * out_channels % 4 == 0 (else OVIS_ERANGE: use the column route). */
+int ovis_deform_conv_implicit_f32(const float* input_nhwc, const float* offset, const float* mask,
+                                  const void* weight_pair, long weight_row_bytes, const float* bias, float* output,
+                                  long ldc, int batch, int channels, int height, int width, int out_channels, int out_h,
+                                  int out_w, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h,
+                                  int pad_w, int dil_h, int dil_w, int deformable_group, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,57 @@ def test_deform_conv_v1_v2_vs_oracle(kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(C=64, Cout=12), dict(C=64, Cout=64, dg=2, stride=2, pad=2, dil=2),
+                                dict(B=3, C=96, Cout=8, H=7, W=6, k=1, pad=0, dg=3), dict(B=1, C=32, Cout=132, H=21, W=19)])
+def test_deform_conv_forward_without_column_buffer_vs_oracle(kw):
+    """Channel counts the implicit-GEMM route takes ((C / deformable_group) % 32 == 0): forward of v1 and modulated v2 with
+    the A tiles sampled inside the split GEMM kernel -- against the fp64 oracle within the three-term split product's
+    3e-5 of the maximum, and against the column route (im2col + fp32 GEMM) of the same call; the backward (column route
+    either way) against the oracle as in the test above."""
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers import deform_conv, modulated_deform_conv
+
+    g = torch.Generator().manual_seed(7)
+    x, w, off, mask, bias = _case(g, **kw)
+    st, pd, dl = (kw.get("stride", 1),) * 2, (kw.get("pad", 1),) * 2, (kw.get("dil", 1),) * 2
+    dg = kw.get("dg", 1)
+    calls = []
+    orig = _C._L.ovis_deform_conv_implicit_f32
+    for modulated in (False, True):
+        xr, wr, orr = x.clone().requires_grad_(True), w.clone().requires_grad_(True), off.clone().requires_grad_(True)
+        want = O.deform_conv2d(xr, orr, wr, mask if modulated else None, bias if modulated else None, st, pd, dl, 1, dg)
+        go = torch.randn(want.shape, generator=g, dtype=torch.float64)
+        want.backward(go)
+
+        def run():
+            xd, wd, od = (t.detach().float().cuda().requires_grad_(True) for t in (x, w, off))
+            if modulated:
+                y = modulated_deform_conv(xd, od, mask.float().cuda(), wd, bias.float().cuda(), st, pd, dl, 1, dg)
+            else:
+                y = deform_conv(xd, od, wd, st, pd, dl, 1, dg, 1)
+            y.backward(go.float().cuda())
+            return y.detach().cpu().double(), [t.grad.cpu().double() for t in (xd, wd, od)]
+
+        n0 = len(calls)
+        _C._L.ovis_deform_conv_implicit_f32 = lambda *a: (calls.append(1), orig(*a))[1]
+        try:
+            got, grads = run()
+        finally:
+            _C._L.ovis_deform_conv_implicit_f32 = orig
+        assert len(calls) == n0 + 1  # the forward really took the implicit route
+        _C.dcn_implicit = False
+        try:
+            col, _ = run()
+        finally:
+            _C.dcn_implicit = True
+        scale = want.abs().max().item()
+        assert (got - want.detach()).abs().max().item() <= 3e-5 * scale
+        assert (got - col).abs().max().item() <= 3e-5 * scale
+        for dev_g, ref_t in zip(grads, (xr, wr, orr)):
+            assert (dev_g - ref_t.grad).abs().max().item() <= 2e-5 * (ref_t.grad.abs().max().item() + 1e-12)
+
+
+@pytest.mark.gpu
 def test_dcn_modules_and_dfconv():
     from cvpr22_cross_modal_pseudo_labeling_amd.layers import DFConv2d, ModulatedDeformConvPack
 

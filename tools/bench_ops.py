@@ -196,6 +196,12 @@ def main():
         off = (torch.randn(2, 18, 100, 168, generator=g) * 2).to(dev)
         ms = timeit(lambda: deform_conv(x, off, w, 1, 1, 1, 1, 1, 2), max(3, args.iters // 4))
         fl = 2.0 * 512 * 512 * 9 * 2 * 100 * 168
+        from cvpr22_cross_modal_pseudo_labeling_amd import _C as _ops
+        _ops.dcn_implicit = False
+        ms_col = timeit(lambda: deform_conv(x, off, w, 1, 1, 1, 1, 1, 2), max(3, args.iters // 4))
+        _ops.dcn_implicit = True
+        res.append({"op": "deform_conv_forward (column route: im2col + fp32 GEMM)", "shape": "[2,512,100,168] 3x3 -> 512",
+                    "ms": ms_col, "TFLOPs": fl / ms_col / 1e9})
         res.append({"op": "deform_conv_forward", "shape": "[2,512,100,168] 3x3 -> 512", "ms": ms, "TFLOPs": fl / ms / 1e9,
                     "frac_fp32_mfma_peak": fl / ms / 1e9 / 157.3, "col_MB": 4 * 512 * 9 * 2 * 100 * 168 / 1e6})
     for r_ in res:
