@@ -77,10 +77,11 @@ class GradLink:
     placeholder, as the activation was in the forward.  The block below takes it (once) instead of gating and
     splitting an fp32 gradient."""
 
-    __slots__ = ("grad_pair",)
+    __slots__ = ("grad_pair", "claimed")
 
     def __init__(self):
         self.grad_pair = None
+        self.claimed = False  # a pair-only output feeds exactly ONE block (its fp32 handle is a placeholder)
 
 
 class _BottleneckPair(Function):
@@ -208,6 +209,11 @@ def bottleneck_pair(x, xp, geom, w1, b1, w2, b2, w3, b3, wd=None, want_pair=Fals
     s1, s2, s3, sd = scales
     pair_only = want_pair and not want_f32 and not pool
     link_in = getattr(xp, "_ovis_grad_link", None) if (xp is not None and (x is None or is_placeholder(x))) else None
+    if link_in is not None and torch.is_grad_enabled():
+        if link_in.claimed:
+            raise RuntimeError("bottleneck_pair: a block output kept in pair layout only can feed one block -- its fp32 "
+                               "handle is a placeholder, so the gradients of two consumers could not be summed")
+        link_in.claimed = True
     link_out = GradLink() if pair_only else None
     out, outp, pooled = _BottleneckPair.apply(x, xp, geom, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, want_pair, wpairs,
                                               pool, want_f32, link_in, link_out)

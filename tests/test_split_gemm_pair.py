@@ -349,6 +349,25 @@ def test_bottleneck_chain_pair_only_vs_fp32_chain(train):
         assert (a - b).norm().item() <= 5e-3 * b.norm().item() + 1e-12
 
 
+def test_pair_only_output_feeds_exactly_one_block():
+    """A block output kept in pair layout only has a placeholder as its fp32 handle: a second consumer's gradient could
+    not be summed into it, so the second ``bottleneck_pair`` on the same pair tensor is refused (loudly, in the forward)."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.backbone import ResNetHead
+    cfg = get_defaults()
+    cfg.freeze()
+    torch.manual_seed(3)
+    head = ResNetHead(cfg).cuda()
+    b0, b1 = head.layer4[0], head.layer4[1]
+    x = torch.randn(4, 7, 7, 1024, device="cuda", requires_grad=True)
+    mid, midp = b0.forward_nhwc(x, prestrided=True, want_pair=True)
+    b1.forward_nhwc(mid, xp=midp)
+    with pytest.raises(RuntimeError, match="can feed one block"):
+        b1.forward_nhwc(mid, xp=midp)
+    with torch.no_grad():  # without autograd nothing has to be summed: allowed
+        b1.forward_nhwc(mid, xp=midp)
+
+
 def test_stem_gemm_matches_convolution():
     """7x7 / stride-2 stem as im2col-pair + split GEMM (+ folded FrozenBN, ReLU, max-pool) vs the fp64 convolution."""
     from cvpr22_cross_modal_pseudo_labeling_amd.modeling.backbone import Stem
