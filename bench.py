@@ -100,10 +100,11 @@ class OpTimer:
         def split_pair_bytes(x):
             return 8 * x.numel()  # 4 B read + hi + lo written
 
-        def gate_split_bytes(dy, gate=None, want_f32=False, pooled=None, pool_rows=0):
+        def gate_split_bytes(dy, gate=None, want_f32=False, pooled=None, pool_rows=0, selected=None, group_slot=None):
             n = dy.numel() if dy is not None else pooled.numel() * pool_rows
             per = (4 if dy is not None else 0) + 4 + (0 if gate is None else (2 if gate.dtype == torch.bfloat16 else 4))
-            return (per + (4 if want_f32 else 0)) * n + (0 if pooled is None else 4 * pooled.numel())
+            return ((per + (4 if want_f32 else 0)) * n + (0 if pooled is None else 4 * pooled.numel())
+                    + (0 if selected is None else 4 * selected.numel() + 4 * group_slot.numel()))
 
         def split_gemm_flops(a_pair, b_pair, *args, **kwargs):
             return 6.0 * a_pair.shape[0] * b_pair.shape[0] * (b_pair.shape[1] // 2)  # 3 products x 2*M*N*K

@@ -659,13 +659,17 @@ def split_pair(x):
     return out
 
 
-def gate_split_pair(dy, gate=None, want_f32=False, pooled=None, pool_rows=0):
+def gate_split_pair(dy, gate=None, want_f32=False, pooled=None, pool_rows=0, selected=None, group_slot=None):
     """g = (dy + pooled[row // pool_rows] / pool_rows) * (y > 0) in pair layout (and as fp32 when ``want_f32``); gate =
     y as fp32 [rows, cols] or as its pair form [rows, 2*cols] bf16 (contiguous), None = no gate; ``pooled`` = the
     gradient of a mean over every ``pool_rows`` consecutive rows ([rows / pool_rows, cols] f32) or None; ``dy`` may be
-    None when ``pooled`` is given.  Returns (g_pair, g_f32 or None)."""
+    None when ``pooled`` is given.  ``selected`` [S * pool_rows, cols] f32 with ``group_slot`` [rows / pool_rows] int32
+    (index into ``selected`` of a group of pool_rows rows, -1 = none): the gradient of a gather of whole row groups, added
+    on the fly instead of being scattered into a zero tensor first.  Returns (g_pair, g_f32 or None)."""
     if dy is None and pooled is None:
         raise RuntimeError("gate_split_pair: dy or pooled must be given")
+    if (selected is None) != (group_slot is None):
+        raise RuntimeError("gate_split_pair: selected and group_slot are given together")
     if pooled is not None:
         if not (pooled.is_cuda and pooled.dtype == torch.float32 and pooled.dim() == 2):
             raise RuntimeError("gate_split_pair: pooled must be a 2-D float32 HIP tensor")
@@ -691,11 +695,18 @@ def gate_split_pair(dy, gate=None, want_f32=False, pooled=None, pool_rows=0):
     g32 = torch.empty((rows, cols), dtype=torch.float32, device=dev) if want_f32 else None
     if out.numel() == 0:
         return out, g32
+    if selected is not None:
+        selected, group_slot = _dev(selected, "selected"), _dev(group_slot, "group_slot", torch.int32)
+        if pool_rows <= 0 or rows % pool_rows or selected.dim() != 2 or selected.shape[1] != cols or \
+                selected.shape[0] % pool_rows or group_slot.numel() != rows // pool_rows:
+            raise RuntimeError("gate_split_pair: selected must be [S * pool_rows, cols] and group_slot [rows / pool_rows]")
     with _on(dev):
-        rc = _L.ovis_gate_split_pair_f32(0 if dy is None else dy.data_ptr(), 0 if dy is None else dy.stride(0),
-                                         0 if gate is None else gate.data_ptr(), is_pair, out.data_ptr(),
-                                         0 if g32 is None else g32.data_ptr(), rows, cols,
-                                         0 if pooled is None else pooled.data_ptr(), pool_rows, _stream())
+        rc = _L.ovis_gate_split_pair_rows_f32(0 if dy is None else dy.data_ptr(), 0 if dy is None else dy.stride(0),
+                                              0 if gate is None else gate.data_ptr(), is_pair, out.data_ptr(),
+                                              0 if g32 is None else g32.data_ptr(), rows, cols,
+                                              0 if pooled is None else pooled.data_ptr(), pool_rows,
+                                              0 if selected is None else selected.data_ptr(),
+                                              0 if group_slot is None else group_slot.data_ptr(), _stream())
     _lib.check(rc, "gate_split_pair")
     return out, g32
 

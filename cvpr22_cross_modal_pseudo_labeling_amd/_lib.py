@@ -50,6 +50,7 @@ SIGNATURES = {
     "ovis_im2col_split_bf16x3_f32": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "ovis_bias_act_f32": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "ovis_split_pair_f32": (_i, [_vp, _l, _vp, _l, _i, _vp]),
+    "ovis_gate_split_pair_rows_f32": (_i, [_vp, _l, _vp, _i, _vp, _vp, _l, _i, _vp, _i, _vp, _vp, _vp]),
     "ovis_gate_split_pair_f32": (_i, [_vp, _l, _vp, _i, _vp, _vp, _l, _i, _vp, _i, _vp]),
     "ovis_im2col_nchw_pair_f32": (_i, [_vp, _vp] + [_i] * 9 + [_vp]),
     "ovis_weight_prep_pair_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

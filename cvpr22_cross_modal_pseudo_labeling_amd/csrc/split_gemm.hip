@@ -854,7 +854,8 @@ __global__ __launch_bounds__(256) void gate_split_pair_kernel(const float* __res
                                                              const void* __restrict__ gate, char* __restrict__ dst,
                                                              float* __restrict__ g32, long rows, int cols,
                                                              const float* __restrict__ gpool, int pool_rows,
-                                                             float pool_scale) {
+                                                             float pool_scale, const float* __restrict__ gsel,
+                                                             const int* __restrict__ group_slot) {
   const int oc = cols >> 3;
   const long total = rows * oc;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -875,6 +876,18 @@ __global__ __launch_bounds__(256) void gate_split_pair_kernel(const float* __res
       *(float4*)(q + 4) = *(const float4*)(gp + 4);
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = dy ? v[k] + q[k] * pool_scale : q[k] * pool_scale;
+    }
+    if (gsel) {  // + the gradient of a row gather: groups (of pool_rows rows) that were selected carry their own dense rows
+      const long grp = r / pool_rows;
+      const int slot = group_slot[grp];
+      if (slot >= 0) {
+        const float* gs = gsel + ((long)slot * pool_rows + (r - grp * pool_rows)) * cols + c;
+        float q[8];
+        *(float4*)q = *(const float4*)gs;
+        *(float4*)(q + 4) = *(const float4*)(gs + 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += q[k];
+      }
     }
     const long poff = r * 4L * cols + (long)(c >> 5) * 128 + (c & 31) * 2;
     if (gate) {
@@ -1061,11 +1074,21 @@ extern "C" int ovis_split_pair_f32(const float* src, long src_row_stride, void* 
 extern "C" int ovis_gate_split_pair_f32(const float* dy, long dy_row_stride, const void* gate, int gate_is_pair,
                                         void* dst_pair, float* g_f32, long rows, int cols, const float* g_pooled,
                                         int pool_rows, void* stream) {
+  return ovis_gate_split_pair_rows_f32(dy, dy_row_stride, gate, gate_is_pair, dst_pair, g_f32, rows, cols, g_pooled,
+                                       pool_rows, nullptr, nullptr, stream);
+}
+
+extern "C" int ovis_gate_split_pair_rows_f32(const float* dy, long dy_row_stride, const void* gate, int gate_is_pair,
+                                             void* dst_pair, float* g_f32, long rows, int cols, const float* g_pooled,
+                                             int pool_rows, const float* g_selected, const int32_t* group_slot,
+                                             void* stream) {
   if (rows < 0 || cols < 0) return OVIS_EINVAL;
   if (rows == 0 || cols == 0) return OVIS_OK;
-  if ((!dy && !g_pooled) || !dst_pair || (g_pooled && (pool_rows <= 0 || rows % pool_rows != 0))) return OVIS_EINVAL;
+  if ((!dy && !g_pooled && !g_selected) || !dst_pair || ((g_pooled || g_selected) && (pool_rows <= 0 || rows % pool_rows != 0)) ||
+      ((g_selected != nullptr) != (group_slot != nullptr)))
+    return OVIS_EINVAL;
   if (cols % 32 != 0 || dy_row_stride % 4 != 0 || ((uintptr_t)dy & 15) || ((uintptr_t)dst_pair & 15) ||
-      ((uintptr_t)gate & 15) || ((uintptr_t)g_f32 & 15) || ((uintptr_t)g_pooled & 15))
+      ((uintptr_t)gate & 15) || ((uintptr_t)g_f32 & 15) || ((uintptr_t)g_pooled & 15) || ((uintptr_t)g_selected & 15))
     return OVIS_ERANGE;
   const float pool_scale = g_pooled ? 1.f / (float)pool_rows : 0.f;
   const long total = rows * (cols / 8);
@@ -1074,7 +1097,7 @@ extern "C" int ovis_gate_split_pair_f32(const float* dy, long dy_row_stride, con
   hipStream_t s = (hipStream_t)stream;
 #define OVIS_GS(GP_, WF_)                                                                                          \
   hipLaunchKernelGGL((gate_split_pair_kernel<GP_, WF_>), dim3(grid), dim3(256), 0, s, dy, dy_row_stride, gate,      \
-                     (char*)dst_pair, g_f32, rows, cols, g_pooled, pool_rows, pool_scale)
+                     (char*)dst_pair, g_f32, rows, cols, g_pooled, pool_rows, pool_scale, g_selected, group_slot)
   if (gate_is_pair) { if (g_f32) OVIS_GS(true, true); else OVIS_GS(true, false); }
   else { if (g_f32) OVIS_GS(false, true); else OVIS_GS(false, false); }
 #undef OVIS_GS

@@ -87,7 +87,7 @@ class GradLink:
 class _BottleneckPair(Function):
     @staticmethod
     def forward(ctx, x, xp, geom, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, want_pair, wpairs, pool, want_f32=True,
-                link_in=None, link_out=None):
+                link_in=None, link_out=None, select=None):
         """x [M, Cin] f32 rows conv1 reads (may be None when wd is given and no input gradient is wanted), xp its pair
         form or None; geom = (h, w) of the map the rows tile; w1/w2/w3/wd RAW convolution weights (wd None = identity
         shortcut) with their folded FrozenBN scales s1/s2/s3/sd (per output channel, no gradient) and shifts b1/b2,
@@ -130,10 +130,15 @@ class _BottleneckPair(Function):
         # node, so that its gradient is broadcast inside the fused gate + split kernel of the backward instead of
         # being materialised ([rows, C] expand) and added to the dense gradient by two tensor ops
         pooled = out.view(-1, h * w, out.shape[1]).mean(dim=1) if pool else None
+        # select [S] int64: also return the rows of the maps `select` ([S, h*w, C]; what the mask head reads: the res5
+        # features of the positive RoIs) as an output of THIS node, so that their gradient reaches the backward's first
+        # kernel as S dense maps -- an index backward would scatter it into a zero [rows, C] tensor (822 MB written and
+        # read back at the step's size) first
+        out_sel = out.view(-1, h * w, out.shape[1]).index_select(0, select) if (select is not None and f32) else None
         gate_src = out if out is not None else outp  # the last ReLU's gate: the fp32 result or the hi halves of its pair form
         if out is None:
             out = outp.new_empty((1,), dtype=torch.float32).expand(outp.shape[0], outp.shape[1] // 2)
-        ctx.save_for_backward(xp, o1p, o2p, gate_src, w1, w2, w3, wd, s1, s2, s3, sd)
+        ctx.save_for_backward(xp, o1p, o2p, gate_src, w1, w2, w3, wd, s1, s2, s3, sd, select if out_sel is not None else None)
         ctx.wts = wts
         ctx.geom = (h, w, kh, kw)
         # link_in: this block's input exists only in pair layout and comes from a block that reads its gradient from the
@@ -143,18 +148,18 @@ class _BottleneckPair(Function):
         ctx.set_materialize_grads(False)  # no zero tensors for absent / non-differentiable gradient slots
         if outp is not None:
             ctx.mark_non_differentiable(outp)
-        return out, outp, pooled
+        return out, outp, pooled, out_sel
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dout, _dpair, dpooled):
+    def backward(ctx, dout, _dpair, dpooled, dsel):
         link_out, link_in = ctx.link_out, ctx.link_in
         linked = link_out.grad_pair if link_out is not None else None
         if link_out is not None:
             link_out.grad_pair = None
-        if dout is None and dpooled is None and linked is None:
-            return (None,) * 20
-        xp, o1p, o2p, out, w1, w2, w3, wd, s1, s2, s3, sd = ctx.saved_tensors   # out: fp32 result or its pair form (gate)
+        if dout is None and dpooled is None and linked is None and dsel is None:
+            return (None,) * 21
+        xp, o1p, o2p, out, w1, w2, w3, wd, s1, s2, s3, sd, select = ctx.saved_tensors   # out: fp32 result or its pair form (gate)
         h, w, kh, kw = ctx.geom
         need = ctx.needs_input_grad
         need_x, need_w1, need_w2, need_w3, need_wd = need[0], need[3], need[6], need[9], need[12]
@@ -171,8 +176,16 @@ class _BottleneckPair(Function):
         else:
             # gate of the block's last ReLU, fused with the split; the identity shortcut needs the gated gradient too: in
             # fp32, or (linked form) in the pair layout just written
+            sel_grad = slot = None
+            if dsel is not None:
+                if dout is None and dpooled is None:
+                    dpooled = dsel.new_zeros((out.shape[0] // (h * w), n3))
+                slot = torch.full((out.shape[0] // (h * w),), -1, dtype=torch.int32, device=dsel.device)
+                slot[select] = torch.arange(select.numel(), dtype=torch.int32, device=dsel.device)
+                sel_grad = dsel.reshape(-1, n3)
             g3p, g3 = _C.gate_split_pair(None if dout is None else dout.reshape(-1, n3), out,
-                                         want_f32=(wd is None and need_x and not to_link), pooled=dpooled, pool_rows=h * w)
+                                         want_f32=(wd is None and need_x and not to_link), pooled=dpooled, pool_rows=h * w,
+                                         selected=sel_grad, group_slot=slot)
         dw3 = _dw(g3p, o2p, w3, s3) if need_w3 else None
         _, g2p = _C.split_gemm_pair_gated(g3p, t3, o2p)                  # (dY W3) gated by relu(o2), split: one kernel
         dw2 = _dw(g2p, o1p, w2, s2, (h, w, kh, kw)) if need_w2 else None
@@ -198,11 +211,11 @@ class _BottleneckPair(Function):
         if wd is not None and need_wd:
             dwd = _dw(g3p, xp, wd, sd)
         return (dx, None, None, dw1, None, None, dw2, None, None, dw3, None, None, dwd, None, None, None, None, None, None,
-                None)
+                None, None)
 
 
 def bottleneck_pair(x, xp, geom, w1, b1, w2, b2, w3, b3, wd=None, want_pair=False, wpairs=None, pool=False,
-                    scales=(None, None, None, None), want_f32=True):
+                    scales=(None, None, None, None), want_f32=True, select=None):
     """(out f32 [M, Cout], out in pair layout or None[, mean of out over the h*w rows of every map when ``pool``]) of
     one bottleneck on the rows x [M, Cin] of an (h, w) map.  w1/w2/w3/wd are the convolution weights as the model
     stores them; ``scales`` = their folded FrozenBN scales (None = weights already folded)."""
@@ -215,8 +228,10 @@ def bottleneck_pair(x, xp, geom, w1, b1, w2, b2, w3, b3, wd=None, want_pair=Fals
                                "handle is a placeholder, so the gradients of two consumers could not be summed")
         link_in.claimed = True
     link_out = GradLink() if pair_only else None
-    out, outp, pooled = _BottleneckPair.apply(x, xp, geom, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, want_pair, wpairs,
-                                              pool, want_f32, link_in, link_out)
+    out, outp, pooled, out_sel = _BottleneckPair.apply(x, xp, geom, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, want_pair,
+                                                       wpairs, pool, want_f32, link_in, link_out, select)
+    if out_sel is not None:
+        out._ovis_selected = (select, out_sel)  # [S, h*w, C] rows of the maps `select`, an output of the same node
     if link_out is not None and outp is not None:
         outp._ovis_grad_link = link_out  # travels with the pair tensor to the block that consumes it
     return (out, outp, pooled) if pool else (out, outp)

@@ -107,7 +107,7 @@ class Bottleneck(nn.Module):
                                    and d.stride == c1.stride))
                 and (d is not None or (c1.stride == (1, 1) and c1.in_channels == c3.out_channels)))
 
-    def _forward_pair(self, x, prestrided, xp, want_pair, pool=False):
+    def _forward_pair(self, x, prestrided, xp, want_pair, pool=False, select=None):
         """The block as ONE autograd node on the pair-layout split GEMM (layers/pair_bottleneck.py): bias, shortcut,
         ReLU and the next layer's operand split live in the GEMM epilogues, the 3x3 is an implicit GEMM."""
         r, h, w, c = x.shape
@@ -123,7 +123,7 @@ class Bottleneck(nn.Module):
         else:
             hs, ws = h, w
             x2d = x.reshape(-1, c)
-        return self._pair_node(x2d, xp, r, hs, ws, want_pair, pool)
+        return self._pair_node(x2d, xp, r, hs, ws, want_pair, pool, select)
 
     def forward_pair_rows(self, xp, r, hs, ws, want_pair=False, pool=False):
         """The block on rows that exist only in pair layout ([r*hs*ws, 2*Cin] bf16, e.g. written by the pooler): needs
@@ -131,7 +131,7 @@ class Bottleneck(nn.Module):
         assert self._fd is not None
         return self._pair_node(None, xp, r, hs, ws, want_pair, pool)
 
-    def _pair_node(self, x2d, xp, r, hs, ws, want_pair, pool):
+    def _pair_node(self, x2d, xp, r, hs, ws, want_pair, pool, select=None):
         from .. import _C
         # RAW weights + folded FrozenBN (scale, shift) pairs: the fold itself happens inside the node's weight-prep kernel
         w1, w2, w3 = self.conv1.weight, self.conv2.weight, self.conv3.weight
@@ -157,13 +157,16 @@ class Bottleneck(nn.Module):
         else:
             b3s = b3 if bd is None else b3 + bd
         res = bottleneck_pair(x2d, xp, (hs, ws), w1, b1, w2, b2, w3, b3s, wd, want_pair, wpairs, pool,
-                              scales=(s1, s2, s3, sd), want_f32=not (want_pair and self.pair_only_chain))
+                              scales=(s1, s2, s3, sd), want_f32=not (want_pair and self.pair_only_chain), select=select)
         out = res[0].view(r, hs, ws, res[0].shape[-1])
         if pool:
             out._ovis_pooled = res[2]  # [R, C] mean over the map, an output of the same autograd node (see pooled())
+        sel = getattr(res[0], "_ovis_selected", None)
+        if sel is not None:
+            out._ovis_selected = sel
         return (out, res[1]) if want_pair else out
 
-    def forward_nhwc(self, x, prestrided=False, xp=None, want_pair=False, pool=False):
+    def forward_nhwc(self, x, prestrided=False, xp=None, want_pair=False, pool=False, select=None):
         """Same block on an NHWC tensor ``x`` [R, H, W, C] (contiguous); ``prestrided``: x already holds only the
         positions conv1 / the shortcut read (the pooler applied their common stride).  The 1x1 convolutions -- 53 % of the
         res5 FLOPs -- become ONE row-major GEMM over all R*H*W positions each ([R*H*W, Cin] x [Cin, Cout], bias
@@ -174,7 +177,7 @@ class Bottleneck(nn.Module):
         ``xp``: the pair-layout form of x when the producer already wrote it; ``want_pair``: also return the pair
         form of the result (or None) for the next block -- both only used by the pair-layout route."""
         if self.pair_gemm and x.is_cuda and self.pair_supported():
-            return self._forward_pair(x, prestrided, xp, want_pair, pool)
+            return self._forward_pair(x, prestrided, xp, want_pair, pool, select)
         r, h, w, c = x.shape
         sy, sx = self.conv1.stride
         if prestrided:
@@ -399,7 +402,7 @@ class ResNetHead(nn.Module):
         b0 = self.layer4[0]
         return bool(self.pooler_stride()) and b0.pair_gemm and b0.pair_supported() and b0._fd is not None
 
-    def forward_pooled_nhwc(self, y, yp=None, shape=None):
+    def forward_pooled_nhwc(self, y, yp=None, shape=None, select=None):
         """y [R, 7, 7, C]: the pooled bins conv1 reads, NHWC (from ``forward_strided_nhwc``) -> [R, 2048, 7, 7] view;
         or y None and yp the same bins in pair layout with shape = (R, 7, 7) (from ``roi_align_forward_strided_pair``)."""
         for i, b in enumerate(self.layer4):
@@ -408,9 +411,10 @@ class ResNetHead(nn.Module):
             elif i + 1 < len(self.layer4):
                 y, yp = b.forward_nhwc(y, prestrided=(i == 0), xp=yp, want_pair=True)
             else:
-                y = b.forward_nhwc(y, prestrided=(i == 0), xp=yp, pool=True)
+                y = b.forward_nhwc(y, prestrided=(i == 0), xp=yp, pool=True, select=select)
         out = y.permute(0, 3, 1, 2)
-        pooled = getattr(y, "_ovis_pooled", None)
-        if pooled is not None:
-            out._ovis_pooled = pooled
+        for attr in ("_ovis_pooled", "_ovis_selected"):  # outputs of the last block's autograd node, carried on its result
+            v = getattr(y, attr, None)
+            if v is not None:
+                setattr(out, attr, v)
         return out

@@ -71,7 +71,7 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
     def forward(self, x, proposals):
         return self.forward_rois(x, self.pooler.convert_to_roi_format(proposals))
 
-    def forward_rois(self, x, rois):
+    def forward_rois(self, x, rois, select=None):
         """``rois`` [R, 5] = (image index into x[0], x1, y1, x2, y2): the same pass on an explicit RoI tensor (lets a
         caller pool RoIs of several proposal lists / image subsets in one go)."""
         p = self.pooler.pooler
@@ -82,8 +82,8 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
                 # frozen features: the bins go to the first GEMM in pair layout, no fp32 copy / split pass in between
                 ph, pw = p.output_size
                 yp, (oh, ow) = _C.roi_align_forward_strided_pair(x[0], rois, p.spatial_scale, ph, pw, p.sampling_ratio, s)
-                return self.head.forward_pooled_nhwc(None, yp, (rois.shape[0], oh, ow))
-            return self.head.forward_pooled_nhwc(p.forward_strided_nhwc(x[0], rois, s))
+                return self.head.forward_pooled_nhwc(None, yp, (rois.shape[0], oh, ow), select=select)
+            return self.head.forward_pooled_nhwc(p.forward_strided_nhwc(x[0], rois, s), select=select)
         return self.head(p(x[0], rois))
 
 
@@ -761,7 +761,11 @@ class CombinedROIHeads(nn.ModuleDict):
             sampled = box.loss_evaluator.subsample_many([(br["proposals"], br["targets"]) for br in branches])
         rois = _C.rois_from_boxes([p.bbox for props in sampled for p in props],
                                   [img for br in branches for img in br["image_ids"]])  # RoIs of every branch, one launch
-        x = box.feature_extractor.forward_rois([feat], rois)
+        # the mask head reads the res5 features of the positive RoIs only: their indices are known from the sampled lists,
+        # so the last res5 block hands those maps out itself (their gradient then enters its backward as dense maps
+        # instead of being scattered into a zero tensor of all RoIs first)
+        sel_pos = positives_index([p for props in sampled for p in props]) if self.mask_on else None
+        x = box.feature_extractor.forward_rois([feat], rois, select=sel_pos)
         pooled = box.predictor.pooled(x)
         counts = [sum(len(p) for p in props) for props in sampled]
         out, off = [], 0
@@ -774,15 +778,19 @@ class CombinedROIHeads(nn.ModuleDict):
             off += cnt
         if self.mask_on:
             mask = self.mask
-            sel = positives_index([p for props in sampled for p in props])
+            sel = sel_pos
             if sel is not None:
                 pos_all = [[positive_proposals(p) for p in props] for props in sampled]
             else:
                 pos_masks = [[p.get_field("labels") > 0 for p in props] for props in sampled]
                 sel = _cat([m for ms in pos_masks for m in ms], 0)
                 pos_all = [[p[m] for p, m in zip(props, ms)] for props, ms in zip(sampled, pos_masks)]
+            handed = getattr(x, "_ovis_selected", None)
             fl = x.permute(0, 2, 3, 1)
-            xs = fl[sel].permute(0, 3, 1, 2) if (fl.is_contiguous() and not x.is_contiguous()) else x[sel]  # ONE index op
+            if handed is not None and handed[0] is sel:
+                xs = handed[1].view(sel.numel(), x.shape[2], x.shape[3], x.shape[1]).permute(0, 3, 1, 2)
+            else:
+                xs = fl[sel].permute(0, 3, 1, 2) if (fl.is_contiguous() and not x.is_contiguous()) else x[sel]  # ONE index op
             off = 0
             for br, pos_props, losses in zip(branches, pos_all, out):
                 k = sum(len(p) for p in pos_props)

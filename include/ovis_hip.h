@@ -321,6 +321,16 @@ int ovis_split_pair_f32(const float* src, long src_row_stride, void* dst_pair, l
 int ovis_gate_split_pair_f32(const float* dy, long dy_row_stride, const void* gate, int gate_is_pair,
                              void* dst_pair, float* g_f32, long rows, int cols, const float* g_pooled,
                              int pool_rows, void* stream);
+/* The same with the gradient of a ROW-GROUP GATHER added on the fly: the rows come in groups of pool_rows (the 7x7
+ * positions of one RoI); group_slot [rows / pool_rows] int32 holds, for a group that a consumer gathered (the mask
+ * head reads the res5 features of the positive RoIs only: mb/modeling/roi_heads/mask_head/mask_head.py:13-41,62-66),
+ * its index in g_selected [num_selected * pool_rows, cols] f32 (dense), -1 otherwise:
+ * g = (dy + g_pooled[group] / pool_rows + g_selected[group_slot[group] * pool_rows + row in group]) * (y > 0).
+ * Replaces the zero-filled [rows, cols] tensor an index backward would build and this kernel would read back.
+ * dy, g_pooled may be NULL; g_selected and group_slot are given together. */
+int ovis_gate_split_pair_rows_f32(const float* dy, long dy_row_stride, const void* gate, int gate_is_pair,
+                                  void* dst_pair, float* g_f32, long rows, int cols, const float* g_pooled,
+                                  int pool_rows, const float* g_selected, const int32_t* group_slot, void* stream);
 
 /* Weight preparation of a (trainable) convolution in one launch: weight [out_channels, in_channels, taps] f32 times the
  * folded FrozenBN scale [out_channels] (may be NULL; mb/layers/batch_norm.py:19-31) -> fwd_pair [out_channels, taps*in]

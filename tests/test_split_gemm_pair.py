@@ -349,6 +349,36 @@ def test_bottleneck_chain_pair_only_vs_fp32_chain(train):
         assert (a - b).norm().item() <= 5e-3 * b.norm().item() + 1e-12
 
 
+def test_gate_split_pair_with_gathered_row_groups():
+    """The gradient of a gather of whole row groups (the mask head reads the positive RoIs' 7x7 maps) handed over as dense
+    maps + a group -> slot table: same result as scattering it into a zero [rows, cols] tensor and adding that first --
+    bit for bit when it is the only dense term next to the pooled gradient (a + b = b + a), to rounding otherwise."""
+    C = _C()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    groups, pr, cols = 37, 49, 96
+    rows = groups * pr
+    y = torch.randn(rows, cols, device="cuda", generator=g)
+    yp = C.split_pair(y)
+    pooled = torch.randn(groups, cols, device="cuda", generator=g)
+    sel = torch.tensor([3, 4, 17, 36, 0], device="cuda")
+    gsel = torch.randn(sel.numel() * pr, cols, device="cuda", generator=g)
+    slot = torch.full((groups,), -1, dtype=torch.int32, device="cuda")
+    slot[sel] = torch.arange(sel.numel(), dtype=torch.int32, device="cuda")
+    dense = torch.zeros(groups, pr, cols, device="cuda")
+    dense[sel] = gsel.view(-1, pr, cols)
+    dense = dense.view(rows, cols)
+    for gate in (y, yp):
+        want_p, want = C.gate_split_pair(dense, gate, want_f32=True, pooled=pooled, pool_rows=pr)
+        got_p, got = C.gate_split_pair(None, gate, want_f32=True, pooled=pooled, pool_rows=pr, selected=gsel, group_slot=slot)
+        assert torch.equal(got, want) and torch.equal(got_p, want_p)
+    dy = torch.randn(rows, cols, device="cuda", generator=g)
+    _, want = C.gate_split_pair(dy + dense, y, want_f32=True, pooled=pooled, pool_rows=pr)
+    _, got = C.gate_split_pair(dy, y, want_f32=True, pooled=pooled, pool_rows=pr, selected=gsel, group_slot=slot)
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        C.gate_split_pair(dy, y, pooled=pooled, pool_rows=pr, selected=gsel)  # the slot table is missing
+
+
 def test_pair_only_output_feeds_exactly_one_block():
     """A block output kept in pair layout only has a placeholder as its fp32 handle: a second consumer's gradient could
     not be summed into it, so the second ``bottleneck_pair`` on the same pair tensor is refused (loudly, in the forward)."""

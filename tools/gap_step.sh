@@ -18,4 +18,5 @@ steady = per_step[: max(1, len(per_step) // 2)]  # the smaller half: steps witho
 print(f"launches per step: {steady[len(steady) // 2]} (median over the steady steps; {len(marks)} steps in the trace)")
 PY
 python tools/step_launch_histogram.py $f 45
+python tools/step_big_small_kernels.py $f 40
 rm -rf $OUT/trace
