@@ -166,7 +166,7 @@ __device__ __forceinline__ void epilogue_store4(const SplitGemmArgs& p, long m, 
 template <int WM, int WN, int MODE, int NS, int OCC, bool DUAL = false>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemmArgs p, int tiles_n, int ntiles) {
   constexpr int BM = WM * 64, BN = WN * 64, NW = WM * WN;
-  constexpr int A_ROWS = MODE == HALO ? BM + 2 * kHalo + 1 : BM;  // HALO: + one row of zeros
+  constexpr int A_ROWS = MODE == HALO ? BM + 2 * kHalo + 2 : BM;  // HALO: + 256 bytes of zeros (one bank period)
   constexpr int ZROW = BM + 2 * kHalo;
   constexpr int A_BYTES = A_ROWS * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int A_PIECES = (MODE == HALO ? BM + 2 * kHalo : BM) / 8;  // 8-row LDS-DMA pieces of the A tile
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
       }
       h_ok[f >> 1] |= mask << ((f & 1) * 16);
     }
-    if (threadIdx.x < 8) *(uint4*)(smem + ZROW * 128 + threadIdx.x * 16) = make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x < 16) *(uint4*)(smem + ZROW * 128 + threadIdx.x * 16) = make_uint4(0u, 0u, 0u, 0u);
   }
 
   f32x4 acc[4][4];
@@ -426,7 +426,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
       // the tap's rows sit dy*W + dx LDS rows further (always inside the halo tile); lanes whose shifted pixel lies
       // outside the map read the zero row instead
       const int L0 = wm * 64 + fr + kHalo + dy * p.W + dx;
-      const int ard0 = L0 * 128 + ((fq ^ ((L0 >> 1) & 7)) << 4), zrd = ZROW * 128 + (fq << 4);
+      // the zero block spans one whole bank period (256 B) and a lane reads it at its regular address modulo 256: the
+      // same banks as the row it replaces, so the mix of zero and regular lanes of a border tap stays conflict-free
+      // (one 128-byte zero row read at chunk fq cost the 3x3 kernel 31 % LDS bank-conflict cycles on the 7x7 maps)
+      const int ard0 = L0 * 128 + ((fq ^ ((L0 >> 1) & 7)) << 4), zrd = ZROW * 128 + (ard0 & 255);
       const int b0 = A_BYTES + (wn * 64 + fr) * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
       int ard[4];
 #pragma unroll
@@ -1367,7 +1370,7 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
   hipStream_t s = (hipStream_t)stream;
 #define OVIS_SG_LAUNCH_(WM_, WN_, MODE_, NS_, OCC_, DUAL_)                                                           \
   do {                                                                                                              \
-    constexpr int a_rows = MODE_ == HALO ? WM_ * 64 + 2 * kHalo + 1 : WM_ * 64;                                      \
+    constexpr int a_rows = MODE_ == HALO ? WM_ * 64 + 2 * kHalo + 2 : WM_ * 64;                                      \
     constexpr int lds = NS_ * (a_rows * 128 + WN_ * 64 * 128);                                                       \
     static bool attr_set = false;                                                                                   \
     if (!attr_set) {                                                                                                \
