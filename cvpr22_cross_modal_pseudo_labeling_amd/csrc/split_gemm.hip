@@ -27,8 +27,10 @@
 //
 // Tile: (WM x 64) x (WN x 64) per workgroup of WM*WN waves, wave tile 64 x 64 (4 x 4 MFMA tiles, 64 accumulator
 // VGPRs); LDS stages of BM x 128 B (A) + BN x 128 B (B); the 16-byte chunk index of a row is XOR-ed with
-// (row >> 1) & 7 (applied to the SOURCE address of the LDS-DMA, so the LDS image stays lane-linear) which makes every
-// ds_read_b128 of a 16-row fragment conflict-free.  NS = 2: the next stage loads under this stage's MFMAs, two
+// row & 7 (applied to the SOURCE address of the LDS-DMA, so the LDS image stays lane-linear) which makes every
+// ds_read_b128 of a 16-row fragment conflict-free -- at ANY row offset, which the halo-tile 3x3 needs: its taps read the
+// fragments dy * W + dx rows further; the earlier (row >> 1) & 7 was conflict-free only at offsets = 0 mod 4 and cost that
+// kernel 2x the LDS cycles on six of its nine taps (tools/microbench/lds_shift_probe.hip).  NS = 2: the next stage loads under this stage's MFMAs, two
 // workgroups per CU (small grids).  NS = 1: one stage, nothing overlaps inside a workgroup, three / four independent
 // workgroups per CU hide each other's load phases (large grids: +7...17 %).
 // Epilogue: the accumulators go through a wave-private LDS staging tile (16 rows x 64 columns, slots XOR-swizzled by
@@ -211,11 +213,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
   // pieces); the 64-bit source addresses are formed at issue time.  The one-stage loops re-derive even that from an
   // opaque copy of the lane id in every iteration (a dozen VALU operations against 48 MFMAs): left to itself the
   // compiler keeps ~30 loop-invariant address registers alive, which costs the fourth workgroup per CU (128 VGPRs).
-  // chunk swizzle of LDS row `row` = piece * 8 + lr: (row >> 1) & 7 = ((piece & 1) * 4 + (lr >> 1)) & 7
+  // chunk swizzle of LDS row `row` = piece * 8 + lr: row & 7 = lr (the same in even and odd pieces: s0 == s1)
   struct LaneGeom { int lr, s0, s1; };
   auto lane_geom = [&](int ln) {
     const int lr = ln >> 3, lc = ln & 7;
-    return LaneGeom{lr, (lc ^ (lr >> 1)) * 16, (lc ^ (4 + (lr >> 1))) * 16};
+    return LaneGeom{lr, (lc ^ lr) * 16, (lc ^ lr) * 16};
   };
   auto clamp_row = [&](int gm) { return gm < 0 ? 0 : (gm > Mi - 1 ? Mi - 1 : gm); };  // rows outside the matrix:
                                                                                        // valid memory, never used unmasked
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
         const unsigned h0 = pack_bf16(v.x, v.y), h1 = pack_bf16(v.z, v.w);
         const unsigned l0 = pack_bf16(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u));
         const unsigned l1 = pack_bf16(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u));
-        const int prow = prow0 + 32 * j, sw = (prow >> 1) & 7;
+        const int prow = prow0 + 32 * j, sw = prow & 7;
         *(uint2*)(smem + prow * 128 + ((chunk ^ sw) << 4) + sub) = make_uint2(h0, h1);
         *(uint2*)(smem + prow * 128 + (((4 + chunk) ^ sw) << 4) + sub) = make_uint2(l0, l1);
       }
@@ -348,11 +350,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
   };
 
   // ---- fragment read addresses.  Fragment f of a wave covers tile rows .. + f*16 + frow: the swizzle term
-  // ((row >> 1) & 7) does not depend on f, so the four fragments of an operand sit 2048 bytes apart. ----
+  // (row & 7) does not depend on f, so the four fragments of an operand sit 2048 bytes apart. ----
   const int wm = wave / WN, wn = wave % WN;
   const int frow = lane & 15, fc = lane >> 4;
-  const int a_rd0 = (wm * 64 + frow) * 128 + ((fc ^ ((frow >> 1) & 7)) << 4);
-  const int b_rd0 = A_BYTES + (wn * 64 + frow) * 128 + ((fc ^ ((frow >> 1) & 7)) << 4);
+  const int a_rd0 = (wm * 64 + frow) * 128 + ((fc ^ (frow & 7)) << 4);
+  const int b_rd0 = A_BYTES + (wn * 64 + frow) * 128 + ((fc ^ (frow & 7)) << 4);
   // HALO: which taps of the lane's row (in each of its 4 fragments) fall inside the map: bit t of a 16-bit field
   unsigned h_ok[2] = {0u, 0u};
   if (MODE == HALO) {
@@ -429,8 +431,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
       // the zero block spans one whole bank period (256 B) and a lane reads it at its regular address modulo 256: the
       // same banks as the row it replaces, so the mix of zero and regular lanes of a border tap stays conflict-free
       // (one 128-byte zero row read at chunk fq cost the 3x3 kernel 31 % LDS bank-conflict cycles on the 7x7 maps)
-      const int ard0 = L0 * 128 + ((fq ^ ((L0 >> 1) & 7)) << 4), zrd = ZROW * 128 + (ard0 & 255);
-      const int b0 = A_BYTES + (wn * 64 + fr) * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
+      const int ard0 = L0 * 128 + ((fq ^ (L0 & 7)) << 4), zrd = ZROW * 128 + (ard0 & 255);
+      const int b0 = A_BYTES + (wn * 64 + fr) * 128 + ((fq ^ (fr & 7)) << 4);
       int ard[4];
 #pragma unroll
       for (int f = 0; f < 4; ++f) ard[f] = ((h_ok[f >> 1] >> ((f & 1) * 16 + t)) & 1u) ? ard0 + f * 2048 : zrd;
