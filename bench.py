@@ -22,11 +22,29 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def _spawn_if_asked():
+    """``python bench.py --gpus N`` with N > 1 and no launcher environment: this process becomes the launcher -- it starts
+    N children (one per GPU, env:// rendezvous on 127.0.0.1, the same command line), relays rank 0's JSON line through
+    its own stdout and exits with the job's code.  It runs BEFORE torch is imported: the parent never touches the GPU
+    and nothing is exec'ed over a process that has (engine/launch.py)."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import launch
+
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--gpus", type=int, default=1)
+    known, _ = pre.parse_known_args()
+    if launch.needs_spawn(known.gpus):
+        sys.exit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], known.gpus))
+
+
+if __name__ == "__main__":
+    _spawn_if_asked()
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 IMS_PER_GPU = 2
@@ -430,6 +448,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher environment says WORLD_SIZE={world}")
+    if torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):  # counting does not initialise the GPU
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -585,6 +607,11 @@ def main():
             "dtype": "f32 (bf16x3 split MFMA, fp32 accum)",
             "data": "synthetic",
             "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+            # gradient exchange of the last step: buckets whose all-reduce was issued from a backward hook (i.e. overlapped
+            # with the rest of the backward) out of all buckets, and the payload
+            "allreduce": {"buckets": len(reducer.buckets), "issued_from_backward_hooks": reducer.hook_launches,
+                          "payload_MB": round(sum(f.numel() * f.element_size() for f in reducer.flat) / 1e6, 1),
+                          "op": "AVG in the collective" if world > 1 else "none (1 rank)"},
             "config": {"workload": f"{name}.yaml R-50-C4, {IMS_PER_GPU} img/GPU 3x800x1333, fwd+bwd+allreduce+SGD",
                        "global_batch": global_batch, "parallelism": f"dp{world}", "losses_finite": finite,
                        "pipelined": bool(overlapped)},

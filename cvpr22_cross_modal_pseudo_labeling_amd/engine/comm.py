@@ -8,7 +8,8 @@ The reference wraps the model in ``DistributedDataParallel(find_unused_parameter
   fp32 bucket buffers (reverse parameter order ~ backward order), so there is no per-step graph walk
   and no gradient copy-in/copy-out;
 * a bucket's all-reduce is issued from an autograd post-accumulate hook the moment its last gradient is
-  written, i.e. it overlaps with the rest of backward; ``finish()`` waits and averages;
+  written, i.e. it overlaps with the rest of backward; ``finish()`` waits (the average is taken
+  inside the collective on RCCL);
 * bucket size defaults to 32 MiB: xGMI is point-to-point (7 links/GPU), ring collectives are per-link
   bound, so a few large messages beat many small ones (student 75 MB -> 3 buckets, teacher 140 MB -> 5).
 """
@@ -64,6 +65,9 @@ class BucketedGradReducer:
 
     def __init__(self, model, bucket_bytes=32 << 20, never_used=None):
         self.world = get_world_size()
+        # RCCL averages inside the collective (ReduceOp.AVG): no pass over the buckets after the wait.  gloo (CPU tests)
+        # has no AVG: there the sum is divided in finish().
+        self._avg_in_collective = self.world > 1 and dist.get_backend() == "nccl"
         params = [p for p in model.parameters() if p.requires_grad]
         params.reverse()
         if never_used is None and hasattr(model, "never_used_parameters"):
@@ -123,7 +127,8 @@ class BucketedGradReducer:
     def _launch(self, bi):
         self.launched[bi] = True
         if self.world > 1:
-            self.handles[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, async_op=True)
+            op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
+            self.handles[bi] = dist.all_reduce(self.flat[bi], op=op, async_op=True)
 
     def zero_grad(self):
         """Replaces optimizer.zero_grad(): grads stay views of the flat buffers."""
@@ -152,7 +157,8 @@ class BucketedGradReducer:
             for bi, h in enumerate(self.handles):
                 if h is not None:
                     h.wait()
-                self.flat[bi].div_(self.world)
+                if not self._avg_in_collective:
+                    self.flat[bi].div_(self.world)
 
     def remove(self):
         for h in self._hooks:
