@@ -313,6 +313,9 @@ def rpn_decode(box_regression, topk_idx, cell_anchors, image_wh, weights, xform_
     return boxes, drop
 
 
+_BOX_DECODE_MAX_IMAGES = 16  # include/ovis_hip.h: OVIS_BOX_DECODE_MAX_IMAGES
+
+
 def box_decode(rel_codes, boxes, weights, xform_clip, rows_per_image=None, image_sizes=None):
     """``BoxCoder.decode`` (modeling/box_coder.py:49-95) in one launch (``ovis_box_decode_f32``): rel_codes [R, 4K] (any row
     stride), boxes [R, 4] -> [R, 4K].  With ``rows_per_image`` (ints, image-major rows) and ``image_sizes`` ((width, height)
@@ -331,15 +334,31 @@ def box_decode(rel_codes, boxes, weights, xform_clip, rows_per_image=None, image
     if r == 0:
         return out
     n = 0 if rows_per_image is None else len(rows_per_image)
-    counts = wh = None
-    if n:
-        counts = (ctypes.c_int32 * n)(*[int(c) for c in rows_per_image])
-        wh = (ctypes.c_float * (2 * n))(*[float(v) for size in image_sizes for v in size])
     wx, wy, ww, wh_ = weights
+    # image sizes travel as kernel arguments, at most _BOX_DECODE_MAX_IMAGES per launch: rows are image-major, so a longer
+    # batch is a few launches over consecutive row ranges (as ovis_rois_from_boxes_f32 does internally)
+    if n and (len(image_sizes) != n or sum(int(c) for c in rows_per_image) != r):
+        raise RuntimeError(f"box_decode: rows_per_image must list {r} rows over {n} images with one (width, height) each")
+    i0 = row0 = 0
     with _on(rel_codes.device):
-        rc = _L.ovis_box_decode_f32(rel_codes.data_ptr(), rel_codes.stride(0), boxes.data_ptr(), boxes.stride(0), r, k, wx, wy,
-                                    ww, wh_, xform_clip, n, counts, wh, out.data_ptr(), _stream())
-    _lib.check(rc, "box_decode")
+        while True:
+            m = min(n - i0, _BOX_DECODE_MAX_IMAGES)
+            counts = wh = None
+            rows = r
+            if n:
+                cs = [int(c) for c in rows_per_image[i0:i0 + m]]
+                rows = sum(cs)
+                counts = (ctypes.c_int32 * m)(*cs)
+                wh = (ctypes.c_float * (2 * m))(*[float(v) for size in image_sizes[i0:i0 + m] for v in size])
+            if rows:
+                rc = _L.ovis_box_decode_f32(rel_codes.data_ptr() + 4 * row0 * rel_codes.stride(0), rel_codes.stride(0),
+                                            boxes.data_ptr() + 4 * row0 * boxes.stride(0), boxes.stride(0), rows, k, wx, wy,
+                                            ww, wh_, xform_clip, m, counts, wh, out.data_ptr() + 16 * k * row0, _stream())
+                _lib.check(rc, "box_decode")
+            i0 += m
+            row0 += rows
+            if i0 >= n:
+                break
     return out
 
 

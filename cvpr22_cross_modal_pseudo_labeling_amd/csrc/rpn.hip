@@ -10,11 +10,14 @@
 //   decode:   widths = x2 - x1 + 1; ctr = x1 + 0.5 * widths; d = code / weight; dw, dh clamped to xform_clip;
 //             pred_ctr = d * widths + ctr; pred_w = exp(dw) * widths; x1' = pred_ctr - 0.5 * pred_w;
 //             x2' = pred_ctr + 0.5 * pred_w - 1
-//   clip:     clamp to [0, image_w - 1] x [0, image_h - 1]
+//   clip:     clamp to [0, image_w - 1] x [0, image_h - 1]   (ternary clamps: non-finite deltas stay non-finite, as torch.clamp)
 //   small:    (x2 - x1 + 1 >= min_size) && (y2 - y1 + 1 >= min_size)   else drop = -1
 #include "ovis_common.h"
 
 namespace {
+
+// clamp(min=0, max=hi) as torch evaluates it: a NaN stays a NaN (same helper as boxes.hip::box_decode_kernel)
+__device__ __forceinline__ float clamp_like_torch(float v, float hi) { return v < 0.f ? 0.f : (v > hi ? hi : v); }
 
 __global__ __launch_bounds__(256) void rpn_decode_kernel(
     const float* __restrict__ reg, long reg_sn, long reg_spos, long reg_sch, const long long* __restrict__ topk_idx,
@@ -36,16 +39,18 @@ __global__ __launch_bounds__(256) void rpn_decode_kernel(
   const float widths = ax2 - ax1 + 1.f, heights = ay2 - ay1 + 1.f;
   const float ctr_x = ax1 + 0.5f * widths, ctr_y = ay1 + 0.5f * heights;
   const float dx = c0 / wx, dy = c1 / wy;
-  const float dw = fminf(c2 / ww, xform_clip), dh = fminf(c3 / wh, xform_clip);
+  // torch.clamp propagates NaN (fminf / fmaxf would return the finite operand and turn a diverged delta into a valid box)
+  const float dw0 = c2 / ww, dh0 = c3 / wh;
+  const float dw = dw0 > xform_clip ? xform_clip : dw0, dh = dh0 > xform_clip ? xform_clip : dh0;
   const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
   const float pw = expf(dw) * widths, ph = expf(dh) * heights;
   float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph;
   float x2 = pcx + 0.5f * pw - 1.f, y2 = pcy + 0.5f * ph - 1.f;
   const float iw = image_wh[2 * n] - 1.f, ih = image_wh[2 * n + 1] - 1.f;
-  x1 = fminf(fmaxf(x1, 0.f), iw);
-  y1 = fminf(fmaxf(y1, 0.f), ih);
-  x2 = fminf(fmaxf(x2, 0.f), iw);
-  y2 = fminf(fmaxf(y2, 0.f), ih);
+  x1 = clamp_like_torch(x1, iw);
+  y1 = clamp_like_torch(y1, ih);
+  x2 = clamp_like_torch(x2, iw);
+  y2 = clamp_like_torch(y2, ih);
   boxes[(size_t)n * K + k] = make_float4(x1, y1, x2, y2);
   const bool keep = (x2 - x1 + 1.f >= min_size) && (y2 - y1 + 1.f >= min_size);
   drop[(size_t)n * K + k] = keep ? 0 : -1;

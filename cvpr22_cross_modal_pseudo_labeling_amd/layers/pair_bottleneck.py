@@ -136,8 +136,8 @@ class _BottleneckPair(Function):
         # read back at the step's size) first
         out_sel = out.view(-1, h * w, out.shape[1]).index_select(0, select) if (select is not None and f32) else None
         gate_src = out if out is not None else outp  # the last ReLU's gate: the fp32 result or the hi halves of its pair form
-        if out is None:
-            out = outp.new_empty((1,), dtype=torch.float32).expand(outp.shape[0], outp.shape[1] // 2)
+        if out is None:  # NaN-filled: any consumer outside the one-block contract shows up in the loss instead of reading garbage
+            out = outp.new_full((1,), float("nan"), dtype=torch.float32).expand(outp.shape[0], outp.shape[1] // 2)
         ctx.save_for_backward(xp, o1p, o2p, gate_src, w1, w2, w3, wd, s1, s2, s3, sd, select if out_sel is not None else None)
         ctx.wts = wts
         ctx.geom = (h, w, kh, kw)
@@ -172,6 +172,9 @@ class _BottleneckPair(Function):
         # the input gradient goes to the block below through the link when that block left one and the fused form applies
         to_link = (need_x and wd is None and link_in is not None and xp.shape[1] // 2 >= 128)
         if linked is not None:
+            if dout is not None and not is_placeholder(dout):
+                raise RuntimeError("_BottleneckPair: a pair-only output received a real fp32 gradient next to the linked one "
+                                   "(a second consumer of the placeholder: hook, retain_grad, slicing ...)")
             g3p, g3 = linked, None  # gated and split by the block above (dout is only a placeholder)
         else:
             # gate of the block's last ReLU, fused with the split; the identity shortcut needs the gated gradient too: in
@@ -199,7 +202,7 @@ class _BottleneckPair(Function):
                     # (dY1 W1 + shortcut gradient) gated by the block input's ReLU, in pair layout only: what the block
                     # below would compute from an fp32 gradient with one more pass over it
                     _, link_in.grad_pair = _C.split_gemm_pair_rp_gated(g1p, t1, g3p, xp)
-                    dx = g1p.new_empty((1,), dtype=torch.float32).expand(xp.shape[0], xp.shape[1] // 2)
+                    dx = g1p.new_full((1,), float("nan"), dtype=torch.float32).expand(xp.shape[0], xp.shape[1] // 2)
                 else:
                     if wd is not None:
                         res, _ = _C.split_gemm_pair(g3p, td)

@@ -107,7 +107,12 @@ class Bottleneck(nn.Module):
                                    and d.stride == c1.stride))
                 and (d is not None or (c1.stride == (1, 1) and c1.in_channels == c3.out_channels)))
 
-    def _forward_pair(self, x, prestrided, xp, want_pair, pool=False, select=None):
+    def takes_pair_only_input(self):
+        """This block can consume an input that exists in pair layout only (conv1 operand and shortcut from the pair form):
+        what a producer must check before it drops the fp32 copy of its output (``pair_only``)."""
+        return bool(self.pair_gemm and self.pair_supported())
+
+    def _forward_pair(self, x, prestrided, xp, want_pair, pool=False, select=None, pair_only=False):
         """The block as ONE autograd node on the pair-layout split GEMM (layers/pair_bottleneck.py): bias, shortcut,
         ReLU and the next layer's operand split live in the GEMM epilogues, the 3x3 is an implicit GEMM."""
         r, h, w, c = x.shape
@@ -123,15 +128,15 @@ class Bottleneck(nn.Module):
         else:
             hs, ws = h, w
             x2d = x.reshape(-1, c)
-        return self._pair_node(x2d, xp, r, hs, ws, want_pair, pool, select)
+        return self._pair_node(x2d, xp, r, hs, ws, want_pair, pool, select, pair_only)
 
-    def forward_pair_rows(self, xp, r, hs, ws, want_pair=False, pool=False):
+    def forward_pair_rows(self, xp, r, hs, ws, want_pair=False, pool=False, pair_only=False):
         """The block on rows that exist only in pair layout ([r*hs*ws, 2*Cin] bf16, e.g. written by the pooler): needs
         the projection shortcut (no fp32 rows for an identity shortcut) and no gradient w.r.t. the input."""
         assert self._fd is not None
-        return self._pair_node(None, xp, r, hs, ws, want_pair, pool)
+        return self._pair_node(None, xp, r, hs, ws, want_pair, pool, None, pair_only)
 
-    def _pair_node(self, x2d, xp, r, hs, ws, want_pair, pool, select=None):
+    def _pair_node(self, x2d, xp, r, hs, ws, want_pair, pool, select=None, pair_only=False):
         from .. import _C
         # RAW weights + folded FrozenBN (scale, shift) pairs: the fold itself happens inside the node's weight-prep kernel
         w1, w2, w3 = self.conv1.weight, self.conv2.weight, self.conv3.weight
@@ -157,7 +162,8 @@ class Bottleneck(nn.Module):
         else:
             b3s = b3 if bd is None else b3 + bd
         res = bottleneck_pair(x2d, xp, (hs, ws), w1, b1, w2, b2, w3, b3s, wd, want_pair, wpairs, pool,
-                              scales=(s1, s2, s3, sd), want_f32=not (want_pair and self.pair_only_chain), select=select)
+                              scales=(s1, s2, s3, sd),
+                              want_f32=not (want_pair and pair_only and self.pair_only_chain), select=select)
         out = res[0].view(r, hs, ws, res[0].shape[-1])
         if pool:
             out._ovis_pooled = res[2]  # [R, C] mean over the map, an output of the same autograd node (see pooled())
@@ -166,7 +172,7 @@ class Bottleneck(nn.Module):
             out._ovis_selected = sel
         return (out, res[1]) if want_pair else out
 
-    def forward_nhwc(self, x, prestrided=False, xp=None, want_pair=False, pool=False, select=None):
+    def forward_nhwc(self, x, prestrided=False, xp=None, want_pair=False, pool=False, select=None, pair_only=False):
         """Same block on an NHWC tensor ``x`` [R, H, W, C] (contiguous); ``prestrided``: x already holds only the
         positions conv1 / the shortcut read (the pooler applied their common stride).  The 1x1 convolutions -- 53 % of the
         res5 FLOPs -- become ONE row-major GEMM over all R*H*W positions each ([R*H*W, Cin] x [Cin, Cout], bias
@@ -175,9 +181,15 @@ class Bottleneck(nn.Module):
         bf16 hi/lo split products on the bf16 matrix pipe (~4e-6 relative error, ``split_gemm = False`` selects
         the fp32 GEMM); the 3x3 goes through MIOpen.  Values equal ``forward`` up to that error.
         ``xp``: the pair-layout form of x when the producer already wrote it; ``want_pair``: also return the pair
-        form of the result (or None) for the next block -- both only used by the pair-layout route."""
+        form of the result (or None) for the next block -- both only used by the pair-layout route.  ``pair_only``: the
+        consumer of the result ``takes_pair_only_input()``, so the fp32 copy may be dropped (the caller looks ahead:
+        ``chain_nhwc``); a block that is NOT on the pair route never receives such an input."""
         if self.pair_gemm and x.is_cuda and self.pair_supported():
-            return self._forward_pair(x, prestrided, xp, want_pair, pool, select)
+            return self._forward_pair(x, prestrided, xp, want_pair, pool, select, pair_only)
+        if is_placeholder(x):
+            raise RuntimeError("Bottleneck.forward_nhwc: the input exists in pair layout only (its fp32 handle is a "
+                               "placeholder) but this block is not on the pair-GEMM route; the producer must keep the "
+                               "fp32 copy (pair_only=False)")
         r, h, w, c = x.shape
         sy, sx = self.conv1.stride
         if prestrided:
@@ -244,6 +256,22 @@ class Bottleneck(nn.Module):
         out = bias_relu_(out, b3 if bd is None else b3 + bd, idn if idn is not None else x.view(-1, c))
         out = out.view(r, ho, wo, out.shape[-1])
         return (out, None) if want_pair else out
+
+
+def chain_nhwc(blocks, y, yp=None, first=None, last=None):
+    """Run consecutive bottlenecks on an NHWC activation.  Every block but the last hands its result on in pair layout;
+    it drops the fp32 copy (``pair_only``) only when the NEXT block can take a pair-only input -- otherwise (e.g.
+    STRIDE_IN_1X1 False: the stage's first block has a strided 3x3 and runs the per-layer route) both forms are
+    written.  ``first`` / ``last``: extra keyword arguments of the first / last block's ``forward_nhwc``."""
+    n = len(blocks)
+    for i, b in enumerate(blocks):
+        kw = dict(first or {}) if i == 0 else {}
+        if i + 1 < n:
+            y, yp = b.forward_nhwc(y, xp=yp, want_pair=True, pair_only=blocks[i + 1].takes_pair_only_input(), **kw)
+        else:
+            kw.update(last or {})
+            y = b.forward_nhwc(y, xp=yp, **kw)
+    return y
 
 
 class Stem(nn.Module):
@@ -341,9 +369,7 @@ class ResNetC4(nn.Module):
             # Trainable stages (teacher training): through the pair-layout autograd nodes as well -- 39.4 vs 42.2 ms per
             # step against MIOpen's NCHW kernels (both with a warm MIOpen kernel cache; ``train_nhwc = False``
             # selects MIOpen).
-            y, yp = x.permute(0, 2, 3, 1).contiguous(), None
-            for i, b in enumerate(blocks):
-                y, yp = b.forward_nhwc(y, xp=yp, want_pair=True) if i + 1 < len(blocks) else (b.forward_nhwc(y, xp=yp), None)
+            y = chain_nhwc(blocks, x.permute(0, 2, 3, 1).contiguous())
             # the C4 map stays in NHWC memory (an NCHW-shaped view of it): the poolers read channels-last maps in place
             # (csrc/roi_align.hip::roi_align_fwd_nhwc_in_strided_kernel) and the RPN head wants NHWC rows anyway
             return [y.permute(0, 3, 1, 2)]
@@ -381,10 +407,8 @@ class ResNetHead(nn.Module):
         (``Bottleneck.forward_nhwc``) and returns the channels_last view of the result; ``nhwc = False``
         keeps the plain per-layer convolution path (also taken for grouped / exotic configurations)."""
         if x.is_cuda and self.nhwc and all(b.nhwc_supported() for b in self.layer4):
-            y, yp = x.permute(0, 2, 3, 1), None  # the first block's stride-2 slice makes this the only NCHW -> NHWC copy
-            for i, b in enumerate(self.layer4):
-                y, yp = b.forward_nhwc(y, xp=yp, want_pair=True) if i + 1 < len(self.layer4) else (b.forward_nhwc(y, xp=yp), None)
-            return y.permute(0, 3, 1, 2)
+            # the first block's stride-2 slice makes this the only NCHW -> NHWC copy
+            return chain_nhwc(list(self.layer4), x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
         return self.layer4(x)
 
     def pooler_stride(self):
@@ -405,13 +429,13 @@ class ResNetHead(nn.Module):
     def forward_pooled_nhwc(self, y, yp=None, shape=None, select=None):
         """y [R, 7, 7, C]: the pooled bins conv1 reads, NHWC (from ``forward_strided_nhwc``) -> [R, 2048, 7, 7] view;
         or y None and yp the same bins in pair layout with shape = (R, 7, 7) (from ``roi_align_forward_strided_pair``)."""
-        for i, b in enumerate(self.layer4):
-            if i == 0 and y is None:
-                y, yp = b.forward_pair_rows(yp, shape[0], shape[1], shape[2], want_pair=True)
-            elif i + 1 < len(self.layer4):
-                y, yp = b.forward_nhwc(y, prestrided=(i == 0), xp=yp, want_pair=True)
-            else:
-                y = b.forward_nhwc(y, prestrided=(i == 0), xp=yp, pool=True, select=select)
+        blocks = list(self.layer4)
+        if y is None:  # bins in pair layout only: the first block runs on them directly
+            y, yp = blocks[0].forward_pair_rows(yp, shape[0], shape[1], shape[2], want_pair=True,
+                                                pair_only=blocks[1].takes_pair_only_input())
+            y = chain_nhwc(blocks[1:], y, yp, last={"pool": True, "select": select})
+        else:
+            y = chain_nhwc(blocks, y, yp, first={"prestrided": True}, last={"pool": True, "select": select})
         out = y.permute(0, 3, 1, 2)
         for attr in ("_ovis_pooled", "_ovis_selected"):  # outputs of the last block's autograd node, carried on its result
             v = getattr(y, attr, None)

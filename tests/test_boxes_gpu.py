@@ -68,6 +68,31 @@ def test_box_decode_equals_tensor_ops(k, clip, weights):
     assert _C.box_decode(codes[:0], boxes[:0], coder.weights, coder.bbox_xform_clip).shape == (0, 4 * k)
 
 
+def test_box_decode_more_images_than_one_launch_carries():
+    """40 images in one call (an eval batch larger than the 16 image sizes a launch carries as kernel arguments, some images
+    without rows): the same bits as decode + clip_to_image image by image."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.box_coder import BoxCoder
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.structures import BoxList
+
+    torch.manual_seed(11)
+    coder = BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
+    per_img = [int(v) for v in torch.randint(0, 60, (40,))]
+    per_img[16] = 0
+    sizes = [(int(400 + 23 * i), int(300 + 17 * i)) for i in range(40)]
+    r = sum(per_img)
+    xy = torch.rand(r, 2, device="cuda") * 900 - 100
+    boxes = torch.cat([xy, xy + torch.rand(r, 2, device="cuda") * 500], 1)
+    codes = torch.randn(r, 8, device="cuda") * 2
+    want = coder._decode_tensor_ops(codes, boxes)
+    at = 0
+    for n, size in zip(per_img, sizes):
+        for j in range(2):
+            BoxList(want[at:at + n, 4 * j:4 * j + 4], size).clip_to_image(remove_empty=False)
+        at += n
+    got = coder.decode(codes, boxes, per_img, sizes)
+    assert torch.equal(got, want)
+
+
 def test_box_decode_argument_errors():
     from cvpr22_cross_modal_pseudo_labeling_amd import _C
 

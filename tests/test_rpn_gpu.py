@@ -92,6 +92,33 @@ def test_rpn_device_pipeline_equals_tensor_ops_full_size(min_size, layout):
         assert float(ws[:-2].min()) >= min_size  # the appended ground truth aside
 
 
+def test_rpn_decode_keeps_non_finite_deltas_non_finite():
+    """A diverged head (NaN / inf regression deltas) must not turn into valid-looking proposals: ``torch.clamp`` propagates
+    NaN (rpn/inference.py:104-114 through box_coder.py:75-76 and bounding_box.py:214-225) and so does the kernel; finite
+    candidates of the same launch are untouched."""
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+
+    torch.manual_seed(2)
+    n, a, h, w, k = 1, 3, 4, 5, 16
+    reg = torch.randn(n, 4 * a, h, w, device="cuda") * 0.2
+    idx = torch.randperm(a * h * w, device="cuda")[:k].view(1, k)
+    cell = torch.tensor([[-8.0, -8, 23, 23], [-24, -8, 39, 23], [-8, -24, 23, 39]], device="cuda")
+    wh = torch.tensor([[80.0, 64.0]], device="cuda")
+    args = (cell, wh, (1.0, 1.0, 1.0, 1.0), 4.135, 0.0, 16)
+    clean, _ = _C.rpn_decode(reg, idx, *args)
+    bad = reg.clone()
+    for j, (comp, val) in enumerate([(0, float("nan")), (2, float("nan")), (3, float("nan")), (1, float("inf"))]):
+        i = int(idx[0, j])
+        aa, pos = i % a, i // a
+        bad[0, 4 * aa + comp, pos // w, pos % w] = val
+    got, _ = _C.rpn_decode(bad, idx, *args)
+    assert torch.isnan(got[0, 0, [0, 2]]).all()      # dx NaN -> x1, x2
+    assert torch.isnan(got[0, 1, [0, 2]]).all()      # dw NaN -> x1, x2 (fminf would have returned xform_clip)
+    assert torch.isnan(got[0, 2, [1, 3]]).all()      # dh NaN -> y1, y2
+    assert torch.equal(got[0, 3, [1, 3]], torch.tensor([63.0, 63.0], device="cuda"))  # +inf clamps to the border, as torch
+    assert torch.equal(got[0, 4:], clean[0, 4:])
+
+
 def test_nms_presorted_batched_vs_oracle(oracle_mod):
     """Score-sorted batched NMS with drop flags == the oracle's NMS on the non-dropped boxes of every image; the second
     count is the number of survivors among the first `below` candidates, and they are a prefix of the list."""

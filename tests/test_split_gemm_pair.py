@@ -322,8 +322,11 @@ def test_bottleneck_chain_pair_only_vs_fp32_chain(train):
     b0 = head.layer4[0]
     b0.pair_only_chain = True
     with torch.no_grad():
-        mid, midp = b0.forward_nhwc(x, prestrided=True, want_pair=True)
+        mid, midp = b0.forward_nhwc(x, prestrided=True, want_pair=True, pair_only=True)
+        both, bothp = b0.forward_nhwc(x, prestrided=True, want_pair=True)  # no look-ahead given: both forms are written
     assert is_placeholder(mid) and midp.shape == (20 * 49, 2 * 2048)
+    assert bool(torch.isnan(mid).all())  # a misuse of the placeholder shows up as NaN, not as plausible garbage
+    assert not is_placeholder(both) and torch.equal(bothp, midp)
     from cvpr22_cross_modal_pseudo_labeling_amd import _C as C
     calls = {"rp_gated": 0, "gate_split": 0}
     rp_gated, gate_split = C.split_gemm_pair_rp_gated, C.gate_split_pair
@@ -390,12 +393,51 @@ def test_pair_only_output_feeds_exactly_one_block():
     head = ResNetHead(cfg).cuda()
     b0, b1 = head.layer4[0], head.layer4[1]
     x = torch.randn(4, 7, 7, 1024, device="cuda", requires_grad=True)
-    mid, midp = b0.forward_nhwc(x, prestrided=True, want_pair=True)
+    mid, midp = b0.forward_nhwc(x, prestrided=True, want_pair=True, pair_only=True)
     b1.forward_nhwc(mid, xp=midp)
     with pytest.raises(RuntimeError, match="can feed one block"):
         b1.forward_nhwc(mid, xp=midp)
     with torch.no_grad():  # without autograd nothing has to be summed: allowed
         b1.forward_nhwc(mid, xp=midp)
+
+
+def test_frozen_trunk_with_stride_in_3x3_keeps_fp32_between_routes():
+    """MODEL.RESNETS.STRIDE_IN_1X1 False: the first block of layer2 / layer3 has a strided 3x3 and is not on the pair-GEMM
+    route, so the block in front of it must NOT drop the fp32 copy of its output (look-ahead in ``chain_nhwc``; a pair-only
+    hand-over would feed that block a placeholder).  Frozen trunk, NHWC chain vs the per-layer NCHW convolutions."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers.pair_bottleneck import is_placeholder
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.backbone import ResNetC4, chain_nhwc
+    cfg = get_defaults()
+    cfg.merge_from_list(["MODEL.RESNETS.STRIDE_IN_1X1", False])
+    cfg.freeze()
+    torch.manual_seed(21)
+    body = ResNetC4(cfg).cuda()
+    for m in body.modules():
+        if hasattr(m, "running_var"):
+            m.weight.uniform_(0.5, 1.0)
+            m.bias.uniform_(-0.1, 0.1)
+    for p in body.parameters():
+        p.requires_grad_(False)
+    assert not body.layer2[0].takes_pair_only_input() and body.layer2[1].takes_pair_only_input()
+    x = torch.randn(1, 3, 128, 160, device="cuda") * 40
+    with torch.no_grad():
+        got = body(x)[0]
+        body.nhwc = False
+        want = body(x)[0]
+        body.nhwc = True
+        # the hand-over in front of the strided block carries real fp32 values; inside a stage it is pair-only
+        y = body.stem.forward_gemm(x).permute(0, 2, 3, 1).contiguous()
+        mid, midp = body.layer1[0].forward_nhwc(y, want_pair=True, pair_only=body.layer1[1].takes_pair_only_input())
+        assert is_placeholder(mid) and midp is not None
+        last1 = chain_nhwc(list(body.layer1), y)
+        out, outp = body.layer1[2].forward_nhwc(body.layer1[1].forward_nhwc(mid, xp=midp), want_pair=True,
+                                                pair_only=body.layer2[0].takes_pair_only_input())
+        assert not is_placeholder(out) and torch.equal(out, last1)
+        with pytest.raises(RuntimeError, match="pair layout only"):
+            body.layer2[0].forward_nhwc(mid.expand(1, 32, 40, 256), xp=None)
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max().item() <= 2e-4 * want.abs().max().item()
 
 
 def test_stem_gemm_matches_convolution():

@@ -1,19 +1,25 @@
 #!/bin/bash
 # Collects the measurement artifacts of a round on the GPU box into gpurun_out/<tag>/ (copy what is to be judged into
 # profiles/): bash tools/collect_round.sh <tag>
-TAG=${1:-r2}; OUT=gpurun_out/$TAG
+set -uo pipefail
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
+cd "$ROOT"
+TAG=${1:-r3}; OUT=gpurun_out/$TAG
 mkdir -p $OUT
-python bench.py --steps 20 --warmup 5 > $OUT/bench_student_default.json 2> $OUT/bench_student_default.err
-python bench.py --steps 60 --warmup 5 --min-seconds 5 --per-shape-csv $OUT/per_shape_student.csv > $OUT/bench_student.json 2> $OUT/bench_student.err
-python bench.py --workload teacher --steps 60 --warmup 5 --min-seconds 5 --per-shape-csv $OUT/per_shape_teacher.csv > $OUT/bench_teacher.json 2> $OUT/bench_teacher.err
-python bench.py --no-pipeline --no-cpu-baseline --steps 30 > $OUT/bench_student_nopipe.json 2>/dev/null
-python tools/bench_ops.py > $OUT/bench_ops.txt 2>&1
-python tools/experiments/op_count.py > $OUT/op_count.txt 2>&1
-bash tools/prof_step.sh student $OUT/prof_student > $OUT/prof_student.txt 2>&1
-bash tools/prof_step.sh teacher $OUT/prof_teacher > $OUT/prof_teacher.txt 2>&1
-bash tools/gap_step.sh student $OUT/gap_student > $OUT/gap_student.txt 2>&1
-bash tools/prof_op.sh roi_bwd $OUT/prof_roi_bwd > $OUT/prof_roi_bwd.txt 2>&1
-bash tools/pmc_step.sh $OUT/pmc_teacher teacher > $OUT/pmc_teacher.log 2>&1
-bash tools/pmc_step.sh $OUT/pmc_student student > $OUT/pmc_student.log 2>&1
+FAILED=""
+step() { "$@" || { FAILED="$FAILED [$*]"; echo "collect_round: FAILED: $*" >&2; }; }   # keep collecting, report at the end
+step bash -c 'python bench.py --steps 20 --warmup 5 > "$0"/bench_student_default.json 2> "$0"/bench_student_default.err' "$OUT"
+step bash -c 'python bench.py --steps 60 --warmup 5 --min-seconds 5 --per-shape-csv "$0"/per_shape_student.csv > "$0"/bench_student.json 2> "$0"/bench_student.err' "$OUT"
+step bash -c 'python bench.py --workload teacher --steps 60 --warmup 5 --min-seconds 5 --per-shape-csv "$0"/per_shape_teacher.csv > "$0"/bench_teacher.json 2> "$0"/bench_teacher.err' "$OUT"
+step bash -c 'python bench.py --no-pipeline --no-cpu-baseline --steps 30 > "$0"/bench_student_nopipe.json 2>/dev/null' "$OUT"
+step bash -c 'python tools/bench_ops.py > "$0"/bench_ops.txt 2>&1' "$OUT"
+step bash -c 'python tools/experiments/op_count.py > "$0"/op_count.txt 2>&1' "$OUT"
+step bash -c 'bash tools/prof_step.sh student "$0"/prof_student > "$0"/prof_student.txt 2>&1' "$OUT"
+step bash -c 'bash tools/prof_step.sh teacher "$0"/prof_teacher > "$0"/prof_teacher.txt 2>&1' "$OUT"
+step bash -c 'bash tools/gap_step.sh student "$0"/gap_student > "$0"/gap_student.txt 2>&1' "$OUT"
+step bash -c 'bash tools/prof_op.sh roi_bwd "$0"/prof_roi_bwd > "$0"/prof_roi_bwd.txt 2>&1' "$OUT"
+step bash -c 'bash tools/pmc_step.sh "$0"/pmc_teacher teacher > "$0"/pmc_teacher.log 2>&1' "$OUT"
+step bash -c 'bash tools/pmc_step.sh "$0"/pmc_student student > "$0"/pmc_student.log 2>&1' "$OUT"
 find $OUT -name "*kernel_trace.csv" -delete
 ls $OUT
+[ -z "$FAILED" ] || { echo "collect_round: steps that failed:$FAILED" >&2; exit 1; }
