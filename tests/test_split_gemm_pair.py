@@ -431,8 +431,8 @@ def test_frozen_trunk_with_stride_in_3x3_keeps_fp32_between_routes():
         mid, midp = body.layer1[0].forward_nhwc(y, want_pair=True, pair_only=body.layer1[1].takes_pair_only_input())
         assert is_placeholder(mid) and midp is not None
         last1 = chain_nhwc(list(body.layer1), y)
-        out, outp = body.layer1[2].forward_nhwc(body.layer1[1].forward_nhwc(mid, xp=midp), want_pair=True,
-                                                pair_only=body.layer2[0].takes_pair_only_input())
+        m2, m2p = body.layer1[1].forward_nhwc(mid, xp=midp, want_pair=True, pair_only=body.layer1[2].takes_pair_only_input())
+        out, outp = body.layer1[2].forward_nhwc(m2, xp=m2p, want_pair=True, pair_only=body.layer2[0].takes_pair_only_input())
         assert not is_placeholder(out) and torch.equal(out, last1)
         with pytest.raises(RuntimeError, match="pair layout only"):
             body.layer2[0].forward_nhwc(mid.expand(1, 32, 40, 256), xp=None)

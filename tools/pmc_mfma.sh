@@ -28,4 +28,4 @@ for grp in "$P1" "$P2"; do
   [ -n "$k" ] && cp "$k" "$OUT/pass${i}_kernel_trace.csv"
 done
 python3 $ROOT/tools/pmc_mfma_reduce.py "$OUT" $WL > "$OUT/mfma_busy_$WL.json" && cat "$OUT/mfma_busy_$WL.json" | head -120
-rm -f "$OUT"/pass*.csv
+rm -f "$OUT"/pass*.csv   # (incl. the kernel traces: only the reduced summary is kept)
