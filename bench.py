@@ -308,6 +308,23 @@ def pmc_traffic(workload, op):
             f"+ write {k['write_MB_per_launch']} MB, from profiles/{os.path.basename(path)} ({d['correction']})")
 
 
+def pmc_mfma_busy(workload, op):
+    """Matrix-pipe busy fraction of the dominant kernel family from hardware counters (SQ_VALU_MFMA_BUSY_CYCLES against
+    the dispatch's active clocks x 1024 SIMDs = rocprofv3's MfmaUtil): the committed summary of the tools/pmc_mfma.sh pass
+    over this same step (counters cannot be read from inside the process), or null."""
+    path = os.path.join(ROOT, "profiles", f"r3_pmc_mfma_busy_{workload}.json")
+    fam = PMC_KERNEL.get(op)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        frac = d["families"][fam]["mfma_busy_frac"]
+    except (OSError, KeyError, ValueError):
+        return None, "no MFMA-busy PMC summary for this kernel under profiles/"
+    per = {k: v["mfma_busy_frac"] for k, v in d["kernels"].items() if k.startswith(fam + "<") and "mfma_busy_frac" in v}
+    return frac, (f"SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x active clocks) over all launches of {fam} in the step, from "
+                  f"profiles/{os.path.basename(path)}; per template instance: {per}")
+
+
 def _median_ms(fn, reps=5):
     fn()  # warm-up
     ts = []
@@ -570,6 +587,7 @@ def main():
         measured_in = (f"{replay_steps} sequential replay steps after the timed region (the timed steps overlap two "
                        "streams)") if replay_steps else "the timed region"
         traffic, traffic_note = pmc_traffic(args.workload, dom)
+        mfma_busy, mfma_busy_note = pmc_mfma_busy(args.workload, dom)
         if k["bound"] == "mfma":
             roofline = {"bound": "mfma", "kernel": dom, "achieved": k["achieved_TFLOPs"], "peak": MFMA_BF16_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": k["achieved_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS,
@@ -580,6 +598,8 @@ def main():
                         "frac_algorithmic_of_fp32_mfma_peak": k["fp32_equiv_TFLOPs"] / MFMA_F32_PEAK_TFLOPS,
                         "traffic": traffic,
                         "traffic_note": traffic_note,
+                        "mfma_busy_frac": mfma_busy,
+                        "mfma_busy_note": mfma_busy_note,
                         "note": ("bf16 matrix-core flops issued: 3 hi/lo products x 2*M*N*K per fp32-accurate product "
                                  f"({k['fp32_equiv_TFLOPs']:.0f} TFLOP/s fp32-equivalent); `peak` is the dense spec figure -- "
                                  f"the MFMA-only ablation of this loop sustains {MFMA_SUSTAINED_TFLOPS:.0f} TFLOP/s on random "

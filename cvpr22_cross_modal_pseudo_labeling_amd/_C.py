@@ -1013,6 +1013,49 @@ def region_noun_align(region_emb, noun_emb):
     return raw, prob, idx
 
 
+def text_embed(table, input_ids, special_tokens_mask):
+    """Word embeddings of tokenised strings (``ovis_text_embed_f32``; language_backbone/transformers.py:27-68 +
+    st_generalized_rcnn.py:202-209): table [V, D] float32, input_ids / special_tokens_mask [N, L] integer tensors as the
+    tokenizer pads them -> [N, D] unit-norm rows (masked mean of the table rows, then F.normalize)."""
+    table = _dev(table, "table")
+    if table.dim() != 2 or input_ids.dim() != 2 or input_ids.shape != special_tokens_mask.shape:
+        raise RuntimeError("text_embed: expected table [V, D] and input_ids / special_tokens_mask [N, L]")
+    if table.requires_grad:
+        raise RuntimeError("text_embed: the embedding table is frozen on this path (MODEL.LANGUAGE_BACKBONE.FT_EMB False)")
+    ids = input_ids.to(device=table.device, dtype=torch.int32).contiguous()
+    sp = special_tokens_mask.to(device=table.device, dtype=torch.int32).contiguous()
+    n, l = ids.shape
+    out = torch.empty((n, table.shape[1]), dtype=torch.float32, device=table.device)
+    if n:
+        with _on(table.device):
+            rc = _L.ovis_text_embed_f32(table.data_ptr(), table.shape[0], table.shape[1], ids.data_ptr(), sp.data_ptr(), n, l,
+                                        out.data_ptr(), _stream())
+        _lib.check(rc, "text_embed")
+    return out
+
+
+def project_polygon_masks(coords, polygon_start, instance_start, gt_index, boxes, image_size, resolution):
+    """Mask targets [P, M, M] for boxes [P, 4] from POLYGON ground truth (``ovis_project_polygon_masks_f32``;
+    mask_head/loss.py:11-42 through PolygonInstance.crop / resize / convert_to_binarymask, segmentation_mask.py:270-334).
+    coords float32 [T] (x, y pairs of all polygons), polygon_start int32 [NP + 1] (float offsets), instance_start int32
+    [G + 1] (polygon ranges), gt_index [P] int64, image_size = (width, height)."""
+    boxes = _dev(boxes, "boxes")
+    coords = _dev(coords, "coords") if coords.numel() else coords
+    polygon_start = _dev(polygon_start, "polygon_start", torch.int32)
+    instance_start = _dev(instance_start, "instance_start", torch.int32)
+    gt_index = _dev(gt_index, "gt_index", torch.int64)
+    p = boxes.shape[0]
+    out = torch.empty((p, resolution, resolution), dtype=torch.float32, device=boxes.device)
+    if p:
+        with _on(boxes.device):
+            rc = _L.ovis_project_polygon_masks_f32(coords.data_ptr() if coords.numel() else 0, polygon_start.data_ptr(),
+                                                   instance_start.data_ptr(), gt_index.data_ptr(), boxes.data_ptr(), p,
+                                                   int(image_size[0]), int(image_size[1]), int(resolution), out.data_ptr(),
+                                                   _stream())
+        _lib.check(rc, "project_polygon_masks")
+    return out
+
+
 def weighted_ce_fwd_bwd(logits, labels, bg_weight, need_grad=True):
     """-> (loss scalar tensor, dlogits or None)"""
     logits, labels = _dev(logits, "logits"), _dev(labels, "labels", torch.int64)

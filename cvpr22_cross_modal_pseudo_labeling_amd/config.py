@@ -106,6 +106,8 @@ def get_defaults():
             "WEIGHT": "", "BACKBONE_PREFIX": "", "LOAD_TRAINER_STATE": True,  # :37-39
             "LOAD_EMB_PRED_FROM_MMSS_HEAD": False, "LOAD_CLASSIFIER": True,  # :40-41
             "MMSS_HEAD": {"TYPES": ("GroundingHead",), "DEFAULT_HEAD": "GroundingHead"},  # :138-140 (checkpoint key rewrite only)
+            "LANGUAGE_BACKBONE": {"TYPE": "BERT-Base", "FREEZE": True, "EMBEDDING_PATH": "",  # :130-135
+                                  "ADD_POSITION_EMBEDDING": False, "FT_EMB": False},
             "LAMBDA_PSEUDO_LABEL": 0.0, "UNCERTAINTY": False, "RESUME": False,  # :42-44
             "UNCERTAINTY_TRAIN_ITER": 10000, "NO_PSEUDO_MASK": False, "REWEIGHT": True,  # :45-47
             "BACKBONE": {"CONV_BODY": "R-50-C4", "FREEZE_CONV_BODY_AT": 2},  # :125-128

@@ -51,6 +51,9 @@ def _record_stream(obj, stream):
         _record_stream(obj.bbox, stream)
         _record_stream(obj.extra_fields, stream)
         _record_stream(getattr(obj, "pos_index", None), stream)  # sampled lists: where their positives sit
+    elif hasattr(obj, "polygon_start"):  # PolygonMasks
+        for t in (obj.coords, obj.polygon_start, obj.instance_start):
+            _record_stream(t, stream)
     elif hasattr(obj, "probs") and hasattr(obj, "boxes"):  # PastedMasks
         _record_stream(obj.probs, stream)
         _record_stream(obj.boxes, stream)

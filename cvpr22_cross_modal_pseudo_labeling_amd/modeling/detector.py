@@ -28,6 +28,7 @@ from .. import _C
 from .backbone import Backbone
 from .roi_heads import CombinedROIHeads, Masker
 from .rpn import RPNModule
+from .language_backbone import BERT, normalize_class_names
 from .structures import BoxList, PastedMasks, to_image_list
 
 
@@ -82,6 +83,9 @@ class STGeneralizedRCNN(nn.Module):
         self.reweight = cfg.MODEL.REWEIGHT
         self.iter = 0
         self.cap_embs = None  # [V, emb_dim] unit-norm caption-vocabulary (LVIS) embeddings
+        self.cap_vocab = None  # ... or the vocabulary's names, embedded through ``self.bert`` (set_caption_vocab_names)
+        # st_generalized_rcnn.py:45: the frozen BERT word-embedding table + tokenizer (state-dict key ``bert.embeddings``)
+        self.bert = BERT(cfg)
 
     def never_used_parameters(self):
         """Trainable parameters no loss depends on (``update_exemplars`` is commented out upstream): the gradient
@@ -94,12 +98,33 @@ class STGeneralizedRCNN(nn.Module):
         iteration, st_generalized_rcnn.py:190-191,202-209)."""
         self.cap_embs = F.normalize(embs.float(), dim=-1)
 
+    def set_caption_vocab_names(self, names):
+        """The caption vocabulary as strings (the reference hard-wires the 1203 LVIS category names,
+        st_generalized_rcnn.py:71-76): embedded through the BERT word-embedding table by ``prepare_model``
+        (st_generalized_rcnn.py:190-191) -- once per table version, not once per iteration."""
+        self.cap_vocab = normalize_class_names(names)
+        self.cap_embs = None
+
+    def extract_emb(self, words):
+        """st_generalized_rcnn.py:202-209."""
+        return self.bert.extract_emb(words)
+
     def set_class_embeddings(self, embs):
         """Seen-class matrix with the all-zero background row 0 (engine/trainer.py:85-90)."""
         self.roi_heads["box"].predictor.set_class_embeddings(embs)
         # own reference: generate_pseudo_label swaps the teacher predictor's matrix for a dummy while it runs, and the
         # frozen half may be running on another thread (engine/trainer.py::PipelinedTrainer)
         self._seen_cls = self.roi_heads["box"].predictor.cls_score
+
+    def _noun_embs(self, target):
+        """[W, D] embeddings of an image's caption nouns: given (``cap_embs`` field), extracted from the strings
+        (``nn_caption`` = 'noun/noun/...', st_generalized_rcnn.py:318,242) or rows of the vocabulary matrix (``ids_cap``)."""
+        if target.has_field("cap_embs"):
+            return target.get_field("cap_embs")
+        by_text = self.cap_vocab is not None or self.cap_embs is None  # a vocabulary given as a matrix has no strings
+        if by_text and target.has_field("nn_caption") and isinstance(target.get_field("nn_caption"), str):
+            return self.bert.extract_emb(target.get_field("nn_caption").split("/"))
+        return self.cap_embs[target.get_field("ids_cap")]
 
     def combine_embs(self, embs):
         # exemplar bank is empty (see module docstring) -> st_generalized_rcnn.py:165-166.  The matrices are constants of
@@ -114,7 +139,12 @@ class STGeneralizedRCNN(nn.Module):
             cache[id(embs)] = hit
         return hit[2]
 
+    def prepare_text(self):
+        if self.cap_vocab is not None:
+            self.cap_embs = self.bert.extract_emb(self.cap_vocab)  # cached: a no-op while the table is unchanged
+
     def prepare_model(self):
+        self.prepare_text()
         student = self.roi_heads_student["box"].predictor
         seen = getattr(self, "_seen_cls", None)
         if seen is None:
@@ -196,6 +226,7 @@ class STGeneralizedRCNN(nn.Module):
             features = self.backbone(images.tensors)
         feat = features[0]
         out = {"feat": feat}
+        self.prepare_text()
         idxs_cap = [i for i, t in enumerate(targets) if t.has_field("ids_cap") and len(t.get_field("ids_cap")) > 0]
         out["idxs_cap"] = idxs_cap
         idxs_gt = [i for i, t in enumerate(targets) if t.has_field("is_det") and t.get_field("is_det") == "Yes"]
@@ -212,8 +243,7 @@ class STGeneralizedRCNN(nn.Module):
             cap_features = [feat if idxs_cap == list(range(feat.shape[0])) else feat[idxs_cap]]  # no copy for "all images"
             cap_proposals = [proposals[i] for i in idxs_cap]
             cap_targets = [targets[i] for i in idxs_cap]
-            noun_embs = [t.get_field("cap_embs") if t.has_field("cap_embs") else self.cap_embs[t.get_field("ids_cap")]
-                         for t in cap_targets]
+            noun_embs = [self._noun_embs(t) for t in cap_targets]
             out["cap_features"] = cap_features
             out["cap_proposals"] = cap_proposals
             out["pseudo_targets"] = self.generate_pseudo_label(cap_features, cap_proposals, noun_embs, cap_targets)

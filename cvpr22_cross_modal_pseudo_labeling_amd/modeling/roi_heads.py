@@ -28,7 +28,7 @@ from ..layers import (Conv2d, ConvTranspose2d, ROIAlign, linear_mfma, smooth_l1_
 from .backbone import ResNetHead
 from .box_coder import BoxCoder
 from .matcher import BalancedPositiveNegativeSampler, Matcher
-from .structures import BoxList, PastedMasks, box_iou, boxlist_nms, cat_boxlist
+from .structures import BoxList, PastedMasks, PolygonMasks, box_iou, boxlist_nms, cat_boxlist
 
 
 def _cat(tensors, dim=0):
@@ -538,8 +538,9 @@ class MaskRCNNLossComputation:
                 continue
             if isinstance(gt_masks, PastedMasks):
                 gt_masks = gt_masks.materialize()
-            fused = (prop.bbox.is_cuda and not self.matcher.allow_low_quality_matches and gt_masks.dim() == 3
-                     and gt_masks.dtype in (torch.bool, torch.uint8))
+            poly = isinstance(gt_masks, PolygonMasks)
+            fused = (prop.bbox.is_cuda and not self.matcher.allow_low_quality_matches
+                     and (poly or (gt_masks.dim() == 3 and gt_masks.dtype in (torch.bool, torch.uint8))))
             if fused:
                 idx, lab, _ = _C.match_encode(tgt.bbox, tgt.get_field("labels"), prop.bbox, self.matcher.high_threshold,
                                               self.matcher.low_threshold, None, between_keeps_label=True)
@@ -549,7 +550,9 @@ class MaskRCNNLossComputation:
                 lab = tgt.get_field("labels")[idx].to(torch.int64)
                 lab[matched == Matcher.BELOW_LOW_THRESHOLD] = 0
             pos = torch.nonzero(lab > 0).squeeze(1)
-            if fused:  # crop + bilinear resize of every positive's mask in one launch (csrc/targets.hip)
+            if poly:   # crop + resize + rasterise every positive's polygons in one launch (csrc/polygons.hip)
+                masks.append(self._project(gt_masks, idx[pos], prop.bbox[pos]))
+            elif fused:  # crop + bilinear resize of every positive's mask in one launch (csrc/targets.hip)
                 masks.append(_C.project_masks(gt_masks, idx[pos], prop.bbox[pos], self.discretization_size))
             else:
                 masks.append(project_masks_on_boxes(gt_masks, idx[pos], prop.bbox[pos], self.discretization_size))
@@ -561,6 +564,11 @@ class MaskRCNNLossComputation:
         if isinstance(gt_masks, PastedMasks):  # pseudo labels: targets straight from the probability maps
             return _C.project_pasted_masks(gt_masks.probs, gt_masks.boxes, gt_index, boxes, gt_masks.image_size, m,
                                            gt_masks.threshold)
+        if isinstance(gt_masks, PolygonMasks):  # COCO polygon ground truth (SegmentationMask mode 'poly')
+            if not gt_masks.coords.is_cuda:
+                gt_masks = gt_masks.to(boxes.device)
+            return _C.project_polygon_masks(gt_masks.coords, gt_masks.polygon_start, gt_masks.instance_start, gt_index, boxes,
+                                            gt_masks.size, m)
         if gt_masks.dim() == 3 and gt_masks.dtype in (torch.bool, torch.uint8):
             return _C.project_masks(gt_masks, gt_index, boxes, m)
         return project_masks_on_boxes(gt_masks, gt_index, boxes, m)

@@ -61,7 +61,12 @@ class BoxList:
             item = torch.nonzero(item).squeeze(1)  # ONE nonzero instead of one per indexed field
         out = BoxList(self.bbox[item], self.size)
         for k, v in self.extra_fields.items():
-            out.add_field(k, v[item] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == len(self) else v)
+            if torch.is_tensor(v):
+                out.add_field(k, v[item] if v.dim() > 0 and v.shape[0] == len(self) else v)
+            elif isinstance(v, PolygonMasks):  # per-box polygon lists follow the boxes (bounding_box.py:233-242)
+                out.add_field(k, v[item])
+            else:
+                out.add_field(k, v)
         return out
 
     def to(self, device):
@@ -112,6 +117,81 @@ class PastedMasks:
         from .roi_heads import Masker
         h, w = self.image_size
         return Masker(self.threshold, self.padding)(self.probs[:, None], BoxList(self.boxes, (w, h)))[:, 0]
+
+
+class PolygonMasks:
+    """Polygon ground-truth masks of one image, the reference's ``SegmentationMask(polygons, size, mode='poly')``
+    (structures/segmentation_mask.py:348-478 over PolygonInstance :208-347) in the flat form the device kernel reads:
+    ``coords`` float32 [T] -- the (x, y) pairs of every polygon back to back --, ``polygon_start`` int32 [NP + 1] (offsets
+    in floats) and ``instance_start`` int32 [G + 1] (polygon ranges of the G instances).  ``size`` = (width, height).
+    Polygons with fewer than 3 vertices are dropped at construction, as ``PolygonInstance.__init__`` does.  The mask
+    head's targets come from ``_C.project_polygon_masks`` (crop -> resize -> rasterise per positive, one launch);
+    ``convert_to_binarymask`` rasterises whole-image masks with the same kernel."""
+
+    def __init__(self, instances, size, _flat=None):
+        self.size = tuple(size)
+        if _flat is not None:
+            self.coords, self.polygon_start, self.instance_start = _flat
+            return
+        coords, pstart, istart = [], [0], [0]
+        for polys in instances:
+            for poly in polys:
+                flat = [float(v) for v in (poly.tolist() if hasattr(poly, "tolist") else poly)]
+                if len(flat) >= 6:  # 3 * 2 coordinates (segmentation_mask.py:227)
+                    coords.extend(flat[: len(flat) // 2 * 2])
+                    pstart.append(len(coords))
+            istart.append(len(pstart) - 1)
+        self.coords = torch.tensor(coords, dtype=torch.float32)
+        self.polygon_start = torch.tensor(pstart, dtype=torch.int32)
+        self.instance_start = torch.tensor(istart, dtype=torch.int32)
+
+    def __len__(self):
+        return self.instance_start.numel() - 1
+
+    def to(self, device):
+        return PolygonMasks(None, self.size, (self.coords.to(device), self.polygon_start.to(device),
+                                              self.instance_start.to(device)))
+
+    def instances(self):
+        """Back to the nested-list form: per instance a list of flat float32 polygons (host tensors)."""
+        c, ps, ist = self.coords.cpu(), self.polygon_start.tolist(), self.instance_start.tolist()
+        return [[c[ps[q]:ps[q + 1]] for q in range(ist[g], ist[g + 1])] for g in range(len(self))]
+
+    def __getitem__(self, item):
+        """Instances selected by an int, a slice, an index tensor or a boolean mask (SegmentationMask.__getitem__,
+        segmentation_mask.py:437-458) -- re-packed on the host: ground-truth lists are a handful of instances."""
+        inst = self.instances()
+        if isinstance(item, int):
+            picked = [inst[item]]
+        elif isinstance(item, slice):
+            picked = inst[item]
+        else:
+            item = torch.as_tensor(item).cpu()
+            idx = torch.nonzero(item).squeeze(1).tolist() if item.dtype == torch.bool else item.reshape(-1).tolist()
+            picked = [inst[i] for i in idx]
+        return PolygonMasks(picked, self.size).to(self.coords.device)
+
+    def transpose(self, method):
+        """FLIP_LEFT_RIGHT (0) / FLIP_TOP_BOTTOM (1): segmentation_mask.py:250-268 (``dim - p - 1`` on one coordinate)."""
+        if method not in (0, 1):
+            raise NotImplementedError("Only FLIP_LEFT_RIGHT and FLIP_TOP_BOTTOM implemented")
+        c = self.coords.clone()
+        c[method::2] = self.size[method] - self.coords[method::2] - TO_REMOVE
+        return PolygonMasks(None, self.size, (c, self.polygon_start, self.instance_start))
+
+    def convert_to_binarymask(self):
+        """uint8 [G, height, width]: every instance rasterised over the whole image (segmentation_mask.py:326-334)."""
+        from .. import _C
+        w, h = self.size
+        g = len(self)
+        if max(w, h) > 64 or not self.coords.is_cuda:
+            raise NotImplementedError("whole-image rasterisation is only wired for device polygons on maps up to 64 x 64; "
+                                      "the training path rasterises per positive at the mask resolution")
+        if w != h:
+            raise NotImplementedError("square maps only (crop + resize to M x M is the training path)")
+        boxes = torch.tensor([[0.0, 0.0, float(w), float(h)]], device=self.coords.device).expand(g, 4).contiguous()
+        idx = torch.arange(g, device=self.coords.device)
+        return _C.project_polygon_masks(self.coords, self.polygon_start, self.instance_start, idx, boxes, self.size, w).to(torch.uint8)
 
 
 def cat_boxlist(boxlists):  # boxlist_ops.py:107-129

@@ -559,6 +559,28 @@ int ovis_deform_conv_implicit_f32(const float* input_nhwc, const float* offset, 
                                   int out_w, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h,
                                   int pad_w, int dil_h, int dil_w, int deformable_group, void* stream);
 
+/* Text side of the cross-modal head: mb/modeling/language_backbone/transformers.py:27-68 (BERT.forward: the frozen
+ * word-embedding table indexed by the token ids, no transformer forward) + mb/modeling/detector/st_generalized_rcnn.py:
+ * 202-209 (extract_emb): out[n] = normalize( sum_l (1 - special[n,l]) * table[ids[n,l]] / sum_l (1 - special[n,l]) ),
+ * normalize = x / max(||x||_2, 1e-12).  table [table_rows, dim] f32 (dim % 4 == 0), input_ids / special_tokens_mask
+ * [num_words, max_tokens] int32 as the tokenizer pads them ([CLS], [SEP], [PAD] carry special = 1), out [num_words,
+ * dim].  The [num_words, max_tokens, dim] tensor the reference builds is never materialised.  A token id outside the
+ * table makes that word's row NaN. */
+int ovis_text_embed_f32(const float* table, long table_rows, int dim, const int32_t* input_ids,
+                        const int32_t* special_tokens_mask, int num_words, int max_tokens, float* out, void* stream);
+
+/* Polygon ground truth -> mask-head targets: project_masks_on_boxes (mb/modeling/roi_heads/mask_head/loss.py:11-42)
+ * for SegmentationMask(mode='poly') targets -- PolygonInstance.crop / resize / convert_to_binarymask
+ * (mb/structures/segmentation_mask.py:270-334), whose rasteriser is pycocotools' rleFrPoly + merge + decode
+ * (pycocotools==2.0, requirements.txt:35; restated, see csrc/polygons.hip).  coords: all polygons' (x, y) float32
+ * pairs back to back; polygon q owns coords[polygon_start[q] .. polygon_start[q+1]) (offsets in floats, even);
+ * ground-truth instance g owns polygons [instance_start[g], instance_start[g+1]) (polygons with < 3 vertices are
+ * skipped, as PolygonInstance.__init__ drops them); gt_index [num] int64 picks the instance of every box; boxes
+ * [num, 4] xyxy in image pixels; out [num, resolution, resolution] f32 in {0, 1}.  resolution <= 64. */
+int ovis_project_polygon_masks_f32(const float* coords, const int32_t* polygon_start, const int32_t* instance_start,
+                                   const int64_t* gt_index, const float* boxes, int num, int image_width,
+                                   int image_height, int resolution, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

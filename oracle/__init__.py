@@ -126,3 +126,66 @@ def roi_pool_backward(grad, argmax, rois, n, c, h, w):
     gin = torch.empty((n, c, h, w), dtype=torch.float32)
     lib().oracle_roi_pool_backward_f32(_p(grad), _p(argmax), _p(rois), _p(gin), r, n, c, h, w, ph, pw)
     return gin
+
+
+def polygon_to_mask(polygons, height, width):
+    """Union of the polygons' masks at height x width (pycocotools frPyObjects -> merge -> decode, restated in
+    ovis_oracle.c::oracle_polygon_to_mask).  polygons: iterable of flat (x0, y0, x1, y1, ...) float sequences."""
+    import numpy as np
+
+    mask = np.zeros((height, width), dtype=np.uint8)
+    for p in polygons:
+        xy = np.ascontiguousarray(np.asarray(p, dtype=np.float64))  # _mask.pyx: np.array(p, dtype=np.double)
+        lib().oracle_polygon_to_mask(ctypes.c_void_p(xy.ctypes.data), int(xy.size // 2), int(height), int(width),
+                                     ctypes.c_void_p(mask.ctypes.data))
+    return torch.from_numpy(mask)
+
+
+def project_polygons_on_boxes(instances, gt_index, boxes, image_size, resolution):
+    """mask_head/loss.py:11-42 for polygon targets: per box, PolygonInstance.crop (segmentation_mask.py:270-296) ->
+    resize((M, M)) (:298-324) -> convert_to_binarymask (:326-334) -> float32 [P, M, M].  instances: per ground truth a list
+    of flat polygons; image_size = (width, height).  The crop / resize arithmetic is float32 tensor (op) python float, as
+    in the reference."""
+    import numpy as np
+
+    W, H = image_size
+    M = resolution
+    out = torch.zeros((len(gt_index), M, M), dtype=torch.float32)
+    for i, (g, box) in enumerate(zip(gt_index.tolist(), boxes.tolist())):
+        xmin, ymin, xmax, ymax = map(float, box)
+        xmin = min(max(xmin, 0), W - 1)
+        ymin = min(max(ymin, 0), H - 1)
+        xmax = min(max(xmax, 0), W)
+        ymax = min(max(ymax, 0), H)
+        xmax = max(xmax, xmin + 1)
+        ymax = max(ymax, ymin + 1)
+        w, h = xmax - xmin, ymax - ymin
+        polys = []
+        for p in instances[g]:
+            p = torch.as_tensor(p, dtype=torch.float32)
+            if len(p) < 6:
+                continue
+            p = p.clone()
+            p[0::2] = p[0::2] - xmin
+            p[1::2] = p[1::2] - ymin
+            rw, rh = float(M) / float(w), float(M) / float(h)
+            if rw == rh:
+                p = p * rw
+            else:
+                p[0::2] *= rw
+                p[1::2] *= rh
+            polys.append(p.numpy())
+        out[i] = polygon_to_mask(polys, M, M).float()
+    return out
+
+
+def text_embed(table, input_ids, special_tokens_mask):
+    """st_generalized_rcnn.py:202-209 (extract_emb) on token ids: masked mean of the table rows, then F.normalize -- in
+    torch on the CPU, expression by expression."""
+    import torch.nn.functional as F
+
+    table = _f(table)
+    emb = table[input_ids.long().cpu()]
+    mask = (1 - special_tokens_mask.cpu()).to(torch.float32)
+    e = (emb * mask[:, :, None]).sum(1) / mask.sum(1)[:, None]
+    return F.normalize(e, dim=-1)

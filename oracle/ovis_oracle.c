@@ -276,3 +276,103 @@ void oracle_roi_pool_backward_f32(const float* grad, const int32_t* argmax, cons
     if (argmax[index] != -1) gin[((long)b * C + c) * H * W + argmax[index]] += grad[index];
   }
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* Polygon -> binary mask.  THIRD-PARTY ALGORITHM, PARITY UNPINNED: the reference calls  */
+/* pycocotools.mask.frPyObjects / merge / decode (structures/segmentation_mask.py:326-334, */
+/* pycocotools==2.0 per requirements.txt:35), which is not under /root/reference and not   */
+/* installed here.  This restates the published algorithm of its common/maskApi.c:         */
+/* rleFrPoly (polygon -> run lengths: x5 upsampling, dense edge walk, y-boundary points at  */
+/* integer pixel columns, sort, zero-run merging), rleMerge with intersect = 0 (union) and   */
+/* rleDecode (column-major runs, starting with a 0-run) -- literally, sort and runs         */
+/* included, so that the device kernel's sort-free "toggle + prefix parity" formulation is  */
+/* checked against the original control flow.  Anchors: the reference's call site above and */
+/* known-answer cases in tests/test_polygons.py (rectangles, triangles, out-of-image        */
+/* vertices) worked out by hand from the algorithm's definition.                             */
+/* ------------------------------------------------------------------------------------ */
+static int cmp_uint(const void* a, const void* b) {
+  uint32_t c = *(const uint32_t*)a, d = *(const uint32_t*)b;
+  return c > d ? 1 : (c < d ? -1 : 0);
+}
+
+/* xy: k vertices (x0, y0, x1, y1, ...) in double; mask [h][w] row-major uint8, OR-ed in (union of polygons). */
+void oracle_polygon_to_mask(const double* xy, int k, int h, int w, uint8_t* mask) {
+  const double scale = 5;
+  int j, m = 0;
+  if (k < 1) return;
+  int* x = (int*)malloc(sizeof(int) * (k + 1));
+  int* y = (int*)malloc(sizeof(int) * (k + 1));
+  for (j = 0; j < k; j++) x[j] = (int)(scale * xy[j * 2 + 0] + .5);
+  x[k] = x[0];
+  for (j = 0; j < k; j++) y[j] = (int)(scale * xy[j * 2 + 1] + .5);
+  y[k] = y[0];
+  for (j = 0; j < k; j++) {
+    int a = abs(x[j] - x[j + 1]), b = abs(y[j] - y[j + 1]);
+    m += (a > b ? a : b) + 1;
+  }
+  int* u = (int*)malloc(sizeof(int) * m);
+  int* v = (int*)malloc(sizeof(int) * m);
+  m = 0;
+  for (j = 0; j < k; j++) {
+    int xs = x[j], xe = x[j + 1], ys = y[j], ye = y[j + 1], dx, dy, t, d, flip;
+    double s;
+    dx = abs(xe - xs);
+    dy = abs(ys - ye);
+    flip = (dx >= dy && xs > xe) || (dx < dy && ys > ye);
+    if (flip) { t = xs; xs = xe; xe = t; t = ys; ys = ye; ye = t; }
+    s = dx >= dy ? (double)(ye - ys) / dx : (double)(xe - xs) / dy;
+    if (dx >= dy) for (d = 0; d <= dx; d++) {
+      t = flip ? dx - d : d;
+      u[m] = t + xs;
+      /* dx == 0 (a repeated vertex): the original evaluates (int)(NaN); that point never meets a neighbour with a
+         different x, so its y is never read -- any value will do */
+      v[m] = dx == 0 ? ys : (int)(ys + s * t + .5);
+      m++;
+    } else for (d = 0; d <= dy; d++) {
+      t = flip ? dy - d : d;
+      v[m] = t + ys;
+      u[m] = (int)(xs + s * t + .5);
+      m++;
+    }
+  }
+  /* points along the y-boundary, downsampled */
+  int n = m;
+  free(x); free(y);
+  x = (int*)malloc(sizeof(int) * (n + 1));
+  y = (int*)malloc(sizeof(int) * (n + 1));
+  m = 0;
+  for (j = 1; j < n; j++) if (u[j] != u[j - 1]) {
+    double xd = (double)(u[j] < u[j - 1] ? u[j] : u[j] - 1), yd;
+    xd = (xd + .5) / scale - .5;
+    if (floor(xd) != xd || xd < 0 || xd > w - 1) continue;
+    yd = (double)(v[j] < v[j - 1] ? v[j] : v[j - 1]);
+    yd = (yd + .5) / scale - .5;
+    if (yd < 0) yd = 0; else if (yd > h) yd = h;
+    yd = ceil(yd);
+    x[m] = (int)xd;
+    y[m] = (int)yd;
+    m++;
+  }
+  /* run lengths from the sorted boundary positions */
+  int cnt = m;
+  uint32_t* a = (uint32_t*)malloc(sizeof(uint32_t) * (cnt + 1));
+  for (j = 0; j < cnt; j++) a[j] = (uint32_t)(x[j] * (int)h + y[j]);
+  a[cnt++] = (uint32_t)(h * w);
+  free(u); free(v); free(x); free(y);
+  qsort(a, cnt, sizeof(uint32_t), cmp_uint);
+  uint32_t p = 0;
+  for (j = 0; j < cnt; j++) { uint32_t t = a[j]; a[j] -= p; p = t; }
+  uint32_t* b = (uint32_t*)malloc(sizeof(uint32_t) * cnt);
+  j = 0; m = 0;
+  b[m++] = a[j++];
+  while (j < cnt) if (a[j] > 0) b[m++] = a[j++]; else { j++; if (j < cnt) b[m - 1] += a[j++]; }
+  /* rleDecode (column-major) OR-ed into the row-major mask: rleMerge(intersect = 0) of the instance's polygons */
+  long pos = 0;
+  uint8_t val = 0;
+  for (j = 0; j < m; j++) {
+    for (uint32_t c = 0; c < b[j] && pos < (long)h * w; c++, pos++)
+      if (val) mask[(pos % h) * w + (pos / h)] = 1;
+    val = !val;
+  }
+  free(a); free(b);
+}

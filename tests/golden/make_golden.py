@@ -336,6 +336,71 @@ def gen_c2_names():
                   sort_keys=True)
 
 
+WORDPIECES = ("[PAD] [UNK] [CLS] [SEP] [MASK] a b c d e f g h i j k l m n o p q r s t u v w x y z ##a ##b ##c ##d ##e ##f ##g "
+              "##h ##i ##j ##k ##l ##m ##n ##o ##p ##q ##r ##s ##t ##u ##v ##w ##x ##y ##z cat dog traffic light sign stop "
+              "fire hydrant hot teddy bear hair drier ##s ##ing ##ed ##er ##board skate surf snow tennis racket wine glass "
+              "cell phone potted plant dining table sports ball baseball bat glove parking meter bench bird horse sheep cow "
+              "elephant zebra giraffe back ##pack umbrella hand ##bag tie suit ##case fr ##is ##bee ski ##is kite person bicycle "
+              "car motor ##cycle air ##plane bus train truck boat").split()
+
+
+def gen_text():
+    """tests/golden/text_embed.npz + tests/golden/wordpiece_vocab.txt: the reference's own ``BERT.forward``
+    (language_backbone/transformers.py:27-68) and ``STGeneralizedRCNN.extract_emb`` (st_generalized_rcnn.py:202-209) on a
+    small WordPiece vocabulary and a random embedding table.  The reference constructor downloads bert-base-uncased, so
+    the object is built without it (``__new__``) and given the pieces its ``forward`` reads: ``tokenizer`` (HuggingFace
+    BertTokenizer over the synthetic vocabulary, behind an adapter that accepts transformers 3.0.2's
+    ``batch_encode_plus(..., pad_to_max_length=True)`` call), ``embeddings`` and ``mlm``; ``extract_emb`` is taken from the
+    reference file's syntax tree (its module imports yacs-dependent code and cannot be imported here) and run unchanged."""
+    import ast
+
+    from transformers import BertTokenizer
+
+    vocab_path = os.path.join(HERE, "wordpiece_vocab.txt")
+    with open(vocab_path, "w") as f:
+        f.write("\n".join(WORDPIECES) + "\n")
+    hf = BertTokenizer(vocab_path, do_lower_case=True)
+
+    class Tok302:  # the call surface of transformers==3.0.2 that transformers.py:28-32 uses
+        def batch_encode_plus(self, text_list, add_special_tokens=True, pad_to_max_length=False, return_special_tokens_mask=False):
+            enc = hf(list(text_list), add_special_tokens=add_special_tokens, padding=bool(pad_to_max_length),
+                     return_special_tokens_mask=return_special_tokens_mask)
+            return {k: v for k, v in enc.items()}
+
+    from maskrcnn_benchmark.modeling.language_backbone.transformers import BERT as RefBERT
+
+    g = torch.Generator().manual_seed(77)
+    table = torch.randn(len(WORDPIECES), 768, generator=g) * 0.05
+    ref = RefBERT.__new__(RefBERT)
+    torch.nn.Module.__init__(ref)
+    ref.tokenizer, ref.mlm = Tok302(), False
+    ref.embeddings = torch.nn.Parameter(table, requires_grad=False)
+    src = open(os.path.join(REF, "maskrcnn_benchmark/modeling/detector/st_generalized_rcnn.py")).read()
+    fn = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "extract_emb")
+    ns = {"torch": torch, "F": torch.nn.functional}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "st_generalized_rcnn.py", "exec"), ns)
+    holder = types.SimpleNamespace(bert=ref)
+    words = ["cat", "traffic light", "Fire Hydrant", "teddy bears", "hair drier", "skateboard", "xylophone zq", "a",
+             "potted plant", "sports ball", "backpack", "frisbee", "wine glasses", "motorcycle", "snowboarding"]
+    cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self  # transformers.py:60 hard-codes .cuda()
+    try:
+        enc = ref(words)
+        emb = ns["extract_emb"](holder, words)
+    finally:
+        torch.Tensor.cuda = cuda
+    # data/datasets/helper/parser.py:10-20 (its module imports spacy / nltk: the function is taken from the syntax tree too)
+    psrc = open(os.path.join(REF, "maskrcnn_benchmark/data/datasets/helper/parser.py")).read()
+    pfn = next(n for n in ast.walk(ast.parse(psrc)) if isinstance(n, ast.FunctionDef) and n.name == "normalize_class_names")
+    pns = {}
+    exec(compile(ast.Module(body=[pfn], type_ignores=[]), "parser.py", "exec"), pns)
+    raw_names = ["aerosol_can", "Bow_(decorative_ribbons)", "T-shirt", "hot/dog", "CD_player", "pop_(soda)", "plain"]
+    np.savez_compressed(os.path.join(HERE, "text_embed.npz"), table=table.numpy(), words=np.array(words),
+                        names_raw=np.array(raw_names), names_normalized=np.array(pns["normalize_class_names"](raw_names)),
+                        input_ids=enc["input_ids"].numpy(), special_tokens_mask=enc["special_tokens_mask"].numpy(),
+                        attention_mask=enc["attention_mask"].numpy(), embeddings=emb.detach().numpy())
+
+
 def main():
     torch.set_num_threads(1)
     ref_c = import_reference()
@@ -344,6 +409,7 @@ def main():
     gen_focal()
     gen_heads()
     gen_c2_names()
+    gen_text()
     print("fixtures written to", HERE)
 
 

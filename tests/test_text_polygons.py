@@ -1,0 +1,230 @@
+"""Text side of the cross-modal head and polygon mask targets.
+
+* text: fixture made by the reference's own ``BERT.forward`` + ``extract_emb`` (tests/golden/make_golden.py::gen_text) --
+  the oracle restatement, the host tokenisation and (gpu) the one-launch kernel all reproduce it;
+* polygons: the rasteriser is pycocotools (absent: parity unpinned by reference outputs) -- the oracle restates its
+  published algorithm literally and is anchored on known answers worked out from the definition; the device kernel is
+  bit-exact against the oracle through the reference's crop -> resize -> rasterise chain."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def z(golden_dir):
+    return np.load(os.path.join(golden_dir, "text_embed.npz"))
+
+
+def _bert(golden_dir, z, device="cpu"):
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.language_backbone import BERT
+
+    table = T(z["table"])
+    b = BERT(None, vocab_file=os.path.join(golden_dir, "wordpiece_vocab.txt"), vocab_size=table.shape[0], hidden_size=table.shape[1])
+    with torch.no_grad():
+        b.embeddings.copy_(table)
+    return b.to(device)
+
+
+# ---- CPU: oracle + host logic ------------------------------------------------------------------------------------------
+def test_oracle_text_embed_matches_reference_fixture(oracle_mod, z):
+    got = oracle_mod.text_embed(T(z["table"]), T(z["input_ids"]), T(z["special_tokens_mask"]))
+    assert torch.allclose(got, T(z["embeddings"]), rtol=0, atol=1e-7)
+
+
+def test_tokenisation_and_forward_fields_match_reference_fixture(golden_dir, z):
+    b = _bert(golden_dir, z)
+    words = [str(w) for w in z["words"]]
+    enc = b.tokenize(words)
+    assert torch.equal(enc["input_ids"], T(z["input_ids"]))
+    assert torch.equal(enc["special_tokens_mask"], T(z["special_tokens_mask"]))
+    assert torch.equal(enc["attention_mask"], T(z["attention_mask"]))
+    out = b(words)  # the reference's return value: the same fields + the gathered table rows
+    assert out["input_embeddings"].shape == (len(words), enc["input_ids"].shape[1], 768)
+    assert torch.equal(out["input_embeddings"][3, 2], T(z["table"])[int(z["input_ids"][3, 2])])
+
+
+def test_normalize_class_names_matches_reference_fixture(z):
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.language_backbone import normalize_class_names
+
+    assert normalize_class_names([str(n) for n in z["names_raw"]]) == [str(n) for n in z["names_normalized"]]
+
+
+def test_bert_state_dict_key_and_missing_vocabulary_error():
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.language_backbone import BERT
+
+    b = BERT(None, vocab_size=16, hidden_size=8)
+    assert list(b.state_dict().keys()) == ["embeddings"]  # ``bert.embeddings`` inside the detector, as in the reference
+    old = os.environ.pop("OVIS_BERT_VOCAB", None)
+    try:
+        with pytest.raises(RuntimeError, match="vocabulary"):
+            b.tokenize(["cat"])
+    finally:
+        if old is not None:
+            os.environ["OVIS_BERT_VOCAB"] = old
+
+
+def _rect(x0, y0, x1, y1):
+    return [x0, y0, x1, y0, x1, y1, x0, y1]
+
+
+def test_oracle_polygon_known_answers(oracle_mod):
+    """Worked out from rleFrPoly's definition: a polygon with integer corners covers the pixels whose centres lie inside
+    it -- columns [x0, x1), rows [y0, y1) for an axis-aligned rectangle, whatever the vertex order; vertices outside the
+    image are clipped; polygons of an instance are merged by union; the pixel on the hypotenuse of a half-square
+    triangle follows the (v + .5) / 5 - .5 down-sampling rule."""
+    m = oracle_mod.polygon_to_mask([_rect(1, 1, 5, 4)], 7, 8)
+    want = torch.zeros(7, 8, dtype=torch.uint8)
+    want[1:4, 1:5] = 1
+    assert torch.equal(m, want)
+    rev = _rect(1, 1, 5, 4)
+    rev = [v for xy in reversed(list(zip(rev[0::2], rev[1::2]))) for v in xy]
+    assert torch.equal(oracle_mod.polygon_to_mask([rev], 7, 8), want)
+    # clipped by the image; union of two polygons
+    m = oracle_mod.polygon_to_mask([_rect(-3, -2, 2, 3), _rect(6, 5, 12, 9)], 7, 8)
+    want = torch.zeros(7, 8, dtype=torch.uint8)
+    want[0:3, 0:2] = 1
+    want[5:7, 6:8] = 1
+    assert torch.equal(m, want)
+    # lower-left triangle of a square: row y keeps the pixels whose centres lie strictly inside, x + .5 + y + .5 < 8
+    # (a centre ON the hypotenuse is outside)
+    m = oracle_mod.polygon_to_mask([[0, 0, 8, 0, 0, 8]], 8, 8)
+    assert m.sum(1).tolist() == [7, 6, 5, 4, 3, 2, 1, 0]
+    assert all(bool(m[y, : 7 - y].all()) for y in range(8))
+    # a polygon thinner than a pixel that contains no pixel centre column: empty
+    assert int(oracle_mod.polygon_to_mask([_rect(2.1, 1, 2.4, 6)], 7, 8).sum()) == 0
+    # fractional corners: the column crossing x = 1.5 .. 4.5 covers centres 2, 3, 4 -> columns 2..4 ... pixel c is inside
+    # when 5 c + 2 (its sample column in the x5 grid) lies in [round(5 x0), round(5 x1))
+    m = oracle_mod.polygon_to_mask([_rect(1.5, 0, 4.5, 3)], 4, 8)
+    cols = [c for c in range(8) if round(5 * 1.5 + 1e-9) <= 5 * c + 2 < round(5 * 4.5 + 1e-9)]
+    assert m[0].nonzero().squeeze(1).tolist() == cols
+
+
+def test_polygon_masks_container_follows_boxlist_indexing():
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.structures import BoxList, PolygonMasks
+
+    inst = [[_rect(1, 1, 5, 4)], [_rect(0, 0, 2, 2), [3, 3, 4, 4]], [[0, 0, 8, 0, 0, 8]]]  # a 2-vertex polygon is dropped
+    pm = PolygonMasks(inst, (20, 10))
+    assert len(pm) == 3 and pm.polygon_start.tolist() == [0, 8, 16, 22] and pm.instance_start.tolist() == [0, 1, 2, 3]
+    bl = BoxList(torch.tensor([[1.0, 1, 5, 4], [0, 0, 2, 2], [0, 0, 8, 8]]), (20, 10))
+    bl.add_field("masks", pm)
+    sub = bl[torch.tensor([2, 0])]
+    got = sub.get_field("masks")
+    assert len(got) == 2 and [p.tolist() for p in got.instances()[0]] == [[0, 0, 8, 0, 0, 8]]
+    assert len(bl[torch.tensor([True, False, True])].get_field("masks")) == 2
+    flipped = pm.transpose(0)  # FLIP_LEFT_RIGHT: x -> width - x - 1
+    assert flipped.instances()[0][0].tolist() == [18, 1, 14, 1, 14, 4, 18, 4]
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_text_embed_kernel_matches_reference_fixture(golden_dir, z):
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+
+    got = _C.text_embed(T(z["table"]).cuda(), T(z["input_ids"]).cuda(), T(z["special_tokens_mask"]).cuda())
+    assert torch.allclose(got.cpu(), T(z["embeddings"]), rtol=0, atol=2e-7)
+    b = _bert(golden_dir, z, "cuda")
+    words = [str(w) for w in z["words"]]
+    emb = b.extract_emb(words)
+    assert torch.allclose(emb.cpu(), T(z["embeddings"]), rtol=0, atol=2e-7)
+    assert b.extract_emb(words) is emb  # cached per (strings, table version)
+    with torch.no_grad():
+        b.embeddings.mul_(2.0)
+    assert b.extract_emb(words) is not emb
+    assert torch.allclose(b.extract_emb(words).cpu(), T(z["embeddings"]), rtol=0, atol=2e-7)  # normalised: scale-free
+
+
+@pytest.mark.gpu
+def test_text_embed_kernel_edge_cases(oracle_mod):
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+
+    g = torch.Generator().manual_seed(3)
+    table = torch.randn(50, 768, generator=g)
+    ids = torch.randint(0, 50, (1203, 9), generator=g)
+    sp = (torch.rand(1203, 9, generator=g) < 0.4).long()
+    sp[:, 1] = 0  # at least one real token per word
+    got = _C.text_embed(table.cuda(), ids.cuda(), sp.cuda())
+    assert torch.allclose(got.cpu(), oracle_mod.text_embed(table, ids, sp), rtol=0, atol=3e-7)
+    ids[7, 1] = 50  # outside the table: the reference's indexing raises, the kernel marks the word
+    got = _C.text_embed(table.cuda(), ids.cuda(), sp.cuda())
+    assert bool(torch.isnan(got[7]).all()) and bool(torch.isfinite(got[6]).all()) and bool(torch.isfinite(got[8]).all())
+    assert _C.text_embed(table.cuda(), ids[:0].cuda(), sp[:0].cuda()).shape == (0, 768)
+    with pytest.raises(RuntimeError):
+        _C.text_embed(table, ids, sp)  # CPU table: no fallback
+    with pytest.raises(RuntimeError):
+        _C.text_embed(table.cuda().requires_grad_(True), ids.cuda(), sp.cuda())
+
+
+def _random_instances(g, n_inst, img_w, img_h):
+    inst = []
+    for _ in range(n_inst):
+        polys = []
+        for _ in range(int(torch.randint(1, 4, (1,), generator=g))):
+            k = int(torch.randint(3, 12, (1,), generator=g))
+            cx, cy = float(torch.rand(1, generator=g)) * img_w, float(torch.rand(1, generator=g)) * img_h
+            r = float(torch.rand(1, generator=g)) * 120 + 10
+            ang = torch.sort(torch.rand(k, generator=g) * 2 * math.pi).values
+            rad = r * (0.4 + 0.6 * torch.rand(k, generator=g))
+            xs, ys = cx + rad * torch.cos(ang), cy + rad * torch.sin(ang)
+            polys.append(torch.stack([xs, ys], 1).reshape(-1).tolist())
+        inst.append(polys)
+    inst[0].append([5.0, 5.0, 9.0, 9.0])                      # < 3 vertices: dropped
+    inst[1].append([40.0, 40.0, 40.0, 40.0, 90.0, 40.0, 90.0, 95.0, 90.0, 95.0, 40.0, 95.0])  # repeated vertices
+    return inst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m", [14, 28])
+def test_project_polygon_masks_bit_exact_vs_oracle(oracle_mod, m):
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.structures import PolygonMasks
+
+    g = torch.Generator().manual_seed(17 + m)
+    img_w, img_h = 640, 427
+    inst = _random_instances(g, 9, img_w, img_h)
+    pm = PolygonMasks(inst, (img_w, img_h)).to("cuda")
+    p = 300
+    gi = torch.randint(0, 9, (p,), generator=g)
+    xy = torch.rand(p, 2, generator=g) * torch.tensor([img_w * 0.9, img_h * 0.9]) - 20
+    wh = torch.rand(p, 2, generator=g) * 250 + 2
+    boxes = torch.cat([xy, xy + wh], 1)
+    boxes[0] = torch.tensor([0.0, 0.0, float(img_w), float(img_h)])        # the whole image
+    boxes[1] = torch.tensor([100.0, 100.0, 100.0, 100.0])                  # degenerate: forced to 1 x 1
+    boxes[2] = torch.tensor([-50.0, -60.0, 30.0, 20.0])                    # clamped at the origin
+    boxes[3] = torch.tensor([600.0, 400.0, 900.0, 700.0])                  # clamped at the far corner
+    boxes[4] = torch.tensor([10.0, 10.0, 110.0, 110.0])                    # square: the equal-ratio branch of resize
+    got = _C.project_polygon_masks(pm.coords, pm.polygon_start, pm.instance_start, gi.cuda(), boxes.cuda(), pm.size, m)
+    want = oracle_mod.project_polygons_on_boxes(pm.instances(), gi, boxes, (img_w, img_h), m)
+    assert got.shape == (p, m, m)
+    assert torch.equal(got.cpu(), want)
+    assert 0.02 < float(want.mean()) < 0.9  # the cases are not all empty / all full
+
+
+@pytest.mark.gpu
+def test_mask_loss_targets_from_polygons_equal_oracle_projection(oracle_mod):
+    """``MaskRCNNLossComputation.prepare_targets`` with a polygon ``masks`` field (SegmentationMask mode 'poly' in the
+    reference): labels from the matcher, targets of the positives = the oracle's crop -> resize -> rasterise."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.roi_heads import MaskRCNNLossComputation
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.structures import BoxList, PolygonMasks
+
+    cfg = get_defaults()
+    cfg.merge_from_list(["MODEL.MASK_ON", True, "MODEL.CLS_AGNOSTIC_MASK", True])
+    cfg.freeze()
+    lc = MaskRCNNLossComputation(cfg)
+    size = (320, 240)
+    gt = torch.tensor([[20.0, 30, 140, 200], [150, 40, 300, 120]])
+    inst = [[[20.0, 30, 140, 30, 140, 200, 80, 230, 20, 200]], [_rect(150, 40, 300, 120), _rect(160, 50, 170, 60)]]
+    tgt = BoxList(gt, size).to("cuda")
+    tgt.add_field("labels", torch.tensor([3, 7], device="cuda"))
+    tgt.add_field("masks", PolygonMasks(inst, size).to("cuda"))
+    props = torch.tensor([[25.0, 35, 135, 190], [148, 45, 290, 118], [5, 5, 30, 30], [30, 20, 150, 210]])
+    labels, masks = lc.prepare_targets([BoxList(props, size).to("cuda")], [tgt])
+    assert labels[0].tolist() == [3, 7, 0, 3]
+    pos = torch.tensor([0, 1, 3])
+    want = oracle_mod.project_polygons_on_boxes(inst, torch.tensor([0, 1, 0]), props[pos], size, lc.discretization_size)
+    assert torch.equal(masks[0].cpu(), want)
