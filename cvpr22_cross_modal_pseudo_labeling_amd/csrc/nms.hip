@@ -13,7 +13,8 @@
 //     the reference's final index sort (nms.cu:127-130) is not needed.
 // Nothing is copied to the host; the caller reads back one int32 (the count) if it needs
 // a dense result tensor.
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "ovis_common.h"
 
@@ -329,22 +330,21 @@ __global__ __launch_bounds__(kReduceThreads) void nms_reduce_pipelined_kernel(
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct NmsLayout {
-  size_t keys_out, idx_in, order, cub_temp, cub_bytes, mask, diag_t, total;
+  size_t keys_out, idx_in, order, sort_temp, sort_bytes, mask, diag_t, total;
 };
 
 int nms_layout(int K, NmsLayout* L) {
   const size_t nb = (size_t)ovis_ceil_div(K, kTile);
-  size_t cub_bytes = 0;
-  hipError_t e = hipcub::DeviceRadixSort::SortPairsDescending(
-      nullptr, cub_bytes, (const float*)nullptr, (float*)nullptr, (const int*)nullptr,
-      (int*)nullptr, K);
+  size_t sort_bytes = 0;
+  hipError_t e = rocprim::radix_sort_pairs_desc(nullptr, sort_bytes, (const float*)nullptr, (float*)nullptr,
+                                                (const int*)nullptr, (int*)nullptr, (size_t)K);
   if (e != hipSuccess) return (int)e;
   size_t off = 0;
   L->keys_out = off; off = align256(off + sizeof(float) * (size_t)K);
   L->idx_in = off;   off = align256(off + sizeof(int) * (size_t)K);
   L->order = off;    off = align256(off + sizeof(int) * (size_t)K);
-  L->cub_temp = off; off = align256(off + cub_bytes);
-  L->cub_bytes = cub_bytes;
+  L->sort_temp = off; off = align256(off + sort_bytes);
+  L->sort_bytes = sort_bytes;
   L->mask = off;     off = align256(off + sizeof(unsigned long long) * (size_t)K * nb);
   L->diag_t = off;   off = align256(off + sizeof(unsigned long long) * (size_t)K);
   L->total = off;
@@ -406,10 +406,10 @@ static int nms_impl(const float* boxes, const float* scores, const int* groups, 
 
   hipLaunchKernelGGL(iota_kernel, dim3(ovis_ceil_div(K, 256)), dim3(256), 0, s, idx_in, K);
   OVIS_LAUNCH_CHECK();
-  size_t cub_bytes = L.cub_bytes;
-  OVIS_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(
-      (void*)(ws + L.cub_temp), cub_bytes, scores, keys_out, (const int*)idx_in, order, K, 0,
-      32, s));
+  size_t sort_bytes = L.sort_bytes;
+  // rocPRIM's device radix sort (ROCm's native primitive library): stable, so equal scores keep the lower index first
+  OVIS_HIP_TRY(rocprim::radix_sort_pairs_desc((void*)(ws + L.sort_temp), sort_bytes, scores, keys_out, (const int*)idx_in,
+                                              order, (size_t)K, 0u, 32u, s));
   dim3 grid(nb, nb);
 #define OVIS_NMS_MASK(GE_, GR_)                                                                            \
   hipLaunchKernelGGL((nms_mask_kernel<GE_, GR_>), grid, dim3(kTile), 0, s, (const float4*)boxes, groups, order, K, nb, \
