@@ -525,7 +525,13 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
   // pieces of 2 rows, double-buffered: 8 pieces per lane
   // NBUF - 1 pieces are in flight ahead of the one being stored; with two ahead the wait for a piece's operands no longer
   // includes the previous piece's stores (vmcnt retires in order).  The single-stage SHIFTED form has no registers for it.
-  constexpr int NBUF = (DUAL || (MODE == SHIFTED && NS == 1)) ? 2 : 3;
+#ifndef OVIS_EPI_NBUF   // experiment knobs (tools/experiments/build_variants.sh); 3 / 2 are the shipped depths
+#define OVIS_EPI_NBUF 3
+#endif
+#ifndef OVIS_EPI_NBUF_DUAL
+#define OVIS_EPI_NBUF_DUAL 2
+#endif
+  constexpr int NBUF = DUAL ? OVIS_EPI_NBUF_DUAL : ((MODE == SHIFTED && NS == 1) ? 2 : OVIS_EPI_NBUF);
   EpilogueOperands ops[NBUF][2];
   uint2 gates[NBUF][2];  // DUAL only
   // The fetches are UNCONDITIONAL straight-line loads (rows / columns outside the problem re-read its last row / first
