@@ -10,5 +10,7 @@ mkdir -p "$OUT"
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python bench.py --no-cpu-baseline --steps 12 --warmup 4 --burn-seconds 1 > $OUT/bench.log 2>&1 || { echo "rocprofv3 / bench.py failed:"; tail -20 $OUT/bench.log; exit 1; }
 f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] || { echo "no *kernel_trace.csv under $OUT/trace"; tail -20 $OUT/bench.log; exit 1; }
-python tools/gap_report.py $f -300 -60 | cut -c1-170 | head -24
+python tools/step_idle_report.py $f | cut -c1-230
+# (bench.py replays a few SEQUENTIAL steps after the timed region for its per-kernel figures: the last steps of the trace
+#  are those; the pipelined steps are the ones with overlap_ms > 0)
 rm -rf $OUT/trace
