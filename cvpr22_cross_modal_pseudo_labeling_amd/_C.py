@@ -1191,6 +1191,9 @@ def _dcn_backward(input, weight, offset, mask, grad_output, grad_input, grad_off
     for t in (grad_input, grad_offset, grad_mask, grad_weight):
         if t is not None and not t.is_contiguous():
             raise RuntimeError("deform_conv backward: gradient buffers must be contiguous")
+    if dcn_implicit and group == 1 and (cin // dg) % 32 == 0 and cout % 32 == 0 and b * plane > 0:
+        return _dcn_backward_rows(input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask, grad_weight,
+                                  scale, kH, kW, dH, dW, padH, padW, dilH, dilW, dg, b, cin, h, w, ho, wo, cout)
     col = torch.empty((cin * K, step, plane), dtype=torch.float32, device=input.device)
     with _on(input.device):
         for s0 in range(0, b, step):
@@ -1227,6 +1230,49 @@ def _dcn_backward(input, weight, offset, mask, grad_output, grad_input, grad_off
                                   col.data_ptr() + 4 * ((g * cin_g * K) * nb * plane + i * plane), nb * plane, 1,
                                   grad_weight[g * cout_g].data_ptr(), cin_g * K, cout_g, cin_g * K, plane,
                                   alpha=scale, accumulate=1)
+
+
+def _dcn_backward_rows(input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask, grad_weight, scale,
+                       kH, kW, dH, dW, padH, padW, dilH, dilW, dg, b, cin, h, w, ho, wo, cout):
+    """The backward without the reference-layout column buffer (csrc/deform_conv_rows.hip): rows = (image, h_out, w_out),
+    k = (tap, channel); dcol = dY . W as ONE split GEMM consumed by one scatter / gather pass (dX in NHWC with coalesced
+    atomics, offset and mask gradients reduced in the wave), the weight gradient as ONE transpose-read split GEMM over the
+    sampled rows written once in pair layout.  Same accumulate / overwrite conventions as the column route."""
+    dev = input.device
+    T, rows = kH * kW, b * ho * wo
+    x_nhwc = input.permute(0, 2, 3, 1).contiguous()
+    gy = grad_output.permute(0, 2, 3, 1).reshape(rows, cout)              # NHWC rows of dY
+    gyp = split_pair(gy.contiguous())
+    geom = (b, cin, h, w, ho, wo, kH, kW, dH, dW, padH, padW, dilH, dilW, dg)
+    mptr = 0 if mask is None else mask.data_ptr()
+    if grad_input is not None or grad_offset is not None:
+        wt = split_pair(weight.permute(2, 3, 1, 0).reshape(T * cin, cout).contiguous())   # B[(t, c), n] = w[n, c, t]
+        dcol, _ = split_gemm_pair(gyp, wt)                                                   # [rows, T * cin] f32
+        dx = torch.zeros((b, h, w, cin), dtype=torch.float32, device=dev) if grad_input is not None else None
+        if grad_offset is not None:
+            grad_offset.zero_()
+            if grad_mask is not None:
+                grad_mask.zero_()
+        with _on(dev):
+            rc = _L.ovis_deform_col2im_rows_f32(dcol.data_ptr(), dcol.stride(0), x_nhwc.data_ptr(), offset.data_ptr(), mptr,
+                                                0 if dx is None else dx.data_ptr(),
+                                                0 if grad_offset is None else grad_offset.data_ptr(),
+                                                0 if grad_mask is None else grad_mask.data_ptr(), *geom, _stream())
+        _lib.check(rc, "deform_col2im_rows")
+        if dx is not None:
+            grad_input += dx.permute(0, 3, 1, 2)
+    if grad_weight is not None:
+        colp = torch.empty((rows, 2 * T * cin), dtype=torch.bfloat16, device=dev)
+        with _on(dev):
+            rc = _L.ovis_deform_im2col_pair_rows_f32(x_nhwc.data_ptr(), offset.data_ptr(), mptr, colp.data_ptr(),
+                                                     2 * colp.stride(0), *geom, _stream())
+        _lib.check(rc, "deform_im2col_pair_rows")
+        if split_gemm_pair_tn_supported(cout, T * cin):
+            dwm = split_gemm_pair_tn(gyp, colp)                                              # [cout, T * cin]
+        else:  # shapes the transpose-read kernel does not take: one library bf16 product, the four hi / lo quadrants summed
+            q = torch.mm(gyp.t(), colp, out_dtype=torch.float32)
+            dwm = q.view(cout // 32, 2, 32, T * cin // 32, 2, 32).sum(dim=(1, 4)).reshape(cout, T * cin)
+        grad_weight.add_(dwm.view(cout, kH, kW, cin).permute(0, 3, 1, 2), alpha=scale)
 
 
 def deform_conv_backward_input(input, offset, gradOutput, gradInput, gradOffset, weight, columns, kW, kH, dW, dH, padW,

@@ -71,6 +71,8 @@ SIGNATURES = {
     "ovis_deform_im2col_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
     "ovis_deform_col2im_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
     "ovis_deform_col2im_coord_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
+    "ovis_deform_im2col_pair_rows_f32": (_i, [_vp, _vp, _vp, _vp, _l] + [_i] * 15 + [_vp]),
+    "ovis_deform_col2im_rows_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "ovis_region_noun_align_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ovis_text_embed_f32": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "ovis_project_polygon_masks_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

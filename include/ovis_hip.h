@@ -581,6 +581,25 @@ int ovis_project_polygon_masks_f32(const float* coords, const int32_t* polygon_s
                                    const int64_t* gt_index, const float* boxes, int num, int image_width,
                                    int image_height, int resolution, float* out, void* stream);
 
+/* Deformable convolution BACKWARD on NHWC rows (csrc/deform_conv_rows.hip; mb/csrc/cuda/deform_conv_cuda.cu:271-497,
+ * 580-694): rows m = (image, h_out, w_out), k = (tap, channel), the layout of ovis_deform_conv_implicit_f32.
+ * ovis_deform_im2col_pair_rows_f32: the sampled (x mask) rows col[m, (t, c)] written ONCE, in pair layout (row stride
+ *   columns_row_bytes >= 4 * taps * channels) -- the X operand of ovis_split_gemm_pair_tn for the weight gradient.
+ * ovis_deform_col2im_rows_f32: one pass over dcol_rows [rows, dcol_ld >= taps * channels] fp32 (= dY . W, an
+ *   ovis_split_gemm_pair product): grad_input_nhwc [batch, height, width, channels] += scatter (fp32 atomics; the caller
+ *   zero-fills), grad_offset [batch, dg*2*taps, out_h, out_w] and grad_mask [batch, dg*taps, out_h, out_w] += the
+ *   coordinate / mask gradients (atomics: the caller zero-fills; grad_mask / mask NULL = v1).  Either output group may be
+ *   NULL.  (channels / deformable_group) % 32 == 0, else OVIS_ERANGE. */
+int ovis_deform_im2col_pair_rows_f32(const float* input_nhwc, const float* offset, const float* mask, void* columns_pair,
+                                     long columns_row_bytes, int batch, int channels, int height, int width, int out_h,
+                                     int out_w, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
+                                     int dil_h, int dil_w, int deformable_group, void* stream);
+int ovis_deform_col2im_rows_f32(const float* dcol_rows, long dcol_ld, const float* input_nhwc, const float* offset,
+                                const float* mask, float* grad_input_nhwc, float* grad_offset, float* grad_mask, int batch,
+                                int channels, int height, int width, int out_h, int out_w, int kernel_h, int kernel_w,
+                                int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int deformable_group,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

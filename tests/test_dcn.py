@@ -123,6 +123,62 @@ def test_deform_conv_forward_without_column_buffer_vs_oracle(kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(C=64, Cout=64, dg=2, stride=2, pad=2, dil=2), dict(C=128, Cout=128, H=12, W=10),
+                                dict(B=3, C=96, Cout=32, H=7, W=6, k=1, pad=0, dg=3), dict(B=1, C=32, Cout=160, H=21, W=19),
+                                dict(B=1, C=256, Cout=32, H=9, W=8), dict(B=2, C=512, Cout=32, H=6, W=7, dg=2, stride=2)])
+def test_deform_conv_backward_on_rows_vs_oracle(kw):
+    """Channel counts the rows route takes ((C / deformable_group) % 32 == 0 and C_out % 32 == 0): the backward of v1 and
+    modulated v2 WITHOUT the reference-layout column buffer -- dcol = dY . W on the split GEMM, one scatter / gather pass
+    for dX / dOffset / dMask, the weight gradient as a transpose-read split GEMM (C=128: the kernel; otherwise its library
+    fallback) over the sampled pair rows -- against the fp64 oracle within the three-term product's 3e-5 of the maximum,
+    and against the column route of the same call."""
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers import deform_conv, modulated_deform_conv
+
+    g = torch.Generator().manual_seed(19)
+    x, w, off, mask, bias = _case(g, **kw)
+    st, pd, dl = (kw.get("stride", 1),) * 2, (kw.get("pad", 1),) * 2, (kw.get("dil", 1),) * 2
+    dg = kw.get("dg", 1)
+    calls = {"col2im_rows": 0, "im2col_rows": 0}
+    o1, o2 = _C._L.ovis_deform_col2im_rows_f32, _C._L.ovis_deform_im2col_pair_rows_f32
+    for modulated in (False, True):
+        xr, wr, orr = x.clone().requires_grad_(True), w.clone().requires_grad_(True), off.clone().requires_grad_(True)
+        mr, br = mask.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        want = O.deform_conv2d(xr, orr, wr, mr if modulated else None, br if modulated else None, st, pd, dl, 1, dg)
+        go = torch.randn(want.shape, generator=g, dtype=torch.float64)
+        want.backward(go)
+
+        def run():
+            xd, wd, od = (t.detach().float().cuda().requires_grad_(True) for t in (x, w, off))
+            md, bd = (t.detach().float().cuda().requires_grad_(True) for t in (mask, bias))
+            if modulated:
+                y = modulated_deform_conv(xd, od, md, wd, bd, st, pd, dl, 1, dg)
+            else:
+                y = deform_conv(xd, od, wd, st, pd, dl, 1, dg, 1)
+            y.backward(go.float().cuda())
+            return [t.grad.cpu().double() for t in ((xd, wd, od) + ((md, bd) if modulated else ()))]
+
+        n0 = dict(calls)
+        _C._L.ovis_deform_col2im_rows_f32 = lambda *a: (calls.__setitem__("col2im_rows", calls["col2im_rows"] + 1), o1(*a))[1]
+        _C._L.ovis_deform_im2col_pair_rows_f32 = lambda *a: (calls.__setitem__("im2col_rows", calls["im2col_rows"] + 1), o2(*a))[1]
+        try:
+            grads = run()
+        finally:
+            _C._L.ovis_deform_col2im_rows_f32, _C._L.ovis_deform_im2col_pair_rows_f32 = o1, o2
+        assert calls["col2im_rows"] == n0["col2im_rows"] + 1 and calls["im2col_rows"] == n0["im2col_rows"] + 1
+        _C.dcn_implicit = False
+        try:
+            col_grads = run()
+        finally:
+            _C.dcn_implicit = True
+        refs = [xr, wr, orr] + ([mr, br] if modulated else [])
+        for got, col, ref_t in zip(grads, col_grads, refs):
+            s_ = ref_t.grad.abs().max().item() + 1e-12
+            assert (got - ref_t.grad).abs().max().item() <= 3e-5 * s_
+            assert (got - col).abs().max().item() <= 3e-5 * s_
+
+
+@pytest.mark.gpu
 def test_dcn_modules_and_dfconv():
     from cvpr22_cross_modal_pseudo_labeling_amd.layers import DFConv2d, ModulatedDeformConvPack
 

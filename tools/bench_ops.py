@@ -204,6 +204,26 @@ def main():
                     "ms": ms_col, "TFLOPs": fl / ms_col / 1e9})
         res.append({"op": "deform_conv_forward", "shape": "[2,512,100,168] 3x3 -> 512", "ms": ms, "TFLOPs": fl / ms / 1e9,
                     "frac_fp32_mfma_peak": fl / ms / 1e9 / 157.3, "col_MB": 4 * 512 * 9 * 2 * 100 * 168 / 1e6})
+    if "dcn" in ops:
+        # backward (dX, dOffset, dW) of the same layer: rows route (split GEMMs, no reference-layout column buffer) vs the
+        # column route (fp32-MFMA GEMMs around im2col / col2im / col2im_coord)
+        from cvpr22_cross_modal_pseudo_labeling_amd import _C as _ops
+        xg, og, wg = x.clone().requires_grad_(True), off.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        gy = torch.randn(2, 512, 100, 168, generator=g).to(dev)
+
+        def fwd_bwd():
+            for t in (xg, og, wg):
+                t.grad = None
+            deform_conv(xg, og, wg, 1, 1, 1, 1, 1, 2).backward(gy)
+
+        ms_fb = timeit(fwd_bwd, max(3, args.iters // 4))
+        _ops.dcn_implicit = False
+        ms_fb_col = timeit(fwd_bwd, max(3, args.iters // 4))
+        _ops.dcn_implicit = True
+        res.append({"op": "deform_conv forward+backward (column route)", "shape": "[2,512,100,168] 3x3 -> 512", "ms": ms_fb_col,
+                    "backward_ms": ms_fb_col - ms_col})
+        res.append({"op": "deform_conv forward+backward (rows route)", "shape": "[2,512,100,168] 3x3 -> 512", "ms": ms_fb,
+                    "backward_ms": ms_fb - ms, "backward_over_forward": (ms_fb - ms) / ms})
     for r_ in res:
         print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r_.items()}))
 
