@@ -458,8 +458,11 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_strided_nhwc_kernel(
 // ---------------------------------------------------------------------------------------
 template <bool FAST>
 __device__ __forceinline__ void pool_nhwc_strided(const f4* __restrict__ img4, const RoiGeom& g, int H, int W, int C4,
-                                                  int bs, int OH, int OW, float* __restrict__ out_r, char* pair_r) {
-  const int items = OH * OW * C4;
+                                                  int bs, int OH, int OW, float* __restrict__ out_r, char* pair_r,
+                                                  int k0 = 0, int KT = -1) {
+  // channel groups [k0, k0 + KT) of the C4 groups of a cell (KT < 0: all of them)
+  if (KT < 0) KT = C4;
+  const int items = OH * OW * KT;
   const int C = C4 * 4;
   if (g.gh == 2 && g.gw == 2) {
     // sampling_ratio 2 (every shipped config): the 2 x 2 samples of a bin are half a bin apart, so for the many RoIs
@@ -468,7 +471,7 @@ __device__ __forceinline__ void pool_nhwc_strided(const f4* __restrict__ img4, c
     // those RoIs (the kernel is bound by the L2 -> CU path) -- and the samples are accumulated from registers in the
     // reference's order with the reference's expressions: the bits do not change.
     for (int item = threadIdx.x; item < items; item += kThreads) {
-      const int k = item % C4, obin = item / C4;
+      const int k = k0 + item % KT, obin = item / KT;
       const int oh = obin / OW;
       const int ph = oh * bs, pw = (obin - oh * OW) * bs;
       const f4* base = img4 + k;
@@ -521,7 +524,7 @@ __device__ __forceinline__ void pool_nhwc_strided(const f4* __restrict__ img4, c
     return;
   }
   for (int item = threadIdx.x; item < items; item += kThreads) {
-    const int k = item % C4, obin = item / C4;
+    const int k = k0 + item % KT, obin = item / KT;
     const int oh = obin / OW;
     const int ph = oh * bs, pw = (obin - oh * OW) * bs;
     const f4* base = img4 + k;
@@ -567,6 +570,80 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc_in_strided_kernel
   const f4* img4 = (const f4*)(in + (long)g.b * H * W * C);
   if (g.pow2) pool_nhwc_strided<true>(img4, g, H, W, C4, bs, OH, OW, out_r, pair_r);
   else pool_nhwc_strided<false>(img4, g, H, W, C4, bs, OH, OW, out_r, pair_r);
+}
+
+// ---------------------------------------------------------------------------------------
+// NHWC map, window staged in LDS.  The direct form above fetches every tap from L1 / L2: 4-16 loads of 16 bytes per (bin,
+// 4 channels), ~1.6 MB per RoI at C = 1024, and is bound by the L2 -> CU path (3.2 GB per 2000-RoI launch: 0.25 ms).  A
+// RoI's WINDOW is ~45 cells (median; p90 ~430): staged once per (RoI, 32-channel tile) -- every cell's 32 channels are one
+// contiguous 128-byte line in NHWC -- the same bins read their taps from LDS (fwd_pool4_strided, the arithmetic of the
+// bit-exact kernel: identical bits) and the L2 -> CU traffic drops to the window bytes.  Windows of more than
+// kSmallWindow cells keep the direct form, on the workgroup's own 32 channels (handing them to a second launch with one
+// workgroup per RoI was tried: the few large RoIs then run on a few workgroups and set the duration -- 289 us in the step
+// against 176 us for this form and 248 us for the direct form alone).
+// ---------------------------------------------------------------------------------------
+template <int NCS, int LDSF = kFwdLdsFloats>
+__device__ __forceinline__ void stage_window4_nhwc(float* win, const float* __restrict__ img_c0, int C, int W,
+                                                   const RoiGeom& g, int wh, int ww) {
+  constexpr int NG = NCS / 4;
+  constexpr int SG = LDSF / NCS;
+  f4* win4 = (f4*)win;
+  const int n = wh * ww * NG;
+  const float inv_ww = 1.f / (float)ww;
+  for (int i = threadIdx.x; i < n; i += kThreads) {
+    const int k = i % NG, idx = i / NG;   // NG consecutive lanes read one contiguous line of a cell
+    const int y = (int)(((float)idx + 0.5f) * inv_ww);
+    const int x = idx - y * ww;
+    win4[k * SG + idx] = *(const f4*)(img_c0 + ((long)(g.wy0 + y) * W + (g.wx0 + x)) * C + 4 * k);
+  }
+}
+
+template <int NCS>
+__device__ __forceinline__ void strided_batch4_nhwc(float* win, const float* __restrict__ img_c0, int C, int H, int W,
+                                                    const RoiGeom& g, int wh, int ww, int bs, int OH, int OW,
+                                                    float* __restrict__ out_rc, char* pair_r, int c_abs) {
+  stage_window4_nhwc<NCS>(win, img_c0, C, W, g, wh, ww);
+  __syncthreads();
+  if (g.pow2)
+    fwd_pool4_strided<NCS, true>((const f4*)win, ww, g, H, W, bs, OH, OW, out_rc, C, pair_r, c_abs);
+  else
+    fwd_pool4_strided<NCS, false>((const f4*)win, ww, g, H, W, bs, OH, OW, out_rc, C, pair_r, c_abs);
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc_in_strided_lds_kernel(
+    const float* __restrict__ in, const float* __restrict__ rois, float* __restrict__ out, int R, int batch, int C,
+    int H, int W, int PH, int PW, int bs, int OH, int OW, float scale, int sampling_ratio, int pair_out) {
+  __shared__ __attribute__((aligned(16))) float win[kFwdLdsFloats];
+  const int r = blockIdx.x % R;
+  const int ct = blockIdx.x / R;            // C % 32 == 0 (checked by the launcher): whole 32-channel tiles
+  const int c_begin = ct * kCPB;
+  const RoiGeom g = make_geom(rois + (long)r * 5, scale, H, W, PH, PW, sampling_ratio, batch);
+  float* out_r = out + (long)r * OH * OW * C;
+  char* pair_r = pair_out ? (char*)out_r : nullptr;
+  if (g.empty) {
+    for (int item = threadIdx.x; item < OH * OW * (kCPB / 4); item += kThreads) {
+      const int k = item % (kCPB / 4), obin = item / (kCPB / 4);
+      if (pair_r) pool_store4_pair(pair_r, obin, c_begin + 4 * k, C, (f4)(0.f));
+      else *(f4*)(out_r + (long)obin * C + c_begin + 4 * k) = (f4)(0.f);
+    }
+    return;
+  }
+  const int wh = g.wy1 - g.wy0 + 1, ww = g.wx1 - g.wx0 + 1;
+  const int warea = wh * ww;
+  const float* img = in + (long)g.b * H * W * C;
+  if (warea > kSmallWindow) {  // direct form on this workgroup's channels
+    if (g.pow2) pool_nhwc_strided<true>((const f4*)img, g, H, W, C >> 2, bs, OH, OW, out_r, pair_r, c_begin >> 2, kCPB / 4);
+    else pool_nhwc_strided<false>((const f4*)img, g, H, W, C >> 2, bs, OH, OW, out_r, pair_r, c_begin >> 2, kCPB / 4);
+    return;
+  }
+  if (warea * 32 <= kFwdLdsFloats) {   // <= 136 cells: the whole tile in one batch
+    strided_batch4_nhwc<32>(win, img + c_begin, C, H, W, g, wh, ww, bs, OH, OW, out_r + c_begin, pair_r, c_begin);
+  } else {                             // <= 272 cells: two batches of 16 channels
+    strided_batch4_nhwc<16>(win, img + c_begin, C, H, W, g, wh, ww, bs, OH, OW, out_r + c_begin, pair_r, c_begin);
+    strided_batch4_nhwc<16>(win, img + c_begin + 16, C, H, W, g, wh, ww, bs, OH, OW, out_r + c_begin + 16, pair_r,
+                            c_begin + 16);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -901,9 +978,15 @@ extern "C" int ovis_roi_align_forward_strided_from_nhwc_f32(const float* input_n
   if (channels % 4 != 0 || (pair_out && channels % 32 != 0) || ((uintptr_t)input_nhwc & 15) || ((uintptr_t)output & 15))
     return OVIS_ERANGE;
   const int oh = (pooled_h + bin_stride - 1) / bin_stride, ow = (pooled_w + bin_stride - 1) / bin_stride;
-  hipLaunchKernelGGL(roi_align_fwd_nhwc_in_strided_kernel, dim3((unsigned)num_rois), dim3(kThreads), 0, (hipStream_t)stream,
-                     input_nhwc, rois, (float*)output, num_rois, batch, channels, height, width, pooled_h, pooled_w,
-                     bin_stride, oh, ow, spatial_scale, sampling_ratio, pair_out);
+  const long tiles = (long)(channels / kCPB) * num_rois;
+  if (channels % kCPB == 0 && tiles <= 0x7fffffffL)
+    hipLaunchKernelGGL(roi_align_fwd_nhwc_in_strided_lds_kernel, dim3((unsigned)tiles), dim3(kThreads), 0,
+                       (hipStream_t)stream, input_nhwc, rois, (float*)output, num_rois, batch, channels, height, width,
+                       pooled_h, pooled_w, bin_stride, oh, ow, spatial_scale, sampling_ratio, pair_out);
+  else
+    hipLaunchKernelGGL(roi_align_fwd_nhwc_in_strided_kernel, dim3((unsigned)num_rois), dim3(kThreads), 0, (hipStream_t)stream,
+                       input_nhwc, rois, (float*)output, num_rois, batch, channels, height, width, pooled_h, pooled_w,
+                       bin_stride, oh, ow, spatial_scale, sampling_ratio, pair_out);
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
 }
