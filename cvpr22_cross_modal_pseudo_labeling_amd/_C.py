@@ -833,6 +833,41 @@ def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f3
     return c, cp
 
 
+def split_gemm_pair_pool_supported(m, n, ch, pool_rows):
+    return bool(_L.ovis_split_gemm_pair_pool_supported(int(m), int(n), int(ch), int(pool_rows)))
+
+
+def split_gemm_pair_rp_pool(a_pair, b_pair, bias, residual_pair, relu, out_f32, out_pair, pool_rows):
+    """``split_gemm_pair(..., residual_pair=...)`` of the LAST bottleneck of a res5 chain with the head's average pooling in the
+    epilogue (``ovis_split_gemm_pair_rp_pool``): also returns the mean of the result over every group of ``pool_rows`` rows
+    ([M / pool_rows, N] fp32); with ``out_f32`` and ``out_pair`` both False the result itself is never written.
+    -> (C f32 or None, C pair or None, pooled)."""
+    for t, name in ((a_pair, "a_pair"), (b_pair, "b_pair")) + (((residual_pair, "residual_pair"),) if residual_pair is not None else ()):
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1):
+            raise RuntimeError(f"split_gemm_pair_rp_pool: {name} must be a 2-D bfloat16 HIP tensor in pair layout")
+    m, ch = a_pair.shape[0], a_pair.shape[1] // 2
+    n, k = b_pair.shape[0], b_pair.shape[1] // 2
+    if k != ch or m % pool_rows or (residual_pair is not None and residual_pair.shape != (m, 2 * n)):
+        raise RuntimeError("split_gemm_pair_rp_pool: shape mismatch")
+    dev = a_pair.device
+    c = torch.empty((m, n), dtype=torch.float32, device=dev) if out_f32 else None
+    cp = torch.empty((m, 2 * n), dtype=torch.bfloat16, device=dev) if out_pair else None
+    pooled = torch.zeros((m // pool_rows, n), dtype=torch.float32, device=dev)
+    if m == 0 or n == 0:
+        return c, cp, pooled
+    if bias is not None:
+        bias = _dev(bias, "bias")
+    with _on(dev):
+        rc = _L.ovis_split_gemm_pair_rp_pool(a_pair.data_ptr(), 2 * a_pair.stride(0), b_pair.data_ptr(), 2 * b_pair.stride(0),
+                                             0 if c is None else c.data_ptr(), n, 0 if cp is None else cp.data_ptr(), 4 * n,
+                                             0 if bias is None else bias.data_ptr(),
+                                             0 if residual_pair is None else residual_pair.data_ptr(),
+                                             0 if residual_pair is None else 2 * residual_pair.stride(0), m, n, ch,
+                                             int(bool(relu)), pooled.data_ptr(), int(pool_rows), 1.0 / pool_rows, _stream())
+    _lib.check(rc, "split_gemm_pair_rp_pool")
+    return c, cp, pooled
+
+
 def weight_prep_pair(w, scale=None, want_transposed=False):
     """w [N, C, KH, KW] f32 (times scale[N]) -> (pair [N, 2*KH*KW*C] tap-major, transposed pair [C, 2*KH*KW*N] or None)
     in one launch; see include/ovis_hip.h."""

@@ -61,6 +61,8 @@ SIGNATURES = {
     "ovis_split_gemm_pair_gated": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _l] + [_i] * 8 + [_vp]),
     "ovis_split_gemm_pair_workspace_bytes": (_sz, [_l, _i, _i, _i, _i, _i, _i]),
     "ovis_split_gemm_pair_rp_gated": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _l, _i, _i, _i, _vp]),
+    "ovis_split_gemm_pair_pool_supported": (_i, [_l, _i, _i, _i]),
+    "ovis_split_gemm_pair_rp_pool": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _l, _i, _i, _i, _vp, _i, _f, _vp]),
     "ovis_split_gemm_pair_rp": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _l, _i, _i, _i, _vp, _sz, _i, _vp]),
     "ovis_split_gemm_pair": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _l] + [_i] * 9
                              + [_vp, _sz, _i, _vp]),

@@ -65,6 +65,7 @@ struct SplitGemmArgs {
   const char* resp; long resp_rs;    // shortcut given in PAIR layout (hi + lo is exact in fp32): the block input a bottleneck
                                      // already holds as its conv1 operand -- no fp32 copy of it has to exist
   const char* gate; long gate_rs;    // optional ReLU gate of a backward pass: pair rows of the forward activation (hi > 0)
+  float* pool; int pool_rows; float pool_scale;  // POOL kernels: pool[m / pool_rows][n] += pool_scale * (final value)
   float* slab;                       // split-K: raw partial sums [kslices][M][N] (then C / Cp / bias / ... are unused here)
   long M; int N; int ch; int ch2; int T; int H; int W; int KH; int KW; int flip; int relu; int gw;
   int kslices; int steps_per_slice;  // k-steps (PLAIN / SHIFTED) or channel blocks (HALO) per slice
@@ -121,8 +122,8 @@ __device__ __forceinline__ void epilogue_fetch4(const EpilogueSource& s, long m,
 // DUAL: a pair-layout shortcut (in `o`) AND a ReLU gate (hi halves in `gate2`) -- the input gradient of an identity
 // bottleneck handed to the block below already gated and split.
 template <bool DUAL = false>
-__device__ __forceinline__ void epilogue_apply4(const SplitGemmArgs& p, long m, int n, long poff, f32x4 v, const f32x4& bias4,
-                                                const EpilogueOperands& o, uint2 gate2 = make_uint2(0u, 0u)) {
+__device__ __forceinline__ f32x4 epilogue_apply4(const SplitGemmArgs& p, long m, int n, long poff, f32x4 v, const f32x4& bias4,
+                                                 const EpilogueOperands& o, uint2 gate2 = make_uint2(0u, 0u)) {
   if (p.bias) v += bias4;
   if (p.res) {
     v.x += __uint_as_float(o.a.x); v.y += __uint_as_float(o.a.y); v.z += __uint_as_float(o.b.x); v.w += __uint_as_float(o.b.y);
@@ -153,6 +154,7 @@ __device__ __forceinline__ void epilogue_apply4(const SplitGemmArgs& p, long m, 
     *(uint2*)d = make_uint2(h01, h23);
     *(uint2*)(d + 64) = make_uint2(l01, l23);
   }
+  return v;
 }
 
 __device__ __forceinline__ void epilogue_store4(const SplitGemmArgs& p, long m, int n, f32x4 v) {
@@ -165,7 +167,14 @@ __device__ __forceinline__ void epilogue_store4(const SplitGemmArgs& p, long m, 
   epilogue_apply4(p, m, n, poff, v, bias4, o);
 }
 
-template <int WM, int WN, int MODE, int NS, int OCC, bool DUAL = false>
+// POOL (plain products, no split-K): the epilogue also adds pool_scale x the final values of every row group of
+// p.pool_rows rows (the 7 x 7 map of one RoI) into p.pool[m / pool_rows][n] -- the head's average pooling
+// (box_head/roi_box_predictors.py:62-66) without a second pass over the [R*49, 2048] result; with C and Cp both null the
+// result itself is never written (the no-grad teacher pass reads nothing but the pooled rows).  A lane sums its 16 rows
+// per map segment of its wave's 64-row span (at most 3 maps for pool_rows >= 32), the four lanes that share the columns
+// are combined by two xor-shuffles, one lane of them issues <= 12 fp32 atomics.  A map meets at most two 64-row spans when
+// pool_rows <= 64, so every pooled value is the sum of at most two addends onto zero: bit-reproducible.
+template <int WM, int WN, int MODE, int NS, int OCC, bool DUAL = false, bool POOL = false>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemmArgs p, int tiles_n, int ntiles) {
   constexpr int BM = WM * 64, BN = WN * 64, NW = WM * WN;
   constexpr int A_ROWS = MODE == HALO ? BM + 2 * kHalo + 2 : BM;  // HALO: + 256 bytes of zeros (one bank period)
@@ -557,6 +566,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
       if constexpr (DUAL) g[j] = *(const uint2*)(gate_col + mc * p.gate_rs);
     }
   };
+  // POOL: map segment boundaries inside this wave's 64 rows (rows [0, b1) belong to the first map, [b1, b2) to the second)
+  f32x4 ps0 = {0.f, 0.f, 0.f, 0.f}, ps1 = ps0, ps2 = ps0;
+  int pool_b1 = 0, pool_b2 = 0;
+  long pool_map0 = 0;
+  if constexpr (POOL) {
+    const long mw = m0 + wm * 64;
+    pool_map0 = mw / p.pool_rows;
+    pool_b1 = (int)((pool_map0 + 1) * p.pool_rows - mw);
+    pool_b2 = pool_b1 + p.pool_rows;
+  }
 #pragma unroll
   for (int i = 0; i < NBUF - 1; ++i) fetch(i, ops[i], gates[i]);
 #pragma unroll
@@ -574,8 +593,35 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
         const long m = m0 + wm * 64 + f * 16 + r;
         if (m < p.M && col_ok) {
           if (slab) *(f32x4*)(slab + m * p.N + n) = v;
-          else epilogue_apply4<DUAL>(p, m, n, poff, v, bias4, ops[piece % NBUF][j], gates[piece % NBUF][j]);
+          else {
+            const f32x4 fin = epilogue_apply4<DUAL>(p, m, n, poff, v, bias4, ops[piece % NBUF][j], gates[piece % NBUF][j]);
+            if constexpr (POOL) {
+              const int rr = f * 16 + r;   // row inside the wave's 64-row span
+              const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+              ps0 += rr < pool_b1 ? fin : z;
+              ps1 += (rr >= pool_b1 && rr < pool_b2) ? fin : z;
+              ps2 += rr >= pool_b2 ? fin : z;
+            }
+          }
         }
+      }
+    }
+  }
+  if constexpr (POOL) {
+    f32x4* ps[3] = {&ps0, &ps1, &ps2};
+#pragma unroll
+    for (int sgm = 0; sgm < 3; ++sgm) {
+      f32x4 v = *ps[sgm];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] += __shfl_xor(v[e], 16, 64);
+        v[e] += __shfl_xor(v[e], 32, 64);
+      }
+      const long first = (m0 + wm * 64) + (sgm == 0 ? 0 : (sgm == 1 ? pool_b1 : pool_b2));  // first row of the segment
+      if (er == 0 && col_ok && first < p.M && (sgm == 0 || (sgm == 1 ? pool_b1 : pool_b2) < 64)) {
+        float* d = p.pool + (pool_map0 + sgm) * p.N + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(d + e, v[e] * p.pool_scale);
       }
     }
   }
@@ -1335,11 +1381,13 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
                                 const void* residual_pair, long residual_pair_row_bytes,
                                 const void* gate_pair, long gate_row_bytes, long m, int n, int channels, int channels2,
                                 int taps_h, int taps_w, int height, int width, int flip, int relu, void* workspace,
-                                size_t workspace_bytes, int config, void* stream) {
+                                size_t workspace_bytes, int config, void* stream, float* pool = nullptr, int pool_rows = 0,
+                                float pool_scale = 1.f) {
   if (m < 0 || n < 0 || channels < 0 || channels2 < 0 || taps_h <= 0 || taps_w <= 0 || !(taps_h & 1) || !(taps_w & 1))
     return OVIS_EINVAL;
   if (m == 0 || n == 0) return OVIS_OK;
-  if (!a_pair || !b_pair || (!c && !c_pair) || channels == 0 || m > 0x7fffff00L) return OVIS_EINVAL;
+  if (!a_pair || !b_pair || (!c && !c_pair && !pool) || channels == 0 || m > 0x7fffff00L) return OVIS_EINVAL;
+  if (pool && (pool_rows < 32 || pool_rows > 64 || ((uintptr_t)pool & 15))) return OVIS_ERANGE;
   const int T = taps_h * taps_w;
   if (T > 1 && (height <= 0 || width <= 0 || height > 32767 || width > 32767 || channels2 != 0)) return OVIS_EINVAL;
   if (channels2 != 0 && !a2_pair) return OVIS_EINVAL;
@@ -1368,6 +1416,7 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
   p.resp = (const char*)residual_pair; p.resp_rs = residual_pair_row_bytes;
   p.gate = (const char*)gate_pair; p.gate_rs = gate_row_bytes;
   p.slab = q.kslices > 1 ? (float*)workspace : nullptr;
+  p.pool = pool; p.pool_rows = pool_rows; p.pool_scale = pool_scale;
   p.M = m; p.N = n; p.ch = channels; p.ch2 = channels2; p.T = T; p.H = height; p.W = width; p.KH = taps_h; p.KW = taps_w;
   p.flip = flip; p.relu = relu;
   p.kslices = q.kslices; p.steps_per_slice = q.steps_per_slice;
@@ -1376,21 +1425,26 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
   const long nblocks = ntiles * q.kslices;
   if (nblocks > 0x7fffffffL) return OVIS_ERANGE;
   hipStream_t s = (hipStream_t)stream;
-#define OVIS_SG_LAUNCH_(WM_, WN_, MODE_, NS_, OCC_, DUAL_)                                                           \
+#define OVIS_SG_LAUNCH__(WM_, WN_, MODE_, NS_, OCC_, DUAL_, POOL_)                                                   \
   do {                                                                                                              \
     constexpr int a_rows = MODE_ == HALO ? WM_ * 64 + 2 * kHalo + 2 : WM_ * 64;                                      \
     constexpr int lds = NS_ * (a_rows * 128 + WN_ * 64 * 128);                                                       \
     static bool attr_set = false;                                                                                   \
     if (!attr_set) {                                                                                                \
-      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<WM_, WN_, MODE_, NS_, OCC_, DUAL_>,           \
+      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)split_gemm_kernel<WM_, WN_, MODE_, NS_, OCC_, DUAL_, POOL_>,    \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));                           \
       attr_set = true;                                                                                              \
     }                                                                                                               \
-    hipLaunchKernelGGL((split_gemm_kernel<WM_, WN_, MODE_, NS_, OCC_, DUAL_>), dim3((unsigned)nblocks),             \
+    hipLaunchKernelGGL((split_gemm_kernel<WM_, WN_, MODE_, NS_, OCC_, DUAL_, POOL_>), dim3((unsigned)nblocks),      \
                        dim3(WM_ * WN_ * 64), lds, s, p, q.tiles_n, (int)ntiles);                                    \
   } while (0)
+#define OVIS_SG_LAUNCH_(WM_, WN_, MODE_, NS_, OCC_, DUAL_) OVIS_SG_LAUNCH__(WM_, WN_, MODE_, NS_, OCC_, DUAL_, false)
 #define OVIS_SG_LAUNCH(WM_, WN_, MODE_, NS_, OCC_) OVIS_SG_LAUNCH_(WM_, WN_, MODE_, NS_, OCC_, false)
-  if (dual) {
+  if (pool) {
+    // pooled epilogue: plain 128-column products without split-K (124 VGPRs: still four workgroups per CU)
+    if (dual || q.narrow || q.mode != PLAIN || q.kslices > 1) return OVIS_ERANGE;
+    if (q.stages == 1) OVIS_SG_LAUNCH__(2, 2, PLAIN, 1, 4, false, true); else OVIS_SG_LAUNCH__(2, 2, PLAIN, 2, 2, false, true);
+  } else if (dual) {
     if (q.narrow || q.mode != PLAIN || q.kslices > 1) return OVIS_ERANGE;
     if (q.stages == 1) OVIS_SG_LAUNCH_(2, 2, PLAIN, 1, 4, true); else OVIS_SG_LAUNCH_(2, 2, PLAIN, 2, 2, true);
   } else if (q.narrow) {
@@ -1402,6 +1456,7 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
   } else {
     if (q.stages == 1) OVIS_SG_LAUNCH(2, 2, PLAIN, 1, 4); else OVIS_SG_LAUNCH(2, 2, PLAIN, 2, 2);
   }
+#undef OVIS_SG_LAUNCH__
 #undef OVIS_SG_LAUNCH_
 #undef OVIS_SG_LAUNCH
   OVIS_LAUNCH_CHECK();
@@ -1439,6 +1494,28 @@ extern "C" int ovis_split_gemm_pair_rp(const void* a_pair, long a_row_bytes, con
   return split_gemm_pair_impl(a_pair, a_row_bytes, nullptr, 0, b_pair, b_row_bytes, c, ldc, c_pair, c_pair_row_bytes, bias,
                               nullptr, 0, residual_pair, residual_pair_row_bytes, nullptr, 0, m, n, channels, 0, 1, 1, 0, 0,
                               0, relu, workspace, workspace_bytes, config, stream);
+}
+
+// conv3 + pair shortcut + ReLU of the LAST bottleneck of a res5 chain with the head's average pooling in the epilogue:
+// pooled [m / pool_rows, n] (ZERO-FILLED by the caller) += pool_scale * result, summed over the pool_rows rows of every
+// map; c and c_pair may both be NULL (nothing but the pooled rows is produced).  OVIS_ERANGE when the launch plan of this
+// shape is not the plain un-split 128-column form (ovis_split_gemm_pair_pool_supported tells in advance).
+extern "C" int ovis_split_gemm_pair_pool_supported(long m, int n, int channels, int pool_rows) {
+  if (m <= 0 || n <= 0 || channels <= 0 || channels % 32 || n % 32 || pool_rows < 32 || pool_rows > 64) return 0;
+  const SplitGemmPlan q = split_gemm_plan(m, n, channels, 0, 1, 1, 0, 0);   // small-M shapes keep their split-K plan
+  return !q.narrow && q.mode == PLAIN && q.kslices == 1;
+}
+
+extern "C" int ovis_split_gemm_pair_rp_pool(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
+                                            float* c, long ldc, void* c_pair, long c_pair_row_bytes, const float* bias,
+                                            const void* residual_pair, long residual_pair_row_bytes, long m, int n,
+                                            int channels, int relu, float* pooled, int pool_rows, float pool_scale,
+                                            void* stream) {
+  if (!pooled) return OVIS_EINVAL;
+  if (n % 32 != 0 || (residual_pair && (residual_pair_row_bytes % 16 != 0 || ((uintptr_t)residual_pair & 15)))) return OVIS_ERANGE;
+  return split_gemm_pair_impl(a_pair, a_row_bytes, nullptr, 0, b_pair, b_row_bytes, c, ldc, c_pair, c_pair_row_bytes, bias,
+                              nullptr, 0, residual_pair, residual_pair_row_bytes, nullptr, 0, m, n, channels, 0, 1, 1, 0, 0,
+                              0, relu, nullptr, 0, 8, stream, pooled, pool_rows, pool_scale);
 }
 
 extern "C" int ovis_split_gemm_pair_gated(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,

@@ -87,7 +87,7 @@ class GradLink:
 class _BottleneckPair(Function):
     @staticmethod
     def forward(ctx, x, xp, geom, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, want_pair, wpairs, pool, want_f32=True,
-                link_in=None, link_out=None, select=None):
+                link_in=None, link_out=None, select=None, pool_only_ok=False):
         """x [M, Cin] f32 rows conv1 reads (may be None when wd is given and no input gradient is wanted), xp its pair
         form or None; geom = (h, w) of the map the rows tile; w1/w2/w3/wd RAW convolution weights (wd None = identity
         shortcut) with their folded FrozenBN scales s1/s2/s3/sd (per output channel, no gradient) and shifts b1/b2,
@@ -124,12 +124,26 @@ class _BottleneckPair(Function):
             out, outp = _C.split_gemm_pair(o2p, w3d, b3, None, True, f32, want_pair, a2_pair=xp)
         elif x_real:
             out, outp = _C.split_gemm_pair(o2p, wpairs["w3"], b3, x, True, f32, want_pair)
-        else:  # the block input exists only as its pair form: shortcut = hi + lo
-            out, outp = _C.split_gemm_pair(o2p, wpairs["w3"], b3, None, True, f32, want_pair, residual_pair=xp)
+        pooled_k = None
+        if wd is None and not x_real:  # the block input exists only as its pair form: shortcut = hi + lo
+            fused_pool = (pool and 32 <= h * w <= 64
+                          and _C.split_gemm_pair_pool_supported(o2p.shape[0], wpairs["w3"].shape[0], o2p.shape[1] // 2, h * w))
+            if fused_pool:
+                # the head's average pooling in THIS GEMM's epilogue (no second pass over the [rows, 2048] result); a pass
+                # that needs neither the backward nor the positives' maps (the no-grad teacher pass) writes the pooled rows only
+                keep = need_bwd or want_pair or select is not None or not pool_only_ok
+                out, outp, pooled_k = _C.split_gemm_pair_rp_pool(o2p, wpairs["w3"], b3, xp, True, keep, want_pair, h * w)
+                if out is None and outp is None:
+                    out = pooled_k.new_full((1,), float("nan")).expand(o2p.shape[0], pooled_k.shape[1])  # never read
+            else:
+                out, outp = _C.split_gemm_pair(o2p, wpairs["w3"], b3, None, True, f32, want_pair, residual_pair=xp)
         # pool: also return the mean over the h*w rows of every map (the head's average pooling) as an output of THIS
         # node, so that its gradient is broadcast inside the fused gate + split kernel of the backward instead of
         # being materialised ([rows, C] expand) and added to the dense gradient by two tensor ops
-        pooled = out.view(-1, h * w, out.shape[1]).mean(dim=1) if pool else None
+        if pooled_k is not None:
+            pooled = pooled_k
+        else:
+            pooled = out.view(-1, h * w, out.shape[1]).mean(dim=1) if pool else None
         # select [S] int64: also return the rows of the maps `select` ([S, h*w, C]; what the mask head reads: the res5
         # features of the positive RoIs) as an output of THIS node, so that their gradient reaches the backward's first
         # kernel as S dense maps -- an index backward would scatter it into a zero [rows, C] tensor (822 MB written and
@@ -158,7 +172,7 @@ class _BottleneckPair(Function):
         if link_out is not None:
             link_out.grad_pair = None
         if dout is None and dpooled is None and linked is None and dsel is None:
-            return (None,) * 21
+            return (None,) * 22
         xp, o1p, o2p, out, w1, w2, w3, wd, s1, s2, s3, sd, select = ctx.saved_tensors   # out: fp32 result or its pair form (gate)
         h, w, kh, kw = ctx.geom
         need = ctx.needs_input_grad
@@ -214,14 +228,16 @@ class _BottleneckPair(Function):
         if wd is not None and need_wd:
             dwd = _dw(g3p, xp, wd, sd)
         return (dx, None, None, dw1, None, None, dw2, None, None, dw3, None, None, dwd, None, None, None, None, None, None,
-                None, None)
+                None, None, None)
 
 
 def bottleneck_pair(x, xp, geom, w1, b1, w2, b2, w3, b3, wd=None, want_pair=False, wpairs=None, pool=False,
-                    scales=(None, None, None, None), want_f32=True, select=None):
+                    scales=(None, None, None, None), want_f32=True, select=None, pool_only_ok=False):
     """(out f32 [M, Cout], out in pair layout or None[, mean of out over the h*w rows of every map when ``pool``]) of
     one bottleneck on the rows x [M, Cin] of an (h, w) map.  w1/w2/w3/wd are the convolution weights as the model
-    stores them; ``scales`` = their folded FrozenBN scales (None = weights already folded)."""
+    stores them; ``scales`` = their folded FrozenBN scales (None = weights already folded).  ``pool_only_ok``: the caller
+    reads nothing but the pooled rows of a no-grad pass, so the [M, Cout] result itself need not be written (its handle is
+    then a NaN placeholder)."""
     s1, s2, s3, sd = scales
     pair_only = want_pair and not want_f32 and not pool
     link_in = getattr(xp, "_ovis_grad_link", None) if (xp is not None and (x is None or is_placeholder(x))) else None
@@ -232,7 +248,7 @@ def bottleneck_pair(x, xp, geom, w1, b1, w2, b2, w3, b3, wd=None, want_pair=Fals
         link_in.claimed = True
     link_out = GradLink() if pair_only else None
     out, outp, pooled, out_sel = _BottleneckPair.apply(x, xp, geom, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, want_pair,
-                                                       wpairs, pool, want_f32, link_in, link_out, select)
+                                                       wpairs, pool, want_f32, link_in, link_out, select, pool_only_ok)
     if out_sel is not None:
         out._ovis_selected = (select, out_sel)  # [S, h*w, C] rows of the maps `select`, an output of the same node
     if link_out is not None and outp is not None:

@@ -112,7 +112,7 @@ class Bottleneck(nn.Module):
         what a producer must check before it drops the fp32 copy of its output (``pair_only``)."""
         return bool(self.pair_gemm and self.pair_supported())
 
-    def _forward_pair(self, x, prestrided, xp, want_pair, pool=False, select=None, pair_only=False):
+    def _forward_pair(self, x, prestrided, xp, want_pair, pool=False, select=None, pair_only=False, pool_only_ok=False):
         """The block as ONE autograd node on the pair-layout split GEMM (layers/pair_bottleneck.py): bias, shortcut,
         ReLU and the next layer's operand split live in the GEMM epilogues, the 3x3 is an implicit GEMM."""
         r, h, w, c = x.shape
@@ -128,7 +128,7 @@ class Bottleneck(nn.Module):
         else:
             hs, ws = h, w
             x2d = x.reshape(-1, c)
-        return self._pair_node(x2d, xp, r, hs, ws, want_pair, pool, select, pair_only)
+        return self._pair_node(x2d, xp, r, hs, ws, want_pair, pool, select, pair_only, pool_only_ok)
 
     def forward_pair_rows(self, xp, r, hs, ws, want_pair=False, pool=False, pair_only=False):
         """The block on rows that exist only in pair layout ([r*hs*ws, 2*Cin] bf16, e.g. written by the pooler): needs
@@ -136,7 +136,7 @@ class Bottleneck(nn.Module):
         assert self._fd is not None
         return self._pair_node(None, xp, r, hs, ws, want_pair, pool, None, pair_only)
 
-    def _pair_node(self, x2d, xp, r, hs, ws, want_pair, pool, select=None, pair_only=False):
+    def _pair_node(self, x2d, xp, r, hs, ws, want_pair, pool, select=None, pair_only=False, pool_only_ok=False):
         from .. import _C
         # RAW weights + folded FrozenBN (scale, shift) pairs: the fold itself happens inside the node's weight-prep kernel
         w1, w2, w3 = self.conv1.weight, self.conv2.weight, self.conv3.weight
@@ -163,7 +163,8 @@ class Bottleneck(nn.Module):
             b3s = b3 if bd is None else b3 + bd
         res = bottleneck_pair(x2d, xp, (hs, ws), w1, b1, w2, b2, w3, b3s, wd, want_pair, wpairs, pool,
                               scales=(s1, s2, s3, sd),
-                              want_f32=not (want_pair and pair_only and self.pair_only_chain), select=select)
+                              want_f32=not (want_pair and pair_only and self.pair_only_chain), select=select,
+                              pool_only_ok=pool_only_ok)
         out = res[0].view(r, hs, ws, res[0].shape[-1])
         if pool:
             out._ovis_pooled = res[2]  # [R, C] mean over the map, an output of the same autograd node (see pooled())
@@ -172,7 +173,8 @@ class Bottleneck(nn.Module):
             out._ovis_selected = sel
         return (out, res[1]) if want_pair else out
 
-    def forward_nhwc(self, x, prestrided=False, xp=None, want_pair=False, pool=False, select=None, pair_only=False):
+    def forward_nhwc(self, x, prestrided=False, xp=None, want_pair=False, pool=False, select=None, pair_only=False,
+                     pool_only_ok=False):
         """Same block on an NHWC tensor ``x`` [R, H, W, C] (contiguous); ``prestrided``: x already holds only the
         positions conv1 / the shortcut read (the pooler applied their common stride).  The 1x1 convolutions -- 53 % of the
         res5 FLOPs -- become ONE row-major GEMM over all R*H*W positions each ([R*H*W, Cin] x [Cin, Cout], bias
@@ -185,7 +187,7 @@ class Bottleneck(nn.Module):
         consumer of the result ``takes_pair_only_input()``, so the fp32 copy may be dropped (the caller looks ahead:
         ``chain_nhwc``); a block that is NOT on the pair route never receives such an input."""
         if self.pair_gemm and x.is_cuda and self.pair_supported():
-            return self._forward_pair(x, prestrided, xp, want_pair, pool, select, pair_only)
+            return self._forward_pair(x, prestrided, xp, want_pair, pool, select, pair_only, pool_only_ok)
         if is_placeholder(x):
             raise RuntimeError("Bottleneck.forward_nhwc: the input exists in pair layout only (its fp32 handle is a "
                                "placeholder) but this block is not on the pair-GEMM route; the producer must keep the "
@@ -426,16 +428,19 @@ class ResNetHead(nn.Module):
         b0 = self.layer4[0]
         return bool(self.pooler_stride()) and b0.pair_gemm and b0.pair_supported() and b0._fd is not None
 
-    def forward_pooled_nhwc(self, y, yp=None, shape=None, select=None):
+    def forward_pooled_nhwc(self, y, yp=None, shape=None, select=None, pooled_only=False):
         """y [R, 7, 7, C]: the pooled bins conv1 reads, NHWC (from ``forward_strided_nhwc``) -> [R, 2048, 7, 7] view;
-        or y None and yp the same bins in pair layout with shape = (R, 7, 7) (from ``roi_align_forward_strided_pair``)."""
+        or y None and yp the same bins in pair layout with shape = (R, 7, 7) (from ``roi_align_forward_strided_pair``).
+        ``pooled_only``: the caller reads nothing but the pooled [R, 2048] rows (``_ovis_pooled``) of a no-grad pass -- the
+        last block may then skip writing its [R*49, 2048] result (the returned view is a NaN placeholder)."""
         blocks = list(self.layer4)
         if y is None:  # bins in pair layout only: the first block runs on them directly
             y, yp = blocks[0].forward_pair_rows(yp, shape[0], shape[1], shape[2], want_pair=True,
                                                 pair_only=blocks[1].takes_pair_only_input())
-            y = chain_nhwc(blocks[1:], y, yp, last={"pool": True, "select": select})
+            y = chain_nhwc(blocks[1:], y, yp, last={"pool": True, "select": select, "pool_only_ok": pooled_only})
         else:
-            y = chain_nhwc(blocks, y, yp, first={"prestrided": True}, last={"pool": True, "select": select})
+            y = chain_nhwc(blocks, y, yp, first={"prestrided": True},
+                           last={"pool": True, "select": select, "pool_only_ok": pooled_only})
         out = y.permute(0, 3, 1, 2)
         for attr in ("_ovis_pooled", "_ovis_selected"):  # outputs of the last block's autograd node, carried on its result
             v = getattr(y, attr, None)

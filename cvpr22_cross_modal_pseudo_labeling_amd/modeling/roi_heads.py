@@ -68,10 +68,10 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
         self.head = ResNetHead(cfg)
         self.out_channels = self.head.out_channels
 
-    def forward(self, x, proposals):
-        return self.forward_rois(x, self.pooler.convert_to_roi_format(proposals))
+    def forward(self, x, proposals, pooled_only=False):
+        return self.forward_rois(x, self.pooler.convert_to_roi_format(proposals), pooled_only=pooled_only)
 
-    def forward_rois(self, x, rois, select=None):
+    def forward_rois(self, x, rois, select=None, pooled_only=False):
         """``rois`` [R, 5] = (image index into x[0], x1, y1, x2, y2): the same pass on an explicit RoI tensor (lets a
         caller pool RoIs of several proposal lists / image subsets in one go)."""
         p = self.pooler.pooler
@@ -82,8 +82,8 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
                 # frozen features: the bins go to the first GEMM in pair layout, no fp32 copy / split pass in between
                 ph, pw = p.output_size
                 yp, (oh, ow) = _C.roi_align_forward_strided_pair(x[0], rois, p.spatial_scale, ph, pw, p.sampling_ratio, s)
-                return self.head.forward_pooled_nhwc(None, yp, (rois.shape[0], oh, ow), select=select)
-            return self.head.forward_pooled_nhwc(p.forward_strided_nhwc(x[0], rois, s), select=select)
+                return self.head.forward_pooled_nhwc(None, yp, (rois.shape[0], oh, ow), select=select, pooled_only=pooled_only)
+            return self.head.forward_pooled_nhwc(p.forward_strided_nhwc(x[0], rois, s), select=select, pooled_only=pooled_only)
         return self.head(p(x[0], rois))
 
 
@@ -381,7 +381,11 @@ class ROIBoxHead(nn.Module):
         if self.training:
             with torch.no_grad():
                 proposals = self.loss_evaluator.subsample(proposals, targets)
-        x = self.feature_extractor(features, proposals)
+        # evaluation / no-grad passes read nothing but the pooled rows of the box features (the predictor here, the teacher's
+        # ``predictor.embed`` in generate_pseudo_label; the mask head pools its own features then): the res5 head's last
+        # block may leave its [R*49, 2048] result unwritten
+        pooled_only = not self.training and not torch.is_grad_enabled()
+        x = self.feature_extractor(features, proposals, pooled_only=pooled_only)
         class_logits, box_regression = self.predictor(x)
         if not self.training:
             return x, self.post_processor((class_logits, box_regression), proposals), {}

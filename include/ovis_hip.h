@@ -600,6 +600,19 @@ int ovis_deform_col2im_rows_f32(const float* dcol_rows, long dcol_ld, const floa
                                 int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int deformable_group,
                                 void* stream);
 
+/* Last bottleneck of a res5 chain with the head's average pooling in the GEMM epilogue (mb/modeling/roi_heads/box_head/
+ * roi_box_predictors.py:62-66: AdaptiveAvgPool2d over the 7 x 7 map of every RoI): act(A.B^T + bias + shortcut) as
+ * ovis_split_gemm_pair_rp, and pooled[m / pool_rows][n] += pool_scale * result summed over the pool_rows rows of every map
+ * (32 <= pool_rows <= 64; `pooled` [ceil(m / pool_rows), n] fp32 must be ZERO-FILLED by the caller; every pooled value
+ * receives at most two fp32 atomic addends: bit-reproducible).  c and c_pair may BOTH be NULL: then nothing but the pooled
+ * rows is written (the no-grad teacher pass).  residual_pair may be NULL.  Plain un-split 128-column launches only:
+ * ovis_split_gemm_pair_pool_supported(m, n, channels, pool_rows) != 0, else OVIS_ERANGE. */
+int ovis_split_gemm_pair_pool_supported(long m, int n, int channels, int pool_rows);
+int ovis_split_gemm_pair_rp_pool(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes, float* c,
+                                 long ldc, void* c_pair, long c_pair_row_bytes, const float* bias,
+                                 const void* residual_pair, long residual_pair_row_bytes, long m, int n, int channels,
+                                 int relu, float* pooled, int pool_rows, float pool_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -284,6 +284,40 @@ def test_split_gemm_pair_rp_gated_equals_two_step_form(m, k, n):
                                    C.split_pair(x[:, :64].contiguous()))
 
 
+@pytest.mark.parametrize("maps,n,k", [(600, 256, 512), (2000, 2048, 512), (301, 128, 64)])
+def test_split_gemm_pair_rp_pool_epilogue(maps, n, k):
+    """conv3 + pair shortcut + ReLU of the last res5 block with the 7 x 7 average pooling in the GEMM epilogue
+    (``ovis_split_gemm_pair_rp_pool``): the fp32 result is bit-identical to the plain launch, the pooled rows equal the mean
+    over every 49-row group of that result to fp32 summation accuracy, the pool-only form (no result written) gives the
+    same pooled bits, two runs are bit-identical (at most two atomic addends per pooled value), and shapes whose launch plan
+    is not the plain un-split form are refused up front."""
+    C = _C()
+    g = torch.Generator(device="cuda").manual_seed(maps + n)
+    m = maps * 49                                   # ragged last row tile (m % 128 != 0) and maps straddling tiles
+    a = C.split_pair(torch.randn(m, k, device="cuda", generator=g))
+    b = C.split_pair(torch.randn(n, k, device="cuda", generator=g) * 0.05)
+    r = C.split_pair(torch.randn(m, n, device="cuda", generator=g))
+    bias = torch.randn(n, device="cuda", generator=g)
+    assert C.split_gemm_pair_pool_supported(m, n, k, 49)
+    want, _ = C.split_gemm_pair(a, b, bias, None, True, True, False, residual_pair=r)
+    got, gotp, pooled = C.split_gemm_pair_rp_pool(a, b, bias, r, True, True, True, 49)
+    assert torch.equal(got, want) and torch.equal(gotp, C.split_pair(want))
+    ref = want.view(maps, 49, n).double().mean(1)
+    assert pooled.shape == (maps, n)
+    assert float((pooled.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    none_c, none_p, pooled_only = C.split_gemm_pair_rp_pool(a, b, bias, r, True, False, False, 49)
+    assert none_c is None and none_p is None and torch.equal(pooled_only, pooled)
+    _, _, again = C.split_gemm_pair_rp_pool(a, b, bias, r, True, False, False, 49)
+    assert torch.equal(again, pooled)
+    # no shortcut operand
+    w2, _ = C.split_gemm_pair(a, b, bias, None, True, True, False)
+    _, _, p2 = C.split_gemm_pair_rp_pool(a, b, bias, None, True, False, False, 49)
+    assert float((p2.double() - w2.view(maps, 49, n).double().mean(1)).abs().max()) <= 2e-6 * float(w2.abs().max())
+    assert not C.split_gemm_pair_pool_supported(490, 2048, 512, 49)     # a handful of row tiles: they keep their split-K plan
+    assert not C.split_gemm_pair_pool_supported(m, 64, k, 49)           # narrow tiles
+    assert not C.split_gemm_pair_pool_supported(m, n, k, 16)            # a 4 x 4 map: more than three maps per 64 rows
+
+
 @pytest.mark.parametrize("train", [False, True])
 def test_bottleneck_chain_pair_only_vs_fp32_chain(train):
     """A res5-like chain (projection block + two identity blocks) with the intermediate results carried in PAIR layout

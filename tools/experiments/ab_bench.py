@@ -1,0 +1,35 @@
+"""A/B of one product switch inside bench.py on the SAME box (boxes of the pool differ by ~2.5 %):
+    python tools/experiments/ab_bench.py <patch> [bench args...]
+runs bench.py alternately unpatched (A) and with the named monkeypatch applied (B), three times each, and prints ms per step.
+Patches: nopool (the res5 head's average pooling as a separate pass), oldpooler (direct channels-last pooler)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PATCHES = {
+    "none": "",
+    "nopool": "from cvpr22_cross_modal_pseudo_labeling_amd import _C; _C.split_gemm_pair_pool_supported = lambda *a: False",
+}
+
+
+def run(patch, args):
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.argv = ['bench.py'] + {args!r}\n{PATCHES[patch]}\n"
+            "import bench\nbench.main()\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if not line:
+        print(out.stderr[-2000:])
+        raise SystemExit("bench failed")
+    d = json.loads(line[-1])
+    return d["ms_per_step"], d["ms_per_step_spread"]
+
+
+if __name__ == "__main__":
+    patch = sys.argv[1]
+    args = sys.argv[2:] or ["--steps", "40", "--warmup", "8", "--no-cpu-baseline"]
+    for i in range(3):
+        for name in ("none", patch):
+            ms, spread = run(name, args)
+            print(f"round {i} {'A (shipped)' if name == 'none' else 'B (' + patch + ')':14s} {ms:7.3f} ms/step  {spread}", flush=True)
