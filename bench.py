@@ -227,6 +227,16 @@ class OpTimer:
         self._wrap("split_gemm_pair", split_gemm_flops, "mfma", split_gemm_bytes, nt_shape)
         self._wrap("split_gemm_pair_gated", split_gemm_flops, "mfma", split_gemm_gated_bytes, nt_shape)
         self._wrap("split_gemm_pair_rp_gated", split_gemm_flops, "mfma", split_gemm_rp_gated_bytes, nt_shape)
+
+        def split_gemm_pool_bytes(a_pair, b_pair, bias, residual_pair, relu, out_f32, out_pair, pool_rows):
+            m, n = a_pair.shape[0], b_pair.shape[0]   # operands, the pair shortcut, whichever results are written, the pooled rows
+            return (2 * a_pair.numel() + 2 * b_pair.numel() + (4 * m * n if residual_pair is not None else 0)
+                    + 4 * m * n * (int(bool(out_f32)) + int(bool(out_pair))) + 4 * (m // pool_rows) * n)
+
+        def pool_shape(a_pair, b_pair, *args, **kwargs):
+            return (a_pair.shape[0], b_pair.shape[0], b_pair.shape[1] // 2, 1)
+
+        self._wrap("split_gemm_pair_rp_pool", split_gemm_flops, "mfma", split_gemm_pool_bytes, pool_shape)
         self._wrap("split_gemm_pair_tn", split_gemm_tn_flops, "mfma", split_gemm_tn_bytes, tn_shape)
 
     def summary(self):
@@ -282,9 +292,9 @@ def per_shape_rows(timer, steps):
 
 # bench.py op name -> kernel family of the committed PMC summary (profiles/r1_pmc_step_hbm_traffic_<workload>.json)
 PMC_KERNEL = {"split_gemm_pair": "split_gemm_kernel", "split_gemm_pair_gated": "split_gemm_kernel",
-              "split_gemm_pair_rp_gated": "split_gemm_kernel",
+              "split_gemm_pair_rp_gated": "split_gemm_kernel", "split_gemm_pair_rp_pool": "split_gemm_kernel",
               "split_gemm_pair_tn": "split_gemm_tn_kernel", "gate_split_pair": "gate_split_pair_kernel",
-              "split_pair": "split_pair_kernel", "roi_align_forward_strided_pair": "roi_align_fwd_strided_nhwc_kernel",
+              "split_pair": "split_pair_kernel", "roi_align_forward_strided_pair": "roi_align_fwd_nhwc_in_strided_lds_kernel",
               "roi_align_forward_strided_nhwc": "roi_align_fwd_strided_nhwc_kernel",
               "roi_align_backward_strided": "roi_bwd_mfma_kernel", "roi_align_backward": "roi_bwd_mfma_kernel"}
 
@@ -293,9 +303,8 @@ def pmc_traffic(workload, op):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes over this same step (FETCH_SIZE and
     WRITE_SIZE in separate passes, gfx950 correction applied: tools/pmc_step.sh); counters cannot be collected from
     inside the process, so the committed summary of the last pass is reported -- or null when there is none."""
-    path = os.path.join(ROOT, "profiles", f"r2_pmc_step_hbm_traffic_{workload}.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", f"r1_pmc_step_hbm_traffic_{workload}.json")
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_pmc_step_hbm_traffic_{workload}.json") for r in (3, 2, 1))
+                 if os.path.exists(q)), "")
     fam = PMC_KERNEL.get(op)
     try:
         with open(path) as f:
