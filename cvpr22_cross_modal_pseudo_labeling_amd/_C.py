@@ -583,6 +583,28 @@ def match_encode(gt_boxes, gt_labels, proposals, high, low, weights=None, betwee
     return idx, lab, reg
 
 
+def rpn_match_encode(gt_boxes, anchors, visibility, high_threshold, low_threshold, allow_low_quality_matches, weights):
+    """The RPN's per-image targets in two launches (``ovis_rpn_match_encode_f32``; rpn/loss.py:21-89): gt_boxes [G, 4],
+    anchors [A, 4], visibility [A] bool -> (labels [A] int64: 1 / 0 / -1, regression targets [A, 4])."""
+    gt_boxes, anchors = _dev(gt_boxes, "gt_boxes"), _dev(anchors, "anchors")
+    if not (visibility.is_cuda and visibility.dtype == torch.bool and visibility.shape == (anchors.shape[0],)):
+        raise RuntimeError("rpn_match_encode: visibility must be a bool HIP tensor [A]")
+    visibility = visibility.contiguous()
+    g, a = gt_boxes.shape[0], anchors.shape[0]
+    if g == 0:
+        raise ValueError("No ground-truth boxes available for one of the images during training")
+    labels = torch.empty((a,), dtype=torch.int64, device=anchors.device)
+    reg = torch.empty((a, 4), dtype=torch.float32, device=anchors.device)
+    scratch = torch.empty((g,), dtype=torch.int32, device=anchors.device)
+    wx, wy, ww, wh = weights
+    with _on(anchors.device):
+        rc = _L.ovis_rpn_match_encode_f32(gt_boxes.data_ptr(), anchors.data_ptr(), visibility.data_ptr(), g, a, high_threshold,
+                                          low_threshold, int(bool(allow_low_quality_matches)), wx, wy, ww, wh, scratch.data_ptr(),
+                                          labels.data_ptr(), reg.data_ptr(), _stream())
+    _lib.check(rc, "rpn_match_encode")
+    return labels, reg
+
+
 def project_masks(masks, gt_index, boxes, resolution):
     """masks [G,H,W] bool / uint8, gt_index [P] int64, boxes [P,4] -> [P, M, M] f32 mask targets (one launch)."""
     if not (masks.is_cuda and masks.dim() == 3 and masks.dtype in (torch.bool, torch.uint8)):

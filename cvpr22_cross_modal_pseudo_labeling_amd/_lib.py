@@ -67,6 +67,7 @@ SIGNATURES = {
     "ovis_split_gemm_pair": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _l] + [_i] * 9
                              + [_vp, _sz, _i, _vp]),
     "ovis_match_encode_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "ovis_rpn_match_encode_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ovis_project_masks_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ovis_gemm_f32": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _i, _i, _i, _vp]),
     "ovis_gemm_ex_f32": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _i, _f, _i, _vp, _l, _i, _i, _i, _vp]),

@@ -71,6 +71,79 @@ __global__ __launch_bounds__(256) void match_encode_kernel(const float* __restri
   }
 }
 
+// ---- RPN targets: anchors x ground truth with the Matcher's LOW-QUALITY matches (rpn/loss.py:21-89; matcher.py:42-112) --------
+// IoU of one anchor / ground-truth pair, the expression of boxlist_iou (structures/boxlist_ops.py:53-89); both passes below
+// evaluate it with the same instructions, so "IoU == the ground truth's best IoU" is an exact comparison as in the reference.
+__device__ __forceinline__ float anchor_iou(const float4 a, const float area_a, const float4 b, const float area_b) {
+  const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x) + 1.f, 0.f);
+  const float h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y) + 1.f, 0.f);
+  const float inter = w * h;
+  return inter / (area_a + area_b - inter);
+}
+
+// pass 1: best[g] = max over the anchors of IoU(g, anchor) (bit pattern of a non-negative float: unsigned max)
+__global__ __launch_bounds__(256) void rpn_best_per_gt_kernel(const float* __restrict__ gt, const float* __restrict__ anchors,
+                                                             int G, int A, unsigned* __restrict__ best) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < A;
+  const float4 b = live ? *(const float4*)(anchors + 4 * p) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float area_b = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
+  for (int g = 0; g < G; ++g) {
+    const float4 a = *(const float4*)(gt + 4 * g);
+    const float area_a = (a.z - a.x + 1.f) * (a.w - a.y + 1.f);
+    float v = live ? anchor_iou(a, area_a, b, area_b) : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(best + g, __float_as_uint(v));
+  }
+}
+
+// pass 2: per anchor the Matcher (argmax, thresholds, low-quality restore), the label 1 / 0 / -1 with the visibility and the
+// between-thresholds rules in the reference's order (rpn/loss.py:60-77), and BoxCoder.encode of the matched ground truth
+__global__ __launch_bounds__(256) void rpn_match_encode_kernel(const float* __restrict__ gt, const float* __restrict__ anchors,
+                                                              const unsigned char* __restrict__ visible, int G, int A,
+                                                              float high, float low, int allow_low_quality,
+                                                              const unsigned* __restrict__ best_per_gt, float wx, float wy,
+                                                              float ww, float wh, long* __restrict__ labels,
+                                                              float* __restrict__ reg) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= A) return;
+  const float4 b = *(const float4*)(anchors + 4 * p);
+  const float area_b = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
+  float best = -1.f;
+  int arg = 0;
+  bool tied = false;
+  for (int g = 0; g < G; ++g) {
+    const float4 a = *(const float4*)(gt + 4 * g);
+    const float area_a = (a.z - a.x + 1.f) * (a.w - a.y + 1.f);
+    const float iou = anchor_iou(a, area_a, b, area_b);
+    if (iou > best) {  // first maximum wins
+      best = iou;
+      arg = g;
+    }
+    tied |= allow_low_quality && __float_as_uint(iou) == best_per_gt[g];
+  }
+  int matched = arg;
+  if (best < low) matched = -1;          // BELOW_LOW_THRESHOLD
+  else if (best < high) matched = -2;    // BETWEEN_THRESHOLDS
+  if (tied) matched = arg;               // an anchor that ties a ground truth's best IoU keeps its argmax
+  long lab = matched >= 0 ? 1 : 0;       // (matched >= 0); BELOW -> 0
+  if (!visible[p]) lab = -1;             // anchors that straddle the image border are ignored
+  if (matched == -2) lab = -1;           // between the thresholds: ignored
+  labels[p] = lab;
+  const float4 a = *(const float4*)(gt + 4 * (matched < 0 ? 0 : matched));   // matched.clamp(min=0)
+  const float ex_w = b.z - b.x + 1.f, ex_h = b.w - b.y + 1.f;
+  const float ex_cx = b.x + 0.5f * ex_w, ex_cy = b.y + 0.5f * ex_h;
+  const float gt_w = a.z - a.x + 1.f, gt_h = a.w - a.y + 1.f;
+  const float gt_cx = a.x + 0.5f * gt_w, gt_cy = a.y + 0.5f * gt_h;
+  float4 r;
+  r.x = wx * (gt_cx - ex_cx) / ex_w;
+  r.y = wy * (gt_cy - ex_cy) / ex_h;
+  r.z = ww * logf(gt_w / ex_w);
+  r.w = wh * logf(gt_h / ex_h);
+  *(float4*)(reg + 4 * p) = r;
+}
+
 __global__ __launch_bounds__(256) void project_masks_kernel(const unsigned char* __restrict__ masks,
                                                            const long* __restrict__ gt_index,
                                                            const float* __restrict__ boxes, int P, int H, int W, int M,
@@ -359,6 +432,30 @@ extern "C" int ovis_match_encode_f32(const float* gt_boxes, const int64_t* gt_la
   hipLaunchKernelGGL(match_encode_kernel, dim3((num_proposals + 255) / 256), dim3(256), 0, (hipStream_t)stream, gt_boxes,
                      (const long*)gt_labels, proposals, num_gt, num_proposals, high_threshold, low_threshold,
                      between_keeps_label, wx, wy, ww, wh, (long*)matched_idx, (long*)labels, regression_targets);
+  OVIS_LAUNCH_CHECK();
+  return OVIS_OK;
+}
+
+extern "C" int ovis_rpn_match_encode_f32(const float* gt_boxes, const float* anchors, const uint8_t* visibility, int num_gt,
+                                         int num_anchors, float high_threshold, float low_threshold,
+                                         int allow_low_quality_matches, float wx, float wy, float ww, float wh,
+                                         uint32_t* best_per_gt_scratch, int64_t* labels, float* regression_targets,
+                                         void* stream) {
+  if (num_gt <= 0 || num_anchors < 0) return OVIS_EINVAL;
+  if (num_anchors == 0) return OVIS_OK;
+  if (!gt_boxes || !anchors || !visibility || !best_per_gt_scratch || !labels || !regression_targets) return OVIS_EINVAL;
+  if (((uintptr_t)gt_boxes & 15) || ((uintptr_t)anchors & 15) || ((uintptr_t)regression_targets & 15)) return OVIS_ERANGE;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)((num_anchors + 255) / 256);
+  if (allow_low_quality_matches) {
+    OVIS_HIP_TRY(hipMemsetAsync(best_per_gt_scratch, 0, sizeof(uint32_t) * (size_t)num_gt, s));
+    hipLaunchKernelGGL(rpn_best_per_gt_kernel, dim3(blocks), dim3(256), 0, s, gt_boxes, anchors, num_gt, num_anchors,
+                       best_per_gt_scratch);
+    OVIS_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(rpn_match_encode_kernel, dim3(blocks), dim3(256), 0, s, gt_boxes, anchors, visibility, num_gt,
+                     num_anchors, high_threshold, low_threshold, allow_low_quality_matches, best_per_gt_scratch, wx, wy, ww, wh,
+                     (long*)labels, regression_targets);
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
 }

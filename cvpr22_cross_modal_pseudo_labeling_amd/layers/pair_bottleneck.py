@@ -65,6 +65,18 @@ def _dw(gp, xp, w, scale, conv=None):
     return d if scale is None else d * scale.view(-1, 1, 1, 1)
 
 
+_NAN_CELL = {}
+
+
+def nan_placeholder(device, rows, cols):
+    """[rows, cols] fp32 view of ONE NaN element per device (zero strides): the handle autograd routes where a value exists
+    in pair layout only.  The element is created once -- a fill launch per placeholder was 24 launches per teacher step."""
+    cell = _NAN_CELL.get(device)
+    if cell is None:
+        cell = _NAN_CELL[device] = torch.full((1,), float("nan"), dtype=torch.float32, device=device)
+    return cell.expand(rows, cols)
+
+
 def is_placeholder(t):
     """A zero-stride stand-in for a block output that exists only in pair layout (see ``_BottleneckPair.forward``)."""
     return t is not None and t.numel() > 1 and all(st == 0 for st in t.stride())
@@ -134,7 +146,7 @@ class _BottleneckPair(Function):
                 keep = need_bwd or want_pair or select is not None or not pool_only_ok
                 out, outp, pooled_k = _C.split_gemm_pair_rp_pool(o2p, wpairs["w3"], b3, xp, True, keep, want_pair, h * w)
                 if out is None and outp is None:
-                    out = pooled_k.new_full((1,), float("nan")).expand(o2p.shape[0], pooled_k.shape[1])  # never read
+                    out = nan_placeholder(pooled_k.device, o2p.shape[0], pooled_k.shape[1])  # never read
             else:
                 out, outp = _C.split_gemm_pair(o2p, wpairs["w3"], b3, None, True, f32, want_pair, residual_pair=xp)
         # pool: also return the mean over the h*w rows of every map (the head's average pooling) as an output of THIS
@@ -151,7 +163,7 @@ class _BottleneckPair(Function):
         out_sel = out.view(-1, h * w, out.shape[1]).index_select(0, select) if (select is not None and f32) else None
         gate_src = out if out is not None else outp  # the last ReLU's gate: the fp32 result or the hi halves of its pair form
         if out is None:  # NaN-filled: any consumer outside the one-block contract shows up in the loss instead of reading garbage
-            out = outp.new_full((1,), float("nan"), dtype=torch.float32).expand(outp.shape[0], outp.shape[1] // 2)
+            out = nan_placeholder(outp.device, outp.shape[0], outp.shape[1] // 2)
         ctx.save_for_backward(xp, o1p, o2p, gate_src, w1, w2, w3, wd, s1, s2, s3, sd, select if out_sel is not None else None)
         ctx.wts = wts
         ctx.geom = (h, w, kh, kw)
@@ -216,7 +228,7 @@ class _BottleneckPair(Function):
                     # (dY1 W1 + shortcut gradient) gated by the block input's ReLU, in pair layout only: what the block
                     # below would compute from an fp32 gradient with one more pass over it
                     _, link_in.grad_pair = _C.split_gemm_pair_rp_gated(g1p, t1, g3p, xp)
-                    dx = g1p.new_full((1,), float("nan"), dtype=torch.float32).expand(xp.shape[0], xp.shape[1] // 2)
+                    dx = nan_placeholder(g1p.device, xp.shape[0], xp.shape[1] // 2)
                 else:
                     if wd is not None:
                         res, _ = _C.split_gemm_pair(g3p, td)

@@ -303,8 +303,51 @@ class RPNPostProcessor(nn.Module):  # inference.py:15-140 (single feature map)
 class RPNLossComputation:  # loss.py:21-131
     def __init__(self, matcher, sampler, box_coder):
         self.matcher, self.sampler, self.box_coder = matcher, sampler, box_coder
+        self.device_targets = True  # False = the tensor-op sequence also on the device (cross-check in the tests)
 
     def __call__(self, anchors, objectness, box_regression, targets):
+        if objectness.is_cuda and self.device_targets:
+            return self._call_device(anchors, objectness, box_regression, targets)
+        return self._call_tensor_ops(anchors, objectness, box_regression, targets)
+
+    def _call_device(self, anchors, objectness, box_regression, targets):
+        """The same two losses without the ~140 tensor-op launches and the six host syncs per step of the sequence below:
+        per image two native calls -- ``_C.rpn_match_encode`` (IoU, Matcher with low-quality matches, the three label
+        rules, delta targets; csrc/targets.hip) and the device fg / bg sampler -- then fixed-shape gathers over the padded
+        [N, batch_size] selections; the number of sampled anchors stays a device scalar (no host read).  The sampler
+        draws its uniformly random subsets from its own key stream (see ``BalancedPositiveNegativeSampler.sample_device``),
+        not from ``torch.randperm``."""
+        from .. import _C
+        n, a, h, w = objectness.shape
+        b = self.sampler.batch_size_per_image
+        sels, slots, counts, labs, regs = [], [], [], [], []
+        for anc, tgt in zip(anchors, targets):
+            lab, reg = _C.rpn_match_encode(tgt.bbox, anc.bbox, anc.get_field("visibility"), self.matcher.high_threshold,
+                                           self.matcher.low_threshold, self.matcher.allow_low_quality_matches,
+                                           self.box_coder.weights)
+            sel, slot, cnt = self.sampler.sample_device(lab)
+            sels.append(sel)
+            slots.append(slot)
+            counts.append(cnt)
+            labs.append(lab)
+            regs.append(reg)
+        sel, slot, cnt = torch.stack(sels), torch.stack(slots), torch.stack(counts)      # [N, B], [N, B], [N, 2]
+        lab, regt = torch.stack(labs), torch.stack(regs)                                 # [N, A], [N, A, 4]
+        ar = torch.arange(b, device=sel.device)[None]
+        valid, pos_valid = ar < cnt[:, 0:1], ar < cnt[:, 1:2]
+        total = valid.sum().to(torch.float32)                                            # sampled_inds.numel()
+        obj = permute_and_flatten(objectness, n, a, 1, h, w).reshape(n, -1)
+        reg = permute_and_flatten(box_regression, n, a, 4, h, w).reshape(n, -1, 4)
+        bce = F.binary_cross_entropy_with_logits(obj.gather(1, sel), lab.gather(1, sel).to(torch.float32), reduction="none")
+        objectness_loss = (bce * valid).sum() / total
+        pos_idx = sel.gather(1, slot.clamp(min=0, max=b - 1))[..., None].expand(-1, -1, 4)  # anchors of the sampled positives
+        d = (reg.gather(1, pos_idx) - regt.gather(1, pos_idx)).abs()
+        beta = 1.0 / 9
+        l1 = torch.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta)                    # layers/smooth_l1_loss.py:6-16
+        box_loss = (l1 * pos_valid[..., None]).sum() / total
+        return objectness_loss, box_loss
+
+    def _call_tensor_ops(self, anchors, objectness, box_regression, targets):
         labels, reg_targets = [], []
         for anc, tgt in zip(anchors, targets):
             matched = self.matcher(box_iou(tgt.bbox, anc.bbox))

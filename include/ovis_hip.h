@@ -442,6 +442,17 @@ int ovis_match_encode_f32(const float* gt_boxes, const int64_t* gt_labels, const
                           int num_proposals, float high_threshold, float low_threshold, int between_keeps_label,
                           float wx, float wy, float ww, float wh, int64_t* matched_idx, int64_t* labels,
                           float* regression_targets, void* stream);
+/* ovis_rpn_match_encode_f32: the RPN's target building (mb/modeling/rpn/loss.py:21-89) for one image: boxlist_iou of
+ * gt_boxes [num_gt, 4] x anchors [num_anchors, 4] -> Matcher WITH low-quality matches (mb/modeling/matcher.py:42-112: an
+ * anchor whose IoU equals a ground truth's best IoU keeps its argmax; pass 1 takes the per-ground-truth maxima into
+ * best_per_gt_scratch [num_gt] uint32, pass 2 compares bit patterns) -> labels [num_anchors] int64: 1 matched, 0 below the
+ * low threshold, -1 ignored (between the thresholds, or visibility[a] == 0: anchors straddling the image border), in the
+ * reference's order of the three rules; regression_targets [num_anchors, 4] = BoxCoder.encode of the matched ground truth
+ * (index clamped at 0) with weights (wx, wy, ww, wh).  allow_low_quality_matches == 0: the plain Matcher. */
+int ovis_rpn_match_encode_f32(const float* gt_boxes, const float* anchors, const uint8_t* visibility, int num_gt,
+                              int num_anchors, float high_threshold, float low_threshold, int allow_low_quality_matches,
+                              float wx, float wy, float ww, float wh, uint32_t* best_per_gt_scratch, int64_t* labels,
+                              float* regression_targets, void* stream);
 int ovis_project_masks_f32(const uint8_t* masks, const int64_t* gt_index, const float* boxes, int num, int height,
                            int width, int resolution, int masks_are_bool, float* out, void* stream);
 /* ovis_sample_fg_bg: BalancedPositiveNegativeSampler of one image (mb/modeling/balanced_positive_negative_sampler.py:

@@ -263,6 +263,20 @@ def gen_heads():
     for i, r in enumerate(res):
         out[f"rpn_boxes{i}"], out[f"rpn_scores{i}"] = r.bbox.numpy(), r.get_field("objectness").numpy()
 
+    # ---- RPN loss (rpn/loss.py:21-131): targets of every anchor and the two losses; the sampler's quotas cover every
+    # candidate (batch 10^6: randperm()[:k] with k = all), so the values do not depend on the random stream
+    from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler as RefSampler
+    from maskrcnn_benchmark.modeling.rpn.loss import RPNLossComputation as RefRPNLoss, generate_rpn_labels
+    rl = RefRPNLoss(Matcher(0.7, 0.3, allow_low_quality_matches=True), RefSampler(10 ** 6, 0.5), BoxCoder(weights=(1.0, 1.0, 1.0, 1.0)),
+                    generate_rpn_labels)
+    rpn_gt = [BoxList(torch.tensor([[10.0, 12, 70, 90], [60, 30, 150, 120], [100, 5, 130, 40]]), (W * 16, H * 16), mode="xyxy"),
+              BoxList(torch.tensor([[5.0, 5, 175, 130], [20, 60, 60, 100]]), (W * 16 - 7, H * 16 - 10), mode="xyxy")]
+    lab, tgt = rl.prepare_targets([a_[0] for a_ in anchors], rpn_gt)
+    lo, lb = rl([[a_[0]] for a_ in anchors], [obj], [reg], rpn_gt)
+    for i in range(2):
+        out[f"rpnloss_gt{i}"], out[f"rpnloss_labels{i}"], out[f"rpnloss_targets{i}"] = rpn_gt[i].bbox.numpy(), lab[i].numpy(), tgt[i].numpy()
+    out["rpnloss_objectness"], out["rpnloss_box"] = np.float32(lo.item()), np.float32(lb.item())
+
     # ---- Masker paste (mask_head/inference.py:124-160)
     m = torch.rand(14, 14, generator=g)
     for i, box in enumerate(([10.3, 20.7, 90.2, 70.9], [-5.0, -8.0, 30.0, 25.0], [100.0, 60.0, 159.0, 119.0])):

@@ -136,6 +136,30 @@ def test_anchors_and_rpn_proposals_match_reference(z):
         assert torch.allclose(r.get_field("objectness"), T(z[f"rpn_scores{i}"]))
 
 
+def _rpn_loss_case(z, device="cpu"):
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling import rpn as R
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.matcher import BalancedPositiveNegativeSampler, Matcher
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.structures import BoxList
+
+    ag = R.AnchorGenerator((32, 64, 128, 256, 512), (0.5, 1.0, 2.0), 16, 0).to(device)
+    H, W = 9, 12
+    sizes = [(H * 16, W * 16), (H * 16 - 10, W * 16 - 7)]
+    anchors = ag(sizes, torch.zeros(2, 1, H, W, device=device))
+    targets = [BoxList(T(z[f"rpnloss_gt{i}"]), (sizes[i][1], sizes[i][0])).to(device) for i in range(2)]
+    loss = R.RPNLossComputation(Matcher(0.7, 0.3, allow_low_quality_matches=True), BalancedPositiveNegativeSampler(10 ** 6, 0.5),
+                                BoxCoder(weights=(1.0, 1.0, 1.0, 1.0)))
+    return loss, anchors, T(z["rpn_obj"]).to(device), T(z["rpn_reg"]).to(device), targets
+
+
+def test_rpn_loss_matches_reference_fixture(z):
+    """RPNLossComputation (rpn/loss.py:21-131), tensor-op form: the reference's two losses on the reference's anchors with
+    quotas that cover every candidate (no dependence on the random stream)."""
+    loss, anchors, obj, reg, targets = _rpn_loss_case(z)
+    lo, lb = loss(anchors, obj, reg, targets)
+    assert abs(float(lo) - float(z["rpnloss_objectness"])) <= 1e-6 * float(z["rpnloss_objectness"])
+    assert abs(float(lb) - float(z["rpnloss_box"])) <= 1e-5 * float(z["rpnloss_box"])
+
+
 def test_sampler_matches_reference_fixture(z):
     """BalancedPositiveNegativeSampler (tensor-op form): the reference's masks when every candidate is taken, its counts
     otherwise (balanced_positive_negative_sampler.py:39-47)."""

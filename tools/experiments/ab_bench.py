@@ -1,7 +1,8 @@
 """A/B of one product switch inside bench.py on the SAME box (boxes of the pool differ by ~2.5 %):
     python tools/experiments/ab_bench.py <patch> [bench args...]
 runs bench.py alternately unpatched (A) and with the named monkeypatch applied (B), three times each, and prints ms per step.
-Patches: nopool (the res5 head's average pooling as a separate pass), oldpooler (direct channels-last pooler)."""
+Patches: nopool (the res5 head's average pooling as a separate pass), rpnloss_ops (the RPN loss as its tensor-op sequence;
+use with --workload teacher)."""
 import json
 import os
 import subprocess
@@ -11,6 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 PATCHES = {
     "none": "",
     "nopool": "from cvpr22_cross_modal_pseudo_labeling_amd import _C; _C.split_gemm_pair_pool_supported = lambda *a: False",
+    "rpnloss_ops": ("from cvpr22_cross_modal_pseudo_labeling_amd.modeling import rpn as _r; "
+                    "_r.RPNLossComputation._call_device = _r.RPNLossComputation._call_tensor_ops"),
 }
 
 

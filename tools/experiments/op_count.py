@@ -73,16 +73,19 @@ def tag_fn(obj, attr, name):
     setattr(obj, attr, wrapped)
 
 
+WL = sys.argv[1] if len(sys.argv) > 1 else "student"   # student | teacher
 dev = torch.device("cuda", 0)
 cfg = get_defaults()
-cfg.merge_from_file(os.path.join(ROOT, "configs", "coco_cap_det", "student_teacher_mask_rcnn_uncertainty.yaml"))
+cfg.merge_from_file(os.path.join(ROOT, "configs", "coco_cap_det",
+                                 ("student_teacher_mask_rcnn_uncertainty" if WL == "student" else "zeroshot_mask") + ".yaml"))
 cfg.merge_from_list(["SOLVER.BASE_LR", 1e-6, "SOLVER.IMS_PER_BATCH", 2])
 cfg.freeze()
 torch.manual_seed(1234)
 model = build_detection_model(cfg).to(dev)
 e_vocab, e_seen = make_embeddings(cfg.MODEL.ROI_BOX_HEAD.EMB_DIM, seed=1234, device=dev)
 model.set_class_embeddings(e_seen)
-model.set_caption_vocab(e_vocab)
+if hasattr(model, "set_caption_vocab"):
+    model.set_caption_vocab(e_vocab)
 images, targets = make_batch(2, device=dev, seed=1234)
 calibrate_stem_bn(model, images)
 model.train()
@@ -97,7 +100,8 @@ torch.cuda.synchronize()
 
 tag_module(model.backbone, "backbone")
 tag_module(model.rpn, "rpn")
-for hn, heads in (("teacher", model.roi_heads), ("student", model.roi_heads_student)):
+for hn, heads in ((("teacher", model.roi_heads), ("student", model.roi_heads_student)) if WL == "student"
+                  else (("heads", model.roi_heads),)):
     for k in ("box", "mask"):
         h = heads[k]
         tag_module(h, f"{hn}.{k}")
@@ -108,10 +112,14 @@ for hn, heads in (("teacher", model.roi_heads), ("student", model.roi_heads_stud
             if hasattr(le, "subsample"):
                 tag_fn(le, "subsample", f"{hn}.{k}.subsample")
             tag_fn(le, "__call__", f"{hn}.{k}.loss")  # instance attribute is not used by (); handled below
-tag_fn(model, "generate_pseudo_label", "generate_pseudo_label")
-tag_fn(model, "compute_dummy_loss", "dummy_loss")
-tag_fn(model, "forward_frozen", "forward_frozen(other)")
-tag_fn(model, "forward_student", "forward_student(other)")
+if WL == "student":
+    tag_fn(model, "generate_pseudo_label", "generate_pseudo_label")
+    tag_fn(model, "compute_dummy_loss", "dummy_loss")
+    tag_fn(model, "forward_frozen", "forward_frozen(other)")
+    tag_fn(model, "forward_student", "forward_student(other)")
+else:
+    tag_fn(model.rpn, "loss_evaluator", "rpn.loss")
+    tag_module(model.rpn.box_selector_train, "rpn.select")
 tag_fn(optimizer, "step", "optimizer.step")
 
 class _CountingLib:
