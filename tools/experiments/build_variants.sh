@@ -19,6 +19,7 @@ for v in "$@"; do
     nbuf5) build nbuf5 "-DOVIS_EPI_NBUF=5" ;;
     dual3) build dual3 "-DOVIS_EPI_NBUF_DUAL=3" ;;
     nbuf4dual3) build nbuf4dual3 "-DOVIS_EPI_NBUF=4 -DOVIS_EPI_NBUF_DUAL=3" ;;
+    base) build base "" ;;
     *) echo "unknown variant $v"; exit 1 ;;
   esac
 done
