@@ -1,15 +1,18 @@
 """Operator surface of ``maskrcnn_benchmark._C`` (maskrcnn_benchmark/csrc/vision.cpp:9-25) on MI355X.
 
 Same names, argument order and return conventions as the reference's pybind module; every op
-is a thin tensor<->pointer shim over the C ABI in ``include/ovis_hip.h``.  Device tensors
-only: CPU tensors raise ``RuntimeError`` (the reference itself raises "Not implemented on the
-CPU" for most of these, csrc/ROIAlign.h:44, csrc/SigmoidFocalLoss.h:23,40).
+is a thin tensor<->pointer shim over the C ABI in ``include/ovis_hip.h``.  Like the reference's module
+(csrc/ROIAlign.h:11-25, csrc/nms.h:10-28) the entry points the CPU-only configuration needs dispatch on the
+tensor's device: HOST tensors go to ``_cpu.py`` (RoIAlign, NMS: ``libovis_cpu.so``; heads / losses: the
+reference's torch-op formulas), DEVICE tensors to the HIP kernels -- never across.  Every other op raises on
+host tensors (the reference raises "Not implemented on the CPU", csrc/ROIAlign.h:44,
+csrc/SigmoidFocalLoss.h:23,40).
 """
 import ctypes
 
 import torch
 
-from . import _lib
+from . import _cpu, _lib
 
 _L = _lib.load()
 
@@ -51,6 +54,8 @@ def _dev(t, name, dtype=torch.float32):
 
 # ---- RoIAlign (csrc/ROIAlign.h:11-46) ---------------------------------------------------------
 def _roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio, exact):
+    if not input.is_cuda:
+        return _cpu.roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio)
     input, rois = _dev(input, "input"), _dev(rois, "rois")
     if rois.dim() != 2 or rois.size(1) != 5 or input.dim() != 4:
         raise RuntimeError("roi_align_forward: expected input [N,C,H,W] and rois [R,5]")
@@ -160,6 +165,9 @@ def roi_align_forward_strided_pair(input, rois, spatial_scale, pooled_height, po
 
 def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels, height,
                        width, sampling_ratio):
+    if not grad.is_cuda:
+        return _cpu.roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels, height,
+                                       width, sampling_ratio)
     grad, rois = _dev(grad, "grad"), _dev(rois, "rois")
     r = rois.size(0)
     gin = torch.empty((batch_size, channels, height, width), dtype=grad.dtype, device=grad.device)
@@ -203,6 +211,8 @@ def roi_align_backward_strided(grad, rois, spatial_scale, pooled_height, pooled_
 def nms_padded(dets, scores, threshold, ge_mode=False):
     """Sync-free form: returns (keep[K] int64 -- first n entries valid, ascending; n as a
     1-element int32 device tensor).  Extension of the reference API for device pipelines."""
+    if not dets.is_cuda:
+        return _cpu.nms_padded(dets, scores, threshold)
     dets, scores = _dev(dets, "dets"), _dev(scores, "scores")
     k = dets.size(0)
     keep = torch.empty((k,), dtype=torch.int64, device=dets.device)
@@ -1031,6 +1041,8 @@ def bias_act_(y, bias=None, residual=None, relu=True):
 
 def gemm_nt(a, b, bias=None):
     """a [M,K] @ b[N,K]^T (+ bias[N]) -> [M,N] on the fp32 matrix cores.  a / b may be any 2-D strided views."""
+    if not a.is_cuda and not b.is_cuda:
+        return _cpu.gemm_nt(a, b, bias)
     if not (a.is_cuda and b.is_cuda):
         raise RuntimeError("gemm_nt: HIP device tensors only")
     if a.dtype != torch.float32 or b.dtype != torch.float32:
@@ -1055,6 +1067,8 @@ def gemm_nt(a, b, bias=None):
 
 def region_noun_align(region_emb, noun_emb):
     """-> (raw max score [W], sigmoid score [W], argmax region [W] int64)"""
+    if not region_emb.is_cuda:
+        return _cpu.region_noun_align(region_emb, noun_emb)
     region_emb, noun_emb = _dev(region_emb, "region_emb"), _dev(noun_emb, "noun_emb")
     p, d = region_emb.shape
     w = noun_emb.shape[0]
@@ -1115,6 +1129,8 @@ def project_polygon_masks(coords, polygon_start, instance_start, gt_index, boxes
 
 def weighted_ce_fwd_bwd(logits, labels, bg_weight, need_grad=True):
     """-> (loss scalar tensor, dlogits or None)"""
+    if not logits.is_cuda:
+        return _cpu.weighted_ce_fwd_bwd(logits, labels, bg_weight, need_grad)
     logits, labels = _dev(logits, "logits"), _dev(labels, "labels", torch.int64)
     p, c = logits.shape
     loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
@@ -1131,6 +1147,8 @@ def weighted_ce_fwd_bwd(logits, labels, bg_weight, need_grad=True):
 def mask_bce_stochastic_fwd_bwd(mu, sigma, eps, pos_index, targets, channel, need_grad=True):
     """mu [P,C,M,M]; sigma [P,1,M,M] or None; eps [P,C,M,M] or None; pos_index [Pp]; targets [Pp,M,M]
     -> (loss, dmu or None, dsigma or None)"""
+    if not mu.is_cuda:
+        return _cpu.mask_bce_stochastic_fwd_bwd(mu, sigma, eps, pos_index, targets, channel, need_grad)
     mu = _dev(mu, "mu")
     p, c = mu.shape[0], mu.shape[1]
     mm = mu.shape[2] * mu.shape[3]

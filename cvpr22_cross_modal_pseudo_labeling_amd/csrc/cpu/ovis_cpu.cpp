@@ -1,0 +1,207 @@
+// libovis_cpu.so: host twins of the two native ops the reference implements on the CPU (RoIAlign forward, NMS) plus the
+// RoIAlign transpose -- see include/ovis_cpu.h for the contract and the reference lines.  Product code for HOST tensors of the
+// reference's CPU-only configuration; device tensors never come here.
+//
+// RoIAlign is evaluated SEPARABLY: the sampling positions of a RoI along y and along x do not depend on each other
+// (the reference's joint table of pooled_h * pooled_w * grid_h * grid_w entries is the outer product of two short per-axis
+// tables), so a RoI builds pooled_h * grid_h + pooled_w * grid_w axis samples once and every channel re-uses them.  The
+// floating-point expressions per output are the reference's, in its order.
+#include "ovis_cpu.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+struct AxisSample {  // one sampling coordinate along one axis
+  int lo, hi;        // the two cells it interpolates between
+  float frac, rest;  // frac = distance from cell lo (the weight of cell hi), rest = 1 - frac (the weight of cell lo)
+  bool inside;       // false: the coordinate lies outside [-1, size] and contributes nothing
+};
+
+AxisSample axis_sample(float v, int size) {
+  AxisSample s{0, 0, 0.f, 0.f, false};
+  if (v < -1.0f || v > (float)size) return s;
+  if (v <= 0.f) v = 0.f;
+  s.lo = (int)v;
+  if (s.lo >= size - 1) {
+    s.hi = s.lo = size - 1;
+    v = (float)s.lo;
+  } else {
+    s.hi = s.lo + 1;
+  }
+  s.frac = v - (float)s.lo;
+  s.rest = 1.f - s.frac;
+  s.inside = true;
+  return s;
+}
+
+struct RoiGeometry {
+  int image;
+  int grid_h, grid_w;
+  float count;
+  std::vector<AxisSample> ys, xs;  // [pooled * grid] per axis, bin-major
+};
+
+RoiGeometry roi_geometry(const float* roi, int height, int width, int pooled_h, int pooled_w, float scale, int sampling_ratio) {
+  RoiGeometry g;
+  g.image = (int)roi[0];
+  const float start_w = roi[1] * scale, start_h = roi[2] * scale, end_w = roi[3] * scale, end_h = roi[4] * scale;
+  const float roi_w = std::max(end_w - start_w, 1.f), roi_h = std::max(end_h - start_h, 1.f);
+  const float bin_h = roi_h / (float)pooled_h, bin_w = roi_w / (float)pooled_w;
+  g.grid_h = sampling_ratio > 0 ? sampling_ratio : (int)std::ceil(roi_h / pooled_h);
+  g.grid_w = sampling_ratio > 0 ? sampling_ratio : (int)std::ceil(roi_w / pooled_w);
+  g.count = (float)(g.grid_h * g.grid_w);
+  g.ys.resize((size_t)pooled_h * g.grid_h);
+  g.xs.resize((size_t)pooled_w * g.grid_w);
+  for (int ph = 0; ph < pooled_h; ++ph)
+    for (int iy = 0; iy < g.grid_h; ++iy)
+      g.ys[(size_t)ph * g.grid_h + iy] = axis_sample(start_h + ph * bin_h + (float)(iy + .5f) * bin_h / (float)g.grid_h, height);
+  for (int pw = 0; pw < pooled_w; ++pw)
+    for (int ix = 0; ix < g.grid_w; ++ix)
+      g.xs[(size_t)pw * g.grid_w + ix] = axis_sample(start_w + pw * bin_w + (float)(ix + .5f) * bin_w / (float)g.grid_w, width);
+  return g;
+}
+
+int thread_count(int threads) {
+#ifdef _OPENMP
+  return threads > 0 ? threads : omp_get_max_threads();
+#else
+  (void)threads;
+  return 1;
+#endif
+}
+
+}  // namespace
+
+extern "C" int ovis_cpu_roi_align_forward_f32(const float* input, const float* rois, float* out, int num_rois, int batch,
+                                              int channels, int height, int width, int pooled_h, int pooled_w,
+                                              float spatial_scale, int sampling_ratio, int threads) {
+  if (num_rois < 0 || batch < 0 || channels < 0 || height <= 0 || width <= 0 || pooled_h <= 0 || pooled_w <= 0) return OVIS_CPU_EINVAL;
+  if (num_rois == 0 || channels == 0) return OVIS_CPU_OK;
+  if (!input || !rois || !out) return OVIS_CPU_EINVAL;
+  for (int r = 0; r < num_rois; ++r) {
+    const int b = (int)rois[(size_t)r * 5];
+    if (b < 0 || b >= batch) return OVIS_CPU_EINVAL;
+  }
+  const size_t plane = (size_t)height * width, bins = (size_t)pooled_h * pooled_w;
+  const int nt = thread_count(threads);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
+  for (int r = 0; r < num_rois; ++r) {
+    const RoiGeometry g = roi_geometry(rois + (size_t)r * 5, height, width, pooled_h, pooled_w, spatial_scale, sampling_ratio);
+    for (int c = 0; c < channels; ++c) {
+      const float* src = input + ((size_t)g.image * channels + c) * plane;
+      float* dst = out + ((size_t)r * channels + c) * bins;
+      for (int ph = 0; ph < pooled_h; ++ph) {
+        for (int pw = 0; pw < pooled_w; ++pw) {
+          float acc = 0.f;
+          for (int iy = 0; iy < g.grid_h; ++iy) {
+            const AxisSample& y = g.ys[(size_t)ph * g.grid_h + iy];
+            if (!y.inside) continue;
+            const float* row_lo = src + (size_t)y.lo * width;
+            const float* row_hi = src + (size_t)y.hi * width;
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+              const AxisSample& x = g.xs[(size_t)pw * g.grid_w + ix];
+              if (!x.inside) continue;
+              const float w1 = y.rest * x.rest, w2 = y.rest * x.frac, w3 = y.frac * x.rest, w4 = y.frac * x.frac;
+              acc += w1 * row_lo[x.lo] + w2 * row_lo[x.hi] + w3 * row_hi[x.lo] + w4 * row_hi[x.hi];
+            }
+          }
+          dst[(size_t)ph * pooled_w + pw] = acc / g.count;
+        }
+      }
+    }
+  }
+  return OVIS_CPU_OK;
+}
+
+extern "C" int ovis_cpu_roi_align_backward_f32(const float* grad_out, const float* rois, float* grad_input, int num_rois,
+                                               int batch, int channels, int height, int width, int pooled_h, int pooled_w,
+                                               float spatial_scale, int sampling_ratio, int threads) {
+  if (num_rois < 0 || batch < 0 || channels < 0 || height <= 0 || width <= 0 || pooled_h <= 0 || pooled_w <= 0) return OVIS_CPU_EINVAL;
+  const size_t plane = (size_t)height * width, bins = (size_t)pooled_h * pooled_w;
+  if ((size_t)batch * channels > 0) {
+    if (!grad_input) return OVIS_CPU_EINVAL;
+    std::memset(grad_input, 0, sizeof(float) * (size_t)batch * channels * plane);
+  }
+  if (num_rois == 0 || channels == 0) return OVIS_CPU_OK;
+  if (!grad_out || !rois) return OVIS_CPU_EINVAL;
+  std::vector<RoiGeometry> geo;
+  geo.reserve(num_rois);
+  for (int r = 0; r < num_rois; ++r) {
+    geo.push_back(roi_geometry(rois + (size_t)r * 5, height, width, pooled_h, pooled_w, spatial_scale, sampling_ratio));
+    if (geo.back().image < 0 || geo.back().image >= batch) return OVIS_CPU_EINVAL;
+  }
+  const int nt = thread_count(threads);
+  // a thread owns channel c of every image: no two threads touch the same plane, RoIs are visited in order
+#pragma omp parallel for schedule(static) num_threads(nt)
+  for (int c = 0; c < channels; ++c) {
+    for (int r = 0; r < num_rois; ++r) {
+      const RoiGeometry& g = geo[r];
+      float* dst = grad_input + ((size_t)g.image * channels + c) * plane;
+      const float* src = grad_out + ((size_t)r * channels + c) * bins;
+      for (int ph = 0; ph < pooled_h; ++ph) {
+        for (int pw = 0; pw < pooled_w; ++pw) {
+          const float top = src[(size_t)ph * pooled_w + pw];
+          for (int iy = 0; iy < g.grid_h; ++iy) {
+            const AxisSample& y = g.ys[(size_t)ph * g.grid_h + iy];
+            if (!y.inside) continue;
+            float* row_lo = dst + (size_t)y.lo * width;
+            float* row_hi = dst + (size_t)y.hi * width;
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+              const AxisSample& x = g.xs[(size_t)pw * g.grid_w + ix];
+              if (!x.inside) continue;
+              row_lo[x.lo] += top * (y.rest * x.rest) / g.count;
+              row_lo[x.hi] += top * (y.rest * x.frac) / g.count;
+              row_hi[x.lo] += top * (y.frac * x.rest) / g.count;
+              row_hi[x.hi] += top * (y.frac * x.frac) / g.count;
+            }
+          }
+        }
+      }
+    }
+  }
+  return OVIS_CPU_OK;
+}
+
+extern "C" int ovis_cpu_nms_f32(const float* boxes, const float* scores, int num_boxes, float threshold, int64_t* keep) {
+  if (num_boxes < 0) return OVIS_CPU_EINVAL;
+  if (num_boxes == 0) return 0;
+  if (!boxes || !scores || !keep) return OVIS_CPU_EINVAL;
+  std::vector<int> order(num_boxes);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return scores[a] > scores[b]; });
+  std::vector<float> area(num_boxes);
+  for (int i = 0; i < num_boxes; ++i) {
+    const float* q = boxes + (size_t)i * 4;
+    area[i] = (q[2] - q[0] + 1) * (q[3] - q[1] + 1);
+  }
+  std::vector<char> gone(num_boxes, 0);
+  for (int oi = 0; oi < num_boxes; ++oi) {
+    const int i = order[oi];
+    if (gone[i]) continue;
+    const float* a = boxes + (size_t)i * 4;
+    for (int oj = oi + 1; oj < num_boxes; ++oj) {
+      const int j = order[oj];
+      if (gone[j]) continue;
+      const float* b = boxes + (size_t)j * 4;
+      const float w = std::max(0.f, std::min(a[2], b[2]) - std::max(a[0], b[0]) + 1);
+      const float h = std::max(0.f, std::min(a[3], b[3]) - std::max(a[1], b[1]) + 1);
+      const float inter = w * h;
+      if (inter / (area[i] + area[j] - inter) >= threshold) gone[j] = 1;
+    }
+  }
+  int n = 0;
+  for (int i = 0; i < num_boxes; ++i)
+    if (!gone[i]) keep[n++] = i;
+  return n;
+}
+
+extern "C" const char* ovis_cpu_version(void) { return "ovis_cpu 1 (RoIAlign fwd/bwd, NMS; fp32, OpenMP)"; }

@@ -1,7 +1,8 @@
 """``SigmoidFocalLoss`` -- maskrcnn_benchmark/layers/sigmoid_focal_loss.py:9-74.
 
-The reference switches to a pure-torch formula for CPU tensors (``sigmoid_focal_loss_cpu``,
-:40-50); this package is device-only, so the module always runs the HIP kernels."""
+Like the reference, the module switches on the logits' device: device tensors run the HIP kernels, host tensors the
+pure-torch formula (``sigmoid_focal_loss_cpu``, :40-50 -- the reference has no native host kernel for this op)."""
+import torch
 from torch import nn
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -30,6 +31,17 @@ class _SigmoidFocalLoss(Function):
 sigmoid_focal_loss_cuda = _SigmoidFocalLoss.apply
 
 
+def sigmoid_focal_loss_cpu(logits, targets, gamma, alpha):
+    """Host tensors: -alpha (1 - p)^gamma log p for the target class, -(1 - alpha) p^gamma log(1 - p) for the other classes of
+    a labelled row (targets >= 0; class c of the logits is label c + 1), elementwise [M, C]."""
+    classes = torch.arange(1, logits.shape[1] + 1, dtype=targets.dtype, device=targets.device).unsqueeze(0)
+    t = targets.unsqueeze(1)
+    p = torch.sigmoid(logits)
+    positive = (1 - p) ** gamma * torch.log(p)
+    negative = p ** gamma * torch.log(1 - p)
+    return -(t == classes).float() * positive * alpha - ((t != classes) * (t >= 0)).float() * negative * (1 - alpha)
+
+
 class SigmoidFocalLoss(nn.Module):
     def __init__(self, gamma, alpha):
         super().__init__()
@@ -37,7 +49,8 @@ class SigmoidFocalLoss(nn.Module):
         self.alpha = alpha
 
     def forward(self, logits, targets):
-        return sigmoid_focal_loss_cuda(logits, targets, self.gamma, self.alpha).sum()
+        loss_func = sigmoid_focal_loss_cuda if logits.is_cuda else sigmoid_focal_loss_cpu
+        return loss_func(logits, targets, self.gamma, self.alpha).sum()
 
     def __repr__(self):
         return f"{self.__class__.__name__}(gamma={self.gamma}, alpha={self.alpha})"

@@ -1,5 +1,6 @@
-"""CPU: the C-ABI library loads and exports exactly what include/ovis_hip.h declares, and the
-product package has no CPU fallback and no dependency on oracle/."""
+"""CPU: the C-ABI library loads and exports exactly what include/ovis_hip.h declares, device-only ops refuse host
+tensors (the host-tensor side of the reference's CPU configuration is tests/test_cpu_config.py), and the product
+package has no dependency on oracle/."""
 import ctypes
 import os
 import re
@@ -35,15 +36,20 @@ def test_every_declaration_cites_the_reference():
     assert text.count("mb/csrc/") >= 6
 
 
-def test_ops_refuse_cpu_tensors():
-    from cvpr22_cross_modal_pseudo_labeling_amd import _C, layers
+def test_device_only_ops_refuse_cpu_tensors():
+    """Ops without a host form in the reference raise on host tensors (csrc/ROIAlign.h:44 "Not implemented on the CPU"); the
+    three the reference serves on the host (RoIAlign forward, NMS, the focal loss's torch formula) are served, by in-package
+    host code -- never by the oracle and never by moving the tensors to the device."""
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
 
     with pytest.raises(RuntimeError):
-        _C.roi_align_forward(torch.zeros(1, 1, 4, 4), torch.zeros(1, 5), 1.0, 2, 2, 0)
+        _C.sigmoid_focalloss_forward(torch.zeros(2, 4), torch.zeros(2, dtype=torch.int32), 4, 2.0, 0.25)
     with pytest.raises(RuntimeError):
-        layers.nms(torch.zeros(3, 4), torch.zeros(3), 0.5)
+        _C.roi_align_forward_strided_pair(torch.zeros(1, 32, 4, 4), torch.zeros(1, 5), 1.0, 14, 14, 0, 2)
     with pytest.raises(RuntimeError):
-        layers.SigmoidFocalLoss(2.0, 0.25)(torch.zeros(2, 4), torch.zeros(2, dtype=torch.int32))
+        _C.split_gemm_pair(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(4, 64, dtype=torch.bfloat16), None, None, False, True, False)
+    out = _C.roi_align_forward(torch.ones(1, 1, 4, 4), torch.tensor([[0.0, 0.0, 0.0, 3.0, 3.0]]), 1.0, 2, 2, 0)
+    assert not out.is_cuda and torch.equal(out, torch.ones(1, 1, 2, 2))
 
 
 def test_product_never_imports_oracle():

@@ -243,8 +243,6 @@ def test_tiny_train_step_on_cpu_with_oracle_ops(name):
     model.train()
     opt = solver.make_optimizer(cfg, model)
     red = comm.BucketedGradReducer(model)
-    with pytest.raises(RuntimeError):  # the product ops themselves refuse CPU tensors
-        model(images, targets)
     with oracle_ops():
         before = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
         losses = trainer.train_step(model, opt, red, images, targets)
