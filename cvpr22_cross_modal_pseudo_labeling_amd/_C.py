@@ -1382,3 +1382,19 @@ def modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, colu
                   8)
     if with_bias:
         grad_bias += grad_output.sum(dim=(0, 2, 3))
+
+
+# ---- optimizer (engine/solver.py) ------------------------------------------------------------------------------------
+def sgd_chunk_elements():
+    return int(_L.ovis_sgd_chunk_elements())
+
+
+def sgd_momentum_multi(items, blocks, lr, weight_decay, momentum, apply_weight_decay):
+    """One launch of the fused SGD update over the tensors described by ``items`` (uint8 device table of 32-byte records
+    {p, g, buf, n}) and ``blocks`` (int32 [B, 2] = (item, chunk)); see include/ovis_hip.h."""
+    if not (items.is_cuda and blocks.is_cuda):
+        raise RuntimeError("sgd_momentum_multi: HIP device tensors only")
+    with _on(items.device):
+        rc = _L.ovis_sgd_momentum_multi_f32(items.data_ptr(), blocks.data_ptr(), blocks.size(0), lr, weight_decay, momentum,
+                                            int(bool(apply_weight_decay)), _stream())
+    _lib.check(rc, "sgd_momentum_multi")

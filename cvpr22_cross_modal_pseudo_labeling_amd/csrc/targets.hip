@@ -187,89 +187,205 @@ __device__ __forceinline__ unsigned sample_key(unsigned long long seed, unsigned
 // class of a matched label: 1 positive (label >= 1), 0 negative (label == 0), 2 ignored (< 0)
 __device__ __forceinline__ int sample_class(long lab) { return lab >= 1 ? 1 : (lab == 0 ? 0 : 2); }
 
-// exclusive block scan of one int per thread (kSampThreads threads); returns the prefix, *total = the sum
+// exclusive block scan of one int per thread (kSampThreads threads); returns the prefix, *total = the sum.  Wave scans by
+// shuffles, the 16 wave totals through LDS: two barriers per scan (the 10-step LDS ladder it replaces had twenty).
 __device__ __forceinline__ int block_exscan(int v, int* sh, int* total) {
-  const int tid = threadIdx.x;
-  sh[tid] = v;
-  __syncthreads();
-  for (int off = 1; off < kSampThreads; off <<= 1) {
-    const int t = tid >= off ? sh[tid - off] : 0;
-    __syncthreads();
-    sh[tid] += t;
-    __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
   }
-  const int incl = sh[tid];
-  *total = sh[kSampThreads - 1];
+  if (lane == 63) sh[wave] = incl;
   __syncthreads();
-  return incl - v;
+  int base = 0, sum = 0;
+#pragma unroll
+  for (int w = 0; w < kSampThreads / 64; ++w) {
+    const int t = sh[w];
+    base += w < wave ? t : 0;
+    sum += t;
+  }
+  *total = sum;
+  __syncthreads();
+  return base + incl - v;
 }
 
+// One workgroup samples one image.  Keys are a hash of (seed, index); a class (positives / negatives) that has more members
+// than wanted keeps its k smallest keys (ties by index).  The k-th key is found by a radix select over the digits
+// [31:24] [23:18] [17:9] [8:0]; CACHE: every element's class and the TOP 14 BITS of its key sit in LDS (2 bytes per element,
+// filled once with coalesced label reads), so the 64-bit hash is evaluated once per element instead of in each of the seven
+// passes over the labels -- on the 63 000 anchors of the RPN sampler the one-CU kernel was bound by exactly that arithmetic
+// (157 us per image); only the handful of elements whose cached bits equal the threshold's are hashed again.  The selection
+// is the same set in the same order as the uncached form (P above the LDS budget).
+template <bool CACHE>
 __global__ __launch_bounds__(kSampThreads) void sample_fg_bg_kernel(const long* __restrict__ labels, int P, int batch_size,
                                                                     int max_pos, unsigned long long seed,
                                                                     long* __restrict__ sel_idx, long* __restrict__ pos_slot,
                                                                     int* __restrict__ counts) {
-  __shared__ int sh[kSampThreads];
-  __shared__ unsigned hist[2][256];
+  extern __shared__ unsigned short cache[];  // CACHE: (class << 14) | (key >> 18) per element
+  __shared__ int sh[kSampThreads / 64];
+  __shared__ unsigned hist[2][512];
   __shared__ unsigned prefix[2], want[2];  // per class: key prefix fixed so far, how many keys below it are still wanted
   const int tid = threadIdx.x;
-  const int chunk = (P + kSampThreads - 1) / kSampThreads;
-  const int i0 = min(tid * chunk, P), i1 = min(i0 + chunk, P);  // contiguous slice: the scans below are in index order
+  // contiguous slices (the scans below are in index order); long slices are a multiple of 8 elements = 16 bytes of cache
+  int chunk = (P + kSampThreads - 1) / kSampThreads;
+  const bool vec = CACHE && chunk >= 16;
+  if (vec) chunk = (chunk + 7) & ~7;
+  const int i0 = min(tid * chunk, P), i1 = min(i0 + chunk, P);
+  // f(i, entry) over the thread's slice, entry = (class << 14) | (key >> 18 when cached); long cached slices: eight entries
+  // per LDS read
+  auto for_slice = [&](auto&& f) {
+    if (CACHE && !vec) {
+      for (int i = i0; i < i1; ++i) f(i, (unsigned)cache[i]);
+    } else if (CACHE) {
+      for (int b = i0; b < i1; b += 8) {
+        const uint4 q = *(const uint4*)(cache + b);
+        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = b + u;
+          if (i < i1) f(i, (w[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
+        }
+      }
+    } else {
+      for (int i = i0; i < i1; ++i) f(i, (unsigned)sample_class(labels[i]) << 14);
+    }
+  };
   // class counts
   int c1 = 0, c0 = 0;
-  for (int i = i0; i < i1; ++i) {
-    const int c = sample_class(labels[i]);
-    c1 += c == 1;
-    c0 += c == 0;
+  if (CACHE) {
+    for (int base = 0; base < P; base += 8 * kSampThreads) {  // coalesced, eight loads in flight per thread
+      long v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * kSampThreads + tid;
+        v[u] = i < P ? labels[i] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * kSampThreads + tid;
+        if (i < P) {
+          const int c = sample_class(v[u]);
+          cache[i] = (unsigned short)(c << 14);
+          c1 += c == 1;
+          c0 += c == 0;
+        }
+      }
+    }
+  } else {
+    for_slice([&](int, unsigned e) {
+      c1 += (e >> 14) == 1;
+      c0 += (e >> 14) == 0;
+    });
   }
   int npos, nneg;
   block_exscan(c1, sh, &npos);
   block_exscan(c0, sh, &nneg);
   const int k_pos = min(npos, max_pos);
   const int k_neg = min(nneg, batch_size - k_pos);
-  // radix select (4 passes of 8 bits, most significant first) of the k-th smallest key of each class: afterwards every
-  // key below thr[c] is selected and `want[c]` of the keys equal to it (lowest indices first)
-  const int kk[2] = {k_neg, k_pos}, nn[2] = {nneg, npos};
+  const int kk[2] = {k_neg, k_pos};
+  const bool need[2] = {k_neg < nneg, k_pos < npos};  // the class needs a threshold (else everything of it is taken)
+  if (CACHE) {
+    for (int i = tid; i < P; i += kSampThreads) {  // a thread revisits the entries it wrote itself
+      const int c = cache[i] >> 14;
+      if (c != 2 && need[c]) cache[i] = (unsigned short)((c << 14) | (sample_key(seed, (unsigned)i) >> 18));
+    }
+  }
   if (tid < 2) {
     prefix[tid] = 0;
     want[tid] = (unsigned)kk[tid];
   }
   __syncthreads();
+  // radix select, most significant digit first: afterwards every key below thr[c] is selected and `want[c]` of the keys
+  // equal to it (lowest indices first)
   for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 24 - 8 * pass;
-    for (int b = tid; b < 512; b += kSampThreads) hist[b >> 8][b & 255] = 0;
+    const int shift = pass == 0 ? 24 : (pass == 1 ? 18 : (pass == 2 ? 9 : 0));
+    const int bits = pass == 0 ? 8 : (pass == 1 ? 6 : 9);
+    const unsigned dmask = (1u << bits) - 1u;
+    for (int b = tid; b < 1024; b += kSampThreads) hist[b >> 9][b & 511] = 0;
     __syncthreads();
     const unsigned pf0 = prefix[0], pf1 = prefix[1];
-    for (int i = i0; i < i1; ++i) {
-      const int c = sample_class(labels[i]);
-      if (c == 2 || kk[c] >= nn[c]) continue;  // everything of the class is taken: no threshold needed
-      const unsigned key = sample_key(seed, (unsigned)i);
+    for_slice([&](int i, unsigned e) {
+      const int c = (int)(e >> 14);
+      if (c == 2 || !need[c]) return;
       const unsigned pf = c ? pf1 : pf0;
-      if (pass == 0 || (key >> (shift + 8)) == (pf >> (shift + 8))) atomicAdd(&hist[c][(key >> shift) & 255], 1u);
-    }
-    __syncthreads();
-    if (tid < 2 && kk[tid] < nn[tid]) {
-      unsigned acc = 0, w = want[tid];
-      int d = 0;
-      for (; d < 256; ++d) {  // first digit whose bucket crosses the number of keys still wanted
-        const unsigned h = hist[tid][d];
-        if (acc + h > w) break;
-        acc += h;
+      unsigned key;
+      if (CACHE) {
+        const unsigned top = e & 0x3fffu;                            // key >> 18
+        if (pass == 1 && (top >> 6) != (pf >> 24)) return;
+        if (pass >= 2 && top != (pf >> 18)) return;
+        key = pass < 2 ? top << 18 : sample_key(seed, (unsigned)i);
+      } else {
+        key = sample_key(seed, (unsigned)i);
       }
-      d = min(d, 255);
-      prefix[tid] |= (unsigned)d << shift;
-      want[tid] = w - acc;
+      if (pass == 0 || (key >> (shift + bits)) == (pf >> (shift + bits))) atomicAdd(&hist[c][(key >> shift) & dmask], 1u);
+    });
+    __syncthreads();
+    // first digit whose bucket crosses the number of keys still wanted: wave c searches class c's histogram -- eight bins
+    // per lane, a wave scan of the lane sums, the crossing lane walks its own bins (one thread walking 512 LDS words cost
+    // ~25 us per pass)
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave < 2 && need[wave]) {  // wave-uniform
+      const int nb = (int)dmask + 1, per = (nb + 63) >> 6;
+      unsigned loc[8], sum = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int b = lane * per + j;
+        loc[j] = (j < per && b < nb) ? hist[wave][b] : 0u;
+        sum += loc[j];
+      }
+      unsigned incl = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+      }
+      const unsigned w = want[wave];
+      const unsigned long long crossing = __ballot(incl > w);
+      const int first = crossing ? __ffsll((long long)crossing) - 1 : 63;
+      if (lane == first) {
+        unsigned acc = incl - sum;
+        int d = lane * per;
+        if (crossing) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (j < per && acc + loc[j] <= w) {
+              acc += loc[j];
+              d = lane * per + j + 1;
+            } else {
+              break;
+            }
+          }
+        } else {  // never for a class that needs a threshold; kept as the scalar walk's end state
+          acc = incl;
+          d = nb;
+        }
+        d = min(d, (int)dmask);
+        prefix[wave] |= (unsigned)d << shift;
+        want[wave] = w - acc;
+      }
     }
     __syncthreads();
   }
   const unsigned thr[2] = {prefix[0], prefix[1]};
   const unsigned ties_wanted[2] = {want[0], want[1]};
+  // -1 below the threshold, 0 equal, +1 above (the cached bits decide all but the few elements that share the threshold's)
+  auto versus_threshold = [&](int i, unsigned e, int c) -> int {
+    if (CACHE) {
+      const unsigned top = e & 0x3fffu, ttop = thr[c] >> 18;
+      if (top != ttop) return top < ttop ? -1 : 1;
+    }
+    const unsigned key = sample_key(seed, (unsigned)i);
+    return key < thr[c] ? -1 : (key == thr[c] ? 0 : 1);
+  };
   // ties (key == thr[c]) are granted in index order: exclusive count of the thread's preceding ties, per class
   int t0 = 0, t1 = 0;
-  for (int i = i0; i < i1; ++i) {
-    const int c = sample_class(labels[i]);
-    if (c == 2 || kk[c] >= nn[c]) continue;
-    if (sample_key(seed, (unsigned)i) == thr[c]) (c ? t1 : t0) += 1;
-  }
+  for_slice([&](int i, unsigned e) {
+    const int c = (int)(e >> 14);
+    if (c == 2 || !need[c]) return;
+    if (versus_threshold(i, e, c) == 0) (c ? t1 : t0) += 1;
+  });
   int tot;
   int tie_before[2];
   tie_before[0] = block_exscan(t0, sh, &tot);
@@ -277,37 +393,31 @@ __global__ __launch_bounds__(kSampThreads) void sample_fg_bg_kernel(const long* 
   // selection flags -> ascending compaction (and the positives' slots inside the compacted list)
   int n_sel = 0, n_ps = 0;
   int seen[2] = {tie_before[0], tie_before[1]};
-  for (int i = i0; i < i1; ++i) {
-    const int c = sample_class(labels[i]);
-    if (c == 2) continue;
-    bool take;
-    if (kk[c] >= nn[c]) take = true;
-    else {
-      const unsigned key = sample_key(seed, (unsigned)i);
-      take = key < thr[c] || (key == thr[c] && (unsigned)(seen[c]++) < ties_wanted[c]);
-    }
+  auto taken = [&](int i, unsigned e, int c) -> bool {
+    if (!need[c]) return true;
+    const int v = versus_threshold(i, e, c);
+    return v < 0 || (v == 0 && (unsigned)(seen[c]++) < ties_wanted[c]);
+  };
+  for_slice([&](int i, unsigned e) {
+    const int c = (int)(e >> 14);
+    if (c == 2) return;
+    const bool take = taken(i, e, c);
     n_sel += take;
     n_ps += take && c == 1;
-  }
+  });
   int total_sel, total_pos;
   int at = block_exscan(n_sel, sh, &total_sel);
   int pat = block_exscan(n_ps, sh, &total_pos);
   seen[0] = tie_before[0];
   seen[1] = tie_before[1];
-  for (int i = i0; i < i1; ++i) {
-    const int c = sample_class(labels[i]);
-    if (c == 2) continue;
-    bool take;
-    if (kk[c] >= nn[c]) take = true;
-    else {
-      const unsigned key = sample_key(seed, (unsigned)i);
-      take = key < thr[c] || (key == thr[c] && (unsigned)(seen[c]++) < ties_wanted[c]);
-    }
-    if (take) {
+  for_slice([&](int i, unsigned e) {
+    const int c = (int)(e >> 14);
+    if (c == 2) return;
+    if (taken(i, e, c)) {
       if (c == 1) pos_slot[pat++] = at;
       sel_idx[at++] = i;
     }
-  }
+  });
   for (int j = total_sel + tid; j < batch_size; j += kSampThreads) sel_idx[j] = 0;
   for (int j = total_pos + tid; j < batch_size; j += kSampThreads) pos_slot[j] = 0;
   if (tid == 0) {
@@ -399,8 +509,20 @@ extern "C" int ovis_sample_fg_bg(const int64_t* labels, int num, int batch_size,
                                  int64_t* selected, int64_t* positive_slots, int32_t* counts, void* stream) {
   if (num < 0 || batch_size <= 0 || max_positives < 0 || max_positives > batch_size) return OVIS_EINVAL;
   if (!selected || !positive_slots || !counts || (num > 0 && !labels)) return OVIS_EINVAL;
-  hipLaunchKernelGGL(sample_fg_bg_kernel, dim3(1), dim3(kSampThreads), 0, (hipStream_t)stream, (const long*)labels, num,
-                     batch_size, max_positives, (unsigned long long)seed, (long*)selected, (long*)positive_slots, counts);
+  constexpr int kCacheBytes = 150 * 1024;  // 2 bytes per element next to the kernel's ~4 KB of static LDS
+  if (2L * num + 16 <= kCacheBytes) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      OVIS_HIP_TRY(hipFuncSetAttribute((const void*)sample_fg_bg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCacheBytes));
+      attr_set = true;
+    }
+    const int lds = ((2 * num + 16 + 255) / 256) * 256;  // a slice reads whole 16-byte groups
+    hipLaunchKernelGGL(sample_fg_bg_kernel<true>, dim3(1), dim3(kSampThreads), lds, (hipStream_t)stream, (const long*)labels, num,
+                       batch_size, max_positives, (unsigned long long)seed, (long*)selected, (long*)positive_slots, counts);
+  } else {
+    hipLaunchKernelGGL(sample_fg_bg_kernel<false>, dim3(1), dim3(kSampThreads), 0, (hipStream_t)stream, (const long*)labels, num,
+                       batch_size, max_positives, (unsigned long long)seed, (long*)selected, (long*)positive_slots, counts);
+  }
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
 }

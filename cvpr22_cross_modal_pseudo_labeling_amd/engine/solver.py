@@ -27,10 +27,16 @@ def make_optimizer(cfg, model):
 
 class GroupFusedSGD(torch.optim.SGD):
     """``torch.optim.SGD`` with the reference's one-group-per-parameter layout (same ``param_groups`` / ``state``, so
-    optimizer checkpoints interchange) whose ``step`` runs the update of ALL groups as six multi-tensor ops with
-    per-tensor scalars, instead of four launches per parameter:  d = g + wd_i p;  buf = momentum_i buf + d (buf = d on
-    the first step);  p -= lr_i buf.  Falls back to the stock step for closures, dampening, nesterov, maximize or sparse
+    optimizer checkpoints interchange) whose ``step`` updates ALL groups together:  d = g + wd_i p;  buf = momentum_i buf + d
+    (buf = d on the first step);  p -= lr_i buf.
+    Device fp32 parameters: ONE native launch per distinct (lr, wd, momentum) -- weights / biases / ``uncertain_pred``: two
+    or three per step -- of ``csrc/optim.hip`` (p, g, buf read, buf, p written once; the table of tensor pointers is built
+    once and rebuilt only when a pointer changes; gradients are stable views of the reducer's flat buckets).  Otherwise
+    (host tensors, other dtypes) six multi-tensor ops with per-tensor scalars -- the same operation sequence, so the two
+    paths give the same bits.  Falls back to the stock step for closures, dampening, nesterov, maximize or sparse
     gradients."""
+
+    native = True  # False: always the multi-tensor form (tests compare the two)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -51,6 +57,9 @@ class GroupFusedSGD(torch.optim.SGD):
                 moms.append(float(g["momentum"]))
         if not params:
             return None
+        if self.native and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and q.is_contiguous() and q.dtype == torch.float32
+               for p, q in zip(params, grads)):
+            return self._step_native(params, grads, wds, lrs, moms)
         d = torch._foreach_add(grads, torch._foreach_mul(params, wds)) if any(wds) else grads
         if any(moms):
             fresh = {i for i, p in enumerate(params) if self.state[p].get("momentum_buffer") is None}
@@ -66,6 +75,54 @@ class GroupFusedSGD(torch.optim.SGD):
             upd = d
         torch._foreach_add_(params, torch._foreach_mul(upd, [-lr for lr in lrs]))
         return None
+
+    def _step_native(self, params, grads, wds, lrs, moms):
+        import numpy as np
+
+        from .. import _C
+
+        bufs = []
+        for p, m in zip(params, moms):
+            if m == 0:
+                bufs.append(None)
+                continue
+            st = self.state[p]
+            if st.get("momentum_buffer") is None:
+                st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)  # 0 * m + d = d: the first step
+            bufs.append(st["momentum_buffer"])
+        key = tuple((p.data_ptr(), q.data_ptr(), 0 if b is None else b.data_ptr(), lr, wd, m)
+                    for p, q, b, lr, wd, m in zip(params, grads, bufs, lrs, wds, moms))
+        cache = self.__dict__.setdefault("_native_tables", {})
+        sig = tuple(k[:3] for k in key)
+        part = tuple((lr, wd, m) for _, _, _, lr, wd, m in key)
+        hit = cache.get("tables")
+        if hit is None or hit[0] != sig or hit[1] != self._partition_of(part):
+            chunk = _C.sgd_chunk_elements()
+            by = {}
+            for i, t in enumerate(part):
+                by.setdefault(t, []).append(i)
+            tables = []
+            dev = params[0].device
+            for t, idx in by.items():
+                items = np.zeros((len(idx), 4), dtype=np.int64)
+                blocks = []
+                for j, i in enumerate(idx):
+                    items[j] = (key[i][0], key[i][1], key[i][2], params[i].numel())
+                    blocks.extend((j, c) for c in range((params[i].numel() + chunk - 1) // chunk))
+                tables.append((idx[0], torch.from_numpy(items.view(np.uint8).reshape(-1)).to(dev),
+                               torch.tensor(blocks, dtype=torch.int32, device=dev).reshape(-1, 2)))
+            hit = (sig, self._partition_of(part), tables)
+            cache["tables"] = hit
+        use_wd = any(wds)
+        for first, items, blocks in hit[2]:
+            _C.sgd_momentum_multi(items, blocks, lrs[first], wds[first], moms[first], use_wd)
+        return None
+
+    @staticmethod
+    def _partition_of(part):
+        """Which tensors share their scalars (the VALUES change with the schedule, the partition does not)."""
+        seen = {}
+        return tuple(seen.setdefault(t, len(seen)) for t in part)
 
 
 class WarmupMultiStepLR(torch.optim.lr_scheduler._LRScheduler):

@@ -624,6 +624,15 @@ int ovis_split_gemm_pair_rp_pool(const void* a_pair, long a_row_bytes, const voi
                                  const void* residual_pair, long residual_pair_row_bytes, long m, int n, int channels,
                                  int relu, float* pooled, int pool_rows, float pool_scale, void* stream);
 
+/* SGD with momentum / weight decay over many tensors in one launch (mb/solver/build.py:8-37 + torch.optim.SGD's update;
+ * engine/solver.py): items = device array of {float* p; const float* g; float* buf; long n} (32 bytes each), blocks = device
+ * array of int2 (item, chunk): block b updates elements [chunk * ovis_sgd_chunk_elements(), ...) of its item with
+ *   d = g + wd * p (when apply_weight_decay);  buf = momentum * buf + d (when momentum != 0);  p += (-lr) * (buf or d)
+ * in exactly that fp32 operation order (bit-identical to the six multi-tensor passes it replaces). */
+int ovis_sgd_momentum_multi_f32(const void* items, const void* blocks, int num_blocks, float lr, float weight_decay,
+                                float momentum, int apply_weight_decay, void* stream);
+int ovis_sgd_chunk_elements(void);
+
 #ifdef __cplusplus
 }
 #endif

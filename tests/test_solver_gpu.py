@@ -1,0 +1,72 @@
+"""GPU: the fused SGD launch (csrc/optim.hip) against the multi-tensor form of engine/solver.py::GroupFusedSGD -- the same
+operation sequence, so the parameters and momentum buffers must agree bit for bit over several steps with a moving learning
+rate, gradients that are unaligned views of flat buffers, parameters without gradient and a late-joining parameter."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(native, seed=0):
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine.solver import GroupFusedSGD
+
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(64, 32, 3, 3), (81,), (4097,), (2048, 512), (1,), (7, 5), (256,), (33, 1000)]
+    params = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in shapes]
+    groups = []
+    for i, p in enumerate(params):
+        bias = p.dim() == 1
+        groups.append({"params": [p], "lr": 0.02 * (2 if bias else 1) * (10 if i == 4 else 1), "weight_decay": 0.0 if bias else 1e-4})
+    opt = GroupFusedSGD(groups, 0.02, momentum=0.9)
+    opt.native = native
+    flat = torch.zeros(sum(p.numel() for p in params) + 3, device="cuda")
+    off = 3  # every gradient view starts at an odd element offset somewhere
+    for p in params:
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    return params, opt, flat
+
+
+def test_fused_sgd_equals_multi_tensor_form_bit_for_bit():
+    pa, oa, fa = _make(True)
+    pb, ob, fb = _make(False)
+    g = torch.Generator().manual_seed(5)
+    for step in range(5):
+        vals = torch.randn(fa.numel(), generator=g).cuda()
+        fa.copy_(vals)
+        fb.copy_(vals)
+        for opt in (oa, ob):
+            for grp in opt.param_groups:
+                grp["lr"] *= 0.5 if step == 2 else 1.1   # the schedule moves every group's rate
+        if step == 3:  # a parameter that gets no gradient this step keeps its value and its buffer
+            keep = pa[5].detach().clone()
+            ga, gb = pa[5].grad, pb[5].grad
+            pa[5].grad = None
+            pb[5].grad = None
+        oa.step()
+        ob.step()
+        if step == 3:
+            assert torch.equal(pa[5].detach(), keep)
+            pa[5].grad, pb[5].grad = ga, gb
+        for x, y in zip(pa, pb):
+            assert torch.equal(x.detach(), y.detach()), (step, tuple(x.shape))
+            bx, by = oa.state[x].get("momentum_buffer"), ob.state[y].get("momentum_buffer")
+            assert (bx is None) == (by is None) and (bx is None or torch.equal(bx, by)), (step, tuple(x.shape))
+
+
+def test_fused_sgd_without_momentum_and_without_decay():
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine.solver import GroupFusedSGD
+
+    res = []
+    for native in (True, False):
+        torch.manual_seed(1)
+        p = [torch.nn.Parameter(torch.randn(5000, device="cuda")), torch.nn.Parameter(torch.randn(17, 3, device="cuda"))]
+        opt = GroupFusedSGD([{"params": [q], "lr": 0.1, "weight_decay": 0.0} for q in p], 0.1, momentum=0.0)
+        opt.native = native
+        for s in range(3):
+            for q in p:
+                q.grad = torch.full_like(q, 0.25 * (s + 1))
+            opt.step()
+        res.append([q.detach().clone() for q in p])
+        assert all("momentum_buffer" not in opt.state[q] or opt.state[q]["momentum_buffer"] is None for q in p)
+    assert all(torch.equal(a, b) for a, b in zip(*res))

@@ -168,3 +168,48 @@ def test_project_pasted_masks_equals_paste_then_project(G, P, size):
     assert got.shape == want.shape == (P, 14, 14)
     assert torch.equal(got, want), int((got != want).sum())
     assert 0.05 < float(got.mean()) < 0.95
+
+
+def _sampler_model(lab, batch, max_pos, seed):
+    """NumPy statement of the sampler: per class the k smallest splitmix64 keys of (seed, index), ties by index."""
+    import numpy as np
+    lab = lab.numpy()
+    with np.errstate(over="ignore"):
+        i = np.arange(lab.shape[0], dtype=np.uint64)
+        z = np.uint64(seed) + (i + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        key = ((z ^ (z >> np.uint64(31))) >> np.uint64(32)).astype(np.int64)
+    pos, neg = np.nonzero(lab >= 1)[0], np.nonzero(lab == 0)[0]
+    k_pos = min(len(pos), max_pos)
+    k_neg = min(len(neg), batch - k_pos)
+    take = lambda idx, k: idx[np.lexsort((idx, key[idx]))[:k]]
+    sel = np.sort(np.concatenate([take(pos, k_pos), take(neg, k_neg)]))
+    return torch.from_numpy(sel), torch.from_numpy(np.nonzero(lab[sel] >= 1)[0])
+
+
+@pytest.mark.parametrize("p,n_pos,n_ign,batch,frac,seed", [(63000, 40, 300, 256, 0.5, 5), (63000, 700, 30000, 256, 0.5, 77),
+                                                           (2007, 900, 0, 512, 0.25, 3), (90000, 5000, 100, 512, 0.25, 9),
+                                                           (76792, 10, 0, 256, 0.5, 1), (76793, 10, 0, 256, 0.5, 1), (70, 30, 5, 16, 0.5, 2)])
+def test_sample_fg_bg_is_the_k_smallest_keys_per_class(p, n_pos, n_ign, batch, frac, seed):
+    """Exact selection against the NumPy model, in the LDS-cached form (P <= 76 792: class + top 14 key bits per element in
+    LDS) and in the uncached one (larger P) -- the two are the same function."""
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+    g = torch.Generator().manual_seed(p + seed)
+    lab = _labels(p, n_pos, n_ign, g)
+    sel, slots, counts = _C.sample_fg_bg(lab.cuda(), batch, int(batch * frac), seed)
+    n, npos = counts.tolist()
+    want_sel, want_slots = _sampler_model(lab, batch, int(batch * frac), seed)
+    assert n == want_sel.numel() and npos == want_slots.numel()
+    assert torch.equal(sel[:n].cpu(), want_sel) and torch.equal(slots[:npos].cpu(), want_slots)
+
+
+def test_sample_fg_bg_ties_follow_the_index():
+    """All-equal keys cannot be forced through the hash, but duplicated THRESHOLD digits can: with 60 000 negatives and 256
+    wanted, several elements share the threshold's top 14 bits (the cached part) and are told apart by the full key."""
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+    lab = torch.zeros(60000, dtype=torch.int64)
+    for seed in range(20):
+        sel, _, counts = _C.sample_fg_bg(lab.cuda(), 256, 0, seed)
+        want, _ = _sampler_model(lab, 256, 0, seed)
+        assert counts.tolist() == [256, 0] and torch.equal(sel.cpu(), want)
