@@ -111,13 +111,18 @@ class RPNHead(nn.Module):  # rpn.py:74-106
         c = self.conv
         if (feature.is_cuda and c.in_channels % 128 == 0 and c.out_channels % 128 == 0 and c.kernel_size == (3, 3)
                 and c.padding == (1, 1) and c.stride == (1, 1) and self.split_gemm):
-            # trainable head (teacher configuration): the 3x3 through the split-GEMM autograd node, the two small
-            # predictors stay convolutions on the NCHW view of its NHWC result
+            # trainable head (teacher configuration): the 3x3 through the split-GEMM autograd node, the two small 1x1
+            # predictors as linear maps of its NHWC rows (layers/cross_modal.py::linear_mfma: the 60-channel box
+            # predictor on the split GEMM, the 15-channel objectness on the exact-fp32 MFMA GEMM) -- no library
+            # convolution in the step; NCHW views of the results
+            from ..layers.cross_modal import linear_mfma
             from ..layers.pair_bottleneck import conv_same_pair
             n, ch, h, w = feature.shape
             t = conv_same_pair(feature.permute(0, 2, 3, 1).reshape(-1, ch), (h, w), c.weight, c.bias, True)
-            t = t.view(n, h, w, -1).permute(0, 3, 1, 2)
-            return self.cls_logits(t), self.bbox_pred(t)
+            a = self.cls_logits.out_channels
+            cls = linear_mfma(t, self.cls_logits.weight.view(a, -1), self.cls_logits.bias)
+            box = linear_mfma(t, self.bbox_pred.weight.view(4 * a, -1), self.bbox_pred.bias)
+            return cls.view(n, h, w, a).permute(0, 3, 1, 2), box.view(n, h, w, 4 * a).permute(0, 3, 1, 2)
         t = F.relu(self.conv(feature))
         return self.cls_logits(t), self.bbox_pred(t)
 
