@@ -43,7 +43,7 @@ def _on(device):
 
 def _dev(t, name, dtype=torch.float32):
     if not t.is_cuda:
-        raise RuntimeError(f"{name} must be a HIP device tensor: this package has no CPU implementation")
+        raise RuntimeError(f"{name} must be a HIP device tensor: this op has no host implementation (as in the reference)")
     if t.dtype != dtype:
         raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
     t = t.contiguous()

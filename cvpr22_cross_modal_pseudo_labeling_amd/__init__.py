@@ -8,8 +8,10 @@ Drop-in for the reference's native-op surface:
 * ``cvpr22_cross_modal_pseudo_labeling_amd.layers``  <->  ``maskrcnn_benchmark.layers``
   (maskrcnn_benchmark/layers/__init__.py:23-46).
 
-There is no CPU implementation in this package: ops raise ``RuntimeError`` for CPU tensors and
-``ImportError`` when the HIP library has not been built (``python -c "import __graft_entry__ as g;
-g.build()"`` or ``make -C cvpr22_cross_modal_pseudo_labeling_amd/csrc``).
+Device tensors are only ever served by the HIP library (``ImportError`` when it has not been built: ``python -c "import
+__graft_entry__ as g; g.build()"`` or ``make -C cvpr22_cross_modal_pseudo_labeling_amd/csrc``) -- there is no fallback.  Like the
+reference's module, the entry points of its CPU-only configuration (``MODEL.DEVICE cpu``) dispatch on the tensor's device: host
+tensors go to in-package host code (``_cpu.py``, ``libovis_cpu.so``: RoIAlign, NMS, the heads' torch formulas); every other op
+raises ``RuntimeError`` on host tensors, as the reference raises "Not implemented on the CPU".
 """
 __version__ = "0.1.0"
