@@ -17,6 +17,8 @@ step bash -c 'python tools/experiments/op_count.py > "$0"/op_count.txt 2>&1' "$O
 step bash -c 'bash tools/prof_step.sh student "$0"/prof_student > "$0"/prof_student.txt 2>&1' "$OUT"
 step bash -c 'bash tools/prof_step.sh teacher "$0"/prof_teacher > "$0"/prof_teacher.txt 2>&1' "$OUT"
 step bash -c 'bash tools/gap_step.sh student "$0"/gap_student > "$0"/gap_student.txt 2>&1' "$OUT"
+step bash -c 'bash tools/fill_step.sh student "$0"/fill_student > "$0"/fill_student.txt 2>&1' "$OUT"
+step bash -c 'bash tools/fill_step.sh teacher "$0"/fill_teacher > "$0"/fill_teacher.txt 2>&1' "$OUT"
 step bash -c 'bash tools/prof_op.sh roi_bwd "$0"/prof_roi_bwd > "$0"/prof_roi_bwd.txt 2>&1' "$OUT"
 step bash -c 'bash tools/pmc_step.sh "$0"/pmc_teacher teacher > "$0"/pmc_teacher.log 2>&1' "$OUT"
 step bash -c 'bash tools/pmc_step.sh "$0"/pmc_student student > "$0"/pmc_student.log 2>&1' "$OUT"
