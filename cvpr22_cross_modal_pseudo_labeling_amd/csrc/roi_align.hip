@@ -979,8 +979,14 @@ extern "C" int ovis_roi_align_forward_strided_from_nhwc_f32(const float* input_n
     return OVIS_ERANGE;
   const int oh = (pooled_h + bin_stride - 1) / bin_stride, ow = (pooled_w + bin_stride - 1) / bin_stride;
   const long tiles = (long)(channels / kCPB) * num_rois;
+  // The LDS form is launched with 40 KB of UNUSED dynamic LDS on top of its 17 KB window tile: two of its workgroups per CU
+  // instead of nine.  Alone the kernel is latency-bound and likes the nine; in the two-stream training step its workgroups
+  // take over the slots of the other stream's GEMM workgroups as those retire and then mostly wait on memory -- same-box
+  // A/B of the pipelined student step: 34.0 ms unpadded (4 and 3 per CU: the same), 33.3 ms at two per CU, 34.0 ms at one,
+  // 33.4 ms with the LDS-free direct form; the single-stream teacher step does not notice (24.2-24.5 ms all forms).
+  constexpr int kCoResidencyPadBytes = 40 * 1024;
   if (channels % kCPB == 0 && tiles <= 0x7fffffffL)
-    hipLaunchKernelGGL(roi_align_fwd_nhwc_in_strided_lds_kernel, dim3((unsigned)tiles), dim3(kThreads), 0,
+    hipLaunchKernelGGL(roi_align_fwd_nhwc_in_strided_lds_kernel, dim3((unsigned)tiles), dim3(kThreads), kCoResidencyPadBytes,
                        (hipStream_t)stream, input_nhwc, rois, (float*)output, num_rois, batch, channels, height, width,
                        pooled_h, pooled_w, bin_stride, oh, ow, spatial_scale, sampling_ratio, pair_out);
   else
