@@ -2,7 +2,7 @@
     python tools/experiments/ab_bench.py <patch> [bench args...]
 runs bench.py alternately unpatched (A) and with the named monkeypatch applied (B), three times each, and prints ms per step.
 Patches: nopool (the res5 head's average pooling as a separate pass), rpnloss_ops (the RPN loss as its tensor-op sequence;
-use with --workload teacher), side_prio0 (the frozen half's stream at normal priority), foreach_sgd (the optimizer step as six multi-tensor passes instead of the fused launch)."""
+use with --workload teacher), lib:<variant> (a variant library of build_variants.sh), side_prio0 (the frozen half's stream at normal priority), foreach_sgd (the optimizer step as six multi-tensor passes instead of the fused launch)."""
 import json
 import os
 import subprocess
@@ -19,8 +19,15 @@ PATCHES = {
 }
 
 
+def _patch_code(patch):
+    if patch.startswith("lib:"):  # a variant library of tools/experiments/build_variants.sh
+        path = os.path.join(ROOT, "tools", "experiments", "variants", f"libovis_hip_{patch[4:]}.so")
+        return f"from cvpr22_cross_modal_pseudo_labeling_amd import _lib; _lib.LIB_PATH = {path!r}"
+    return PATCHES[patch]
+
+
 def run(patch, args):
-    code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.argv = ['bench.py'] + {args!r}\n{PATCHES[patch]}\n"
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.argv = ['bench.py'] + {args!r}\n{_patch_code(patch)}\n"
             "import bench\nbench.main()\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
