@@ -31,7 +31,10 @@ def test_fused_sgd_equals_multi_tensor_form_bit_for_bit():
     pa, oa, fa = _make(True)
     pb, ob, fb = _make(False)
     g = torch.Generator().manual_seed(5)
-    for step in range(5):
+    taken = []
+    cached = oa._step_cached
+    oa._step_cached = lambda groups: (taken.append(cached(groups)), taken[-1])[1]
+    for step in range(7):
         vals = torch.randn(fa.numel(), generator=g).cuda()
         fa.copy_(vals)
         fb.copy_(vals)
@@ -52,6 +55,8 @@ def test_fused_sgd_equals_multi_tensor_form_bit_for_bit():
             assert torch.equal(x.detach(), y.detach()), (step, tuple(x.shape))
             bx, by = oa.state[x].get("momentum_buffer"), ob.state[y].get("momentum_buffer")
             assert (bx is None) == (by is None) and (bx is None or torch.equal(bx, by)), (step, tuple(x.shape))
+    # steady-state steps take the cached path; the first step, the step without a gradient and the one after it do not
+    assert taken == [False, True, True, False, False, True, True], taken
 
 
 def test_fused_sgd_without_momentum_and_without_decay():
