@@ -300,12 +300,30 @@ PMC_KERNEL = {"split_gemm_pair": "split_gemm_kernel", "split_gemm_pair_gated": "
               "roi_align_backward_strided": "roi_bwd_mfma_kernel", "roi_align_backward": "roi_bwd_mfma_kernel"}
 
 
+def _latest_profile(stem):
+    """The newest round's committed summary ``profiles/r<N>_<stem>.json`` ('' when there is none)."""
+    import glob
+    import re
+    found = []
+    for q in glob.glob(os.path.join(ROOT, "profiles", f"r*_{stem}.json")):
+        m = re.match(r"r(\d+)_", os.path.basename(q))
+        if m:
+            found.append((int(m.group(1)), q))
+    return max(found)[1] if found else ""
+
+
+def _stale(d, fam):
+    """Why the committed summary ``d`` no longer describes kernel family ``fam`` of THIS tree (None: it does)."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.utils import provenance
+    return provenance.stale_reason(d, fam)
+
+
 def pmc_traffic(workload, op):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes over this same step (FETCH_SIZE and
     WRITE_SIZE in separate passes, gfx950 correction applied: tools/pmc_step.sh); counters cannot be collected from
-    inside the process, so the committed summary of the last pass is reported -- or null when there is none."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_pmc_step_hbm_traffic_{workload}.json") for r in (3, 2, 1))
-                 if os.path.exists(q)), "")
+    inside the process, so the committed summary of the last pass is reported -- or null when there is none, or when the
+    kernel's source has changed since that pass (the summary stamps the digests of csrc/: utils/provenance.py)."""
+    path = _latest_profile(f"pmc_step_hbm_traffic_{workload}")
     fam = PMC_KERNEL.get(op)
     try:
         with open(path) as f:
@@ -313,6 +331,9 @@ def pmc_traffic(workload, op):
         k = d["kernels"][fam]
     except (OSError, KeyError, ValueError):
         return None, "no PMC summary for this kernel under profiles/"
+    why = _stale(d, fam)
+    if why:
+        return None, f"profiles/{os.path.basename(path)} is STALE for {fam}: {why}; re-collect with tools/pmc_step.sh"
     return (k["hbm_MB_per_launch"] * 1e6,
             f"bytes per launch of {fam} (all {k['launches']} launches, gated ones included): read {k['read_MB_per_launch']} MB "
             f"+ write {k['write_MB_per_launch']} MB, from profiles/{os.path.basename(path)} ({d['correction']})")
@@ -322,7 +343,7 @@ def pmc_mfma_busy(workload, op):
     """Matrix-pipe busy fraction of the dominant kernel family from hardware counters (SQ_VALU_MFMA_BUSY_CYCLES against
     the dispatch's active clocks x 1024 SIMDs = rocprofv3's MfmaUtil): the committed summary of the tools/pmc_mfma.sh pass
     over this same step (counters cannot be read from inside the process), or null."""
-    path = os.path.join(ROOT, "profiles", f"r3_pmc_mfma_busy_{workload}.json")
+    path = _latest_profile(f"pmc_mfma_busy_{workload}")
     fam = PMC_KERNEL.get(op)
     try:
         with open(path) as f:
@@ -330,6 +351,9 @@ def pmc_mfma_busy(workload, op):
         frac = d["families"][fam]["mfma_busy_frac"]
     except (OSError, KeyError, ValueError):
         return None, "no MFMA-busy PMC summary for this kernel under profiles/"
+    why = _stale(d, fam)
+    if why:
+        return None, f"profiles/{os.path.basename(path)} is STALE for {fam}: {why}; re-collect with tools/pmc_mfma.sh"
     per = {k: v["mfma_busy_frac"] for k, v in d["kernels"].items() if k.startswith(fam + "<") and "mfma_busy_frac" in v}
     return frac, (f"SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x active clocks) over all launches of {fam} in the step, from "
                   f"profiles/{os.path.basename(path)}; per template instance: {per}")
@@ -458,9 +482,16 @@ def cpu_baseline(workload):
             "host_cpus": os.cpu_count(), "host_seconds": round(host_s, 1)}
 
 
-def main():
+TINY_OVERRIDES = ["MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 300, "MODEL.RPN.PRE_NMS_TOP_N_TEST", 200, "MODEL.RPN.POST_NMS_TOP_N_TRAIN", 60,
+                  "MODEL.RPN.POST_NMS_TOP_N_TEST", 40, "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 16]
+TINY_BATCH = dict(height=128, width=160, num_gt=3, num_nouns=2, n_vocab=50)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks of the job (default: WORLD_SIZE under a launcher, else 1); N > 1 without a launcher environment "
+                         "makes this process the launcher of its N ranks")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="student", choices=["student", "teacher"])
@@ -470,78 +501,121 @@ def main():
     ap.add_argument("--burn-seconds", type=float, default=3.0, help="GPU clock warm-up before the warm-up steps")
     ap.add_argument("--no-pipeline", action="store_true", help="plain sequential step (no side-stream overlap)")
     ap.add_argument("--per-shape-csv", default="", help="write one row per distinct split-GEMM shape of the step")
-    args = ap.parse_args()
+    ap.add_argument("--secondary-steps", type=int, default=10,
+                    help="after the student region: this many timed steps of the teacher configuration (zeroshot_mask.yaml, "
+                         "BASELINE config 2) reported under `secondary`; 0 = skip")
+    # DRY RUN of the multi-rank control flow without GPUs: the same rank code (rendezvous, parameter broadcast, barriers,
+    # step-count calibration, MAX-reduce of the elapsed time, replay on every rank with live all-reduces, per-rank gather)
+    # on the product's own host path (MODEL.DEVICE cpu, BASELINE configs[0]) over gloo.  Never a measurement.
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = DRY RUN on the in-package host path")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL on cuda, gloo on cpu)")
+    ap.add_argument("--tiny", action="store_true", help="DRY RUN size: 128x160 images, a few dozen RoIs")
+    ap.add_argument("--fault-inject", default="", help=argparse.SUPPRESS)  # "RANK:STEP": that rank dies inside the timed region (tests)
+    args = ap.parse_args(argv)
+    return args
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher environment says WORLD_SIZE={world}")
-    if torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):  # counting does not initialise the GPU
-        raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", init_method="env://", device_id=dev)
 
-    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+def build_workload(args, workload, dev, world, rank):
     from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
     from cvpr22_cross_modal_pseudo_labeling_amd.data.synthetic import calibrate_stem_bn, make_batch, make_embeddings
     from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm, solver, trainer
     from cvpr22_cross_modal_pseudo_labeling_amd.modeling.detector import build_detection_model
 
     cfg = get_defaults()
-    name = "student_teacher_mask_rcnn_uncertainty" if args.workload == "student" else "zeroshot_mask"
+    name = "student_teacher_mask_rcnn_uncertainty" if workload == "student" else "zeroshot_mask"
     cfg.merge_from_file(os.path.join(ROOT, "configs", "coco_cap_det", name + ".yaml"))
     # synthetic run: a tiny LR keeps random-init weights finite over many steps (the optimizer step still runs)
-    cfg.merge_from_list(["SOLVER.BASE_LR", 1e-6, "SOLVER.IMS_PER_BATCH", IMS_PER_GPU * world])
+    cfg.merge_from_list(["SOLVER.BASE_LR", 1e-6, "SOLVER.IMS_PER_BATCH", IMS_PER_GPU * world, "MODEL.DEVICE", dev.type]
+                        + (TINY_OVERRIDES if args.tiny else []))
     cfg.freeze()
-
     torch.manual_seed(1234)  # identical initial weights on every rank; broadcast anyway
     model = build_detection_model(cfg).to(dev)
-    e_vocab, e_seen = make_embeddings(cfg.MODEL.ROI_BOX_HEAD.EMB_DIM, seed=1234, device=dev)
+    batch_kw = TINY_BATCH if args.tiny else {}
+    e_vocab, e_seen = make_embeddings(cfg.MODEL.ROI_BOX_HEAD.EMB_DIM, seed=1234, device=dev,
+                                      **({"n_vocab": TINY_BATCH["n_vocab"]} if args.tiny else {}))
     model.set_class_embeddings(e_seen)
     if hasattr(model, "set_caption_vocab"):
         model.set_caption_vocab(e_vocab)
-    images, targets = make_batch(IMS_PER_GPU, device=dev, seed=1234 + rank)
+    images, targets = make_batch(IMS_PER_GPU, device=dev, seed=1234 + rank, **batch_kw)
     calibrate_stem_bn(model, images)
     comm.broadcast_parameters(model)
     model.train()
     optimizer = solver.make_optimizer(cfg, model)
     scheduler = solver.make_lr_scheduler(cfg, optimizer)
     reducer = comm.BucketedGradReducer(model)
+    reducer.measure_wait = world > 1
+    pipe = trainer.PipelinedTrainer(model, optimizer, reducer, scheduler)
+    if args.no_pipeline:
+        pipe.enabled = False
+    return name, model, images, targets, reducer, pipe
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus is None:
+        args.gpus = world  # under a launcher (torchrun --nproc-per-node N bench.py) the flag may be omitted
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher environment says WORLD_SIZE={world}")
+    on_gpu = args.device == "cuda"
+    dry_run = (not on_gpu) or args.tiny
+    if on_gpu:
+        # counting devices does not initialise the GPU.  A launcher that exports LOCAL_WORLD_SIZE tells how many ranks share
+        # this node; without it (older launchers, multi-node) only this rank's own device index can be checked.
+        need = int(os.environ["LOCAL_WORLD_SIZE"]) if "LOCAL_WORLD_SIZE" in os.environ else local_rank + 1
+        if torch.cuda.device_count() < need:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback (--device cpu is the dry run "
+                             "of the multi-rank control flow on the CPU-only configuration, not a fallback)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
+        torch.set_num_threads(max(1, int(os.environ.get("OMP_NUM_THREADS", "2"))))
+    backend = args.backend or ("nccl" if on_gpu else "gloo")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if on_gpu:
+            dist.init_process_group(backend, init_method="env://", device_id=dev)
+        else:
+            dist.init_process_group(backend, init_method="env://")
+    fault = tuple(int(x) for x in args.fault_inject.split(":")) if args.fault_inject else None
+
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+
+    name, model, images, targets, reducer, pipe = build_workload(args, args.workload, dev, world, rank)
     timer = OpTimer(_C)
-    timer.install()
+    if on_gpu:
+        timer.install()
 
     def sync():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     # Student-teacher workload: two-stream software pipeline (engine/trainer.py::PipelinedTrainer) -- the frozen half
     # (trunk, RPN, teacher pseudo-labelling) of step k+1 overlaps the student backward of step k.  Every timed step
     # still executes one frozen half and one student half; the synthetic batch is the same resident tensor each step.
     # Device warm-up (not a training step): a fresh, idle GPU takes a few seconds of load to reach its sustained clocks,
     # and the first process on a box measured 12-20 % slower without it.
-    burn = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
-    t_burn = time.perf_counter()
-    while time.perf_counter() - t_burn < args.burn_seconds:
-        for _ in range(20):
-            burn @ burn
-        torch.cuda.synchronize()
-    del burn
-    pipe = trainer.PipelinedTrainer(model, optimizer, reducer, scheduler)
-    if args.no_pipeline:
-        pipe.enabled = False
+    if on_gpu and args.burn_seconds > 0:
+        burn = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+        t_burn = time.perf_counter()
+        while time.perf_counter() - t_burn < args.burn_seconds:
+            for _ in range(20):
+                burn @ burn
+            torch.cuda.synchronize()
+        del burn
     nxt = (images, targets)
     for _ in range(args.warmup):
         pipe.step(images, targets, nxt)
     sync()
     overlapped = pipe.enabled
-    timer.enabled = not overlapped  # sequential workloads: per-kernel HIP-event timing live in the timed region
+    timer.enabled = on_gpu and not overlapped  # sequential workloads: per-kernel HIP-event timing live in the timed region
     if args.min_seconds > 0:  # calibrate the step count on a short untimed probe (same count on every rank)
         t0 = time.perf_counter()
         for _ in range(3):
@@ -552,44 +626,105 @@ def main():
             dist.all_reduce(probe, op=dist.ReduceOp.MAX)
         args.steps = max(args.steps, int(args.min_seconds / float(probe.item())) + 1)
         timer.records.clear()
+    reducer.exposed_wait_ms()  # drop the warm-up / probe records
     # the K timed steps, bracketed by barrier + synchronize; in between, un-synchronised host timestamps every few
     # steps give the spread of the step time inside the region (they do not stall the pipeline)
     chunk = max(1, args.steps // 8)
     marks = []
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if fault is not None and fault == (rank, i):
+            os._exit(13)  # test hook: a rank lost inside the timed region must end the whole job with a non-zero code
         loss_dict = pipe.step(images, targets, nxt)
         if (i + 1) % chunk == 0:
             marks.append((i + 1, time.perf_counter()))
     sync()
-    elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed = time.perf_counter() - t0
     chunk_ms = [1e3 * (b[1] - a[1]) / (b[0] - a[0]) for a, b in zip(marks[:-1], marks[1:])]
     pipe.drain()
+    waits = reducer.exposed_wait_ms()
+    hook_launches, n_buckets = reducer.hook_launches, len(reducer.buckets)
     timer.enabled = False
     replay_steps = 0
-    if overlapped:
+    if overlapped or not on_gpu:
         # In the pipelined step two streams share the GPU, so an event pair around one kernel also spans kernels of the
         # other stream.  The per-kernel roofline figures therefore come from a sequential replay of the same step
         # right after the timed region (same launches, one stream); `value` is the pipelined, timed region only.
+        # (The dry run has nothing to time per kernel; it replays so that this branch -- every rank, live all-reduces --
+        # has executed somewhere before an 8-GPU node sees it.)
         replay_steps = max(3, args.steps // 4)
         pipe.enabled = False
         for _ in range(2):  # settle the caching allocator on the single-stream allocation pattern first
             pipe.step(images, targets, nxt)
         sync()
-        timer.enabled = True
+        timer.enabled = on_gpu
         for _ in range(replay_steps):
             pipe.step(images, targets, nxt)
         sync()
         timer.enabled = False
     timer.enabled = False
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own view of the region: its wall time, its step count, how long its finish() stalled on the
+        # collectives per step (the exposed part of the exchange) and how many buckets its backward hooks issued
+        mine = torch.tensor([own_elapsed, float(args.steps), sum(waits) / max(len(waits), 1), max(waits, default=0.0),
+                             float(hook_launches)], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = [{"rank": r, "elapsed_s": round(float(g[0]), 4), "steps": int(g[1]),
+                     "allreduce_exposed_wait_ms_mean": round(float(g[2]), 3), "allreduce_exposed_wait_ms_max": round(float(g[3]), 3),
+                     "issued_from_backward_hooks": int(g[4])} for r, g in enumerate(gathered)]
     finite = all(bool(torch.isfinite(v).all()) for v in loss_dict.values())
+    payload_mb = round(sum(f.numel() * f.element_size() for f in reducer.flat) / 1e6, 1)
+
+    # Secondary figure (BASELINE config 2): a short timed region of the teacher configuration after the student one, so
+    # that the driver's single command also observes the teacher step.  Same protocol (warm-up, barrier + synchronize on
+    # both sides, MAX over ranks); the student model is released first.
+    secondary = None
+    shape_rows = per_shape_rows(timer, replay_steps or args.steps) if (args.per_shape_csv and rank == 0) else None
+    if args.workload == "student" and args.secondary_steps > 0:
+        kernels_primary = timer.summary() if rank == 0 else None
+        timer.records.clear()
+        for k in timer.bytes:
+            timer.bytes[k] = 0.0
+        del pipe, reducer, model
+        if on_gpu:
+            torch.cuda.empty_cache()
+        name2, model2, images2, targets2, reducer2, pipe2 = build_workload(args, "teacher", dev, world, rank)
+        for _ in range(3):
+            pipe2.step(images2, targets2, None)
+        sync()
+        timer.enabled = on_gpu
+        t0 = time.perf_counter()
+        for _ in range(args.secondary_steps):
+            loss2 = pipe2.step(images2, targets2, None)
+        sync()
+        el2 = time.perf_counter() - t0
+        timer.enabled = False
+        if world > 1:
+            t = torch.tensor([el2], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = float(t.item())
+        if rank == 0:
+            k2 = timer.summary()
+            secondary = {"workload": (f"{name2}.yaml R-50-C4 teacher, {IMS_PER_GPU} img/GPU "
+                                      f"{'3x128x160 TINY' if args.tiny else '3x800x1333'}, fwd+bwd+allreduce+SGD"),
+                         "steps": args.secondary_steps, "warmup": 3, "ms_per_step": round(1e3 * el2 / args.secondary_steps, 3),
+                         "images_per_s": round(IMS_PER_GPU * world * args.secondary_steps / el2, 3),
+                         "losses_finite": all(bool(torch.isfinite(v).all()) for v in loss2.values()),
+                         "allreduce_payload_MB": round(sum(f.numel() * f.element_size() for f in reducer2.flat) / 1e6, 1),
+                         "kernels": {n: {kk: round(vv, 3) if isinstance(vv, float) else vv for kk, vv in k2[n].items()}
+                                     for n in ("roi_align_backward_strided", "roi_align_forward_strided_nhwc", "split_gemm_pair",
+                                               "split_gemm_pair_gated", "split_gemm_pair_tn", "nms_presorted_batched") if n in k2}}
+        del pipe2, reducer2, model2
+    else:
+        kernels_primary = timer.summary() if rank == 0 else None
 
     if rank == 0:
-        kernels = timer.summary()
+        kernels = kernels_primary
         # the roofline object describes the hand-written kernel the step spends most time in (the split GEMM:
         # matrix-core bound; the byte kernels: HBM-bound); every native op is listed under "kernels"
         dom = max(kernels, key=lambda n: kernels[n]["launches"] * kernels[n]["avg_us"]) if kernels else "none"
@@ -598,7 +733,9 @@ def main():
                        "streams)") if replay_steps else "the timed region"
         traffic, traffic_note = pmc_traffic(args.workload, dom)
         mfma_busy, mfma_busy_note = pmc_mfma_busy(args.workload, dom)
-        if k["bound"] == "mfma":
+        if not kernels:
+            roofline = None  # dry run on the host path: nothing was launched on a GPU
+        elif k["bound"] == "mfma":
             roofline = {"bound": "mfma", "kernel": dom, "achieved": k["achieved_TFLOPs"], "peak": MFMA_BF16_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": k["achieved_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS,
                         # ALGORITHMIC flops of the fp32 convolutions (2*M*N*K) over the same time: against the bf16 matrix
@@ -622,9 +759,11 @@ def main():
                         "traffic_note": traffic_note,
                         "measured_in": measured_in}
         global_batch = IMS_PER_GPU * world
+        metric = ("images/sec student-teacher train step (COCO 800x1333)" if args.workload == "student"
+                  else "images/sec teacher train step (COCO 800x1333)")
+        size = "3x128x160 TINY" if args.tiny else "3x800x1333"
         out = {
-            "metric": "images/sec student-teacher train step (COCO 800x1333)" if args.workload == "student"
-            else "images/sec teacher train step (COCO 800x1333)",
+            "metric": metric + (" [DRY RUN: control-flow check of the multi-rank path, NOT a measurement]" if dry_run else ""),
             "value": global_batch * args.steps / elapsed,
             "unit": "images/sec",
             "n_gpus": world,
@@ -634,21 +773,29 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (bf16x3 split MFMA, fp32 accum)",
+            "dtype": "f32 (bf16x3 split MFMA, fp32 accum)" if on_gpu else "f32 (host path)",
             "data": "synthetic",
+            "dry_run": dry_run,
+            "device": args.device,
+            "backend": backend if world > 1 else None,
             "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
-            # gradient exchange of the last step: buckets whose all-reduce was issued from a backward hook (i.e. overlapped
-            # with the rest of the backward) out of all buckets, and the payload
-            "allreduce": {"buckets": len(reducer.buckets), "issued_from_backward_hooks": reducer.hook_launches,
-                          "payload_MB": round(sum(f.numel() * f.element_size() for f in reducer.flat) / 1e6, 1),
-                          "op": "AVG in the collective" if world > 1 else "none (1 rank)"},
-            "config": {"workload": f"{name}.yaml R-50-C4, {IMS_PER_GPU} img/GPU 3x800x1333, fwd+bwd+allreduce+SGD",
+            # gradient exchange of the last timed step: buckets whose all-reduce was issued from a backward hook (i.e.
+            # overlapped with the rest of the backward) out of all buckets, the payload, and -- per step -- how long
+            # finish() stalled on the collectives after the backward (max over ranks of each rank's mean)
+            "allreduce": {"buckets": n_buckets, "issued_from_backward_hooks": hook_launches,
+                          "payload_MB": payload_mb,
+                          "op": ("AVG in the collective" if backend == "nccl" else "SUM, divided after the wait") if world > 1 else "none (1 rank)",
+                          "exposed_wait_ms_per_step": (max(r["allreduce_exposed_wait_ms_mean"] for r in per_rank) if per_rank else 0.0)},
+            "ranks": per_rank,
+            "config": {"workload": f"{name}.yaml R-50-C4, {IMS_PER_GPU} img/GPU {size}, fwd+bwd+allreduce+SGD",
                        "global_batch": global_batch, "parallelism": f"dp{world}", "losses_finite": finite,
                        "pipelined": bool(overlapped)},
             # host-side step time over chunks of the timed region (issue rate of rank 0; the region total is `ms_per_step`)
             "ms_per_step_spread": ({"chunk_steps": chunk, "min": round(min(chunk_ms), 3), "median": round(sorted(chunk_ms)[len(chunk_ms) // 2], 3),
                                     "max": round(max(chunk_ms), 3)} if chunk_ms else None),
+            "replay_steps": replay_steps,
             "roofline": roofline,
+            "secondary": secondary,
             "kernels": {n: {kk: round(vv, 3) if isinstance(vv, float) else vv for kk, vv in v.items()}
                         for n, v in kernels.items()},
         }
@@ -656,12 +803,13 @@ def main():
             with open(args.per_shape_csv, "w") as f:
                 f.write("op,M,N,K,taps,launches_per_step,avg_us,bf16_TFLOPs_issued,fp32_equiv_TFLOPs,tiles_or_tn_tiles,"
                         "rounds_of_resident_workgroups,us_per_step\n")
-                for r in per_shape_rows(timer, replay_steps or args.steps):
+                for r in shape_rows:
                     f.write(",".join(str(round(x, 3)) if isinstance(x, float) else str(x) for x in r) + "\n")
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and on_gpu:
             out["cpu_baseline"] = cpu_baseline(args.workload)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

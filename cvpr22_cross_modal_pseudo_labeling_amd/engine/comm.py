@@ -74,6 +74,11 @@ class BucketedGradReducer:
             never_used = model.never_used_parameters()
         self._never_used = {id(p) for p in (never_used or ())}
         self.hook_launches = 0  # buckets whose all-reduce was issued from a backward hook in the current step
+        # measure_wait: record, per step, how long finish() stalls on the collectives -- the EXPOSED part of the exchange
+        # (what backward did not hide).  Device buckets: an event pair on the current stream around the waits (RCCL's
+        # ``wait()`` only makes the stream wait, the host runs on); host buckets (gloo): wall time of the waits.
+        self.measure_wait = False
+        self._wait_records = []  # (start_event, end_event) or seconds
         self.buckets = []
         cur, cur_bytes = [], 0
         for p in params:
@@ -154,11 +159,33 @@ class BucketedGradReducer:
             self._launch(bi)
         self._next = len(self.buckets)
         if self.world > 1:
-            for bi, h in enumerate(self.handles):
+            measure = self.measure_wait
+            on_device = measure and self.flat and self.flat[0].is_cuda
+            if on_device:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            elif measure:
+                import time
+                t0 = time.perf_counter()
+            for h in self.handles:
                 if h is not None:
                     h.wait()
-                if not self._avg_in_collective:
-                    self.flat[bi].div_(self.world)
+            if on_device:
+                e1.record()
+                self._wait_records.append((e0, e1))
+            elif measure:
+                self._wait_records.append(time.perf_counter() - t0)
+            if not self._avg_in_collective:
+                for flat in self.flat:
+                    flat.div_(self.world)
+
+    def exposed_wait_ms(self, clear=True):
+        """Per-step stall of finish() on the collectives, in ms (list; needs ``measure_wait``; device events must have
+        completed: call after a synchronize)."""
+        out = [r[0].elapsed_time(r[1]) if isinstance(r, tuple) else 1e3 * r for r in self._wait_records]
+        if clear:
+            self._wait_records = []
+        return out
 
     def remove(self):
         for h in self._hooks:

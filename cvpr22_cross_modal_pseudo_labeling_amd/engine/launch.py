@@ -9,6 +9,7 @@ the other ranks' stdout is joined to stderr.  The first child that fails ends th
 children are terminated by PID and the parent returns that child's exit code.
 """
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -37,37 +38,75 @@ def needs_spawn(requested, env=None):
     return requested > 1 and "WORLD_SIZE" not in env
 
 
+class _Terminated(Exception):
+    """SIGTERM reached the launcher (``timeout``, a scheduler): unwinds ``spawn_ranks`` so that its ``finally`` ends the ranks."""
+
+
+def _stop(children):
+    """Terminate, then kill, exactly the processes this launcher started (by PID, never by pattern)."""
+    live = [c for c in children if c.poll() is None]
+    for c in live:
+        try:
+            c.terminate()
+        except OSError:
+            pass
+    deadline = time.time() + 10
+    for c in live:
+        try:
+            c.wait(timeout=max(0.1, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            try:
+                c.kill()
+            except OSError:
+                pass
+            c.wait()
+
+
 def spawn_ranks(argv, nproc, master_port=None, env=None, poll_seconds=0.2, python=None):
     """Run ``python argv...`` as ``nproc`` ranks and wait for all of them.  Returns the job's exit code: 0 when every
-    rank exited 0, else the code of the first rank seen failing (the others are terminated)."""
+    rank exited 0, else the code of the first rank seen failing (the others are terminated).  Whatever ends the wait --
+    a failing rank, SIGTERM / SIGINT to the launcher, a ``Popen`` that raises half-way through the spawn -- no started
+    rank is left behind holding its GPU and the rendezvous port."""
     if nproc < 1:
         raise ValueError("nproc must be >= 1")
     port = master_port or free_port()
     cmd = [python or sys.executable] + list(argv)
     children = []
-    for r in range(nproc):
-        children.append(subprocess.Popen(cmd, env=rank_env(r, nproc, port, env),
-                                         stdout=None if r == 0 else sys.stderr))
+
+    def on_term(signum, frame):
+        raise _Terminated(signum)
+
+    old_term = None
+    try:
+        old_term = signal.signal(signal.SIGTERM, on_term)
+    except ValueError:  # not the main thread: the caller's handlers stay
+        old_term = None
     code = 0
-    alive = set(range(nproc))
-    while alive and code == 0:
-        for r in sorted(alive):
-            rc = children[r].poll()
-            if rc is None:
-                continue
-            alive.discard(r)
-            if rc != 0:
-                code = rc if rc > 0 else 128 - rc  # killed by signal s: 128 + s, as a shell reports it
-                sys.stderr.write(f"launch: rank {r} (pid {children[r].pid}) exited with {rc}; stopping the other ranks\n")
-                break
-        if alive and code == 0:
-            time.sleep(poll_seconds)
-    for r in alive:  # only after a failure: end the exact PIDs this call started
-        children[r].terminate()
-    for r in alive:
-        try:
-            children[r].wait(timeout=10)
-        except subprocess.TimeoutExpired:
-            children[r].kill()
-            children[r].wait()
+    try:
+        for r in range(nproc):
+            children.append(subprocess.Popen(cmd, env=rank_env(r, nproc, port, env),
+                                             stdout=None if r == 0 else sys.stderr))
+        alive = set(range(nproc))
+        while alive and code == 0:
+            for r in sorted(alive):
+                rc = children[r].poll()
+                if rc is None:
+                    continue
+                alive.discard(r)
+                if rc != 0:
+                    code = rc if rc > 0 else 128 - rc  # killed by signal s: 128 + s, as a shell reports it
+                    sys.stderr.write(f"launch: rank {r} (pid {children[r].pid}) exited with {rc}; stopping the other ranks\n")
+                    break
+            if alive and code == 0:
+                time.sleep(poll_seconds)
+    except _Terminated as e:
+        code = 128 + int(e.args[0])
+        sys.stderr.write(f"launch: signal {e.args[0]} received; stopping the ranks\n")
+    except KeyboardInterrupt:
+        code = 130
+        sys.stderr.write("launch: interrupted; stopping the ranks\n")
+    finally:
+        _stop(children)
+        if old_term is not None:
+            signal.signal(signal.SIGTERM, old_term)
     return code

@@ -124,9 +124,17 @@ class GroupFusedSGD(torch.optim.SGD):
         classes = {}
         for i, p in enumerate(params):
             classes.setdefault((lrs[i], wds[i], moms[i]), []).append(index[id(p)])
-        launches = [(classes[(lrs[first], wds[first], moms[first])], items, blocks) for first, items, blocks in hit[2]]
-        every = [(p, (p.grad.data_ptr() if (p.grad is not None and p.requires_grad) else 0)) for g in self.param_groups for p in g["params"]]
-        cache["fast"] = (len(self.param_groups), every, launches, use_wd)
+        launches = [(classes[(lrs[first], wds[first], moms[first])], items, blocks, moms[first] != 0) for first, items, blocks in hit[2]]
+        # ... and every pointer the device tables hold: the parameter's own storage and its momentum buffer (an
+        # ``optimizer.load_state_dict``, a ``state.clear()`` or a ``p.data`` swap replaces them behind the cache's back)
+        used = {id(p): b for p, b in zip(params, bufs)}
+        every = []
+        for g in self.param_groups:
+            for p in g["params"]:
+                live = p.grad is not None and p.requires_grad
+                b = used.get(id(p)) if live else None
+                every.append((p, p.data_ptr() if live else 0, p.grad.data_ptr() if live else 0, b, 0 if b is None else b.data_ptr()))
+        cache["fast"] = (len(self.param_groups), every, launches)
         return None
 
     def _step_cached(self, groups):
@@ -138,15 +146,24 @@ class GroupFusedSGD(torch.optim.SGD):
         fast = cache.get("fast") if cache else None
         if fast is None or fast[0] != len(groups):
             return False
-        _, every, launches, use_wd = fast
-        for p, ptr in every:
+        _, every, launches = fast
+        state = self.state
+        for p, pptr, gptr, buf, bptr in every:
             g = p.grad
-            if (g.data_ptr() if (g is not None and p.requires_grad) else 0) != ptr:
+            if g is None or not p.requires_grad:
+                if gptr != 0:
+                    return False
+                continue
+            if g.data_ptr() != gptr or p.data_ptr() != pptr:
+                return False
+            if buf is not None and (state[p].get("momentum_buffer") is not buf or buf.data_ptr() != bptr):
                 return False
         scalars = []
-        for members, _, _ in launches:
+        for members, _, _, has_buf in launches:
             g0 = groups[members[0]]
             lr, wd, mom = g0["lr"], g0["weight_decay"], g0["momentum"]
+            if (mom != 0) != has_buf:
+                return False  # momentum switched on / off: the tables hold no (or stale) buffer pointers
             for gi in members:
                 g = groups[gi]
                 if g["lr"] != lr or g["weight_decay"] != wd or g["momentum"] != mom or g["dampening"] != 0 or g["nesterov"] \
@@ -156,9 +173,26 @@ class GroupFusedSGD(torch.optim.SGD):
         if len(set(scalars)) != len(scalars):
             return False  # two classes have met (e.g. a rate of zero): let the general path re-partition
         from .. import _C
-        for (lr, wd, mom), (_, items, blocks) in zip(scalars, launches):
+        use_wd = any(wd != 0 for _, wd, _ in scalars)  # from the CURRENT scalars: a decay switched on later must apply
+        for (lr, wd, mom), (_, items, blocks, _) in zip(scalars, launches):
             _C.sgd_momentum_multi(items, blocks, lr, wd, mom, use_wd)
         return True
+
+    def _drop_native_tables(self):
+        self.__dict__.pop("_native_tables", None)
+
+    def load_state_dict(self, state_dict):
+        """A resumed run gets NEW momentum buffers (and possibly new scalars): the cached device tables point at the old ones."""
+        self._drop_native_tables()
+        return super().load_state_dict(state_dict)
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._drop_native_tables()
+
+    def add_param_group(self, param_group):
+        self._drop_native_tables()
+        return super().add_param_group(param_group)
 
     @staticmethod
     def _partition_of(part):

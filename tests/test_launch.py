@@ -80,3 +80,35 @@ def test_bench_becomes_the_launcher_before_importing_torch(tmp_path):
     assert "--gpus 2" in res.stderr and "visible" in res.stderr, res.stderr[-2000:]
     assert (tmp_path / "torch_seen_parent").read_text() == "False"
     assert (tmp_path / "torch_seen_0").read_text() == "True" and (tmp_path / "torch_seen_1").exists()
+
+
+def test_sigterm_to_the_launcher_ends_every_rank(tmp_path):
+    """a launcher killed by ``timeout`` / a scheduler must not orphan its ranks (they would keep their GPUs and
+    the rendezvous port)."""
+    import signal
+    import time
+
+    child = tmp_path / "child.py"
+    child.write_text("import os, sys, time\n"
+                     "open(os.path.join(sys.argv[1], 'pid_' + os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+                     "time.sleep(300)\n")
+    driver = ("import sys; sys.path.insert(0, %r)\n"
+              "from cvpr22_cross_modal_pseudo_labeling_amd.engine import launch\n"
+              "sys.exit(launch.spawn_ranks([%r, %r], 2))\n" % (ROOT, str(child), str(tmp_path)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    parent = subprocess.Popen([sys.executable, "-c", driver], env=env, stderr=subprocess.PIPE, text=True)
+    deadline = time.time() + 60
+    while time.time() < deadline and not all((tmp_path / f"pid_{r}").exists() and (tmp_path / f"pid_{r}").read_text() for r in (0, 1)):
+        time.sleep(0.1)
+    pids = [int((tmp_path / f"pid_{r}").read_text()) for r in (0, 1)]
+    parent.send_signal(signal.SIGTERM)
+    assert parent.wait(timeout=30) == 128 + signal.SIGTERM
+    time.sleep(0.5)
+    for pid in pids:  # both ranks are gone (signal 0 = existence probe of the exact PID)
+        try:
+            os.kill(pid, 0)
+            alive = open(f"/proc/{pid}/stat").read().split()[2] != "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, pid
+    assert "stopping the ranks" in parent.stderr.read()

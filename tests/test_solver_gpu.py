@@ -75,3 +75,63 @@ def test_fused_sgd_without_momentum_and_without_decay():
         res.append([q.detach().clone() for q in p])
         assert all("momentum_buffer" not in opt.state[q] or opt.state[q]["momentum_buffer"] is None for q in p)
     assert all(torch.equal(a, b) for a, b in zip(*res))
+
+
+def test_fused_sgd_survives_load_state_dict_state_clear_data_swap_and_late_decay():
+    """the cached step must notice everything that replaces a pointer its device tables hold -- a mid-run
+    ``load_state_dict`` (new momentum buffers), ``state.clear()``, a ``p.data`` swap -- and a weight decay switched on later;
+    each against the multi-tensor form, bit for bit."""
+    import copy
+
+    pa, oa, fa = _make(True)
+    pb, ob, fb = _make(False)
+    g = torch.Generator().manual_seed(9)
+
+    def both(fn):
+        fn(pa, oa)
+        fn(pb, ob)
+
+    def step():
+        vals = torch.randn(fa.numel(), generator=g).cuda()
+        fa.copy_(vals)
+        fb.copy_(vals)
+        oa.step()
+        ob.step()
+        for x, y in zip(pa, pb):
+            assert torch.equal(x.detach(), y.detach()), tuple(x.shape)
+            bx, by = oa.state[x].get("momentum_buffer"), ob.state[y].get("momentum_buffer")
+            assert (bx is None) == (by is None) and (bx is None or torch.equal(bx, by)), tuple(x.shape)
+
+    step()
+    step()
+    saved = copy.deepcopy(oa.state_dict())  # momentum after two steps
+    step()
+    step()
+    both(lambda p, o: o.load_state_dict(copy.deepcopy(saved)))  # resume: buffers are NEW tensors holding the older momentum
+    assert "_native_tables" not in oa.__dict__
+    old = [oa.state[p]["momentum_buffer"] for p in pa]
+    step()
+    assert all(oa.state[p]["momentum_buffer"] is b for p, b in zip(pa, old))  # the loaded buffers are the ones updated
+    step()
+    both(lambda p, o: o.state.clear())  # momentum dropped: the next step starts buffers afresh
+    step()
+    step()
+
+    def swap(p, o):  # new storage behind a parameter (what a checkpoint loader that assigns .data does)
+        p[3].data = p[3].data.clone()
+    both(swap)
+    step()
+    for o in (oa, ob):  # decay switched on for the bias groups (0 -> non-zero) and off everywhere else
+        for grp in o.param_groups:
+            grp["weight_decay"] = 5e-4 if grp["weight_decay"] == 0 else 0.0
+    step()
+    step()
+    for o in (oa, ob):
+        for grp in o.param_groups:
+            grp["weight_decay"] = 0.0  # no class decays any more ...
+    step()
+    for o in (oa, ob):
+        for grp in o.param_groups:
+            grp["weight_decay"] = 1e-3  # ... and then all of them do: the cached launch must apply it
+    step()
+    step()

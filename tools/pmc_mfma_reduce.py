@@ -17,6 +17,8 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cvpr22_cross_modal_pseudo_labeling_amd.utils import provenance  # noqa: E402
 CUS, SIMDS, XCDS = 256, 4, 8
 OURS = set()
 for src in glob.glob(os.path.join(ROOT, "cvpr22_cross_modal_pseudo_labeling_amd", "csrc", "*.hip")):
@@ -93,6 +95,7 @@ def main():
         res["kernels"][k] = {kk: (round(vv, 1) if isinstance(vv, float) and kk.endswith("_per_launch") else vv) for kk, vv in e.items()}
     res["families"] = {f.split(":")[0]: {"mfma_busy_frac": round(tot[f] / (SIMDS * CUS * tot[f.split(':')[0] + ':act']), 4)}
                        for f in tot if f.endswith(":busy") and tot[f.split(":")[0] + ":act"] > 0}
+    res["provenance"] = provenance.stamp(names)
     print(json.dumps(res, indent=1))
 
 

@@ -10,9 +10,14 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cvpr22_cross_modal_pseudo_labeling_amd.utils import provenance  # noqa: E402
 OURS = set()  # __global__ functions of csrc/*.hip: the hand-written kernels (torch / rocPRIM kernels are left out)
 for src in glob.glob(os.path.join(ROOT, "cvpr22_cross_modal_pseudo_labeling_amd", "csrc", "*.hip")):
     OURS.update(re.findall(r"__global__[^;{]*?void\s+(\w+)\s*\(", open(src).read(), re.S))
+
+
+INSTANCES = set()  # template instances the profiled run launched, as the profiler printed them
 
 
 def load(path):
@@ -25,6 +30,8 @@ def load(path):
             m = re.search(r"(?:\(anonymous namespace\)::)?(\w+)(?:<[^>]*>)?\(", name.replace("void ", ""))
             if m and m.group(1) in OURS:
                 agg[m.group(1)].append(float(r["Counter_Value"]))
+                full = re.match(r"(\w+(?:<[^(]*>)?)\(", name.replace("void ", "").replace("(anonymous namespace)::", ""))
+                INSTANCES.add(full.group(1) if full else m.group(1))
     return agg
 
 
@@ -42,4 +49,5 @@ for k in sorted(set(fetch) | set(write)):
     fb, wb = 2 * 1024 * sum(f) / max(len(f), 1), 1024 * sum(w) / max(len(w), 1)
     out["kernels"][k] = {"launches": n, "read_MB_per_launch": round(fb / 1e6, 3), "write_MB_per_launch": round(wb / 1e6, 3),
                          "hbm_MB_per_launch": round((fb + wb) / 1e6, 3)}
+out["provenance"] = provenance.stamp(INSTANCES)
 print(json.dumps(out, indent=1))
