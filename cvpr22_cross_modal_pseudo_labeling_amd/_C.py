@@ -1145,8 +1145,9 @@ def weighted_ce_fwd_bwd(logits, labels, bg_weight, need_grad=True):
 
 
 def mask_bce_stochastic_fwd_bwd(mu, sigma, eps, pos_index, targets, channel, need_grad=True):
-    """mu [P,C,M,M]; sigma [P,1,M,M] or None; eps [P,C,M,M] or None; pos_index [Pp]; targets [Pp,M,M]
-    -> (loss, dmu or None, dsigma or None)"""
+    """mu [P,C,M,M]; sigma [P,1,M,M] or None; eps [P,C,M,M] or None; pos_index [Pp]; targets [Pp,M,M]; channel: int (one
+    logit channel for every positive: class-agnostic masks) or int64 tensor [Pp] (the positives' class labels:
+    mask_logits[positive_inds, labels_pos], mask_head/loss.py:131-141) -> (loss, dmu or None, dsigma or None)"""
     if not mu.is_cuda:
         return _cpu.mask_bce_stochastic_fwd_bwd(mu, sigma, eps, pos_index, targets, channel, need_grad)
     mu = _dev(mu, "mu")
@@ -1163,9 +1164,18 @@ def mask_bce_stochastic_fwd_bwd(mu, sigma, eps, pos_index, targets, channel, nee
     scratch = torch.empty((max(npos, 1),), dtype=torch.float32, device=mu.device)
     ptr = lambda t: 0 if t is None else t.data_ptr()
     with _on(mu.device):
-        rc = _L.ovis_mask_bce_stochastic_fwd_bwd_f32(mu.data_ptr(), ptr(sigma), ptr(eps), pos_index.data_ptr(),
-                                                     targets.data_ptr(), loss.data_ptr(), ptr(dmu), ptr(dsigma),
-                                                     scratch.data_ptr(), p, npos, c, mm, channel, _stream())
+        if torch.is_tensor(channel):
+            channel = _dev(channel, "channel", torch.int64)
+            if channel.numel() != npos:
+                raise RuntimeError(f"mask_bce_stochastic_fwd_bwd: {channel.numel()} channels for {npos} positives")
+            rc = _L.ovis_mask_bce_stochastic_classes_fwd_bwd_f32(mu.data_ptr(), ptr(sigma), ptr(eps), pos_index.data_ptr(),
+                                                                 channel.data_ptr(), targets.data_ptr(), loss.data_ptr(),
+                                                                 ptr(dmu), ptr(dsigma), scratch.data_ptr(), p, npos, c, mm,
+                                                                 _stream())
+        else:
+            rc = _L.ovis_mask_bce_stochastic_fwd_bwd_f32(mu.data_ptr(), ptr(sigma), ptr(eps), pos_index.data_ptr(),
+                                                         targets.data_ptr(), loss.data_ptr(), ptr(dmu), ptr(dsigma),
+                                                         scratch.data_ptr(), p, npos, c, mm, channel, _stream())
     _lib.check(rc, "mask_bce_stochastic_fwd_bwd")
     return loss[0], dmu, dsigma
 

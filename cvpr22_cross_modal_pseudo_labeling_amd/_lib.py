@@ -83,6 +83,7 @@ SIGNATURES = {
     "ovis_sgd_chunk_elements": (_i, []),
     "ovis_weighted_ce_fwd_bwd_f32": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp]),
     "ovis_mask_bce_stochastic_fwd_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ovis_mask_bce_stochastic_classes_fwd_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

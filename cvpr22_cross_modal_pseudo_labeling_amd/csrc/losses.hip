@@ -75,10 +75,16 @@ __global__ __launch_bounds__(256) void mask_bce_kernel(const float* __restrict__
                                                       const float* __restrict__ targets,
                                                       float* __restrict__ dmu, float* __restrict__ dsigma,
                                                       float* __restrict__ row_loss, int num_pos, int C, int MM,
-                                                      int channel) {
+                                                      int channel_fixed, const long long* __restrict__ channels) {
   __shared__ float part[4];
   const int i = blockIdx.x;
   const long p = pos_index[i];
+  // per-positive logit channel (class-specific masks: labels_pos, mask_head/loss.py:131-141) or one for all (class-agnostic)
+  int channel = channel_fixed;
+  if (channels) {
+    const long long c = channels[i];
+    channel = c < 0 ? 0 : (c >= C ? C - 1 : (int)c);
+  }
   const float* mu_p = mu + (p * C + channel) * MM;
   const float* ep = eps ? eps + (p * C + channel) * MM : nullptr;
   const float* sg = sigma ? sigma + p * MM : nullptr;
@@ -120,12 +126,10 @@ extern "C" int ovis_weighted_ce_fwd_bwd_f32(const float* logits, const int64_t* 
   return OVIS_OK;
 }
 
-extern "C" int ovis_mask_bce_stochastic_fwd_bwd_f32(const float* mu, const float* sigma, const float* eps,
-                                                    const int64_t* pos_index, const float* targets,
-                                                    float* loss, float* dmu, float* dsigma,
-                                                    float* row_scratch, int num_rois, int num_pos,
-                                                    int num_channels, int mask_pixels, int channel,
-                                                    void* stream) {
+static int mask_bce_launch(const float* mu, const float* sigma, const float* eps, const int64_t* pos_index,
+                           const float* targets, float* loss, float* dmu, float* dsigma, float* row_scratch,
+                           int num_rois, int num_pos, int num_channels, int mask_pixels, int channel,
+                           const int64_t* channels, void* stream) {
   if (num_rois < 0 || num_pos < 0 || num_channels <= 0 || mask_pixels <= 0 || channel < 0 ||
       channel >= num_channels || !loss)
     return OVIS_EINVAL;
@@ -139,9 +143,30 @@ extern "C" int ovis_mask_bce_stochastic_fwd_bwd_f32(const float* mu, const float
   if (!mu || !pos_index || !targets || !row_scratch) return OVIS_EINVAL;
   hipLaunchKernelGGL(mask_bce_kernel, dim3(num_pos), dim3(256), 0, s, mu, sigma, eps,
                      (const long long*)pos_index, targets, dmu, dsigma, row_scratch, num_pos, num_channels,
-                     mask_pixels, channel);
+                     mask_pixels, channel, (const long long*)channels);
   OVIS_LAUNCH_CHECK();
   hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, row_scratch, loss, num_pos, 1.f);
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
+}
+
+extern "C" int ovis_mask_bce_stochastic_fwd_bwd_f32(const float* mu, const float* sigma, const float* eps,
+                                                    const int64_t* pos_index, const float* targets,
+                                                    float* loss, float* dmu, float* dsigma,
+                                                    float* row_scratch, int num_rois, int num_pos,
+                                                    int num_channels, int mask_pixels, int channel,
+                                                    void* stream) {
+  return mask_bce_launch(mu, sigma, eps, pos_index, targets, loss, dmu, dsigma, row_scratch, num_rois, num_pos,
+                         num_channels, mask_pixels, channel, nullptr, stream);
+}
+
+extern "C" int ovis_mask_bce_stochastic_classes_fwd_bwd_f32(const float* mu, const float* sigma, const float* eps,
+                                                            const int64_t* pos_index, const int64_t* channels,
+                                                            const float* targets, float* loss, float* dmu,
+                                                            float* dsigma, float* row_scratch, int num_rois,
+                                                            int num_pos, int num_channels, int mask_pixels,
+                                                            void* stream) {
+  if (num_pos > 0 && !channels) return OVIS_EINVAL;
+  return mask_bce_launch(mu, sigma, eps, pos_index, targets, loss, dmu, dsigma, row_scratch, num_rois, num_pos,
+                         num_channels, mask_pixels, 0, channels, stream);
 }

@@ -44,6 +44,7 @@ class DFConv2d(nn.Module):
             padding = dilation * (kernel_size - 1) // 2
             base = kernel_size * kernel_size
         self.offset_base_channels = base
+        self.deformable_groups = deformable_groups
         offset_channels = base * (3 if with_modulated_dcn else 2)
         conv_block = ModulatedDeformConv if with_modulated_dcn else DeformConv
         self.offset = Conv2d(in_channels, deformable_groups * offset_channels, kernel_size=kernel_size, stride=stride,
@@ -64,5 +65,7 @@ class DFConv2d(nn.Module):
         if not self.with_modulated_dcn:
             return self.conv(x, self.offset(x))
         offset_mask = self.offset(x)
-        n = self.offset_base_channels  # the reference hard-codes 18 / 9 (3x3 kernels, one deformable group)
+        # the reference hard-codes 18 / 9 (3x3 kernels, ONE deformable group; with more groups its slices no longer match
+        # the channels DeformConv expects): here the split follows the groups -- identical for deformable_groups = 1
+        n = self.offset_base_channels * self.deformable_groups
         return self.conv(x, offset_mask[:, : 2 * n], offset_mask[:, -n:].sigmoid())

@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..layers import Conv2d, FrozenBatchNorm2d, bias_relu_, split_conv_same, split_linear
+from ..layers import Conv2d, DFConv2d, FrozenBatchNorm2d, bias_relu_, split_conv_same, split_linear
 from ..layers.pair_bottleneck import bottleneck_pair, is_placeholder, pair_weight
 
 
@@ -47,8 +47,9 @@ class ConvBN(nn.Module):
 
 class Bottleneck(nn.Module):
     def __init__(self, in_channels, bottleneck_channels, out_channels, num_groups=1, stride_in_1x1=True,
-                 stride=1, dilation=1):
+                 stride=1, dilation=1, dcn_config=None):
         super().__init__()
+        dcn_config = dcn_config or {}
         self.downsample = None
         if in_channels != out_channels:
             down_stride = stride if dilation == 1 else 1
@@ -61,16 +62,28 @@ class Bottleneck(nn.Module):
         stride_1x1, stride_3x3 = (stride, 1) if stride_in_1x1 else (1, stride)
         self.conv1 = Conv2d(in_channels, bottleneck_channels, kernel_size=1, stride=stride_1x1, bias=False)
         self.bn1 = FrozenBatchNorm2d(bottleneck_channels)
-        self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, kernel_size=3, stride=stride_3x3,
-                            padding=dilation, bias=False, groups=num_groups, dilation=dilation)
+        # resnet.py:286-300: a stage listed in MODEL.RESNETS.STAGE_WITH_DCN builds its 3x3 as a deformable convolution
+        # (offsets -- and masks, WITH_MODULATED_DCN -- predicted by an ordinary 3x3; layers/misc.py::DFConv2d, parameter
+        # names ``conv2.offset.*`` / ``conv2.conv.*`` as in the reference)
+        self.with_dcn = bool(dcn_config.get("stage_with_dcn", False))
+        if self.with_dcn:
+            self.conv2 = DFConv2d(bottleneck_channels, bottleneck_channels,
+                                  with_modulated_dcn=dcn_config.get("with_modulated_dcn", False), kernel_size=3,
+                                  stride=stride_3x3, groups=num_groups, dilation=dilation,
+                                  deformable_groups=dcn_config.get("deformable_groups", 1), bias=False)
+        else:
+            self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, kernel_size=3, stride=stride_3x3,
+                                padding=dilation, bias=False, groups=num_groups, dilation=dilation)
         self.bn2 = FrozenBatchNorm2d(bottleneck_channels)
         self.conv3 = Conv2d(bottleneck_channels, out_channels, kernel_size=1, bias=False)
         self.bn3 = FrozenBatchNorm2d(out_channels)
-        for l in (self.conv1, self.conv2, self.conv3):
+        # (the initialisation ORDER is kept as it was before the deformable variant existed: the seeded tiny models of
+        # tests/ draw the same weights)
+        for l in (self.conv1,) + (() if self.with_dcn else (self.conv2,)) + (self.conv3,):
             nn.init.kaiming_uniform_(l.weight, a=1)
         # fused views over the same parameters (no extra state_dict entries)
         self._f1 = [ConvBN(self.conv1, self.bn1)]
-        self._f2 = [ConvBN(self.conv2, self.bn2)]
+        self._f2 = [ConvBN(self.conv2, self.bn2)] if not self.with_dcn else None
         self._f3 = [ConvBN(self.conv3, self.bn3)]
         self._fd = [ConvBN(self.downsample[0], self.downsample[1])] if self.downsample is not None else None
         self.conv3x3_nchw = None  # None = by autograd mode (see forward_nhwc)
@@ -85,7 +98,10 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         out = F.relu_(self._f1[0](x))
-        out = F.relu_(self._f2[0](out))
+        if self.with_dcn:  # the deformable 3x3 (csrc/split_gemm.hip DEFORM mode / deform_conv*.hip), then its FrozenBN affine
+            out = F.relu_(self.bn2(self.conv2(out)))
+        else:
+            out = F.relu_(self._f2[0](out))
         out = self._f3[0](out)
         identity = self._fd[0](x) if self._fd is not None else x
         out += identity
@@ -93,7 +109,7 @@ class Bottleneck(nn.Module):
 
     def nhwc_supported(self):
         c1, c2, c3 = self.conv1, self.conv2, self.conv3
-        return (c1.kernel_size == (1, 1) and c3.kernel_size == (1, 1) and c1.groups == 1 and c3.groups == 1
+        return (not self.with_dcn and c1.kernel_size == (1, 1) and c3.kernel_size == (1, 1) and c1.groups == 1 and c3.groups == 1
                 and c1.padding == (0, 0) and c3.padding == (0, 0) and c3.stride == (1, 1))
 
     def pair_supported(self):
@@ -314,11 +330,11 @@ class Stem(nn.Module):
 
 
 def _make_stage(in_channels, bottleneck_channels, out_channels, block_count, num_groups, stride_in_1x1,
-                first_stride, dilation=1):
+                first_stride, dilation=1, dcn_config=None):
     blocks, stride = [], first_stride
     for _ in range(block_count):
         blocks.append(Bottleneck(in_channels, bottleneck_channels, out_channels, num_groups, stride_in_1x1,
-                                 stride, dilation))
+                                 stride, dilation, dcn_config))
         stride = 1
         in_channels = out_channels
     return nn.Sequential(*blocks)
@@ -335,8 +351,6 @@ class ResNetC4(nn.Module):
         r = cfg.MODEL.RESNETS
         if cfg.MODEL.BACKBONE.CONV_BODY != "R-50-C4":
             raise NotImplementedError("only R-50-C4 (the body every shipped config uses) is built")
-        if any(r.STAGE_WITH_DCN):
-            raise NotImplementedError("STAGE_WITH_DCN is not wired into the trunk in this build")
         self.stem = Stem(r.STEM_OUT_CHANNELS)
         in_channels = r.STEM_OUT_CHANNELS
         width = r.NUM_GROUPS * r.WIDTH_PER_GROUP
@@ -345,7 +359,10 @@ class ResNetC4(nn.Module):
             factor = 2 ** (index - 1)
             out_channels = r.RES2_OUT_CHANNELS * factor
             stage = _make_stage(in_channels, width * factor, out_channels, count, r.NUM_GROUPS,
-                                r.STRIDE_IN_1X1, first_stride=int(index > 1) + 1)
+                                r.STRIDE_IN_1X1, first_stride=int(index > 1) + 1,
+                                dcn_config={"stage_with_dcn": r.STAGE_WITH_DCN[index - 1],          # resnet.py:110-124
+                                            "with_modulated_dcn": r.WITH_MODULATED_DCN,
+                                            "deformable_groups": r.DEFORMABLE_GROUPS})
             name = f"layer{index}"
             self.add_module(name, stage)
             self.stages.append(name)
@@ -364,8 +381,11 @@ class ResNetC4(nn.Module):
         x = self.stem.forward_gemm(x) if (self.nhwc and self.stem.gemm_supported(x)) else self.stem(x)
         blocks = [b for name in self.stages for b in getattr(self, name)]
         frozen = not any(p.requires_grad for p in self.parameters())
-        if (x.is_cuda and self.nhwc and all(b.nhwc_supported() for b in blocks)
-                and (frozen or (self.train_nhwc and all(b.pair_gemm and b.pair_supported() for b in blocks)))):
+        plain = [b for b in blocks if not b.with_dcn]
+        if (x.is_cuda and self.nhwc and all(b.nhwc_supported() for b in plain)
+                and (frozen or (self.train_nhwc and all(b.pair_gemm and b.pair_supported() for b in plain)))):
+            if len(plain) != len(blocks):
+                return [self._forward_mixed(x, blocks)]
             # layer1-3 in NHWC with the split-GEMM bottlenecks of the res5 head (1x1 = row-major GEMM, 3x3 = implicit
             # GEMM).  Frozen trunk (student-teacher configuration): always.
             # Trainable stages (teacher training): through the pair-layout autograd nodes as well -- 39.4 vs 42.2 ms per
@@ -379,6 +399,25 @@ class ResNetC4(nn.Module):
         for name in self.stages:
             x = getattr(self, name)(x)
         return [x]
+
+    @staticmethod
+    def _forward_mixed(x, blocks):
+        """A trunk with deformable stages (STAGE_WITH_DCN): runs of ordinary bottlenecks stay on the NHWC pair-GEMM chain,
+        a deformable block runs its own NCHW forward (``_C`` deformable ops take the reference's NCHW tensors) between two
+        layout copies.  Returns the NCHW-shaped view of NHWC memory the poolers / RPN head read."""
+        y = x.permute(0, 2, 3, 1).contiguous()
+        run = []
+        for b in blocks:
+            if not b.with_dcn:
+                run.append(b)
+                continue
+            if run:
+                y = chain_nhwc(run, y)
+                run = []
+            y = b(y.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1).contiguous()
+        if run:
+            y = chain_nhwc(run, y)
+        return y.permute(0, 3, 1, 2)
 
 
 class Backbone(nn.Sequential):

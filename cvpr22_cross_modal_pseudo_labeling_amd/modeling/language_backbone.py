@@ -34,16 +34,14 @@ def normalize_class_names(names):
 
 class BERT(nn.Module):
     VOCAB_SIZE, HIDDEN_SIZE = 30522, 768  # bert-base-uncased (BertConfig.from_pretrained, transformers.py:11)
+    CACHE_ENTRIES = 64  # extract_emb results kept: the vocabulary names + the recent per-image noun lists
 
     def __init__(self, cfg=None, vocab_file=None, vocab_size=None, hidden_size=None, tokenizer=None):
         super().__init__()
         lb = getattr(getattr(cfg, "MODEL", None), "LANGUAGE_BACKBONE", None)
-        ft_emb = bool(lb.FT_EMB) if lb is not None else False
-        if ft_emb:
-            raise NotImplementedError("MODEL.LANGUAGE_BACKBONE.FT_EMB: the word-embedding table is frozen on this path "
-                                      "(every shipped config; transformers.py:24)")
+        ft_emb = bool(lb.FT_EMB) if lb is not None else False  # transformers.py:24: requires_grad = FT_EMB
         v, h = vocab_size or self.VOCAB_SIZE, hidden_size or self.HIDDEN_SIZE
-        self.embeddings = nn.Parameter(torch.empty(v, h).normal_(0.0, 0.02), requires_grad=False)
+        self.embeddings = nn.Parameter(torch.empty(v, h).normal_(0.0, 0.02), requires_grad=ft_emb)
         self.out_channels = h
         self.mlm = False  # transformers.py:34 asserts it
         self._vocab_file = vocab_file
@@ -94,13 +92,31 @@ class BERT(nn.Module):
         from .. import _C
         words = tuple(words)
         table = self.embeddings
+        if table.requires_grad and torch.is_grad_enabled():
+            # MODEL.LANGUAGE_BACKBONE.FT_EMB: the table is being trained, so the embeddings must stay in the graph -- the
+            # reference's own tensor-op formula (st_generalized_rcnn.py:202-209), uncached (the table moves every step)
+            enc = self.tokenize(words)
+            ids = enc["input_ids"].to(table.device)
+            keep = (1 - enc["special_tokens_mask"]).to(table.device, torch.float32)
+            emb = (table[ids] * keep[:, :, None]).sum(1) / keep.sum(1)[:, None]
+            return torch.nn.functional.normalize(emb, dim=-1)
         key = (words, table._version, table.device, table.data_ptr())
-        hit = self._cache.get("last")
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        hit = self._cache.get(key)
+        if hit is not None:
+            self._cache[key] = self._cache.pop(key)  # most recently used last
+            return hit
         if not table.is_cuda:
             raise RuntimeError("BERT.extract_emb: the table must be on the HIP device (the product path has no CPU fallback)")
         enc = self.tokenize(words)
         emb = _C.text_embed(table.detach(), enc["input_ids"], enc["special_tokens_mask"])
-        self._cache["last"] = (key, emb)
+        # keyed by the strings: the per-image noun lists of a step must not evict the 1203-name vocabulary entry (the
+        # reference re-tokenises it every iteration, st_generalized_rcnn.py:190-191).  A new table version drops everything.
+        for k in [k for k in self._cache if k[1:] != key[1:]]:
+            del self._cache[k]
+        while len(self._cache) >= self.CACHE_ENTRIES:
+            # evict the least recently used entry, sparing the LONGEST list: that one is the caption vocabulary
+            longest = max(self._cache, key=lambda k: len(k[0]))
+            victim = next((k for k in self._cache if k is not longest), longest)
+            del self._cache[victim]
+        self._cache[key] = emb
         return emb

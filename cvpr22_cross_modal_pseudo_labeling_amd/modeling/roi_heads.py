@@ -91,25 +91,33 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
 # box head
 # ------------------------------------------------------------------------------------------------
 class FastRCNNPredictor(nn.Module):
-    """avgpool -> emb_pred Linear -> dot product with the class-embedding matrix; agnostic box deltas."""
+    """avgpool -> emb_pred Linear -> dot product with the class-embedding matrix; agnostic box deltas (EMBEDDING_BASED, every
+    shipped config).  EMBEDDING_BASED False = the plain Fast R-CNN predictor (roi_box_predictors.py:33-40): a learned
+    ``cls_score`` Linear over NUM_CLASSES and per-class box deltas unless CLS_AGNOSTIC_BBOX_REG."""
 
     def __init__(self, cfg, in_channels, is_teacher=False):
         super().__init__()
         bh = cfg.MODEL.ROI_BOX_HEAD
         self.embedding_based = bh.EMBEDDING_BASED
-        if not self.embedding_based:
-            raise NotImplementedError("only the embedding-based classifier (every shipped config) is built")
-        assert cfg.MODEL.CLS_AGNOSTIC_BBOX_REG
-        self.emb_dim = bh.EMB_DIM
-        self.emb_pred = nn.Linear(in_channels, self.emb_dim)
-        nn.init.normal_(self.emb_pred.weight, mean=0, std=0.01)
-        nn.init.constant_(self.emb_pred.bias, 0)
-        self.num_classes = None
-        self.cls_score = None  # [C, emb_dim], set by set_class_embeddings after the optimizer is made
-        if bh.FREEZE_EMB_PRED:
-            self.emb_pred.weight.requires_grad = False
-            self.emb_pred.bias.requires_grad = False
-        self.bbox_pred = nn.Linear(in_channels, 2 * 4)
+        if self.embedding_based:
+            assert cfg.MODEL.CLS_AGNOSTIC_BBOX_REG
+            self.emb_dim = bh.EMB_DIM
+            self.emb_pred = nn.Linear(in_channels, self.emb_dim)
+            nn.init.normal_(self.emb_pred.weight, mean=0, std=0.01)
+            nn.init.constant_(self.emb_pred.bias, 0)
+            num_bbox_reg_classes = 2
+            self.num_classes = None
+            self.cls_score = None  # [C, emb_dim], set by set_class_embeddings after the optimizer is made
+            if bh.FREEZE_EMB_PRED:
+                self.emb_pred.weight.requires_grad = False
+                self.emb_pred.bias.requires_grad = False
+        else:
+            self.num_classes = bh.NUM_CLASSES
+            num_bbox_reg_classes = 2 if cfg.MODEL.CLS_AGNOSTIC_BBOX_REG else self.num_classes
+            self.cls_score = nn.Linear(in_channels, self.num_classes)
+            nn.init.normal_(self.cls_score.weight, mean=0, std=0.01)
+            nn.init.constant_(self.cls_score.bias, 0)
+        self.bbox_pred = nn.Linear(in_channels, num_bbox_reg_classes * 4)
         nn.init.normal_(self.bbox_pred.weight, mean=0, std=0.001)
         nn.init.constant_(self.bbox_pred.bias, 0)
 
@@ -131,28 +139,38 @@ class FastRCNNPredictor(nn.Module):
         x = self.pooled(x)
         # both Linear layers share the pooled operand: one GEMM over the concatenated [768 + 8, 2048] weight, built
         # already padded with zero rows to the split GEMM's 128-column tiles (one cat, no separate pad)
-        n = self.emb_dim + self.bbox_pred.out_features
+        first = self.emb_pred if self.embedding_based else self.cls_score
+        n1 = first.out_features
+        n = n1 + self.bbox_pred.out_features
         pad = (-n) % 128 if x.is_cuda else 0
         zw, zb = self._zero_rows(pad, x)
-        w = torch.cat([self.emb_pred.weight, self.bbox_pred.weight] + ([zw] if pad else []), 0)
-        b = torch.cat([self.emb_pred.bias, self.bbox_pred.bias] + ([zb] if pad else []), 0)
+        w = torch.cat([first.weight, self.bbox_pred.weight] + ([zw] if pad else []), 0)
+        b = torch.cat([first.bias, self.bbox_pred.bias] + ([zb] if pad else []), 0)
         y = linear_mfma(x, w, b)
-        cls_emb, bbox = y[:, : self.emb_dim], y[:, self.emb_dim:n]
-        cls_logit = text_logits(cls_emb, self.cls_score)  # einsum('pe,ce->pc')
+        head, bbox = y[:, :n1], y[:, n1:n]
+        if not self.embedding_based:
+            return head, bbox  # cls_score(x), bbox_pred(x): roi_box_predictors.py:70-72
+        cls_logit = text_logits(head, self.cls_score)  # einsum('pe,ce->pc')
         return cls_logit, bbox
 
     def _zero_rows(self, pad, x):
         z = getattr(self, "_zero_pad", None)
         if pad and (z is None or z[0].shape[0] != pad or z[0].device != x.device):
-            z = (x.new_zeros((pad, self.emb_pred.in_features)), x.new_zeros((pad,)))
+            z = (x.new_zeros((pad, self.bbox_pred.in_features)), x.new_zeros((pad,)))
             self._zero_pad = z
         return z if pad else (None, None)
 
     def embed(self, x):
         """region embeddings only (teacher alignment pass)"""
+        if not self.embedding_based:
+            raise RuntimeError("FastRCNNPredictor.embed: MODEL.ROI_BOX_HEAD.EMBEDDING_BASED is False -- there is no embedding "
+                               "projection to align with text")
         return linear_mfma(self.pooled(x), self.emb_pred.weight, self.emb_pred.bias)
 
     def set_class_embeddings(self, embs):
+        if not self.embedding_based:  # (the reference would overwrite its Linear with the matrix and fail in forward)
+            raise RuntimeError("set_class_embeddings: MODEL.ROI_BOX_HEAD.EMBEDDING_BASED is False -- the classifier is a "
+                               "learned Linear over NUM_CLASSES")
         self.num_classes = embs.shape[0]
         self.cls_score = embs.to(self.emb_pred.weight.device)
 
@@ -386,6 +404,11 @@ class ROIBoxHead(nn.Module):
         # block may leave its [R*49, 2048] result unwritten
         pooled_only = not self.training and not torch.is_grad_enabled()
         x = self.feature_extractor(features, proposals, pooled_only=pooled_only)
+        if pooled_only and getattr(x, "_ovis_pooled", None) is not None:
+            # the pass may have produced NOTHING but the pooled rows (the [R, 2048, 7, 7] view is then a NaN placeholder):
+            # hand the [R, 2048] rows themselves on as the box features -- ``predictor.pooled`` / ``embed`` take 2-D input --
+            # so that no consumer of ``package_x['bbox']`` can read the placeholder
+            x = x._ovis_pooled
         class_logits, box_regression = self.predictor(x)
         if not self.training:
             return x, self.post_processor((class_logits, box_regression), proposals), {}
@@ -589,11 +612,12 @@ class MaskRCNNLossComputation:
             pos = torch.nonzero(labels > 0).squeeze(1)
         if mask_targets.numel() == 0:
             return mu.sum() * 0
-        if not self.cls_agnostic_mask:
-            raise NotImplementedError("fused mask loss is class-agnostic (CLS_AGNOSTIC_MASK, every shipped config)")
         self.mask_targets, self.positive_inds = mask_targets, pos
         e = None if eps is None else eps.reshape(mu.shape)
-        return stochastic_mask_bce(mu, sigma, e, pos, mask_targets.reshape(pos.numel(), -1), 1)
+        # class-agnostic: every positive reads logit channel 1 (labels_pos * 0 + 1); class-specific: the channel of its
+        # label (mask_logits[positive_inds, labels_pos], mask_head/loss.py:131-141) -- an index into the same kernel
+        channel = 1 if self.cls_agnostic_mask else labels.index_select(0, pos)
+        return stochastic_mask_bce(mu, sigma, e, pos, mask_targets.reshape(pos.numel(), -1), channel)
 
     def __call__(self, proposals, mask_logits, targets):
         repeat = 1
@@ -702,7 +726,7 @@ class ROIMaskHead(nn.Module):
                 x = features[sel]
         else:
             x = self.feature_extractor(features, proposals)
-        if self.training and self.cls_agnostic_mask:
+        if self.training:
             return x, proposals, dict(loss_mask=self.fused_training_loss(x, proposals, targets, compute_uncertain, eps))
         if compute_uncertain:
             mask_logits, scale = self.predictor(x, True, eps=eps)
@@ -727,8 +751,8 @@ class ROIMaskHead(nn.Module):
 
 
 def _mask_fused_training_loss(self, x, proposals, targets, compute_uncertain=False, eps=None):
-    """Training loss of the class-agnostic mask head on the positives' features x (fused stochastic BCE; noise drawn on
-    the device unless injected)."""
+    """Training loss of the mask head (class-agnostic or class-specific logits) on the positives' features x (fused
+    stochastic BCE; noise drawn on the device unless injected)."""
     mu, sigma = self.predictor.forward_parts(x)
     if compute_uncertain and sigma is not None:
         self.log, self.avg_uncertain = sigma.max(), sigma.mean()

@@ -520,6 +520,9 @@ int ovis_region_noun_align_f32(const float* region_emb, const float* noun_emb, f
  *     (either may be NULL) are fully written (zero outside the positives).  sigma / eps may be NULL
  *     (plain BCE).  mu [num_rois, C, pixels], sigma [num_rois, pixels], eps [num_rois, C, pixels],
  *     targets [num_pos, pixels].  row_scratch: num_pos floats.
+ *     `_classes_`: the logit channel of positive i is channels[i] (class-specific masks,
+ *     CLS_AGNOSTIC_MASK False: mask_logits[positive_inds, labels_pos], mask_head/loss.py:131-141;
+ *     values outside [0, C) are clamped); eps, when given, is read at the same channel.
  * ---------------------------------------------------------------------------------- */
 int ovis_weighted_ce_fwd_bwd_f32(const float* logits, const int64_t* labels, float bg_weight,
                                  float* loss, float* dlogits, float* row_scratch, int num_rows,
@@ -529,6 +532,11 @@ int ovis_mask_bce_stochastic_fwd_bwd_f32(const float* mu, const float* sigma, co
                                          float* dmu, float* dsigma, float* row_scratch, int num_rois,
                                          int num_pos, int num_channels, int mask_pixels, int channel,
                                          void* stream);
+int ovis_mask_bce_stochastic_classes_fwd_bwd_f32(const float* mu, const float* sigma, const float* eps,
+                                                 const int64_t* pos_index, const int64_t* channels,
+                                                 const float* targets, float* loss, float* dmu, float* dsigma,
+                                                 float* row_scratch, int num_rois, int num_pos,
+                                                 int num_channels, int mask_pixels, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Deformable convolution v1 / v2 building blocks      mb/csrc/deform_conv.h:11-190
