@@ -81,12 +81,13 @@ def test_frozen_half_at_baseline_size_vs_oracle_backed_cpu():
         assert torch.allclose(tg_.get_field("scores").cpu(), tc.get_field("scores"), rtol=1e-3, atol=1e-4)
 
 
-def _share_sampling(model, cpu_model):
+def _share_sampling(model, cpu_model, evaluators=None):
     """The BASELINE sampler configuration (512 RoIs per image and branch, drawn by the device sampler's own key stream): the
     device side records the index lists it draws; the CPU side's sampler -- called in the same order, pseudo-label branch
     first, then the ground-truth branch, image by image -- hands out exactly those rows instead of drawing from torch's
-    generator (whose stream the device kernel cannot follow)."""
-    box_gpu, box_cpu = model.roi_heads_student["box"].loss_evaluator, cpu_model.roi_heads_student["box"].loss_evaluator
+    generator (whose stream the device kernel cannot follow).  ``evaluators`` = (device-side, CPU-side) loss evaluators whose
+    ``sampler`` is shared (default: the student's box head)."""
+    box_gpu, box_cpu = evaluators or (model.roi_heads_student["box"].loss_evaluator, cpu_model.roi_heads_student["box"].loss_evaluator)
     drawn = []
     sample_device = box_gpu.sampler.sample_device
 
@@ -140,15 +141,20 @@ def test_student_half_at_baseline_size_matches_oracle_backed_cpu(sampled):
         grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None}
         return {k: float(v.detach()) for k, v in losses.items()}, grads
 
-    import contextlib
-    l_gpu, g_gpu = run(model, frozen, tg, contextlib.nullcontext())
+    from tests.gate_forcing import forced_gates, record_gates, rel_l2
+
+    sites = []
+    l_gpu, g_gpu = run(model, frozen, tg, record_gates(sites))
+    assert len(sites) == 10  # three bottlenecks x three ReLUs + the mask head's
 
     if sampled:
         assert len(drawn) == 4 and all(int(c[0]) == 512 for _, c in drawn)  # two branches x two images, full quotas
+        replay = list(drawn)
     frozen_cpu = _to(frozen, "cpu")
     l_cpu, g_cpu = run(cpu_model, frozen_cpu, targets, oracle_ops())
     if sampled:
         assert not drawn  # the CPU side consumed every recorded draw
+        drawn.extend(replay)  # ... and takes them once more for the gate-forced run below
 
     assert set(l_gpu) == set(l_cpu) and len(l_cpu) >= 5
     for k in l_cpu:
@@ -161,6 +167,22 @@ def test_student_half_at_baseline_size_matches_oracle_backed_cpu(sampled):
             assert d <= 5e-3 * nv + 1e-7, (n, d, nv)
             checked += 1
     assert checked >= 15, checked
+
+    # Where do the 5e-3 come from?  The same CPU computation with its ReLUs gated by the masks the GPU kernels read
+    # (tests/gate_forcing.py): both sides then differentiate the SAME piecewise-linear function, what is left is the
+    # arithmetic of the products -- and that is inside the north_star's 1e-3 on every tensor.
+    cpu_model.iter -= 1
+    import contextlib
+    with contextlib.ExitStack() as stack:
+        stack.enter_context(oracle_ops())
+        fg = stack.enter_context(forced_gates(sites))
+        l_f, g_f = run(cpu_model, frozen_cpu, targets, contextlib.nullcontext())
+    assert fg.all_consumed() and fg.forced == 20 and fg.plain == 0  # two branch passes x ten ReLU sites, every row range used
+    assert 0 < fg.flipped <= 1e-3 * fg.elements  # a handful of gates do differ between the two arithmetics ...
+    for k in l_cpu:
+        assert abs(l_f[k] - l_cpu[k]) <= 1e-6 * max(abs(l_cpu[k]), 1e-3)  # (the forward is the CPU's own)
+    rel = rel_l2(g_gpu, g_f)
+    assert len(rel) >= 15 and max(rel.values()) <= 1e-3, sorted(rel.items(), key=lambda kv: -kv[1])[:5]  # ... and explain the rest
 
 
 def test_trainable_trunk_and_rpn_head_at_baseline_size_vs_plain_torch_cpu():
@@ -206,7 +228,12 @@ def test_trainable_trunk_and_rpn_head_at_baseline_size_vs_plain_torch_cpu():
         grads = {n: p.grad.detach().float().cpu() for n, p in named.items() if p.grad is not None}
         return [o.detach().float().cpu() for o in outs], grads
 
-    o_gpu, g_gpu = run(model, images.cuda())
+    from tests.gate_forcing import forced_gates, record_gates, rel_l2
+
+    sites = []
+    with record_gates(sites):
+        o_gpu, g_gpu = run(model, images.cuda())
+    assert len(sites) == 31  # layer2 (4) + layer3 (6) bottlenecks x three ReLUs + the RPN head's (frozen layer1 records nothing)
     o_cpu, g_cpu = run(cpu_model, images)
     assert tuple(o_cpu[0].shape) == (2, 1024, 50, 84)
     for a, b in zip(o_gpu, o_cpu):
@@ -216,3 +243,97 @@ def test_trainable_trunk_and_rpn_head_at_baseline_size_vs_plain_torch_cpu():
     for n, r in rel.items():
         assert r <= (3e-3 if ("cls_logits" in n or "bbox_pred" in n) else 2e-2), (n, r)
     assert max(rel[n] for n in rel if "cls_logits" in n or "bbox_pred" in n) <= 1e-4
+
+    # The depth-dependent growth above IS the gate flips: with the CPU side's ReLUs gated by the masks the GPU kernels read
+    # (tests/gate_forcing.py) every tensor is within the north_star's 1e-3, thirty ReLUs deep included.
+    with forced_gates(sites) as fg:
+        o_f, g_f = run(cpu_model, images)
+    assert fg.all_consumed() and fg.forced == 31 and fg.plain == 10  # (stem + nine layer1 ReLUs: frozen, no gradient crosses them)
+    assert 0 < fg.flipped <= 1e-4 * fg.elements
+    rel_f = rel_l2(g_gpu, g_f)
+    assert set(rel_f) == set(rel) and max(rel_f.values()) <= 1e-3, sorted(rel_f.items(), key=lambda kv: -kv[1])[:5]
+
+
+
+def test_teacher_step_at_baseline_size_matches_oracle_backed_cpu():
+    """BASELINE config 2 end to end at full size: ``zeroshot_mask.yaml`` (generalized_rcnn.py:37-73), two 800 x 1333 images, the
+    SHIPPED samplers (256 anchors / image for the RPN loss, rpn/loss.py:21-131; 512 RoIs / image for the heads) -- trainable
+    trunk on the pair GEMMs with gradient links, device RPN loss, strided pooler forward AND backward into the trunk
+    (layers/roi_align.py:26-45), res5 head, cross-modal box head, mask head -- against the same step on CPU tensors in plain
+    torch fp32 with the native ops routed to the oracle.  What is random or tie-prone on the way is shared, as in the
+    student-half test: the device side's proposal sets (a top-k / NMS near-tie must not hand the two sides different boxes;
+    proposals carry no gradient) and the draws of both device samplers are recorded and replayed by the CPU side.
+    All five losses to 1e-3; every trainable gradient element-wise (relative L2 per tensor): 5e-3 for the heads, 2e-2 for the
+    trunk as in the tests above, and 1e-3 EVERYWHERE once the CPU side's ReLUs are gated like the GPU's."""
+    import contextlib
+
+    from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+    from cvpr22_cross_modal_pseudo_labeling_amd.data.synthetic import calibrate_stem_bn, make_batch, make_embeddings
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.detector import build_detection_model
+    from tests.gate_forcing import forced_gates, record_gates, rel_l2
+    from tests.oracle_backend import oracle_ops
+
+    torch.manual_seed(0)
+    cfg = get_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, "configs/coco_cap_det/zeroshot_mask.yaml"))
+    cfg.freeze()
+    model = build_detection_model(cfg)
+    _, e_seen = make_embeddings(cfg.MODEL.ROI_BOX_HEAD.EMB_DIM, seed=1234)
+    images, targets = make_batch(2, seed=1234)
+    calibrate_stem_bn(model, images)
+    model.train()
+    cpu_model = copy.deepcopy(model)
+    cpu_model.set_class_embeddings(e_seen)
+    model = model.cuda()
+    model.set_class_embeddings(e_seen.cuda())
+
+    # shared: proposals (recorded on the device, handed to the CPU side) and both samplers' draws
+    proposals = []
+    select = model.rpn.box_selector_train.forward
+
+    def recording(*a, **k):
+        out = select(*a, **k)
+        proposals.append([b.to("cpu") for b in out])
+        return out
+
+    model.rpn.box_selector_train.forward = recording
+    cpu_model.rpn.box_selector_train.forward = lambda *a, **k: proposals[0]
+    drawn_rpn = _share_sampling(model, cpu_model, (model.rpn.loss_evaluator, cpu_model.rpn.loss_evaluator))
+    drawn_box = _share_sampling(model, cpu_model, (model.roi_heads["box"].loss_evaluator, cpu_model.roi_heads["box"].loss_evaluator))
+
+    def run(m, x, tgs, ctx):
+        for p in m.parameters():
+            p.grad = None
+        with ctx:
+            losses = m(x, tgs)
+            sum(losses.values()).backward()
+        grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None}
+        return {k: float(v.detach()) for k, v in losses.items()}, grads
+
+    sites = []
+    l_gpu, g_gpu = run(model, images.cuda(), [t.to("cuda") for t in targets], record_gates(sites))
+    assert len(proposals) == 1 and [len(b) for b in proposals[0]] == [2007, 2007]  # 2000 proposals + 7 ground truths per image
+    assert len(drawn_rpn) == 2 and all(int(c[0]) == 256 for _, c in drawn_rpn)
+    assert len(drawn_box) == 2 and all(int(c[0]) == 512 for _, c in drawn_box)
+    assert len(sites) == 31 + 10  # trunk + RPN head, res5 + mask head
+    replay = list(drawn_rpn), list(drawn_box)
+
+    l_cpu, g_cpu = run(cpu_model, images, targets, oracle_ops())
+    assert not drawn_rpn and not drawn_box
+    assert set(l_gpu) == set(l_cpu) == {"loss_classifier", "loss_box_reg", "loss_mask", "loss_objectness", "loss_rpn_box_reg"}
+    for k in l_cpu:
+        assert abs(l_gpu[k] - l_cpu[k]) <= 1e-3 * max(abs(l_cpu[k]), 1e-3), (k, l_gpu[k], l_cpu[k])
+    rel = rel_l2(g_gpu, g_cpu)
+    assert len(rel) >= 50 and set(g_gpu) == set(g_cpu)
+    for n, r in rel.items():
+        assert r <= (2e-2 if n.startswith("backbone") else 5e-3), (n, r)
+
+    drawn_rpn.extend(replay[0])
+    drawn_box.extend(replay[1])
+    with contextlib.ExitStack() as stack:
+        stack.enter_context(oracle_ops())
+        fg = stack.enter_context(forced_gates(sites))
+        l_f, g_f = run(cpu_model, images, targets, contextlib.nullcontext())
+    assert fg.all_consumed() and fg.forced == 41 and fg.plain == 10
+    rel_f = rel_l2(g_gpu, g_f)
+    assert set(rel_f) == set(rel) and max(rel_f.values()) <= 1e-3, sorted(rel_f.items(), key=lambda kv: -kv[1])[:5]
