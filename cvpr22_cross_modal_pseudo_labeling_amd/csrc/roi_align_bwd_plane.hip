@@ -32,12 +32,27 @@
 namespace {
 using namespace ovis_roi;
 
-constexpr int kRI = 4;         // items per round (one barrier per round)
-constexpr int kGDepth = 8;    // G tiles in flight per wave = two rounds (8 waves x 8 x 784 B = 50 KB per CU)
-constexpr int kRing = 3;      // table ring depth in rounds: consumed | landed | in flight
-constexpr int kRoundBytes = 2 * kRI * 1024;  // 4 tx blocks + 4 ty blocks
+#ifndef OVIS_ROI_KRI
+#define OVIS_ROI_KRI 4
+#endif
+#ifndef OVIS_ROI_KRING
+#define OVIS_ROI_KRING 3
+#endif
+// Round geometry.  A round = kRI items between two workgroup barriers; its table blocks (2 KB per item) sit in one slot of a
+// ring of kRing rounds in the 24 KB the planes leave of the CU's LDS: three slots of four items (tables requested two rounds
+// ahead).  Two slots of six (-DOVIS_ROI_KRI=6 -DOVIS_ROI_KRING=2: a round's tables requested when the previous round
+// starts, a third fewer barriers) measured 1 % faster at twelve G tiles / origins in flight, which costs scalar-register
+// spills once anything else is added -- kept as a build option.
+constexpr int kRI = OVIS_ROI_KRI;        // items per round (one barrier per round)
+constexpr int kGDepth = 2 * kRI;         // G tiles in flight per wave = two rounds
+constexpr int kRing = OVIS_ROI_KRING;    // table ring depth in rounds
+constexpr int kAhead = kRing - 1;        // a round's tables are requested this many rounds before it is consumed
+constexpr int kRoundBytes = 2 * kRI * 1024;  // kRI tx blocks + kRI ty blocks
+static_assert(kRing == 2 || kRing == 3, "ring depth");
+static_assert(kRing * kRoundBytes <= 24 * 1024, "the table ring has 24 KB");
 constexpr int kListPad = 4 * kGDepth;        // zero-contribution items after the last real one
 constexpr int kPlanThreads = 256;
+constexpr unsigned kReuseT = 2u;  // item flag, bit 1 of the footprint origin's byte offset
 
 // ---------------------------------------------------------------------------------------------------
 // Plan kernel.
@@ -106,10 +121,16 @@ __global__ __launch_bounds__(kPlanThreads) void roi_bwd_plan_kernel(
         all += t;
       }
       int o = base + before + incl - nb;
+      // A RoI's blocks are consecutive items, yb fastest.  An item's first stage depends on (RoI, xb) only -- T = G . Ax_xb --
+      // so bit 1 of the origin offset (a multiple of 4) tells the main kernel that the previous item was (xb, yb - 1) of the
+      // same RoI: its split first-stage result, still in registers, IS this item's -- no G split, no stage 1, no T split
+      // (20 vector + 3 matrix instructions of an item's ~56; one wave-uniform branch per item pays for it).  Re-using the
+      // split G tile across xb as well costs a second branch per item and measured as a loss.
       for (int xb = 0; xb < nbx; ++xb)
         for (int yb = 0; yb < nby; ++yb)
           my[o++] = (u4){(unsigned)r * (unsigned)(C * TH * TW) * 4u,
-                         (unsigned)(block_origin(g.wy0, yb, H) * W + block_origin(g.wx0, xb, W)) * 4u,
+                         (unsigned)(block_origin(g.wy0, yb, H) * W + block_origin(g.wx0, xb, W)) * 4u |
+                             (yb > 0 ? kReuseT : 0u),
                          (unsigned)(r * NXB + xb) * 1024u, (unsigned)(r * NYB + yb) * 1024u};
       base += all;
       __syncthreads();
@@ -179,6 +200,11 @@ __global__ __launch_bounds__(kPlanThreads) void roi_bwd_plan_kernel(
 // ---------------------------------------------------------------------------------------------------
 #define OVIS_GLOAD4(dst, voff, sbase) \
   asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory")
+// G tile through a raw buffer descriptor over the channel's tiles: the item's byte offset is the SCALAR offset operand, so a
+// request costs no 64-bit address arithmetic (every instruction of the item loop is paid for in issue slots)
+typedef int i4 __attribute__((ext_vector_type(4)));
+#define OVIS_BLOAD4(dst, voff, rsrc, soff) \
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory")
 #define OVIS_WAIT1(N, a) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "i"(N) : "memory")
 
 __device__ __forceinline__ void lds_dma16(const void* gsrc_lane, unsigned lds_dst_wave) {
@@ -200,8 +226,9 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
   const int W = WC ? WC : W_rt;
   // no static LDS in this kernel: the dynamic segment starts at LDS address 0, which the DMA destinations rely on
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int P = 2 * kRI / NW;  // table blocks each wave DMAs per round
-  static_assert(2 * kRI % NW == 0 && kGDepth == 2 * kRI, "round geometry");
+  // table blocks each wave DMAs per round; when 2 * kRI is no multiple of NW the last waves request a block a second time
+  // (same bytes to the same place), so that every wave has the same number of loads in flight (the waits are counted)
+  constexpr int P = (2 * kRI + NW - 1) / NW;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = blockIdx.x % batch;
@@ -221,19 +248,20 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
   // so that no lane reads past its row (the plan kernel zeroes the duplicated k-slots in tx).  Rows q >= PH re-read
   // row PH - 1: finite values that meet zero ty entries (i >= PH).
   const unsigned g_lane = (unsigned)(min(q, PH - 1) * PW + min(4 * s, PW - 4)) * 4u;
-  const char* gbase = (const char*)(gout + (long)c * PHPW);
+  const unsigned long long gb = (unsigned long long)(gout + (long)c * PHPW);
+  const i4 rsrc = {(int)(unsigned)gb, (int)((unsigned)(gb >> 32) & 0xffffu), -1, 0x00020000};  // stride 0, no bound, 32-bit data
   const char* txl = (const char*)tx + lane * 16;
   const char* tyl = (const char*)ty + lane * 16;
   const unsigned lane_cell = (unsigned)(4 * s * W + q) * 4u;  // byte offset of the lane's first footprint cell
 
-  // this wave's DMA duty for round `rr` into ring slot `slot`: blocks b = wave*P .. wave*P+P-1 of the round's 8,
-  // block b = {tx, ty}[b >> 2] of item rr*4 + (b & 3); lands at ring_base + slot*kRoundBytes + b*1024
+  // this wave's DMA duty for round `rr` into ring slot `slot`: blocks b = wave*P .. wave*P+P-1 (mod 2 kRI) of the round's
+  // 2 kRI, block b = {tx, ty}[b / kRI] of item rr*kRI + b % kRI; lands at ring_base + slot*kRoundBytes + b*1024
   auto dma_round = [&](int rr, unsigned slot) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      const int b = wave * P + p;
-      const u4 e = my[rr * kRI + (b & 3)];
-      const char* src = (b >> 2) ? tyl + e.w : txl + e.z;
+      const int b = (wave * P + p) % (2 * kRI);
+      const u4 e = my[rr * kRI + b % kRI];
+      const char* src = (b / kRI) ? tyl + e.w : txl + e.z;
       lds_dma16(src, ring_base + slot * kRoundBytes + (unsigned)b * 1024u);
     }
   };
@@ -242,18 +270,19 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
   unsigned org[kGDepth];  // its footprint origin (LDS byte offset inside the plane)
 #pragma unroll
   for (int d = 0; d < kGDepth; ++d) rg[d] = (f4){0.f, 0.f, 0.f, 0.f};
-#define OVIS_FETCH(d, e)                       \
-  do {                                         \
-    const char* pg_ = gbase + (e).x;           \
-    OVIS_GLOAD4(rg[d], g_lane, pg_);           \
-    org[d] = (e).y;                            \
+#define OVIS_FETCH(d, e)                           \
+  do {                                             \
+    OVIS_BLOAD4(rg[d], g_lane, rsrc, (e).x);       \
+    org[d] = (e).y;                                \
   } while (0)
 
-  // prologue, in the steady-state issue order: DMA(0) G(0..3) DMA(1) G(4..7)
+  // prologue, in the steady-state issue order: DMA G(0 .. kRI-1) DMA G(kRI .. 2 kRI-1).  Ring of three: the tables of
+  // rounds 0 and 1; ring of two: round 0's tables twice (the second request keeps the count of loads in flight what the
+  // counted waits of the first items assume; it rewrites slot 0 with the bytes it already holds)
   dma_round(0, 0);
 #pragma unroll
   for (int d = 0; d < kRI; ++d) { const u4 e = my[d]; OVIS_FETCH(d, e); }
-  dma_round(1, 1);
+  dma_round(kAhead == 2 ? 1 : 0, kAhead == 2 ? 1 : 0);
 #pragma unroll
   for (int d = kRI; d < kGDepth; ++d) { const u4 e = my[d]; OVIS_FETCH(d, e); }
   u4 epre = my[kGDepth];  // entry of the item to prefetch next
@@ -263,25 +292,47 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
   // Software pipeline: the footprint of item k-1 is folded into the plane while item k runs through the matrix
   // pipe.  Starts with a zero footprint at cell 0 (adds 0.0f, FIT) / nothing (masked).
   f4 w_prev = {0.f, 0.f, 0.f, 0.f};
+  u4 b2 = {0u, 0u, 0u, 0u};  // split first-stage result, kept for the RoI's further blocks of the same column strip
   unsigned cell_prev = lane_cell;
   bool on_prev = false;  // masked form only: does the lane own a column of the previous footprint
   unsigned slot = 0;     // ring slot of the round being consumed
 
+#if defined(OVIS_ROI_PROBE_TIME) || defined(OVIS_ROI_PROBE_ITEM)  /* timing probes (wrong output): shader-clock stamps summed per wave */
+  unsigned long long pt_a = 0, pt_b = 0, pt_c = 0, pt_d = 0, acc_ab = 0, acc_bc = 0, acc_cd = 0, acc_da = 0, pt_prev_d = 0;
+  unsigned long long it_a = 0, it_b = 0, it_c = 0, it_prev = 0;
+#define OVIS_PROBE_OUT 1
+#endif
+#ifdef OVIS_ROI_PROBE_TIME   /* stamps at the round's seams */
+#define OVIS_STAMP(x) asm volatile("s_memtime %0" : "=s"(x)::"memory")
+#else
+#define OVIS_STAMP(x)
+#endif
+#ifdef OVIS_ROI_PROBE_ITEM   /* stamps inside every item */
+#define OVIS_STAMP2(x) asm volatile("s_memtime %0" : "=s"(x)::"memory")
+#else
+#define OVIS_STAMP2(x)
+#endif
   // cnt is a multiple of kGDepth; the list runs kListPad zero-contribution items past it
   for (int k0 = 0; k0 < cnt; k0 += kGDepth) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       {
-        const unsigned slot2 = slot + 2 >= kRing ? slot + 2 - kRing : slot + 2;
-        dma_round(k0 / kRI + half + 2, slot2);
+        OVIS_STAMP(pt_a);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned slot2 = slot + kAhead >= kRing ? slot + kAhead - kRing : slot + kAhead;
+        dma_round(k0 / kRI + half + kAhead, slot2);
+        __builtin_amdgcn_sched_barrier(0);
+        OVIS_STAMP(pt_b);
         __builtin_amdgcn_sched_barrier(0);
       }
       const char* tab = smem + ring_base + slot * kRoundBytes + lane * 16;
+      // entries of the items this round requests (two rounds ahead): one base per round, constant offsets per item
+      const u4* ent = my + (k0 + half * kRI + kGDepth);
 #pragma unroll
       for (int i = 0; i < kRI; ++i) {
         const int d = half * kRI + i;
-        const int k = k0 + d;
-        const unsigned cell = org[d] + lane_cell;
+        const unsigned fl = org[d] & 3u;
+        const unsigned cell = (org[d] & ~3u) + lane_cell;
         float* pp = (float*)((char*)plane + cell_prev);
         float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
         if (FIT) {
@@ -290,11 +341,17 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
         const u4 bx = *(const u4*)(tab + i * 1024);
         const u4 ay = *(const u4*)(tab + (kRI + i) * 1024);
         __builtin_amdgcn_sched_barrier(0);
+        OVIS_STAMP2(it_a);
         OVIS_WAIT1(kGDepth - 1 + 2 * P, rg[d]);  // G(k) has landed
+        OVIS_STAMP2(it_b);
         __builtin_amdgcn_sched_barrier(0);
-        // stage 1: T[i][x] = sum_j G[i][j] Ax[j][x]
-        const u4 a1 = split_bf16(rg[d]);
-        const f4 t = mfma3(a1, bx, (f4){0.f, 0.f, 0.f, 0.f});
+        // stage 1: T[i][x] = sum_j G[i][j] Ax[j][x], then its hi/lo split (T's accumulator layout -- col = lane & 15,
+        // row = 4s + e -- is the B-operand layout of stage 2) -- unless the previous item (same RoI, same xb) left this
+        // very operand in b2: ONE wave-uniform branch per item
+        if (!(fl & kReuseT)) {
+          const u4 a1 = split_bf16(rg[d]);
+          b2 = split_bf16(mfma3(a1, bx, (f4){0.f, 0.f, 0.f, 0.f}));
+        }
         // previous item's footprint (its reads were issued above, their latency is behind stage 1 by now)
         if (FIT) {
           pp[0] = v0 + w_prev.x;
@@ -308,9 +365,7 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
           if (y + 2 < H) pp[2 * W] += w_prev.z;
           if (y + 3 < H) pp[3 * W] += w_prev.w;
         }
-        // stage 2: dW[y][x] = sum_i Ay[i][y] T[i][x]; T's accumulator layout (col = lane & 15, row = 4s + e) is
-        // the B-operand layout, so it only needs the hi/lo split
-        const u4 b2 = split_bf16(t);
+        // stage 2: dW[y][x] = sum_i Ay[i][y] T[i][x]
         w_prev = mfma3(ay, b2, (f4){0.f, 0.f, 0.f, 0.f});
         cell_prev = cell;
         if (!FIT) on_prev = (int)(org[d] >> 2) % W + q < W;
@@ -318,13 +373,33 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
         __builtin_amdgcn_sched_barrier(0);
         OVIS_FETCH(d, epre);
         __builtin_amdgcn_sched_barrier(0);
-        epre = my[k + kGDepth + 1];
+        epre = ent[i + 1];
+#ifdef OVIS_ROI_PROBE_ITEM
+        OVIS_STAMP2(it_c);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(it_a), "+s"(it_b), "+s"(it_c)::"memory");
+        acc_ab += it_b - it_a;   /* clocks in the wait for the G tile */
+        acc_bc += it_c - it_b;   /* the rest of the item */
+        if (it_prev) acc_cd += it_a - it_prev;  /* previous item's end -> the wait (plane / table reads issued) */
+        it_prev = it_c;
+#endif
       }
       // the wave's DMAs for the next round have landed (nothing younger than G(k+1) is forced); all waves have
       // finished reading this round's slot once they pass the barrier
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(kGDepth + P) : "memory");
+      OVIS_STAMP(pt_c);
+      // the tables of the next round were requested kAhead round starts ago: what may still be in flight behind them are
+      // the G refills since (kRI per round) and the table requests of the round starts after theirs
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(kRI * kAhead + (kAhead - 1) * P) : "memory");
+      OVIS_STAMP(pt_d);
       __builtin_amdgcn_sched_barrier(0);
+#ifdef OVIS_ROI_PROBE_TIME
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pt_a), "+s"(pt_b), "+s"(pt_c), "+s"(pt_d)::"memory");
+      acc_ab += pt_b - pt_a;
+      acc_bc += pt_c - pt_b;
+      acc_cd += pt_d - pt_c;
+      if (pt_prev_d) acc_da += pt_a - pt_prev_d;
+      pt_prev_d = pt_d;
+#endif
       slot = slot + 1 >= kRing ? 0 : slot + 1;
     }
   }
@@ -350,6 +425,11 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
   if (live) {
     float* dst = gin + ((long)n * C + c) * HW;
     for (int i = lane; i < HW; i += 64) dst[i] = plane[i];
+#ifdef OVIS_PROBE_OUT
+    if (lane == 0) {
+      dst[0] = (float)acc_ab; dst[1] = (float)acc_bc; dst[2] = (float)acc_cd; dst[3] = (float)acc_da; dst[4] = (float)cnt;
+    }
+#endif
   }
 }
 
@@ -371,7 +451,9 @@ extern "C" size_t ovis_roi_align_backward_workspace_bytes(int num_rois, int batc
 static int plane_waves(int height, int width) {
   const size_t stride = align_up((size_t)height * width * sizeof(float), 16);
   const size_t room = 160 * 1024 - (size_t)kRing * kRoundBytes;
+#ifndef OVIS_ROI_PROBE_NW4  /* timing probe: four waves (one per SIMD) per workgroup where eight would fit */
   if (8 * stride <= room) return 8;
+#endif
   if (4 * stride <= room) return 4;
   return 0;
 }

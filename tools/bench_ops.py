@@ -13,6 +13,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--lib" in sys.argv:  # an experiment build (tools/experiments/*_variants.sh) instead of the regular library
+    from cvpr22_cross_modal_pseudo_labeling_amd import _lib  # noqa: E402
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from cvpr22_cross_modal_pseudo_labeling_amd import _C  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
@@ -50,6 +53,7 @@ def bench_rois(r, n_img, g, kind="uniform"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ops", default="roi_fwd,roi_bwd,nms,focal,gemm,dcn,res5,split_gemm")
+    ap.add_argument("--lib", default="", help="path of an experiment build of libovis_hip.so (handled before the import)")
     ap.add_argument("--iters", type=int, default=20)
     args = ap.parse_args()
     ops = args.ops.split(",")
