@@ -43,6 +43,9 @@
 #include <stdlib.h>
 
 #include "ovis_common.h"
+#ifndef OVIS_SG_GW
+#define OVIS_SG_GW 4   // column tiles per group of the tile order (A/B builds: -DOVIS_SG_GW=16, profiles/r4_column_group_ab.txt)
+#endif
 
 namespace {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -1440,7 +1443,7 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
   p.M = m; p.N = n; p.ch = channels; p.ch2 = channels2; p.T = T; p.H = height; p.W = width; p.KH = taps_h; p.KW = taps_w;
   p.flip = flip; p.relu = relu;
   p.kslices = q.kslices; p.steps_per_slice = q.steps_per_slice;
-  p.gw = (q.tiles_n % 4 == 0) ? 4 : q.tiles_n;   // column groups of 4 weight tiles (2 MB) stay in an XCD's L2
+  p.gw = (q.tiles_n % OVIS_SG_GW == 0) ? OVIS_SG_GW : (q.tiles_n % 4 == 0) ? 4 : q.tiles_n;   // column groups of 4 weight tiles (2 MB) stay in an XCD's L2
   const long ntiles = (long)q.tiles_m * q.tiles_n;
   const long nblocks = ntiles * q.kslices;
   if (nblocks > 0x7fffffffL) return OVIS_ERANGE;
@@ -1595,7 +1598,7 @@ extern "C" int ovis_deform_conv_implicit_f32(const float* input_nhwc, const floa
   p.Ho = out_h; p.Wo = out_w; p.sh = stride_h; p.sw = stride_w; p.ph = pad_h; p.pw = pad_w; p.dlh = dil_h; p.dlw = dil_w;
   p.dg = deformable_group;
   const int tiles_m = (int)((m + 127) / 128), tiles_n = (out_channels + 127) / 128;
-  p.gw = (tiles_n % 4 == 0) ? 4 : tiles_n;
+  p.gw = (tiles_n % OVIS_SG_GW == 0) ? OVIS_SG_GW : (tiles_n % 4 == 0) ? 4 : tiles_n;
   const long ntiles = (long)tiles_m * tiles_n;
   if (ntiles > 0x7fffffffL) return OVIS_ERANGE;
   constexpr int lds = 128 * 128 + 128 * 128;

@@ -4,14 +4,14 @@
 set -uo pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
 cd "$ROOT"
-TAG=${1:-r3}; OUT=gpurun_out/$TAG
+TAG=${1:-r4}; OUT=gpurun_out/$TAG
 mkdir -p $OUT
 FAILED=""
 step() { "$@" || { FAILED="$FAILED [$*]"; echo "collect_round: FAILED: $*" >&2; }; }   # keep collecting, report at the end
 step bash -c 'python bench.py --steps 20 --warmup 5 > "$0"/bench_student_default.json 2> "$0"/bench_student_default.err' "$OUT"
-step bash -c 'python bench.py --steps 60 --warmup 5 --min-seconds 5 --per-shape-csv "$0"/per_shape_student.csv > "$0"/bench_student.json 2> "$0"/bench_student.err' "$OUT"
+step bash -c 'python bench.py --secondary-steps 0 --steps 60 --warmup 5 --min-seconds 5 --per-shape-csv "$0"/per_shape_student.csv > "$0"/bench_student.json 2> "$0"/bench_student.err' "$OUT"
 step bash -c 'python bench.py --workload teacher --steps 60 --warmup 5 --min-seconds 5 --per-shape-csv "$0"/per_shape_teacher.csv > "$0"/bench_teacher.json 2> "$0"/bench_teacher.err' "$OUT"
-step bash -c 'python bench.py --no-pipeline --no-cpu-baseline --steps 30 > "$0"/bench_student_nopipe.json 2>/dev/null' "$OUT"
+step bash -c 'python bench.py --no-pipeline --no-cpu-baseline --secondary-steps 0 --steps 30 > "$0"/bench_student_nopipe.json 2>/dev/null' "$OUT"
 step bash -c 'python tools/bench_ops.py > "$0"/bench_ops.txt 2>&1' "$OUT"
 step bash -c 'python tools/experiments/op_count.py > "$0"/op_count.txt 2>&1' "$OUT"
 step bash -c 'bash tools/prof_step.sh student "$0"/prof_student > "$0"/prof_student.txt 2>&1' "$OUT"
@@ -22,6 +22,8 @@ step bash -c 'bash tools/fill_step.sh teacher "$0"/fill_teacher > "$0"/fill_teac
 step bash -c 'bash tools/prof_op.sh roi_bwd "$0"/prof_roi_bwd > "$0"/prof_roi_bwd.txt 2>&1' "$OUT"
 step bash -c 'bash tools/pmc_step.sh "$0"/pmc_teacher teacher > "$0"/pmc_teacher.log 2>&1' "$OUT"
 step bash -c 'bash tools/pmc_step.sh "$0"/pmc_student student > "$0"/pmc_student.log 2>&1' "$OUT"
+step bash -c 'bash tools/pmc_mfma.sh "$0"/pmc_mfma_student student > "$0"/pmc_mfma_student.log 2>&1' "$OUT"
+step bash -c 'bash tools/pmc_mfma.sh "$0"/pmc_mfma_teacher teacher > "$0"/pmc_mfma_teacher.log 2>&1' "$OUT"
 find $OUT -name "*kernel_trace.csv" -delete
 ls $OUT
 [ -z "$FAILED" ] || { echo "collect_round: steps that failed:$FAILED" >&2; exit 1; }

@@ -20,6 +20,7 @@ for v in "$@"; do
     dual3) build dual3 "-DOVIS_EPI_NBUF_DUAL=3" ;;
     nbuf4dual3) build nbuf4dual3 "-DOVIS_EPI_NBUF=4 -DOVIS_EPI_NBUF_DUAL=3" ;;
     base) build base "" ;;
+    *:*) build "${v%%:*}" "${v#*:}" ;;   # name:"compiler flags"
     *) echo "unknown variant $v"; exit 1 ;;
   esac
 done

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 WL=${1:-student}; OUT=${2:-gpurun_out/gap_$WL}
 case "$OUT" in /*) ;; *) OUT="$ROOT/$OUT";; esac   # relative paths are relative to the repository root, whatever the caller's cwd
 mkdir -p "$OUT"
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python bench.py --workload $WL --no-pipeline --no-cpu-baseline --steps 8 --warmup 3 --burn-seconds 1 > $OUT/bench.log 2>&1 || { echo "rocprofv3 / bench.py failed:"; tail -20 $OUT/bench.log; exit 1; }
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python bench.py --workload $WL --no-pipeline --no-cpu-baseline --secondary-steps 0 --steps 8 --warmup 3 --burn-seconds 1 > $OUT/bench.log 2>&1 || { echo "rocprofv3 / bench.py failed:"; tail -20 $OUT/bench.log; exit 1; }
 f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] || { echo "no *kernel_trace.csv under $OUT/trace"; tail -20 $OUT/bench.log; exit 1; }
 python tools/gap_report.py $f -250 -50 | cut -c1-170

@@ -20,7 +20,7 @@ for grp in "$P1" "$P2"; do
   i=$((i+1))
   [ -n "$grp" ] || continue
   rm -rf /tmp/pmcmfma_$i
-  timeout 900 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmcmfma_$i -o p -- python3 $ROOT/bench.py --workload $WL --steps 2 --warmup 2 --no-cpu-baseline --no-pipeline --burn-seconds 0 > /tmp/pmcmfma_$i.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmcmfma_$i -o p -- python3 $ROOT/bench.py --workload $WL --steps 2 --warmup 2 --no-cpu-baseline --no-pipeline --burn-seconds 0 --secondary-steps 0 > /tmp/pmcmfma_$i.log 2>&1
   f=$(find /tmp/pmcmfma_$i -name "*counter_collection.csv" | head -1)
   if [ -z "$f" ]; then echo "pass $i ($grp): no output"; tail -5 /tmp/pmcmfma_$i.log; continue; fi
   cp "$f" "$OUT/pass$i.csv"

@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $ROOT/$OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcstep_$c -o p -- python3 $ROOT/bench.py --workload $WL --steps 2 --warmup 2 --no-cpu-baseline --no-pipeline --burn-seconds 0 > /tmp/pmcstep_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcstep_$c -o p -- python3 $ROOT/bench.py --workload $WL --steps 2 --warmup 2 --no-cpu-baseline --no-pipeline --burn-seconds 0 --secondary-steps 0 > /tmp/pmcstep_$c.log 2>&1
   f=$(find /tmp/pmcstep_$c -name "*counter_collection.csv" | head -1)
   if [ -z "$f" ]; then echo "pass $c: no output"; tail -5 /tmp/pmcstep_$c.log; exit 1; fi
   cp $f $ROOT/$OUT/$c.csv

@@ -19,3 +19,7 @@ cpf $S/gap_student.txt $D/${P}_gap_report_student_nopipe.txt
 cpf $S/prof_roi_bwd/t_kernel_stats.csv $D/${P}_roi_bwd_kernel_stats.csv
 cpf $S/pmc_teacher/hbm_traffic_teacher.json $D/${P}_pmc_step_hbm_traffic_teacher.json
 cpf $S/pmc_student/hbm_traffic_student.json $D/${P}_pmc_step_hbm_traffic_student.json
+cpf $S/pmc_mfma_student/mfma_busy_student.json $D/${P}_pmc_mfma_busy_student.json
+cpf $S/pmc_mfma_teacher/mfma_busy_teacher.json $D/${P}_pmc_mfma_busy_teacher.json
+cpf $S/fill_student.txt $D/${P}_step_fill_report_student.txt
+cpf $S/fill_teacher.txt $D/${P}_step_fill_report_teacher.txt
