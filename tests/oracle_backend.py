@@ -1,7 +1,9 @@
-"""TEST-ONLY: lets the host-side model code run on CPU tensors by routing the native-op entry points
-of ``cvpr22_cross_modal_pseudo_labeling_amd._C`` to the CPU oracle.  The product package never does this
-(its ops raise on CPU tensors); tests use it to (a) exercise the Python plumbing without a GPU and
-(b) produce the CPU side of GPU-vs-oracle comparisons of whole-model steps."""
+"""TEST-ONLY: routes the native-op entry points of ``cvpr22_cross_modal_pseudo_labeling_amd._C`` to the CPU oracle for
+host tensors.  The product package never does this: a host tensor is served by its own in-package host code
+(``_cpu.py`` + ``libovis_cpu.so``, the reference's CPU-only configuration) or, for ops the reference has no host form of,
+refused with ``RuntimeError``; nothing in the package imports ``oracle/``.  Tests use this context (a) to produce the CPU
+side of GPU-vs-oracle comparisons of whole-model steps with the ORACLE's arithmetic and (b) to check the in-package host
+path against the oracle (tests/test_cpu_config.py)."""
 import contextlib
 
 import torch
