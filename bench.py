@@ -510,6 +510,10 @@ def parse_args(argv=None):
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = DRY RUN on the in-package host path")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL on cuda, gloo on cpu)")
     ap.add_argument("--tiny", action="store_true", help="DRY RUN size: 128x160 images, a few dozen RoIs")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="DRY RUN on a box with fewer GPUs than ranks: rank r runs on device r %% visible devices (RCCL refuses two "
+                         "ranks on one device, so this needs --backend gloo); exercises the DEVICE side of the N > 1 path -- "
+                         "streams, hooks, the pipelined trainer next to live collectives -- never a measurement")
     ap.add_argument("--fault-inject", default="", help=argparse.SUPPRESS)  # "RANK:STEP": that rank dies inside the timed region (tests)
     args = ap.parse_args(argv)
     return args
@@ -560,25 +564,28 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher environment says WORLD_SIZE={world}")
     on_gpu = args.device == "cuda"
-    dry_run = (not on_gpu) or args.tiny
+    dry_run = (not on_gpu) or args.tiny or args.share_gpu
+    if args.share_gpu and (args.backend or "nccl") == "nccl":
+        raise SystemExit("bench.py --share-gpu: RCCL does not place two ranks on one device; pass --backend gloo")
     if on_gpu:
         # counting devices does not initialise the GPU.  A launcher that exports LOCAL_WORLD_SIZE tells how many ranks share
         # this node; without it (older launchers, multi-node) only this rank's own device index can be checked.
-        need = int(os.environ["LOCAL_WORLD_SIZE"]) if "LOCAL_WORLD_SIZE" in os.environ else local_rank + 1
+        need = 1 if args.share_gpu else int(os.environ["LOCAL_WORLD_SIZE"]) if "LOCAL_WORLD_SIZE" in os.environ else local_rank + 1
         if torch.cuda.device_count() < need:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node")
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback (--device cpu is the dry run "
                              "of the multi-rank control flow on the CPU-only configuration, not a fallback)")
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
+        index = local_rank % torch.cuda.device_count() if args.share_gpu else local_rank
+        torch.cuda.set_device(index)
+        dev = torch.device("cuda", index)
     else:
         dev = torch.device("cpu")
         torch.set_num_threads(max(1, int(os.environ.get("OMP_NUM_THREADS", "2"))))
     backend = args.backend or ("nccl" if on_gpu else "gloo")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if on_gpu:
+        if on_gpu and backend == "nccl":
             dist.init_process_group(backend, init_method="env://", device_id=dev)
         else:
             dist.init_process_group(backend, init_method="env://")
@@ -670,8 +677,9 @@ def main():
         elapsed = float(t.item())
         # every rank's own view of the region: its wall time, its step count, how long its finish() stalled on the
         # collectives per step (the exposed part of the exchange) and how many buckets its backward hooks issued
+        gdev = dev if backend == "nccl" else torch.device("cpu")  # (gloo gathers host tensors only)
         mine = torch.tensor([own_elapsed, float(args.steps), sum(waits) / max(len(waits), 1), max(waits, default=0.0),
-                             float(hook_launches)], device=dev, dtype=torch.float64)
+                             float(hook_launches)], device=gdev, dtype=torch.float64)
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
         per_rank = [{"rank": r, "elapsed_s": round(float(g[0]), 4), "steps": int(g[1]),

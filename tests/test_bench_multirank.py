@@ -11,6 +11,8 @@ import socket
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
@@ -84,3 +86,25 @@ def test_bench_flag_mismatch_and_missing_gpu_are_refused_with_reasons():
     assert res.returncode != 0 and "WORLD_SIZE=2" in res.stderr
     res = subprocess.run([sys.executable, BENCH, "--steps", "1"], capture_output=True, text=True, env=_env(), timeout=300)
     assert res.returncode != 0 and ("GPU" in res.stderr or "MI355X" in res.stderr)  # no CPU fallback of the measured path
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_sharing_the_gpu_over_gloo_device_side_dry_run():
+    """The DEVICE side of the N > 1 path on a one-GPU box: two ranks on the same MI355X (``--share-gpu``; RCCL refuses that, so the
+    collectives go over gloo), HIP ops, two-stream pipelined trainer with its worker thread next to live all-reduces issued from
+    backward hooks, event-timed exposed wait, replay, secondary region.  What stays unexecuted without a multi-GPU node: RCCL itself
+    (``ReduceOp.AVG``, ``device_id`` init)."""
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--share-gpu", "--tiny", "--steps", "4", "--warmup", "2",
+                          "--secondary-steps", "2", "--burn-seconds", "0", "--no-cpu-baseline"], capture_output=True, text=True,
+                         env=_env(), timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = _json_lines(res.stdout)
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["device"] == "cuda" and d["backend"] == "gloo" and d["n_gpus"] == 2 and d["rccl_ranks"] == 2
+    assert d["config"]["pipelined"] is True and d["config"]["losses_finite"] is True and d["config"]["global_batch"] == 4
+    assert d["allreduce"]["issued_from_backward_hooks"] == d["allreduce"]["buckets"] >= 3
+    assert all(r["issued_from_backward_hooks"] == d["allreduce"]["buckets"] and r["steps"] == d["steps"] for r in d["ranks"])
+    assert d["allreduce"]["exposed_wait_ms_per_step"] > 0 and d["replay_steps"] >= 3
+    assert d["roofline"] is not None and d["kernels"]  # the HIP ops ran: per-kernel figures from the replay
+    assert d["secondary"]["losses_finite"] is True and d["secondary"]["images_per_s"] > 0
