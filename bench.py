@@ -554,6 +554,40 @@ def build_workload(args, workload, dev, world, rank):
     return name, model, images, targets, reducer, pipe
 
 
+def run_secondary(args, dev, world, rank, on_gpu, timer, sync):
+    """A short timed region of the teacher configuration (zeroshot_mask.yaml, BASELINE config 2) after the student one: same
+    protocol (warm-up, barrier + synchronize on both sides, MAX over ranks).  Returns the `secondary` object (rank 0) or None."""
+    secondary = None
+    name2, model2, images2, targets2, reducer2, pipe2 = build_workload(args, "teacher", dev, world, rank)
+    for _ in range(3):
+        pipe2.step(images2, targets2, None)
+    sync()
+    timer.enabled = on_gpu
+    t0 = time.perf_counter()
+    for _ in range(args.secondary_steps):
+        loss2 = pipe2.step(images2, targets2, None)
+    sync()
+    el2 = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([el2], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el2 = float(t.item())
+    if rank == 0:
+        k2 = timer.summary()
+        secondary = {"workload": (f"{name2}.yaml R-50-C4 teacher, {IMS_PER_GPU} img/GPU "
+                                  f"{'3x128x160 TINY' if args.tiny else '3x800x1333'}, fwd+bwd+allreduce+SGD"),
+                     "steps": args.secondary_steps, "warmup": 3, "ms_per_step": round(1e3 * el2 / args.secondary_steps, 3),
+                     "images_per_s": round(IMS_PER_GPU * world * args.secondary_steps / el2, 3),
+                     "losses_finite": all(bool(torch.isfinite(v).all()) for v in loss2.values()),
+                     "allreduce_payload_MB": round(sum(f.numel() * f.element_size() for f in reducer2.flat) / 1e6, 1),
+                     "kernels": {n: {kk: round(vv, 3) if isinstance(vv, float) else vv for kk, vv in k2[n].items()}
+                                 for n in ("roi_align_backward_strided", "roi_align_forward_strided_nhwc", "split_gemm_pair",
+                                           "split_gemm_pair_gated", "split_gemm_pair_tn", "nms_presorted_batched") if n in k2}}
+    del pipe2, reducer2, model2
+    return secondary
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -701,33 +735,12 @@ def main():
         del pipe, reducer, model
         if on_gpu:
             torch.cuda.empty_cache()
-        name2, model2, images2, targets2, reducer2, pipe2 = build_workload(args, "teacher", dev, world, rank)
-        for _ in range(3):
-            pipe2.step(images2, targets2, None)
-        sync()
-        timer.enabled = on_gpu
-        t0 = time.perf_counter()
-        for _ in range(args.secondary_steps):
-            loss2 = pipe2.step(images2, targets2, None)
-        sync()
-        el2 = time.perf_counter() - t0
-        timer.enabled = False
-        if world > 1:
-            t = torch.tensor([el2], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el2 = float(t.item())
-        if rank == 0:
-            k2 = timer.summary()
-            secondary = {"workload": (f"{name2}.yaml R-50-C4 teacher, {IMS_PER_GPU} img/GPU "
-                                      f"{'3x128x160 TINY' if args.tiny else '3x800x1333'}, fwd+bwd+allreduce+SGD"),
-                         "steps": args.secondary_steps, "warmup": 3, "ms_per_step": round(1e3 * el2 / args.secondary_steps, 3),
-                         "images_per_s": round(IMS_PER_GPU * world * args.secondary_steps / el2, 3),
-                         "losses_finite": all(bool(torch.isfinite(v).all()) for v in loss2.values()),
-                         "allreduce_payload_MB": round(sum(f.numel() * f.element_size() for f in reducer2.flat) / 1e6, 1),
-                         "kernels": {n: {kk: round(vv, 3) if isinstance(vv, float) else vv for kk, vv in k2[n].items()}
-                                     for n in ("roi_align_backward_strided", "roi_align_forward_strided_nhwc", "split_gemm_pair",
-                                               "split_gemm_pair_gated", "split_gemm_pair_tn", "nms_presorted_batched") if n in k2}}
-        del pipe2, reducer2, model2
+        try:  # the headline above is complete: a failure in here must not take the line with it
+            secondary = run_secondary(args, dev, world, rank, on_gpu, timer, sync)
+        except Exception as e:  # noqa: BLE001 -- reported in the line
+            if world > 1:
+                raise  # a rank that fell out of the collectives' order cannot carry on
+            secondary = {"error": f"{type(e).__name__}: {e}"[:400]}
     else:
         kernels_primary = timer.summary() if rank == 0 else None
 

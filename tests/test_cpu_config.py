@@ -239,3 +239,61 @@ def test_config0_teacher_on_cpu_inference_returns_detections():
         assert det.bbox.shape[1] == 4 and not det.bbox.is_cuda
         assert det.has_field("scores") and det.has_field("labels")
         assert bool(torch.isfinite(det.bbox).all())
+
+
+def test_config0_variants_linear_classifier_per_class_boxes_and_masks_on_cpu():
+    """The configuration variants of round 4 on the HOST path (MODEL.DEVICE cpu): ``EMBEDDING_BASED False`` (a learned Linear over
+    NUM_CLASSES, roi_box_predictors.py:33-40), per-class box deltas (box_head/loss.py:156-160) and class-specific mask logits
+    (mask_head/loss.py:131-141: one logit channel per positive through the same fused loss entry point) -- the product's host code
+    against the same step with every native entry point routed to the oracle; eval-mode inference returns masks."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm, solver, trainer
+    from cvpr22_cross_modal_pseudo_labeling_amd.data.synthetic import make_batch
+
+    extra = ["MODEL.ROI_BOX_HEAD.EMBEDDING_BASED", False, "MODEL.ROI_BOX_HEAD.NUM_CLASSES", 9, "MODEL.CLS_AGNOSTIC_BBOX_REG", False,
+             "MODEL.CLS_AGNOSTIC_MASK", False]
+    results = []
+    for use_oracle in (False, True):
+        torch.manual_seed(0)
+        from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+        from cvpr22_cross_modal_pseudo_labeling_amd.data.synthetic import calibrate_stem_bn
+        from cvpr22_cross_modal_pseudo_labeling_amd.modeling.detector import build_detection_model
+
+        cfg = get_defaults()
+        cfg.merge_from_file(os.path.join(ROOT, "configs/coco_cap_det/zeroshot_mask.yaml"))
+        cfg.merge_from_list(["MODEL.DEVICE", "cpu", "MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 300, "MODEL.RPN.POST_NMS_TOP_N_TRAIN", 60,
+                             "MODEL.RPN.PRE_NMS_TOP_N_TEST", 200, "MODEL.RPN.POST_NMS_TOP_N_TEST", 40,
+                             "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 16, "SOLVER.BASE_LR", 1e-5] + extra)
+        cfg.freeze()
+        model = build_detection_model(cfg)
+        pred = model.roi_heads["box"].predictor
+        assert pred.cls_score.weight.shape == (9, 2048) and pred.bbox_pred.weight.shape == (36, 2048)
+        with pytest.raises(RuntimeError):
+            model.set_class_embeddings(torch.zeros(9, 768))  # no embedding head to set
+        images, targets = make_batch(2, height=128, width=160, num_gt=3, num_nouns=2, n_vocab=50, n_seen=9)
+        calibrate_stem_bn(model, images)
+        with torch.no_grad():
+            pred.cls_score.weight.mul_(30.0)
+            pred.bbox_pred.weight.mul_(30.0)
+        model.train()
+        opt = solver.make_optimizer(cfg, model)
+        red = comm.BucketedGradReducer(model)
+        torch.manual_seed(11)
+        if use_oracle:
+            with oracle_ops():
+                losses = trainer.train_step(model, opt, red, images, targets)
+        else:
+            losses = trainer.train_step(model, opt, red, images, targets)
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        red.remove()
+        results.append(({k: float(v) for k, v in losses.items()}, grads, model, images))
+    (la, ga, model, images), (lb, gb, _, _) = results
+    for k in la:
+        assert np.isfinite(la[k]) and abs(la[k] - lb[k]) <= 1e-5 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+    for n in ga:
+        assert torch.allclose(ga[n], gb[n], rtol=1e-3, atol=1e-7), n
+    gm = ga["roi_heads.mask.predictor.mask_fcn_logits.weight"].flatten(1).abs().sum(1)
+    assert float(gm[0]) == 0.0 and int((gm > 0).sum()) >= 2  # only the logit channels of the positives' classes train
+    model.eval()
+    with torch.no_grad():
+        det = model(images)
+    assert len(det) == 2 and all(d.has_field("mask") and d.has_field("labels") for d in det)
