@@ -1088,6 +1088,8 @@ def text_embed(table, input_ids, special_tokens_mask):
     """Word embeddings of tokenised strings (``ovis_text_embed_f32``; language_backbone/transformers.py:27-68 +
     st_generalized_rcnn.py:202-209): table [V, D] float32, input_ids / special_tokens_mask [N, L] integer tensors as the
     tokenizer pads them -> [N, D] unit-norm rows (masked mean of the table rows, then F.normalize)."""
+    if not table.is_cuda:  # MODEL.DEVICE cpu: the reference's tensor-op formula on host tensors
+        return _cpu.text_embed(table.detach(), input_ids.to(torch.int64), special_tokens_mask.to(torch.int64))
     table = _dev(table, "table")
     if table.dim() != 2 or input_ids.dim() != 2 or input_ids.shape != special_tokens_mask.shape:
         raise RuntimeError("text_embed: expected table [V, D] and input_ids / special_tokens_mask [N, L]")
@@ -1110,6 +1112,8 @@ def project_polygon_masks(coords, polygon_start, instance_start, gt_index, boxes
     mask_head/loss.py:11-42 through PolygonInstance.crop / resize / convert_to_binarymask, segmentation_mask.py:270-334).
     coords float32 [T] (x, y pairs of all polygons), polygon_start int32 [NP + 1] (float offsets), instance_start int32
     [G + 1] (polygon ranges), gt_index [P] int64, image_size = (width, height)."""
+    if not boxes.is_cuda:
+        return _cpu.project_polygon_masks(coords, polygon_start, instance_start, gt_index, boxes, image_size, resolution)
     boxes = _dev(boxes, "boxes")
     coords = _dev(coords, "coords") if coords.numel() else coords
     polygon_start = _dev(polygon_start, "polygon_start", torch.int32)

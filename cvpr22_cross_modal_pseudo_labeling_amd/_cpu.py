@@ -19,6 +19,7 @@ SIGNATURES = {
     "ovis_cpu_roi_align_forward_f32": (_i, [_vp, _vp, _vp] + [_i] * 7 + [_f, _i, _i]),
     "ovis_cpu_roi_align_backward_f32": (_i, [_vp, _vp, _vp] + [_i] * 7 + [_f, _i, _i]),
     "ovis_cpu_nms_f32": (_i, [_vp, _vp, _i, _f, _vp]),
+    "ovis_cpu_project_polygon_masks_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i]),
     "ovis_cpu_version": (ctypes.c_char_p, []),
 }
 _lib = None
@@ -144,3 +145,26 @@ def mask_bce_stochastic_fwd_bwd(mu, sigma, eps, pos_index, targets, channel, nee
         dsigma = torch.zeros_like(sigma)
         dsigma.index_put_((pos_index, torch.zeros_like(pos_index)), dsel * eps[pos_index, channel], accumulate=True)
     return loss, dmu, dsigma
+
+
+# ---- mask_head/loss.py:11-42 for polygon targets (segmentation_mask.py:270-334 + pycocotools' rasteriser) ----------------------
+def project_polygon_masks(coords, polygon_start, instance_start, gt_index, boxes, image_size, resolution):
+    boxes = _host(boxes, "boxes")
+    coords = _host(coords, "coords") if coords.numel() else coords
+    polygon_start, instance_start = _host(polygon_start, "polygon_start", torch.int32), _host(instance_start, "instance_start", torch.int32)
+    gt_index = _host(gt_index, "gt_index", torch.int64)
+    p = boxes.shape[0]
+    out = torch.empty((p, resolution, resolution), dtype=torch.float32)
+    if p:
+        _check(load().ovis_cpu_project_polygon_masks_f32(coords.data_ptr() if coords.numel() else 0, polygon_start.data_ptr(),
+                                                        instance_start.data_ptr(), gt_index.data_ptr(), boxes.data_ptr(), p,
+                                                        int(image_size[0]), int(image_size[1]), int(resolution), out.data_ptr(), 0),
+               "project_polygon_masks")
+    return out
+
+
+# ---- st_generalized_rcnn.py:202-209 (extract_emb) on host tensors: the reference's own tensor-op formula -----------------------
+def text_embed(table, input_ids, special_tokens_mask):
+    keep = (1 - special_tokens_mask).to(torch.float32)
+    emb = (table[input_ids] * keep[:, :, None]).sum(1) / keep.sum(1)[:, None]
+    return F.normalize(emb, dim=-1)

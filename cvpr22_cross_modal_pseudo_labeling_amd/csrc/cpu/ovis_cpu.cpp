@@ -204,4 +204,91 @@ extern "C" int ovis_cpu_nms_f32(const float* boxes, const float* scores, int num
   return n;
 }
 
-extern "C" const char* ovis_cpu_version(void) { return "ovis_cpu 1 (RoIAlign fwd/bwd, NMS; fp32, OpenMP)"; }
+// ---- polygon ground truth -> M x M mask targets (mask_head/loss.py:11-42 on SegmentationMask(mode='poly') targets) ------------
+// PolygonInstance.crop (segmentation_mask.py:270-296: python-float clamps of the box) -> resize (:298-324: float32 tensor x
+// python scalar) -> convert_to_binarymask (:326-334: pycocotools.mask.frPyObjects -> merge -> decode; pycocotools==2.0,
+// common/maskApi.c rleFrPoly / rleMerge / rleDecode -- a third-party dependency outside /root/reference, its published
+// algorithm followed here as in csrc/polygons.hip).  Host form: one positive at a time, a dense walk of every edge on the
+// x5 grid; a boundary point TOGGLES its column-major position and the decoded mask is the running parity of the toggles
+// (equal positions cancel, as equal run boundaries do in the RLE) -- no sort, no run lengths.
+static inline void edge_point(int xs, int ys, int xe, int ye, int d, int& u, int& v) {
+  const int dx = std::abs(xe - xs), dy = std::abs(ys - ye);
+  const bool flip = (dx >= dy && xs > xe) || (dx < dy && ys > ye);
+  if (flip) { std::swap(xs, xe); std::swap(ys, ye); }
+  if (dx >= dy) {
+    const int t = flip ? dx - d : d;
+    u = t + xs;
+    v = dx == 0 ? ys : (int)(ys + ((double)(ye - ys) / dx) * t + .5);
+  } else {
+    const int t = flip ? dy - d : d;
+    v = t + ys;
+    u = (int)(xs + ((double)(xe - xs) / dy) * t + .5);
+  }
+}
+
+extern "C" int ovis_cpu_project_polygon_masks_f32(const float* coords, const int32_t* polygon_start, const int32_t* instance_start,
+                                                  const int64_t* gt_index, const float* boxes, int num, int image_width,
+                                                  int image_height, int resolution, float* out, int threads) {
+  if (num < 0 || resolution <= 0 || image_width <= 0 || image_height <= 0) return OVIS_CPU_EINVAL;
+  if (num == 0) return OVIS_CPU_OK;
+  if (!polygon_start || !instance_start || !gt_index || !boxes || !out) return OVIS_CPU_EINVAL;
+  const int M = resolution, npos = M * M;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic)
+#endif
+  for (int p = 0; p < num; ++p) {
+    std::vector<int> toggles(npos + 1);
+    std::vector<char> acc(npos, 0);
+    double xmin = boxes[4 * (size_t)p], ymin = boxes[4 * (size_t)p + 1], xmax = boxes[4 * (size_t)p + 2], ymax = boxes[4 * (size_t)p + 3];
+    xmin = std::min(std::max(xmin, 0.0), (double)(image_width - 1));
+    ymin = std::min(std::max(ymin, 0.0), (double)(image_height - 1));
+    xmax = std::min(std::max(xmax, 0.0), (double)image_width);
+    ymax = std::min(std::max(ymax, 0.0), (double)image_height);
+    xmax = std::max(xmax, xmin + 1.0);
+    ymax = std::max(ymax, ymin + 1.0);
+    const float fxmin = (float)xmin, fymin = (float)ymin;
+    const float rw = (float)((double)M / (xmax - xmin)), rh = (float)((double)M / (ymax - ymin));
+    const int64_t g = gt_index[p];
+    for (int poly = instance_start[g]; poly < instance_start[g + 1]; ++poly) {
+      const int c0 = polygon_start[poly], k = (polygon_start[poly + 1] - c0) / 2;
+      if (k < 3) continue;  // PolygonInstance.__init__ drops polygons with fewer than 6 numbers
+      std::fill(toggles.begin(), toggles.end(), 0);
+      for (int j = 0; j < k; ++j) {
+        const int jn = j + 1 == k ? 0 : j + 1;
+        const float ax = (coords[c0 + 2 * j] - fxmin) * rw, ay = (coords[c0 + 2 * j + 1] - fymin) * rh;
+        const float bx = (coords[c0 + 2 * jn] - fxmin) * rw, by = (coords[c0 + 2 * jn + 1] - fymin) * rh;
+        const int xs = (int)(5.0 * (double)ax + .5), ys = (int)(5.0 * (double)ay + .5);
+        const int xe = (int)(5.0 * (double)bx + .5), ye = (int)(5.0 * (double)by + .5);
+        const int steps = std::max(std::abs(xe - xs), std::abs(ye - ys));
+        int u0, v0;
+        edge_point(xs, ys, xe, ye, 0, u0, v0);
+        for (int d = 1; d <= steps; ++d) {
+          int u1, v1;
+          edge_point(xs, ys, xe, ye, d, u1, v1);
+          if (u1 != u0) {
+            double xd = ((double)(u1 < u0 ? u1 : u1 - 1) + .5) / 5.0 - .5;
+            if (std::floor(xd) == xd && xd >= 0 && xd <= M - 1) {
+              double yd = ((double)std::min(v1, v0) + .5) / 5.0 - .5;
+              yd = std::ceil(yd < 0 ? 0.0 : (yd > M ? (double)M : yd));
+              toggles[(int)xd * M + (int)yd] ^= 1;
+            }
+          }
+          u0 = u1;
+          v0 = v1;
+        }
+      }
+      int parity = 0;
+      for (int i = 0; i < npos; ++i) {
+        parity ^= toggles[i];
+        if (parity) acc[i] = 1;  // union over the instance's polygons (rleMerge, intersect = 0)
+      }
+    }
+    float* o = out + (size_t)p * npos;  // out[p][y][x]; positions are column-major (x * M + y), as the RLE counts
+    for (int y = 0; y < M; ++y)
+      for (int x = 0; x < M; ++x) o[y * M + x] = (float)acc[x * M + y];
+  }
+  return OVIS_CPU_OK;
+}
+
+extern "C" const char* ovis_cpu_version(void) { return "ovis_cpu 2 (RoIAlign fwd/bwd, NMS, polygon mask targets; fp32, OpenMP)"; }

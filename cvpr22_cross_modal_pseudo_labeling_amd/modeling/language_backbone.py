@@ -105,9 +105,7 @@ class BERT(nn.Module):
         if hit is not None:
             self._cache[key] = self._cache.pop(key)  # most recently used last
             return hit
-        if not table.is_cuda:
-            raise RuntimeError("BERT.extract_emb: the table must be on the HIP device (the product path has no CPU fallback)")
-        enc = self.tokenize(words)
+        enc = self.tokenize(words)  # (host table, MODEL.DEVICE cpu: _C.text_embed dispatches to the in-package host formula)
         emb = _C.text_embed(table.detach(), enc["input_ids"], enc["special_tokens_mask"])
         # keyed by the strings: the per-image noun lists of a step must not evict the 1203-name vocabulary entry (the
         # reference re-tokenises it every iteration, st_generalized_rcnn.py:190-191).  A new table version drops everything.

@@ -592,7 +592,7 @@ class MaskRCNNLossComputation:
             return _C.project_pasted_masks(gt_masks.probs, gt_masks.boxes, gt_index, boxes, gt_masks.image_size, m,
                                            gt_masks.threshold)
         if isinstance(gt_masks, PolygonMasks):  # COCO polygon ground truth (SegmentationMask mode 'poly')
-            if not gt_masks.coords.is_cuda:
+            if gt_masks.coords.device != boxes.device:
                 gt_masks = gt_masks.to(boxes.device)
             return _C.project_polygon_masks(gt_masks.coords, gt_masks.polygon_start, gt_masks.instance_start, gt_index, boxes,
                                             gt_masks.size, m)

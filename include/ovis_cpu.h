@@ -38,6 +38,15 @@ int ovis_cpu_roi_align_backward_f32(const float* grad_out, const float* rois, fl
  * survivors; returns their number (< 0: bad argument). */
 int ovis_cpu_nms_f32(const float* boxes, const float* scores, int num_boxes, float threshold, int64_t* keep);
 
+/* Polygon ground truth -> mask targets: project_masks_on_boxes (mb/modeling/roi_heads/mask_head/loss.py:11-42) for
+ * SegmentationMask(mode='poly') -- PolygonInstance.crop / resize / convert_to_binarymask (mb/structures/segmentation_mask.py:270-334,
+ * pycocotools==2.0 rleFrPoly + merge + decode).  Host twin of ovis_project_polygon_masks_f32 (include/ovis_hip.h): coords float32
+ * (x, y pairs of all polygons), polygon_start int32 [NP + 1] (float offsets), instance_start int32 [G + 1] (polygon ranges),
+ * gt_index [num] int64, boxes [num, 4]; out [num, M, M] (1.0 inside). */
+int ovis_cpu_project_polygon_masks_f32(const float* coords, const int32_t* polygon_start, const int32_t* instance_start,
+                                       const int64_t* gt_index, const float* boxes, int num, int image_width, int image_height,
+                                       int resolution, float* out, int threads);
+
 const char* ovis_cpu_version(void);
 
 #ifdef __cplusplus
