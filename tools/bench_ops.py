@@ -54,6 +54,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ops", default="roi_fwd,roi_bwd,nms,focal,gemm,dcn,res5,split_gemm")
     ap.add_argument("--lib", default="", help="path of an experiment build of libovis_hip.so (handled before the import)")
+    ap.add_argument("--roi-kinds", default="uniform,rpn_like", help="RoI distributions of the RoIAlign micro-benchmarks")
     ap.add_argument("--iters", type=int, default=20)
     args = ap.parse_args()
     ops = args.ops.split(",")
@@ -63,7 +64,7 @@ def main():
     if "roi_fwd" in ops or "roi_bwd" in ops:
         n, c, h, w, r = 2, 1024, 50, 84, 1024
         x = torch.randn(n, c, h, w, generator=g).to(dev)
-        for kind in ("uniform", "rpn_like"):
+        for kind in args.roi_kinds.split(","):
             rois = bench_rois(r, n, g, kind).to(dev)
             alg = 4 * r * c * 196 + 4 * n * c * h * w + 20 * r
             if "roi_fwd" in ops:
