@@ -21,10 +21,18 @@ from cvpr22_cross_modal_pseudo_labeling_amd import _C  # noqa: E402
 HBM_PEAK_GBS = 8000.0
 
 
-def timeit(fn, iters, warmup=3):
+def timeit(fn, iters, warmup=3, warm_seconds=0.3):
+    """Mean ms per call over `iters` launches after the GPU has been kept busy with the same op for `warm_seconds` (an idle part
+    needs a few hundred ms of load to reach its sustained clock: 20 launches from idle read 4-20 % slow, box dependent)."""
+    import time
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < warm_seconds:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
