@@ -20,6 +20,7 @@ SIGNATURES = {
     "ovis_cpu_roi_align_backward_f32": (_i, [_vp, _vp, _vp] + [_i] * 7 + [_f, _i, _i]),
     "ovis_cpu_nms_f32": (_i, [_vp, _vp, _i, _f, _vp]),
     "ovis_cpu_project_polygon_masks_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i]),
+    "ovis_cpu_polygons_to_masks_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i]),
     "ovis_cpu_version": (ctypes.c_char_p, []),
 }
 _lib = None
@@ -160,6 +161,19 @@ def project_polygon_masks(coords, polygon_start, instance_start, gt_index, boxes
                                                         instance_start.data_ptr(), gt_index.data_ptr(), boxes.data_ptr(), p,
                                                         int(image_size[0]), int(image_size[1]), int(resolution), out.data_ptr(), 0),
                "project_polygon_masks")
+    return out
+
+
+def polygons_to_masks(coords, polygon_start, instance_start, image_size):
+    """uint8 [G, height, width] whole-image masks of the G polygon instances (segmentation_mask.py:326-334)."""
+    coords = _host(coords, "coords") if coords.numel() else coords
+    polygon_start, instance_start = _host(polygon_start, "polygon_start", torch.int32), _host(instance_start, "instance_start", torch.int32)
+    g = instance_start.numel() - 1
+    w, h = int(image_size[0]), int(image_size[1])
+    out = torch.empty((g, h, w), dtype=torch.uint8)
+    if g:
+        _check(load().ovis_cpu_polygons_to_masks_u8(coords.data_ptr() if coords.numel() else 0, polygon_start.data_ptr(),
+                                                   instance_start.data_ptr(), g, w, h, out.data_ptr(), 0), "polygons_to_masks")
     return out
 
 

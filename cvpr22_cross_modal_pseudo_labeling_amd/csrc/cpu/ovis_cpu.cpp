@@ -226,6 +226,69 @@ static inline void edge_point(int xs, int ys, int xe, int ye, int d, int& u, int
   }
 }
 
+// Walks the closed polygon whose x5-grid vertices are (xs[j], ys[j]) and toggles the column-major position of every boundary point
+// (rleFrPoly steps 2-4) on a w x h grid: toggles has w * h + 1 entries.
+static void toggle_boundary(const std::vector<int>& xs, const std::vector<int>& ys, int w, int h, std::vector<int>& toggles) {
+  const int k = (int)xs.size();
+  for (int j = 0; j < k; ++j) {
+    const int jn = j + 1 == k ? 0 : j + 1;
+    const int steps = std::max(std::abs(xs[jn] - xs[j]), std::abs(ys[jn] - ys[j]));
+    int u0, v0;
+    edge_point(xs[j], ys[j], xs[jn], ys[jn], 0, u0, v0);
+    for (int d = 1; d <= steps; ++d) {
+      int u1, v1;
+      edge_point(xs[j], ys[j], xs[jn], ys[jn], d, u1, v1);
+      if (u1 != u0) {
+        const double xd = ((double)(u1 < u0 ? u1 : u1 - 1) + .5) / 5.0 - .5;
+        if (std::floor(xd) == xd && xd >= 0 && xd <= w - 1) {
+          double yd = ((double)std::min(v1, v0) + .5) / 5.0 - .5;
+          yd = std::ceil(yd < 0 ? 0.0 : (yd > h ? (double)h : yd));
+          toggles[(size_t)xd * h + (size_t)yd] ^= 1;
+        }
+      }
+      u0 = u1;
+      v0 = v1;
+    }
+  }
+}
+
+// Whole-image masks of polygon instances: SegmentationMask(mode='poly').convert('mask') (mb/structures/segmentation_mask.py:326-334:
+// frPyObjects -> merge -> decode at the image size, no crop / resize).  out [num_instances, height, width] uint8.
+extern "C" int ovis_cpu_polygons_to_masks_u8(const float* coords, const int32_t* polygon_start, const int32_t* instance_start,
+                                             int num_instances, int width, int height, uint8_t* out, int threads) {
+  if (num_instances < 0 || width <= 0 || height <= 0) return OVIS_CPU_EINVAL;
+  if (num_instances == 0) return OVIS_CPU_OK;
+  if (!polygon_start || !instance_start || !out) return OVIS_CPU_EINVAL;
+  const size_t npos = (size_t)width * height;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic)
+#endif
+  for (int g = 0; g < num_instances; ++g) {
+    std::vector<int> toggles(npos + 1);
+    uint8_t* o = out + (size_t)g * npos;
+    std::memset(o, 0, npos);
+    for (int poly = instance_start[g]; poly < instance_start[g + 1]; ++poly) {
+      const int c0 = polygon_start[poly], k = (polygon_start[poly + 1] - c0) / 2;
+      if (k < 3) continue;
+      std::fill(toggles.begin(), toggles.end(), 0);
+      std::vector<int> xs(k), ys(k);
+      for (int j = 0; j < k; ++j) {  // _mask.pyx hands the coordinates over as doubles: float32 -> double is exact
+        xs[j] = (int)(5.0 * (double)coords[c0 + 2 * j] + .5);
+        ys[j] = (int)(5.0 * (double)coords[c0 + 2 * j + 1] + .5);
+      }
+      toggle_boundary(xs, ys, width, height, toggles);
+      int parity = 0;
+      for (int x = 0; x < width; ++x)
+        for (int y = 0; y < height; ++y) {
+          parity ^= toggles[(size_t)x * height + y];
+          if (parity) o[(size_t)y * width + x] = 1;
+        }
+    }
+  }
+  return OVIS_CPU_OK;
+}
+
 extern "C" int ovis_cpu_project_polygon_masks_f32(const float* coords, const int32_t* polygon_start, const int32_t* instance_start,
                                                   const int64_t* gt_index, const float* boxes, int num, int image_width,
                                                   int image_height, int resolution, float* out, int threads) {
@@ -254,30 +317,13 @@ extern "C" int ovis_cpu_project_polygon_masks_f32(const float* coords, const int
       const int c0 = polygon_start[poly], k = (polygon_start[poly + 1] - c0) / 2;
       if (k < 3) continue;  // PolygonInstance.__init__ drops polygons with fewer than 6 numbers
       std::fill(toggles.begin(), toggles.end(), 0);
-      for (int j = 0; j < k; ++j) {
-        const int jn = j + 1 == k ? 0 : j + 1;
+      std::vector<int> xs(k), ys(k);
+      for (int j = 0; j < k; ++j) {  // crop + resize in float32, then rleFrPoly's scale-by-5 rounding in double
         const float ax = (coords[c0 + 2 * j] - fxmin) * rw, ay = (coords[c0 + 2 * j + 1] - fymin) * rh;
-        const float bx = (coords[c0 + 2 * jn] - fxmin) * rw, by = (coords[c0 + 2 * jn + 1] - fymin) * rh;
-        const int xs = (int)(5.0 * (double)ax + .5), ys = (int)(5.0 * (double)ay + .5);
-        const int xe = (int)(5.0 * (double)bx + .5), ye = (int)(5.0 * (double)by + .5);
-        const int steps = std::max(std::abs(xe - xs), std::abs(ye - ys));
-        int u0, v0;
-        edge_point(xs, ys, xe, ye, 0, u0, v0);
-        for (int d = 1; d <= steps; ++d) {
-          int u1, v1;
-          edge_point(xs, ys, xe, ye, d, u1, v1);
-          if (u1 != u0) {
-            double xd = ((double)(u1 < u0 ? u1 : u1 - 1) + .5) / 5.0 - .5;
-            if (std::floor(xd) == xd && xd >= 0 && xd <= M - 1) {
-              double yd = ((double)std::min(v1, v0) + .5) / 5.0 - .5;
-              yd = std::ceil(yd < 0 ? 0.0 : (yd > M ? (double)M : yd));
-              toggles[(int)xd * M + (int)yd] ^= 1;
-            }
-          }
-          u0 = u1;
-          v0 = v1;
-        }
+        xs[j] = (int)(5.0 * (double)ax + .5);
+        ys[j] = (int)(5.0 * (double)ay + .5);
       }
+      toggle_boundary(xs, ys, M, M, toggles);
       int parity = 0;
       for (int i = 0; i < npos; ++i) {
         parity ^= toggles[i];
@@ -291,4 +337,4 @@ extern "C" int ovis_cpu_project_polygon_masks_f32(const float* coords, const int
   return OVIS_CPU_OK;
 }
 
-extern "C" const char* ovis_cpu_version(void) { return "ovis_cpu 2 (RoIAlign fwd/bwd, NMS, polygon mask targets; fp32, OpenMP)"; }
+extern "C" const char* ovis_cpu_version(void) { return "ovis_cpu 3 (RoIAlign fwd/bwd, NMS, polygon masks and mask targets; fp32, OpenMP)"; }

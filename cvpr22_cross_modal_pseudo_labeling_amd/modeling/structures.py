@@ -184,9 +184,13 @@ class PolygonMasks:
         from .. import _C
         w, h = self.size
         g = len(self)
-        if max(w, h) > 64 or not self.coords.is_cuda:
-            raise NotImplementedError("whole-image rasterisation is only wired for device polygons on maps up to 64 x 64; "
-                                      "the training path rasterises per positive at the mask resolution")
+        if not self.coords.is_cuda:  # host polygons (dataset side, MODEL.DEVICE cpu): any image size, libovis_cpu.so
+            from .. import _cpu
+            return _cpu.polygons_to_masks(self.coords, self.polygon_start, self.instance_start, self.size)
+        if max(w, h) > 64:
+            raise NotImplementedError("whole-image rasterisation of DEVICE polygons is wired for maps up to 64 x 64 (the training "
+                                      "path rasterises per positive at the mask resolution); convert on the host: "
+                                      "``masks.to('cpu').convert_to_binarymask()``")
         if w != h:
             raise NotImplementedError("square maps only (crop + resize to M x M is the training path)")
         boxes = torch.tensor([[0.0, 0.0, float(w), float(h)]], device=self.coords.device).expand(g, 4).contiguous()

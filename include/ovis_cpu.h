@@ -47,6 +47,11 @@ int ovis_cpu_project_polygon_masks_f32(const float* coords, const int32_t* polyg
                                        const int64_t* gt_index, const float* boxes, int num, int image_width, int image_height,
                                        int resolution, float* out, int threads);
 
+/* Whole-image masks of polygon instances, SegmentationMask(mode='poly').convert('mask') (mb/structures/segmentation_mask.py:326-334:
+ * pycocotools frPyObjects -> merge -> decode at the image size).  out [num_instances, height, width] uint8 (1 inside). */
+int ovis_cpu_polygons_to_masks_u8(const float* coords, const int32_t* polygon_start, const int32_t* instance_start, int num_instances,
+                                  int width, int height, uint8_t* out, int threads);
+
 const char* ovis_cpu_version(void);
 
 #ifdef __cplusplus

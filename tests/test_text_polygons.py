@@ -188,6 +188,25 @@ def test_host_project_polygon_masks_bit_exact_vs_oracle(oracle_mod, m):
     assert _C.project_polygon_masks(pm.coords, pm.polygon_start, pm.instance_start, gi[:0], boxes[:0], pm.size, m).shape == (0, m, m)
 
 
+def test_host_whole_image_masks_of_polygon_instances_vs_oracle(oracle_mod):
+    """``PolygonMasks.convert_to_binarymask()`` on the host (segmentation_mask.py:326-334: frPyObjects -> merge -> decode at the image
+    size, any size) == the oracle's restatement of pycocotools, instance by instance; device polygons above 64 x 64 still refuse."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.structures import PolygonMasks
+
+    g = torch.Generator().manual_seed(5)
+    img_w, img_h = 333, 250
+    inst = _random_instances(g, 6, img_w, img_h)
+    inst.append([_rect(10, 20, 110, 90), _rect(200, 100, 320, 240)])      # two rectangles of one instance: union
+    inst.append([[-30.0, -20.0, 400.0, 10.0, 50.0, 300.0]])              # reaches outside the image on three sides
+    pm = PolygonMasks(inst, (img_w, img_h))
+    masks = pm.convert_to_binarymask()
+    assert masks.shape == (len(inst), img_h, img_w) and masks.dtype == torch.uint8
+    for i, polys in enumerate(pm.instances()):
+        assert torch.equal(masks[i], oracle_mod.polygon_to_mask([p.tolist() for p in polys], img_h, img_w)), i
+    assert int(masks[6, 50, 50]) == 1 and int(masks[6, 150, 250]) == 1 and int(masks[6, 5, 5]) == 0  # known answers
+    assert PolygonMasks([], (img_w, img_h)).convert_to_binarymask().shape == (0, img_h, img_w)
+
+
 def test_host_mask_loss_targets_from_polygons(oracle_mod):
     """``MaskRCNNLossComputation.prepare_targets`` on HOST tensors with a polygon ``masks`` field (MODEL.DEVICE cpu with real COCO
     ground truth): targets of the positives = the oracle's crop -> resize -> rasterise."""
