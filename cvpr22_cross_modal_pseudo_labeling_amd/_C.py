@@ -850,7 +850,6 @@ def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f3
         raise RuntimeError("split_gemm_pair: residual must be a float32 [M, N] HIP tensor with unit column stride")
     with _on(dev):
         nbytes = _L.ovis_split_gemm_pair_workspace_bytes(m, n, ch, ch2, kh, kw, w) if not (config & 8) else 0
-        nbytes = max(nbytes, (config >> 8) * m * n * 4)   # probes: a forced number of K slices
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
         rc = _L.ovis_split_gemm_pair(a_pair.data_ptr(), 2 * a_pair.stride(0),
                                      0 if a2_pair is None else a2_pair.data_ptr(),

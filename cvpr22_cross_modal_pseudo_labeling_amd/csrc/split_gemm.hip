@@ -187,7 +187,6 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
   constexpr int AI = (A_PIECES + NW - 1) / NW;                        // per wave
   constexpr int BI = BN / 8 / NW;
   static_assert(MODE != HALO || NS == 1, "the halo tile is single-staged");
-  static_assert(NS <= 6 && (NS <= 2 || MODE == PLAIN || MODE == SHIFTED), "ring depths of the plain / shifted forms");
   static_assert(NW * 4096 <= STAGE * NS, "epilogue staging fits the k-loop's LDS");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -508,7 +507,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
         compute_static(smem);
         __syncthreads();
       }
-    } else if (NS == 2) {
+    } else {
       // one __syncthreads per k-step (its fence drains this wave's DMAs: stage kb landed, stage kb-1's buffer free),
       // the next stage in flight under the MFMAs
       const LaneGeom g = lane_geom(lane);
@@ -517,34 +516,6 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
         __syncthreads();
         if (kb + 1 < kb1) issue((kb + 1 - kb0) & 1, kb + 1, g);
         compute_static(smem + ((kb - kb0) & 1) * STAGE);
-      }
-      __syncthreads();  // every wave is done with the stages: the epilogue reuses them
-    } else {
-      // Ring of NS stages, NS - 1 of them in flight (grids that leave CUs idle: one workgroup per CU owns most of its LDS
-      // and a k-step is bound by the latency of its DMA, ~1.2-1.6 us, not by 0.3 us of MFMAs).  vmcnt retires in order, so
-      // "stage kb has landed" = at most the DMAs of the stages issued after it are outstanding: a counted wait
-      // (LPS instructions per lane and stage), then a raw barrier (no fence: a fence would drain the ring).  The stage the
-      // next DMA overwrites is the one computed in the previous iteration -- every wave is past it at this barrier.
-      constexpr int LPS = AI + BI;
-      static_assert((NS - 2) * LPS <= 63, "vmcnt is a 6-bit counter");
-      const LaneGeom g = lane_geom(lane);
-#pragma unroll
-      for (int s = 0; s < NS - 1; ++s)
-        if (kb0 + s < kb1) issue(s, kb0 + s, g);
-      int st = 0, ld = NS - 1;
-      for (int kb = kb0; kb < kb1; ++kb) {
-        const int rem = kb1 - 1 - kb;  // stages issued after kb's
-#define OVIS_RING_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory")
-        if (rem >= NS - 2) OVIS_RING_WAIT((NS - 2) * LPS);
-        else if (NS > 5 && rem == 3) OVIS_RING_WAIT(NS > 5 ? 3 * LPS : 0);
-        else if (NS > 4 && rem == 2) OVIS_RING_WAIT(NS > 4 ? 2 * LPS : 0);
-        else if (NS > 3 && rem == 1) OVIS_RING_WAIT(NS > 3 ? LPS : 0);
-        else OVIS_RING_WAIT(0);
-#undef OVIS_RING_WAIT
-        if (kb + NS - 1 < kb1) issue(ld, kb + NS - 1, g);
-        compute_static(smem + st * STAGE);
-        st = st + 1 == NS ? 0 : st + 1;
-        ld = ld + 1 == NS ? 0 : ld + 1;
       }
       __syncthreads();  // every wave is done with the stages: the epilogue reuses them
     }
@@ -1357,7 +1328,7 @@ extern "C" int ovis_split_gemm_pair_tn(const void* g_pair, long g_row_bytes, con
 // ---- launch plan of the NT kernel (shared by the launcher and the workspace query) ----
 namespace {
 struct SplitGemmPlan {
-  int mode, narrow, stages, kslices, steps_per_slice, tiles_m, tiles_n, ring;
+  int mode, narrow, stages, kslices, steps_per_slice, tiles_m, tiles_n;
 };
 
 // config: 0 = choose; otherwise a bit set for tests / A-B probes: 1 = one LDS stage, 2 = two stages, 4 = never use
@@ -1416,16 +1387,6 @@ SplitGemmPlan split_gemm_plan(long m, int n, int channels, int channels2, int ta
   }
   if (config & 1) q.stages = 1;
   if ((config & 2) && q.mode != HALO && !q.narrow) q.stages = 2;
-  q.ring = 0;
-  if ((config & 48) && q.mode != HALO && !q.narrow) {   // probes: 16 = ring of 4 stages, 32 = 64-row tile ring 5, 48 = 64-row ring 3
-    q.ring = (config >> 4) & 3;
-    if (q.ring >= 2) q.tiles_m = (int)((m + 63) / 64);
-  }
-  if ((config >> 8) > 0 && q.mode != HALO && !q.narrow) {   // probes: forced number of K slices
-    const int sl = config >> 8;
-    q.steps_per_slice = (units + sl - 1) / sl;
-    q.kslices = (units + q.steps_per_slice - 1) / q.steps_per_slice;
-  }
   return q;
 }
 }  // namespace
@@ -1463,11 +1424,11 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
       ((uintptr_t)residual & 15) || ((uintptr_t)workspace & 15) || ldc % 4 != 0 || ldr % 4 != 0 ||
       c_pair_row_bytes % 16 != 0)
     return OVIS_ERANGE;
-  if (config < 0 || config > 0xffff) return OVIS_ERANGE;
+  if (config < 0 || config > 15) return OVIS_ERANGE;
   SplitGemmPlan q = split_gemm_plan(m, n, channels, channels2, taps_h, taps_w, width, config);
   if (q.kslices > 1 && (!workspace || workspace_bytes < (size_t)q.kslices * (size_t)m * (size_t)n * sizeof(float))) {
     // no (or too small a) workspace: the un-split grid
-    q = split_gemm_plan(m, n, channels, channels2, taps_h, taps_w, width, (config & 0xff) | 8);
+    q = split_gemm_plan(m, n, channels, channels2, taps_h, taps_w, width, config | 8);
   }
   SplitGemmArgs p;
   p.A = (const char*)a_pair; p.a_rs = a_row_bytes;
@@ -1513,18 +1474,10 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
     if (q.mode == PLAIN) OVIS_SG_LAUNCH(2, 1, PLAIN, 1, 2); else OVIS_SG_LAUNCH(2, 1, SHIFTED, 1, 2);
   } else if (q.mode == HALO) {
     OVIS_SG_LAUNCH(2, 2, HALO, 1, 4);
-  } else if (q.ring && (dual || pool)) {
-    return OVIS_ERANGE;
   } else if (q.mode == SHIFTED) {
-    if (q.ring == 1) OVIS_SG_LAUNCH(2, 2, SHIFTED, 4, 1);
-    else if (q.ring == 2) OVIS_SG_LAUNCH(1, 2, SHIFTED, 5, 1);
-    else if (q.ring == 3) OVIS_SG_LAUNCH(1, 2, SHIFTED, 3, 2);
-    else if (q.stages == 1) OVIS_SG_LAUNCH(2, 2, SHIFTED, 1, 4); else OVIS_SG_LAUNCH(2, 2, SHIFTED, 2, 2);
+    if (q.stages == 1) OVIS_SG_LAUNCH(2, 2, SHIFTED, 1, 4); else OVIS_SG_LAUNCH(2, 2, SHIFTED, 2, 2);
   } else {
-    if (q.ring == 1) OVIS_SG_LAUNCH(2, 2, PLAIN, 4, 1);
-    else if (q.ring == 2) OVIS_SG_LAUNCH(1, 2, PLAIN, 5, 1);
-    else if (q.ring == 3) OVIS_SG_LAUNCH(1, 2, PLAIN, 3, 2);
-    else if (q.stages == 1) OVIS_SG_LAUNCH(2, 2, PLAIN, 1, 4); else OVIS_SG_LAUNCH(2, 2, PLAIN, 2, 2);
+    if (q.stages == 1) OVIS_SG_LAUNCH(2, 2, PLAIN, 1, 4); else OVIS_SG_LAUNCH(2, 2, PLAIN, 2, 2);
   }
 #undef OVIS_SG_LAUNCH__
 #undef OVIS_SG_LAUNCH_
