@@ -1444,6 +1444,12 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
   p.flip = flip; p.relu = relu;
   p.kslices = q.kslices; p.steps_per_slice = q.steps_per_slice;
   p.gw = (q.tiles_n % OVIS_SG_GW == 0) ? OVIS_SG_GW : (q.tiles_n % 4 == 0) ? 4 : q.tiles_n;   // column groups of 4 weight tiles (2 MB) stay in an XCD's L2
+#ifdef OVIS_SG_GW_SHORTK   // experiment knobs: other group widths for short / long K (the group's weight bytes follow K)
+  if (T * channels + channels2 <= 512 && q.tiles_n % OVIS_SG_GW_SHORTK == 0) p.gw = OVIS_SG_GW_SHORTK;
+#endif
+#ifdef OVIS_SG_GW_LONGK
+  if (T * channels + channels2 >= 2048 && q.mode != HALO && q.tiles_n % OVIS_SG_GW_LONGK == 0) p.gw = OVIS_SG_GW_LONGK;
+#endif
   const long ntiles = (long)q.tiles_m * q.tiles_n;
   const long nblocks = ntiles * q.kslices;
   if (nblocks > 0x7fffffffL) return OVIS_ERANGE;
