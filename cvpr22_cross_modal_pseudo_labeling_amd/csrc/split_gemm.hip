@@ -717,6 +717,9 @@ __global__ __launch_bounds__(256, 2) void split_gemm_tn_kernel(SplitGemmTnArgs p
     tdy = tap / p.KW - p.KH / 2;
     tdx = tap % p.KW - p.KW / 2;
     off_rows = tdy * p.W + tdx;
+#ifdef OVIS_TN_ABL_NOSHIFT   // ablation (wrong results): every tap reads the un-shifted rows
+    off_rows = 0;
+#endif
   }
   const long step0 = (long)slice * p.steps_per_slice;
   const long steps_total = (p.M + 31) >> 5;
@@ -762,7 +765,11 @@ __global__ __launch_bounds__(256, 2) void split_gemm_tn_kernel(SplitGemmTnArgs p
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       x_ok[i] = m_row[i] < Mi;
+#ifdef OVIS_TN_ABL_NOMASK     // ablation (wrong results): no tap masks
+      if (false) {
+#else
       if (CONV && SMALL) {
+#endif
         x_ok[i] = x_ok[i] && ((tap_mask >> x_x[i]) & 1ull) != 0ull;
         int q = x_x[i] + step_q;
         if (q >= HW) q -= HW;
