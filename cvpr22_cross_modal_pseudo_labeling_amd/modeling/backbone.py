@@ -276,20 +276,23 @@ class Bottleneck(nn.Module):
         return (out, None) if want_pair else out
 
 
-def chain_nhwc(blocks, y, yp=None, first=None, last=None):
+def chain_nhwc(blocks, y, yp=None, first=None, last=None, then=None):
     """Run consecutive bottlenecks on an NHWC activation.  Every block but the last hands its result on in pair layout;
     it drops the fp32 copy (``pair_only``) only when the NEXT block can take a pair-only input -- otherwise (e.g.
     STRIDE_IN_1X1 False: the stage's first block has a strided 3x3 and runs the per-layer route) both forms are
-    written.  ``first`` / ``last``: extra keyword arguments of the first / last block's ``forward_nhwc``."""
+    written.  ``first`` / ``last``: extra keyword arguments of the first / last block's ``forward_nhwc``.  ``then``: the
+    block a LATER call continues the chain with -- the last block then hands on ``(y, yp)`` exactly as it would inside
+    one chain (the frozen prefix of the trunk, run ahead on a side stream: ``ResNetC4.forward_prefix``)."""
     n = len(blocks)
     for i, b in enumerate(blocks):
         kw = dict(first or {}) if i == 0 else {}
-        if i + 1 < n:
-            y, yp = b.forward_nhwc(y, xp=yp, want_pair=True, pair_only=blocks[i + 1].takes_pair_only_input(), **kw)
+        nxt = blocks[i + 1] if i + 1 < n else then
+        if nxt is not None:
+            y, yp = b.forward_nhwc(y, xp=yp, want_pair=True, pair_only=nxt.takes_pair_only_input(), **kw)
         else:
             kw.update(last or {})
             y = b.forward_nhwc(y, xp=yp, **kw)
-    return y
+    return (y, yp) if then is not None else y
 
 
 class Stem(nn.Module):
@@ -377,13 +380,38 @@ class ResNetC4(nn.Module):
             for p in m.parameters():
                 p.requires_grad = False
 
-    def forward(self, x):
-        x = self.stem.forward_gemm(x) if (self.nhwc and self.stem.gemm_supported(x)) else self.stem(x)
-        blocks = [b for name in self.stages for b in getattr(self, name)]
+    def _chain_ok(self, x, blocks):
         frozen = not any(p.requires_grad for p in self.parameters())
         plain = [b for b in blocks if not b.with_dcn]
-        if (x.is_cuda and self.nhwc and all(b.nhwc_supported() for b in plain)
-                and (frozen or (self.train_nhwc and all(b.pair_gemm and b.pair_supported() for b in plain)))):
+        return (x.is_cuda and self.nhwc and all(b.nhwc_supported() for b in plain)
+                and (frozen or (self.train_nhwc and all(b.pair_gemm and b.pair_supported() for b in plain))))
+
+    def forward_prefix(self, x):
+        """Stem and the FROZEN leading blocks (FREEZE_CONV_BODY_AT) on the NHWC chain: ``(y, yp, n_blocks)`` for
+        ``forward(prefix=...)``, or None when there is nothing to run ahead (no frozen block before a trainable one, a
+        deformable trunk, the per-layer NCHW route, a host tensor).  Nothing in it depends on a trainable parameter, so a
+        training loop may run it for the NEXT batch beside this batch's backward (engine/trainer.py::PipelinedTrainer);
+        the values are those of the un-split chain -- the last frozen block hands on what the next block takes."""
+        blocks = [b for name in self.stages for b in getattr(self, name)]
+        k = 0
+        while k < len(blocks) and not any(p.requires_grad for p in blocks[k].parameters()):
+            k += 1
+        if (k == 0 or k == len(blocks) or any(b.with_dcn for b in blocks) or not self._chain_ok(x, blocks)
+                or not (self.nhwc and self.stem.gemm_supported(x))):
+            return None
+        with torch.no_grad():
+            x = self.stem.forward_gemm(x)
+            y, yp = chain_nhwc(blocks[:k], x.permute(0, 2, 3, 1).contiguous(), then=blocks[k])
+        return y, yp, k
+
+    def forward(self, x, prefix=None):
+        blocks = [b for name in self.stages for b in getattr(self, name)]
+        if prefix is not None:  # the rest of the chain on the result of ``forward_prefix`` (same values as the whole chain)
+            y, yp, k = prefix
+            return [chain_nhwc(blocks[k:], y, yp).permute(0, 3, 1, 2)]
+        x = self.stem.forward_gemm(x) if (self.nhwc and self.stem.gemm_supported(x)) else self.stem(x)
+        plain = [b for b in blocks if not b.with_dcn]
+        if self._chain_ok(x, blocks):
             if len(plain) != len(blocks):
                 return [self._forward_mixed(x, blocks)]
             # layer1-3 in NHWC with the split-GEMM bottlenecks of the res5 head (1x1 = row-major GEMM, 3x3 = implicit

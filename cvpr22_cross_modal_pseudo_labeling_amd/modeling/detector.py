@@ -42,11 +42,21 @@ class GeneralizedRCNN(nn.Module):
     def set_class_embeddings(self, embs):
         self.roi_heads["box"].predictor.set_class_embeddings(embs)
 
-    def forward(self, images, targets=None):
+    def forward_frozen(self, images, targets=None):
+        """The part of a training step no trainable parameter feeds: stem + the frozen leading stages of the trunk
+        (FREEZE_CONV_BODY_AT).  ``PipelinedTrainer`` runs it for the next batch on a side stream beside this batch's
+        backward; ``forward_student`` continues from it with the values the un-split ``forward`` computes."""
+        images = to_image_list(images)
+        return {"images": images, "prefix": self.backbone.body.forward_prefix(images.tensors)}
+
+    def forward_student(self, frozen, targets):
+        return self.forward(frozen["images"], targets, prefix=frozen["prefix"])
+
+    def forward(self, images, targets=None, prefix=None):
         if self.training and targets is None:
             raise ValueError("In training mode, targets should be passed")
         images = to_image_list(images)
-        features = self.backbone(images.tensors)
+        features = self.backbone(images.tensors) if prefix is None else self.backbone.body(images.tensors, prefix=prefix)
         proposals, proposal_losses = self.rpn(images, features, targets)
         _, result, detector_losses = self.roi_heads(features, proposals, targets)
         if self.training:
