@@ -1266,6 +1266,17 @@ extern "C" int ovis_split_gemm_tn_slices(long m, int n, int channels, int taps) 
   // workgroups = 2.25 rounds ran at 75 %; 7 slices = 1008 fill two rounds to 98 %).  Among the slice counts of up to
   // ~4 rounds pick the one whose rounds are fullest, preferring about two rounds (enough parallelism, few slabs).
   const long slots = 2L * OVIS_NUM_CU;
+  if (steps >= 128 && steps <= 1100 && tiles <= slots) {
+    // Short contractions with few output tiles (the trainable trunk of the teacher step: M = 8400 / 33400 rows, 4-36
+    // tiles): a workgroup's fixed costs (slab write, launch) and the slab reduction weigh as much as its k-steps, so ONE
+    // round of workgroups with at least 16 k-steps each beats two rounds of shorter slices -- layer3's 3x3 (36 tiles):
+    // 14 slices 43 us against 53 us with 28; its 1x1s (16 tiles): 16 slices 25 us against 28 with 32; layer2's 3x3
+    // (9 tiles): 56 against 113 (profiles/r4_tn_slices_small_m.txt).
+    long s = slots / tiles;
+    if (s > steps / 16) s = steps / 16;
+    if (s > 256) s = 256;
+    return (int)(s < 1 ? 1 : s);
+  }
   long s_max = (4 * slots + tiles - 1) / tiles;
   if (s_max > steps / 8) s_max = steps / 8;                              // at least 8 k-steps per slice
   if (s_max > 256) s_max = 256;
