@@ -940,10 +940,14 @@ def split_gemm_pair_gated(a_pair, b_pair, gate_pair, conv=None, out_f32=False, o
     if m == 0 or n == 0:
         return c, cp
     with _on(dev):
-        rc = _L.ovis_split_gemm_pair_gated(a_pair.data_ptr(), 2 * a_pair.stride(0), b_pair.data_ptr(), 2 * b_pair.stride(0),
-                                           0 if c is None else c.data_ptr(), n, 0 if cp is None else cp.data_ptr(), 4 * n,
-                                           gate_pair.data_ptr(), 2 * gate_pair.stride(0), m, n, ch, kh, kw, h, w,
-                                           int(bool(flip)), config, _stream())
+        # under-filled grids take the plan's K slices (the slab reduction applies the gate)
+        nbytes = _L.ovis_split_gemm_pair_workspace_bytes(m, n, ch, 0, kh, kw, w) if not (config & 8) else 0
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
+        rc = _L.ovis_split_gemm_pair_gated_ws(a_pair.data_ptr(), 2 * a_pair.stride(0), b_pair.data_ptr(),
+                                              2 * b_pair.stride(0), 0 if c is None else c.data_ptr(), n,
+                                              0 if cp is None else cp.data_ptr(), 4 * n, gate_pair.data_ptr(),
+                                              2 * gate_pair.stride(0), m, n, ch, kh, kw, h, w, int(bool(flip)),
+                                              0 if ws is None else ws.data_ptr(), nbytes, config, _stream())
     _lib.check(rc, "split_gemm_pair_gated")
     return c, cp
 

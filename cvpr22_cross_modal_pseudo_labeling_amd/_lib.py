@@ -59,6 +59,7 @@ SIGNATURES = {
     "ovis_split_gemm_tn_slices": (_i, [_l, _i, _i, _i]),
     "ovis_split_gemm_pair_tn": (_i, [_vp, _l, _vp, _l, _vp, _i, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "ovis_split_gemm_pair_gated": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _l] + [_i] * 8 + [_vp]),
+    "ovis_split_gemm_pair_gated_ws": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _l] + [_i] * 7 + [_vp, _sz, _i, _vp]),
     "ovis_split_gemm_pair_workspace_bytes": (_sz, [_l, _i, _i, _i, _i, _i, _i]),
     "ovis_split_gemm_pair_rp_gated": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _l, _i, _i, _i, _vp]),
     "ovis_split_gemm_pair_pool_supported": (_i, [_l, _i, _i, _i]),

@@ -1576,6 +1576,20 @@ extern "C" int ovis_split_gemm_pair_gated(const void* a_pair, long a_row_bytes, 
                               height, width, flip, 0, nullptr, 0, config | 8, stream);
 }
 
+// The same with a split-K workspace (ovis_split_gemm_pair_workspace_bytes of the same problem): under-filled grids -- the
+// data gradients of the teacher step's trainable trunk, 132 tiles walking 72 k-steps -- take the plan's K slices like
+// the forward products do; the gate is applied by the slab reduction's epilogue.
+extern "C" int ovis_split_gemm_pair_gated_ws(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
+                                             float* c, long ldc, void* c_pair, long c_pair_row_bytes,
+                                             const void* gate_pair, long gate_row_bytes, long m, int n, int channels,
+                                             int taps_h, int taps_w, int height, int width, int flip, void* workspace,
+                                             size_t workspace_bytes, int config, void* stream) {
+  if (!gate_pair || gate_row_bytes % 16 != 0 || ((uintptr_t)gate_pair & 15) || n % 32 != 0) return OVIS_ERANGE;
+  return split_gemm_pair_impl(a_pair, a_row_bytes, nullptr, 0, b_pair, b_row_bytes, c, ldc, c_pair, c_pair_row_bytes,
+                              nullptr, nullptr, 0, nullptr, 0, gate_pair, gate_row_bytes, m, n, channels, 0, taps_h, taps_w,
+                              height, width, flip, 0, workspace, workspace_bytes, config, stream);
+}
+
 // The input gradient of an identity bottleneck, ready for the block below: (A @ B^T + shortcut gradient given in pair
 // layout) * (block input > 0), written in pair layout (and / or fp32).  See include/ovis_hip.h.
 extern "C" int ovis_split_gemm_pair_rp_gated(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,

@@ -358,6 +358,17 @@ int ovis_split_gemm_pair_gated(const void* a_pair, long a_row_bytes, const void*
                                long gate_row_bytes, long m, int n, int channels, int taps_h, int taps_w,
                                int height, int width, int flip, int config, void* stream);
 
+/* ovis_split_gemm_pair_gated with a split-K workspace (size: ovis_split_gemm_pair_workspace_bytes(m, n, channels, 0,
+ * taps_h, taps_w, width); NULL / too small = the un-split grid): grids that leave most CUs idle while every workgroup
+ * walks a long K (the data gradients of a trainable trunk on 50 x 84 maps) are cut into K slices as in
+ * ovis_split_gemm_pair; the slab reduction applies the gate and writes c / c_pair.  Same results as the un-split call up
+ * to the fp32 summation order of the slices (fixed: reproducible). */
+int ovis_split_gemm_pair_gated_ws(const void* a_pair, long a_row_bytes, const void* b_pair, long b_row_bytes,
+                                  float* c, long ldc, void* c_pair, long c_pair_row_bytes, const void* gate_pair,
+                                  long gate_row_bytes, long m, int n, int channels, int taps_h, int taps_w,
+                                  int height, int width, int flip, void* workspace, size_t workspace_bytes,
+                                  int config, void* stream);
+
 /* The input gradient of an identity bottleneck (mb/modeling/backbone/resnet.py:290-342: out = relu(conv3(..) + x)), handed
  * to the block below ready for use: C = (A B^T + r) * (x > 0) -- r the gradient arriving through the shortcut, given in
  * pair layout (residual_pair: hi + lo), x the block input in pair layout (gate_pair: the block below's ReLU output, only

@@ -662,16 +662,32 @@ def test_split_gemm_pair_gated_epilogue():
     a, b = torch.randn(m, k, device="cuda"), torch.randn(n, k, device="cuda")
     y = torch.randn(m, n, device="cuda").clamp(min=0)
     ap, bp, yp = C.split_pair(a), C.split_pair(b), C.split_pair(y)
-    d, _ = C.split_gemm_pair(ap, bp, config=8)  # the gated form never cuts K into slices: same summation order
-    want_p, want = C.gate_split_pair(d, yp, want_f32=True)
-    got, got_p = C.split_gemm_pair_gated(ap, bp, yp, out_f32=True, out_pair=True)
-    assert torch.equal(got, want) and torch.equal(got_p, want_p)
+    # the gated form follows the same launch plan as the plain product (K slices on under-filled grids, the gate applied by
+    # the slab reduction): same summation order, so the comparison is exact for every config
+    for cfg in (0, 8):
+        d, _ = C.split_gemm_pair(ap, bp, config=cfg)
+        want_p, want = C.gate_split_pair(d, yp, want_f32=True)
+        got, got_p = C.split_gemm_pair_gated(ap, bp, yp, out_f32=True, out_pair=True, config=cfg)
+        assert torch.equal(got, want) and torch.equal(got_p, want_p)
     wm = torch.randn(n, 9 * k, device="cuda")
     wp = C.split_pair(wm)
-    d, _ = C.split_gemm_pair(ap, wp, conv=(7, 7, 3, 3, True), config=8)
-    want_p, _ = C.gate_split_pair(d, yp)
-    _, got_p = C.split_gemm_pair_gated(ap, wp, yp, conv=(7, 7, 3, 3, True))
-    assert torch.equal(got_p, want_p)
+    for cfg in (0, 8):
+        d, _ = C.split_gemm_pair(ap, wp, conv=(7, 7, 3, 3, True), config=cfg)
+        want_p, _ = C.gate_split_pair(d, yp)
+        _, got_p = C.split_gemm_pair_gated(ap, wp, yp, conv=(7, 7, 3, 3, True), config=cfg)
+        assert torch.equal(got_p, want_p)
+    # the teacher step's layer3 data gradient (50 x 84 maps, 132 tiles walking 72 k-steps: four K slices): sliced == plain
+    # product + gate bit for bit, and within the split product's error of the un-split order
+    m2, c2 = 2 * 50 * 84, 256
+    a2, y2 = torch.randn(m2, c2, device="cuda"), torch.randn(m2, c2, device="cuda").clamp(min=0)
+    w2 = torch.randn(c2, 9 * c2, device="cuda") / (9 * c2) ** 0.5
+    a2p, y2p, w2p = C.split_pair(a2), C.split_pair(y2), C.split_pair(w2)
+    d, _ = C.split_gemm_pair(a2p, w2p, conv=(50, 84, 3, 3, True))
+    want_p, want = C.gate_split_pair(d, y2p, want_f32=True)
+    got, got_p = C.split_gemm_pair_gated(a2p, w2p, y2p, conv=(50, 84, 3, 3, True), out_f32=True)
+    assert torch.equal(got, want) and torch.equal(got_p, want_p)
+    unsplit, _ = C.split_gemm_pair_gated(a2p, w2p, y2p, conv=(50, 84, 3, 3, True), out_f32=True, out_pair=False, config=8)
+    assert (got - unsplit).abs().max().item() <= 1e-5 * unsplit.abs().max().item()
 
 
 def test_split_gemm_full_size_properties():
