@@ -85,4 +85,9 @@ def test_tn_slice_count_fills_the_rounds_of_resident_workgroups():
         rounds = -(-blocks // slots)
         assert blocks / (rounds * slots) >= 0.88, (m, n, ch, taps, s, blocks)
     assert f(100352, 512, 512, 9) == 7          # 1008 workgroups: two rounds, 98 % full
+    # short contractions with few tiles (the teacher step's trainable trunk): ONE round, >= 16 k-steps per slice
+    for (m, n, ch, taps), want in (((8400, 256, 256, 9), 14), ((8400, 1024, 256, 1), 16), ((8400, 256, 1024, 1), 16),
+                                   ((33400, 128, 128, 9), 56)):
+        s = f(m, n, ch, taps)
+        assert s == want and s * (n // 128) * (taps * ch // 128) <= slots and ((m + 31) // 32) // s >= 16, (m, n, ch, taps, s)
     assert f(64, 128, 128, 1) == 1 and f(0, 128, 128, 1) == 1   # tiny / empty problems: one slice

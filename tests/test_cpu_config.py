@@ -229,6 +229,28 @@ def test_config0_teacher_on_cpu_trains_and_matches_the_oracle_backed_run():
         assert torch.allclose(pa[n], pb[n], rtol=1e-4, atol=1e-7), n
 
 
+def test_teacher_frozen_half_on_the_host_is_the_plain_forward():
+    """``GeneralizedRCNN.forward_frozen`` / ``forward_student`` (what ``PipelinedTrainer`` drives on the GPU) on host tensors: the
+    trunk has no prefix to run ahead there (``forward_prefix`` -> None: the NHWC pair chain is device-only), and the split step is
+    the plain forward -- same losses, bit for bit; the trainer itself stays disabled without a GPU."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm, solver, trainer
+
+    cfg, model, images, targets = _cpu_model("zeroshot_mask")
+    model.train()
+    torch.manual_seed(11)
+    want = {k: float(v) for k, v in model(images, targets).items()}
+    torch.manual_seed(11)
+    frozen = model.forward_frozen(images, targets)
+    assert frozen["prefix"] is None
+    got = {k: float(v) for k, v in model.forward_student(frozen, targets).items()}
+    assert got == want
+    opt = solver.make_optimizer(cfg, model)
+    red = comm.BucketedGradReducer(model)
+    pipe = trainer.PipelinedTrainer(model, opt, red)
+    assert pipe.enabled == torch.cuda.is_available()
+    red.remove()
+
+
 def test_config0_teacher_on_cpu_inference_returns_detections():
     cfg, model, images, targets = _cpu_model("zeroshot_mask")
     model.eval()
