@@ -1,0 +1,295 @@
+"""Generates tests/golden/step_student.npz and step_teacher.npz by running the REFERENCE's own detector classes --
+``STGeneralizedRCNN`` (modeling/detector/st_generalized_rcnn.py:27-418: ``prepare_model``, ``generate_pseudo_label``,
+``forward`` with its branch split, class-matrix swaps, ``adaptive_lamb`` and dummy losses) and ``GeneralizedRCNN``
+(detector/generalized_rcnn.py:16-73) -- built from the reference's real ``config/defaults.py`` + its shipped yaml
+files + the overrides of ``step_case.COMMON_OPTS``, on the CPU of the build container.  Run there only:
+
+    python oracle/build_ref.py && python tests/golden/make_step_golden.py
+
+How the reference is made to run here (tests/golden/ref_import.py): stand-in modules for packages this image lacks,
+``maskrcnn_benchmark._C`` = the reference's own csrc compiled for the CPU, ``torch.Tensor.cuda`` = identity,
+the BERT constructor replaced (it downloads bert-base-uncased) by one that installs a HuggingFace ``BertTokenizer`` over
+``step_case.WORDPIECES`` and a seeded embedding table -- ``BERT.forward`` and ``extract_emb`` run unchanged.
+
+What is captured besides the returned losses: the fg / bg samplers' masks (``BalancedPositiveNegativeSampler.__call__``
+wrapped), the mask head's noise (``torch.randn`` wrapped), the region x noun score matrix (``torch.einsum`` wrapped),
+proposals of both RPN modes, the pseudo labels, and after ``sum(losses).backward()`` a digest of every gradient
+(step_case.grad_digest).  ``STGeneralizedRCNN`` is run one image per call (it is only correct there);
+``GeneralizedRCNN`` on the two-image batch.  Only inputs / outputs are stored -- no reference source text.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+import step_case as case  # noqa: E402
+
+
+class Capture:
+    """Wraps the three random / intermediate call sites for the duration of one forward."""
+
+    def __init__(self, sampler_cls):
+        self.sampler_cls = sampler_cls
+        self.samples, self.randn, self.einsum = [], [], []
+
+    def __enter__(self):
+        cap = self
+        self._call, self._randn, self._einsum = self.sampler_cls.__call__, torch.randn, torch.einsum
+
+        def call(sampler, matched_idxs):
+            pos, neg = cap._call(sampler, matched_idxs)
+            cap.samples.append((sampler.batch_size_per_image, [p.clone() for p in pos], [n.clone() for n in neg]))
+            return pos, neg
+
+        def randn(*a, **k):
+            out = cap._randn(*a, **k)
+            cap.randn.append(out.clone())
+            return out
+
+        def einsum(eq, *ops):
+            out = cap._einsum(eq, *ops)
+            cap.einsum.append((eq, out.detach().clone()))
+            return out
+
+        self.sampler_cls.__call__, torch.randn, torch.einsum = call, randn, einsum
+        return self
+
+    def __exit__(self, *exc):
+        self.sampler_cls.__call__, torch.randn, torch.einsum = self._call, self._randn, self._einsum
+
+
+def make_bert_class(RefBERT):
+    from transformers import BertTokenizer
+
+    vocab_path = os.path.join(HERE, "step_wordpiece_vocab.txt")
+    with open(vocab_path, "w") as f:
+        f.write("\n".join(case.WORDPIECES) + "\n")
+    hf = BertTokenizer(vocab_path, do_lower_case=True)
+
+    class Tok302:  # the call surface of transformers==3.0.2 that language_backbone/transformers.py:28-32 uses
+        def batch_encode_plus(self, text_list, add_special_tokens=True, pad_to_max_length=False, return_special_tokens_mask=False):
+            enc = hf(list(text_list), add_special_tokens=add_special_tokens, padding=bool(pad_to_max_length),
+                     return_special_tokens_mask=return_special_tokens_mask)
+            return {k: v for k, v in enc.items()}
+
+    class LocalBERT(RefBERT):
+        def __init__(self, cfg):
+            torch.nn.Module.__init__(self)
+            self.tokenizer, self.mlm = Tok302(), False
+            self.embeddings = torch.nn.Parameter(torch.zeros(len(case.WORDPIECES), case.EMB_DIM), requires_grad=False)
+
+    return LocalBERT
+
+
+def load_seeded(model):
+    """Every parameter / FrozenBN buffer of the reference model <- step_case.seeded_tensor(its first state-dict name)."""
+    first = {}
+    with torch.no_grad():
+        for name, t in list(model.named_parameters()) + list(model.named_buffers()):
+            if id(t) in first or not case.is_seeded(name):
+                continue
+            first[id(t)] = name
+            t.copy_(case.seeded_tensor(name, t.shape))
+    # (state-dict name, shape, the name its value was seeded under: a module reachable under two names -- the mask head
+    # shares the box head's feature extractor, roi_heads.py:21-22 -- has one tensor and two entries)
+    return [(n, tuple(t.shape), first[id(t)]) for n, t in model.state_dict(keep_vars=True).items() if case.is_seeded(n)]
+
+
+def make_target(BoxList, SegmentationMask, c, with_caption):
+    t = BoxList(c["boxes"].clone(), (case.IMAGE_W, case.IMAGE_H), mode="xyxy")
+    t.add_field("labels", c["labels"].clone())
+    t.add_field("masks", SegmentationMask(c["masks"].clone(), (case.IMAGE_W, case.IMAGE_H), mode="mask"))
+    if with_caption:
+        t.add_field("nn_caption", c["nn_caption"])
+        t.add_field("ids_cap", c["ids_cap"].clone())
+        t.add_field("is_det", "Yes")
+    return t
+
+
+def put_boxes(out, key, boxlists, fields=()):
+    for i, b in enumerate(boxlists):
+        out[f"{key}{i}_bbox"] = b.bbox.detach().numpy()
+        for f in fields:
+            out[f"{key}{i}_{f}"] = b.get_field(f).detach().numpy()
+
+
+def put_grads(out, model, prefix="grad"):
+    names = []
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        d = case.grad_digest(name, p.grad)
+        out[f"{prefix}:{name}:values"] = d["values"]
+        out[f"{prefix}:{name}:norm_sum"] = np.array([d["norm"], d["sum"]])
+        names.append(name)
+    out[f"{prefix}_names"] = np.array(names)
+
+
+def put_samples(out, key, cap, batch_size):
+    """Masks of the RoI (or RPN) sampler's calls in call order, one (pos, neg) pair per image."""
+    k = 0
+    for bs, pos, neg in cap.samples:
+        if bs != batch_size:
+            continue
+        for p, n in zip(pos, neg):
+            out[f"{key}{k}_pos"], out[f"{key}{k}_neg"] = p.numpy().astype(np.bool_), n.numpy().astype(np.bool_)
+            k += 1
+    out[f"{key}_count"] = np.int64(k)
+
+
+def gen_student():
+    from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+    from maskrcnn_benchmark.modeling.language_backbone import transformers as ref_lb
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.segmentation_mask import SegmentationMask
+
+    ref_import._namespace_pkg("maskrcnn_benchmark.modeling.detector",
+                              os.path.join(ref_import.REF, "maskrcnn_benchmark/modeling/detector"))
+    ref_lb.BERT = make_bert_class(ref_lb.BERT)
+    from maskrcnn_benchmark.modeling.detector import st_generalized_rcnn as st_mod
+
+    cfg = ref_import.reference_cfg("student_teacher_mask_rcnn_uncertainty.yaml", case.COMMON_OPTS)
+    out = {}
+    e_seen = case.text_embeddings()
+    for img_index in range(2):
+        # a fresh model per image: every run is "iteration 0" (prepare_model copies the teacher heads into the student)
+        model = st_mod.STGeneralizedRCNN(cfg)
+        names = load_seeded(model)
+        model.class_names = list(case.SEEN_NAMES)
+        model.roi_heads["box"].predictor.set_class_embeddings(e_seen.clone())
+        model.train()
+        c = case.image_case(img_index, model.cap_vocab)
+        target = make_target(BoxList, SegmentationMask, c, True)
+        key = f"img{img_index}_"
+        with Capture(BalancedPositiveNegativeSampler) as cap:
+            losses = model(c["image"][None], [target])
+            # the frozen half again, piece by piece, for the intermediate values (same modules, same state)
+            with torch.no_grad():
+                from maskrcnn_benchmark.structures.image_list import to_image_list
+                images = to_image_list(c["image"][None])
+                feats = model.backbone(images.tensors)
+                model.rpn.eval()
+                props_test, _ = model.rpn(images, feats, None)
+                caps = [target.get_field("nn_caption").split("/")]
+                n_einsum = len(cap.einsum)
+                pseudo = model.generate_pseudo_label([feats[0]], props_test, caps, [target])
+                scores_pw = [o for eq, o in cap.einsum[n_einsum:] if eq == "pd,wd->pw"][0]
+        n_roi_calls = sum(1 for bs, _, _ in cap.samples if bs == cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE)
+        assert n_roi_calls == 2, n_roi_calls  # pseudo-label branch, then ground-truth branch
+        total = sum(losses.values())
+        total.backward()
+        assert set(losses) == {"loss_box_reg", "loss_classifier", "loss_mask", "loss_box_reg_pseudo",
+                               "loss_classifier_pseudo", "loss_mask_pseudo"}
+        out[key + "features"] = feats[0].numpy()
+        put_boxes(out, key + "proposals_test", props_test, ("objectness",))
+        out[key + "region_noun_scores"] = scores_pw.numpy()
+        out[key + "aligned_idx"] = scores_pw.argmax(0).numpy()
+        top2 = scores_pw.topk(2, dim=0).values
+        out[key + "aligned_margin"] = (top2[0] - top2[1]).numpy()
+        pl = pseudo[0]
+        out[key + "pseudo_bbox"] = pl.bbox.numpy()
+        for f in ("labels", "scores", "consistencies", "embs"):
+            out[key + "pseudo_" + f] = pl.get_field(f).numpy()
+        pm = pl.get_field("masks").get_mask_tensor()
+        pm = pm[None] if pm.dim() == 2 else pm
+        out[key + "pseudo_masks_packed"] = np.packbits(pm.numpy().astype(np.bool_), axis=-1)
+        # train-mode proposals of the ground-truth branch (ground-truth boxes appended, rpn/inference.py:51-74)
+        with torch.no_grad():
+            model.rpn.train()
+            with Capture(BalancedPositiveNegativeSampler):
+                props_train, _ = model.rpn(images, feats, [target])
+        put_boxes(out, key + "proposals_train", props_train)
+        put_samples(out, key + "roi_sample", cap, cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE)
+        eps = [r for r in cap.randn if r.dim() == 5]
+        assert len(eps) == 1
+        out[key + "mask_eps"] = eps[0].numpy()
+        out[key + "avg_uncertain"] = np.float64(model.roi_heads_student["mask"].avg_uncertain.item())
+        out[key + "adaptive_lamb"] = np.float64(float(model.adaptive_lamb))
+        for k, v in losses.items():
+            out[key + k] = np.float64(v.item())
+        put_grads(out, model, key + "grad")
+        print(key, {k: round(v.item(), 6) for k, v in losses.items()}, "lamb", float(model.adaptive_lamb),
+              "margin", out[key + "aligned_margin"])
+    out["state_names"] = np.array([n for n, _, _ in names])
+    out["state_shapes"] = np.array([",".join(map(str, s)) for _, s, _ in names])
+    out["state_seeded_as"] = np.array([c for _, _, c in names])
+    out["cap_vocab"] = np.array(model.cap_vocab)
+    out["opts"] = np.array([str(o) for o in case.COMMON_OPTS])
+    np.savez_compressed(os.path.join(HERE, "step_student.npz"), **out)
+
+
+def gen_teacher():
+    from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+    from maskrcnn_benchmark.modeling.detector.generalized_rcnn import GeneralizedRCNN
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.segmentation_mask import SegmentationMask
+
+    # The one op of the teacher step the reference cannot run on a CPU (csrc/ROIAlign.h:44 "Not implemented on the CPU"):
+    # the RoIAlign backward is served by the oracle's restatement of ROIAlign_cuda.cu:178-254, which tests/test_oracle.py
+    # pins as the exact adjoint of the reference's own compiled forward kernel.
+    import oracle
+    import maskrcnn_benchmark.layers  # noqa: F401
+    ref_roi_align = sys.modules["maskrcnn_benchmark.layers.roi_align"]  # (the package re-exports a function of this name)
+
+    class _CWithBackward:
+        def __getattr__(self, name):
+            return getattr(sys.modules["maskrcnn_benchmark._C"], name)
+
+        @staticmethod
+        def roi_align_backward(grad, rois, scale, ph, pw, n, c, h, w, sampling_ratio):
+            return oracle.roi_align_backward(grad, rois, scale, ph, pw, n, c, h, w, sampling_ratio)
+
+    ref_roi_align._C = _CWithBackward()
+    cfg = ref_import.reference_cfg("zeroshot_mask.yaml", case.COMMON_OPTS)
+    model = GeneralizedRCNN(cfg)
+    names = load_seeded(model)
+    model.roi_heads["box"].predictor.set_class_embeddings(case.text_embeddings())
+    model.train()
+    from maskrcnn_benchmark.data.datasets.helper.lvis_v1_categories import LVIS_CATEGORIES  # noqa: F401  (names only)
+    cases = [case.image_case(i, ["-"] * 1203) for i in range(2)]
+    targets = [make_target(BoxList, SegmentationMask, c, False) for c in cases]
+    images = torch.stack([c["image"] for c in cases])
+    out = {}
+    with Capture(BalancedPositiveNegativeSampler) as cap:
+        losses = model(images, targets)
+    sum(losses.values()).backward()
+    assert set(losses) == {"loss_box_reg", "loss_classifier", "loss_mask", "loss_objectness", "loss_rpn_box_reg"}
+    put_samples(out, "rpn_sample", cap, cfg.MODEL.RPN.BATCH_SIZE_PER_IMAGE)
+    put_samples(out, "roi_sample", cap, cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE)
+    assert out["rpn_sample_count"] == 2 and out["roi_sample_count"] == 2
+    with torch.no_grad():
+        from maskrcnn_benchmark.structures.image_list import to_image_list
+        il = to_image_list(images)
+        feats = model.backbone(il.tensors)
+        with Capture(BalancedPositiveNegativeSampler):
+            props, _ = model.rpn(il, feats, targets)
+    out["features"] = feats[0].numpy()
+    put_boxes(out, "proposals_train", props)
+    for k, v in losses.items():
+        out[k] = np.float64(v.item())
+    put_grads(out, model)
+    out["state_names"] = np.array([n for n, _, _ in names])
+    out["state_shapes"] = np.array([",".join(map(str, s)) for _, s, _ in names])
+    out["state_seeded_as"] = np.array([c for _, _, c in names])
+    out["opts"] = np.array([str(o) for o in case.COMMON_OPTS])
+    print("teacher", {k: round(v.item(), 6) for k, v in losses.items()})
+    np.savez_compressed(os.path.join(HERE, "step_teacher.npz"), **out)
+
+
+def main():
+    torch.set_num_threads(1)
+    torch.manual_seed(20260101)
+    ref_import.install()
+    torch.Tensor.cuda = lambda self, *a, **k: self  # box_head/loss.py:42,173, language_backbone/transformers.py:60
+    gen_student()
+    gen_teacher()
+    for f in ("step_student.npz", "step_teacher.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
