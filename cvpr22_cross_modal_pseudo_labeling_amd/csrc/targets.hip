@@ -164,10 +164,11 @@ __global__ __launch_bounds__(256) void project_masks_kernel(const unsigned char*
   const float xmax = fmaxf(fminf(fmaxf(b2, 0.f), (float)W), xmin + 1.f);
   const float ymax = fmaxf(fminf(fmaxf(b3, 0.f), (float)H), ymin + 1.f);
   const float w = xmax - xmin, h = ymax - ymin;
-  // "size / M" with a scalar divisor is a multiplication by the reciprocal in the tensor-op formulation
-  const float inv_m = 1.f / (float)M;
-  const float sy = fmaxf(((float)dy + 0.5f) * (h * inv_m) - 0.5f, 0.f);
-  const float sx = fmaxf(((float)dx + 0.5f) * (w * inv_m) - 0.5f, 0.f);
+  // scale = in / out as ONE correctly rounded division (area_pixel_compute_scale of F.interpolate; segmentation_mask.py:
+  // 150-155): a crop whose size is a multiple of M must give integer source positions -- zero weight on the second tap --
+  // which size * (1 / M) misses by an ulp (tests/test_step_golden.py: the reference's own step disagreed there)
+  const float sy = fmaxf(((float)dy + 0.5f) * (h / (float)M) - 0.5f, 0.f);
+  const float sx = fmaxf(((float)dx + 0.5f) * (w / (float)M) - 0.5f, 0.f);
   float y0 = floorf(sy), x0 = floorf(sx);
   const float ly = sy - y0, lx = sx - x0;
   y0 = fminf(y0, h - 1.f);
@@ -470,9 +471,8 @@ __global__ __launch_bounds__(256) void project_pasted_masks_kernel(const float* 
   const float xmax = fmaxf(fminf(fmaxf(b2, 0.f), (float)W), xmin + 1.f);
   const float ymax = fmaxf(fminf(fmaxf(b3, 0.f), (float)H), ymin + 1.f);
   const float w = xmax - xmin, h = ymax - ymin;
-  const float inv_m = 1.f / (float)M;
-  const float sy = fmaxf(((float)dy + 0.5f) * (h * inv_m) - 0.5f, 0.f);
-  const float sx = fmaxf(((float)dx + 0.5f) * (w * inv_m) - 0.5f, 0.f);
+  const float sy = fmaxf(((float)dy + 0.5f) * (h / (float)M) - 0.5f, 0.f);
+  const float sx = fmaxf(((float)dx + 0.5f) * (w / (float)M) - 0.5f, 0.f);
   float y0 = floorf(sy), x0 = floorf(sx);
   const float ly = sy - y0, lx = sx - x0;
   y0 = fminf(y0, h - 1.f);

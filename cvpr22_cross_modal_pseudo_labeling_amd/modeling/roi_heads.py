@@ -520,8 +520,12 @@ def project_masks_on_boxes(masks, gt_index, boxes, M):
     w, h = xmax - xmin, ymax - ymin  # crop is [ymin:ymax, xmin:xmax]
     dst = torch.arange(M, device=boxes.device, dtype=torch.float32)
 
+    m_t = torch.full((1, 1), float(M), device=boxes.device)
+
     def axis(size, lo):
-        src = ((dst[None, :] + 0.5) * (size[:, None] / M) - 0.5).clamp(min=0)  # [P,M]
+        # in / out as a tensor-by-tensor division: correctly rounded on every device (tensor / python-scalar is a
+        # multiplication by the reciprocal on the GPU, an ulp off where the crop size is a multiple of M)
+        src = ((dst[None, :] + 0.5) * (size[:, None] / m_t) - 0.5).clamp(min=0)  # [P,M]
         i0 = src.floor()
         lam = src - i0
         i0 = torch.minimum(i0, size[:, None] - 1)

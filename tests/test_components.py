@@ -535,3 +535,9 @@ def test_detectron_checkpointer_loads_c2_pickle_and_catalog_names(tmp_path, monk
     check(model2)
     with pytest.raises(RuntimeError, match="R-101.pkl"):
         DetectronCheckpointer(cfg, model2).load("catalog://ImageNetPretrained/MSRA/R-101")
+
+
+def test_project_masks_formula_on_crops_that_are_multiples_of_the_resolution():
+    """The host side of tests/test_targets_gpu.py's case (crop sizes 14 k: exact-zero second-tap weights)."""
+    from tests.test_targets_gpu import test_project_masks_on_crops_that_are_multiples_of_the_resolution as case
+    case(False)

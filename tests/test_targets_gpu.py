@@ -69,6 +69,48 @@ def test_project_masks_vs_tensor_ops(dtype):
     assert _C.project_masks(masks, idx[:0].cuda(), boxes[:0].cuda(), 14).shape == (0, 14, 14)
 
 
+def _interpolate_project(masks, idx, boxes, M):
+    """project_masks_on_boxes as the reference spells it (mask_head/loss.py:31-42 on a BinaryMaskList,
+    segmentation_mask.py:117-156): python-rounded crop, F.interpolate(bilinear, align_corners=False), type_as."""
+    out = []
+    H, W = masks.shape[-2:]
+    for b, g in zip(boxes.tolist(), idx.tolist()):
+        xmin, ymin, xmax, ymax = [round(float(v)) for v in b]
+        xmin, ymin = min(max(xmin, 0), W - 1), min(max(ymin, 0), H - 1)
+        xmax, ymax = max(min(max(xmax, 0), W), xmin + 1), max(min(max(ymax, 0), H), ymin + 1)
+        crop = masks[g, ymin:ymax, xmin:xmax]
+        r = torch.nn.functional.interpolate(crop[None, None].float(), size=(M, M), mode="bilinear", align_corners=False)[0, 0]
+        out.append(r.type_as(masks).float())
+    return torch.stack(out)
+
+
+@pytest.mark.parametrize("on_gpu", [False, True])
+def test_project_masks_on_crops_that_are_multiples_of_the_resolution(on_gpu):
+    """Crops of 14, 28, 42, 56 ... pixels put every source position on a pixel centre (or exactly between two): the second
+    tap's weight is exactly 0 there, and 'any weight on a set pixel' (bool masks) must not count it.  The scale has to be
+    the correctly rounded in / out of F.interpolate -- size * (1 / 14) is an ulp high for 42 and 84 (found by the
+    reference-made whole-step fixture, tests/test_step_golden.py).  Against the reference's own formulation on the CPU."""
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.roi_heads import project_masks_on_boxes
+    g = torch.Generator().manual_seed(5)
+    H, W, G = 128, 160, 3
+    masks = torch.rand(G, H, W, generator=g) > 0.35        # salt-and-pepper: every tap matters
+    boxes = []
+    for k in range(1, 9):
+        for j in range(1, 7):
+            x0, y0 = float(torch.randint(0, W - 14 * k + 1, (1,), generator=g)), float(torch.randint(0, H - 14 * j + 1, (1,), generator=g))
+            boxes.append([x0 + 0.2, y0 - 0.3, x0 + 14 * k - 0.4, y0 + 14 * j + 0.3])
+    boxes = torch.tensor(boxes)
+    idx = torch.randint(0, G, (boxes.shape[0],), generator=g)
+    want = _interpolate_project(masks, idx, boxes, 14)
+    dev = "cuda" if on_gpu else "cpu"
+    got_formula = project_masks_on_boxes(masks.to(dev), idx.to(dev), boxes.to(dev), 14).cpu()
+    assert torch.equal(got_formula, want), int((got_formula != want).sum())
+    if on_gpu:
+        got = _C.project_masks(masks.cuda(), idx.cuda(), boxes.cuda(), 14).cpu()
+        assert torch.equal(got, want), int((got != want).sum())
+
+
 # ---- device fg / bg sampler (csrc/targets.hip::sample_fg_bg_kernel) ------------------------------------------------------
 def _labels(p, n_pos, n_ign, g):
     lab = torch.zeros(p, dtype=torch.int64)
