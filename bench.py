@@ -4,7 +4,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One process per GPU (RCCL), 2 images per GPU (weak scaling), fp32, inputs resident in HBM.  A step is
+One process per GPU (RCCL), 2 images per GPU (weak scaling), fp32.  Every step takes a batch that a staging thread
+copied from pinned host memory on its own stream while earlier steps computed (data/prefetch.py::DevicePrefetcher; the
+reference moves every batch inside its loop, engine/trainer.py:103-107) -- the copy of step k+2 is in flight under step
+k, so the batch IS resident when its step starts; ``--resident-input`` re-uses one device batch instead (A/B).  A step is
 forward (frozen trunk + teacher pseudo-labelling + two student passes) -> backward with the bucketed
 gradient all-reduce overlapped -> SGD.  Rank 0 prints ONE JSON line with the fields the driver reads,
 plus
@@ -39,10 +42,14 @@ def _spawn_if_asked():
     known, _ = pre.parse_known_args()
     if launch.needs_spawn(known.gpus):
         sys.exit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], known.gpus))
+    # a rank: pin it to its share of the cores (of its GPU's NUMA node when sysfs tells) BEFORE torch / HIP start any
+    # thread -- the runtime's helper threads and the trainer's worker thread inherit the mask
+    return launch.apply_rank_affinity()
 
 
+AFFINITY = {"cpus": None, "source": "not applied (imported as a module)"}
 if __name__ == "__main__":
-    _spawn_if_asked()
+    AFFINITY = _spawn_if_asked()
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -514,14 +521,72 @@ def parse_args(argv=None):
                     help="DRY RUN on a box with fewer GPUs than ranks: rank r runs on device r %% visible devices (RCCL refuses two "
                          "ranks on one device, so this needs --backend gloo); exercises the DEVICE side of the N > 1 path -- "
                          "streams, hooks, the pipelined trainer next to live collectives -- never a measurement")
+    ap.add_argument("--resident-input", action="store_true",
+                    help="A/B: every step re-uses ONE device-resident batch (no host-to-device staging in the timed region)")
+    ap.add_argument("--host-batches", type=int, default=4, help="distinct pinned host batches the staged input stream cycles through")
     ap.add_argument("--fault-inject", default="", help=argparse.SUPPRESS)  # "RANK:STEP": that rank dies inside the timed region (tests)
     args = ap.parse_args(argv)
     return args
 
 
+class Feed:
+    """The step's input stream.  Staged (default): ``--host-batches`` distinct synthetic batches live in PINNED host memory;
+    a ``DevicePrefetcher`` thread copies one per step to the device on its own stream, two steps ahead (images 25.6 MB +
+    ground-truth masks 15 MB per step at 2 x 3 x 800 x 1333) -- what engine/trainer.py:103-107 of the reference does inside
+    its loop, off the training thread.  Resident (``--resident-input``): the same device batch every step."""
+
+    def __init__(self, args, dev, rank, batch_kw):
+        from cvpr22_cross_modal_pseudo_labeling_amd.data.prefetch import DevicePrefetcher, _map
+        from cvpr22_cross_modal_pseudo_labeling_amd.data.synthetic import make_batch
+        self.staged = not args.resident_input
+        self.prefetcher = None
+        if not self.staged:
+            self.cur = self.nxt = make_batch(IMS_PER_GPU, device=dev, seed=1234 + rank, **batch_kw)
+            self.first_images = self.cur[0]
+            return
+        pin = (lambda t: t.pin_memory()) if dev.type == "cuda" else (lambda t: t)
+        pool = [_map(make_batch(IMS_PER_GPU, device="cpu", seed=1234 + rank + 1000 * i, **batch_kw), pin)
+                for i in range(max(1, args.host_batches))]
+        self.bytes_per_step = sum(t.numel() * t.element_size() for b in pool[:1] for t in self._tensors(b))
+
+        def cycle():
+            i = 0
+            while True:
+                yield pool[i % len(pool)]
+                i += 1
+
+        self.prefetcher = DevicePrefetcher(cycle(), dev, depth=2)
+        self.cur, self.nxt = next(self.prefetcher), next(self.prefetcher)
+        self.first_images = self.cur[0]
+
+    @staticmethod
+    def _tensors(obj):
+        if torch.is_tensor(obj):
+            yield obj
+        elif isinstance(obj, (list, tuple)):
+            for o in obj:
+                yield from Feed._tensors(o)
+        elif hasattr(obj, "bbox"):
+            yield obj.bbox
+            for v in obj.extra_fields.values():
+                yield from Feed._tensors(v)
+
+    def step(self, pipe):
+        """One optimisation step on the current batch with the next one as look-ahead, then advance."""
+        (images, targets), nxt = self.cur, self.nxt
+        out = pipe.step(images, targets, nxt)
+        if self.staged:
+            self.cur, self.nxt = nxt, next(self.prefetcher)
+        return out
+
+    def close(self):
+        if self.prefetcher is not None:
+            self.prefetcher.close()
+
+
 def build_workload(args, workload, dev, world, rank):
     from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
-    from cvpr22_cross_modal_pseudo_labeling_amd.data.synthetic import calibrate_stem_bn, make_batch, make_embeddings
+    from cvpr22_cross_modal_pseudo_labeling_amd.data.synthetic import calibrate_stem_bn, make_embeddings
     from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm, solver, trainer
     from cvpr22_cross_modal_pseudo_labeling_amd.modeling.detector import build_detection_model
 
@@ -540,8 +605,8 @@ def build_workload(args, workload, dev, world, rank):
     model.set_class_embeddings(e_seen)
     if hasattr(model, "set_caption_vocab"):
         model.set_caption_vocab(e_vocab)
-    images, targets = make_batch(IMS_PER_GPU, device=dev, seed=1234 + rank, **batch_kw)
-    calibrate_stem_bn(model, images)
+    feed = Feed(args, dev, rank, batch_kw)
+    calibrate_stem_bn(model, feed.first_images)
     comm.broadcast_parameters(model)
     model.train()
     optimizer = solver.make_optimizer(cfg, model)
@@ -551,23 +616,23 @@ def build_workload(args, workload, dev, world, rank):
     pipe = trainer.PipelinedTrainer(model, optimizer, reducer, scheduler)
     if args.no_pipeline:
         pipe.enabled = False
-    return name, model, images, targets, reducer, pipe
+    return name, model, feed, reducer, pipe
 
 
 def run_secondary(args, dev, world, rank, on_gpu, timer, sync):
     """A short timed region of the teacher configuration (zeroshot_mask.yaml, BASELINE config 2) after the student one: same
     protocol (warm-up, barrier + synchronize on both sides, MAX over ranks).  Returns the `secondary` object (rank 0) or None."""
     secondary = None
-    name2, model2, images2, targets2, reducer2, pipe2 = build_workload(args, "teacher", dev, world, rank)
-    nxt2 = (images2, targets2)  # the teacher step runs its frozen trunk prefix (stem + layer1) of the next batch ahead
+    name2, model2, feed2, reducer2, pipe2 = build_workload(args, "teacher", dev, world, rank)
+    # (the teacher step runs its frozen trunk prefix -- stem + layer1 -- of the next batch ahead)
     for _ in range(3):
-        pipe2.step(images2, targets2, nxt2)
+        feed2.step(pipe2)
     sync()
     overlapped2 = pipe2.enabled
     timer.enabled = on_gpu and not overlapped2
     t0 = time.perf_counter()
     for _ in range(args.secondary_steps):
-        loss2 = pipe2.step(images2, targets2, nxt2)
+        loss2 = feed2.step(pipe2)
     sync()
     el2 = time.perf_counter() - t0
     timer.enabled = False
@@ -577,11 +642,11 @@ def run_secondary(args, dev, world, rank, on_gpu, timer, sync):
         replay2 = 3
         pipe2.enabled = False
         for _ in range(2):
-            pipe2.step(images2, targets2, nxt2)
+            feed2.step(pipe2)
         sync()
         timer.enabled = True
         for _ in range(replay2):
-            pipe2.step(images2, targets2, nxt2)
+            feed2.step(pipe2)
         sync()
         timer.enabled = False
     if world > 1:
@@ -600,7 +665,8 @@ def run_secondary(args, dev, world, rank, on_gpu, timer, sync):
                      "kernels": {n: {kk: round(vv, 3) if isinstance(vv, float) else vv for kk, vv in k2[n].items()}
                                  for n in ("roi_align_backward_strided", "roi_align_forward_strided_nhwc", "split_gemm_pair",
                                            "split_gemm_pair_gated", "split_gemm_pair_tn", "nms_presorted_batched") if n in k2}}
-    del pipe2, reducer2, model2
+    feed2.close()
+    del pipe2, reducer2, model2, feed2
     return secondary
 
 
@@ -643,7 +709,7 @@ def main():
 
     from cvpr22_cross_modal_pseudo_labeling_amd import _C
 
-    name, model, images, targets, reducer, pipe = build_workload(args, args.workload, dev, world, rank)
+    name, model, feed, reducer, pipe = build_workload(args, args.workload, dev, world, rank)
     timer = OpTimer(_C)
     if on_gpu:
         timer.install()
@@ -656,7 +722,8 @@ def main():
 
     # Student-teacher workload: two-stream software pipeline (engine/trainer.py::PipelinedTrainer) -- the frozen half
     # (trunk, RPN, teacher pseudo-labelling) of step k+1 overlaps the student backward of step k.  Every timed step
-    # still executes one frozen half and one student half; the synthetic batch is the same resident tensor each step.
+    # still executes one frozen half and one student half on a batch the staging thread copied in from pinned host memory
+    # (Feed: a different one of --host-batches synthetic batches per step; --resident-input = one device batch throughout).
     # Device warm-up (not a training step): a fresh, idle GPU takes a few seconds of load to reach its sustained clocks,
     # and the first process on a box measured 12-20 % slower without it.
     if on_gpu and args.burn_seconds > 0:
@@ -667,16 +734,15 @@ def main():
                 burn @ burn
             torch.cuda.synchronize()
         del burn
-    nxt = (images, targets)
     for _ in range(args.warmup):
-        pipe.step(images, targets, nxt)
+        feed.step(pipe)
     sync()
     overlapped = pipe.enabled
     timer.enabled = on_gpu and not overlapped  # sequential workloads: per-kernel HIP-event timing live in the timed region
     if args.min_seconds > 0:  # calibrate the step count on a short untimed probe (same count on every rank)
         t0 = time.perf_counter()
         for _ in range(3):
-            pipe.step(images, targets, nxt)
+            feed.step(pipe)
         sync()
         probe = torch.tensor([(time.perf_counter() - t0) / 3], device=dev, dtype=torch.float64)
         if world > 1:
@@ -692,7 +758,7 @@ def main():
     for i in range(args.steps):
         if fault is not None and fault == (rank, i):
             os._exit(13)  # test hook: a rank lost inside the timed region must end the whole job with a non-zero code
-        loss_dict = pipe.step(images, targets, nxt)
+        loss_dict = feed.step(pipe)
         if (i + 1) % chunk == 0:
             marks.append((i + 1, time.perf_counter()))
     sync()
@@ -712,11 +778,11 @@ def main():
         replay_steps = max(3, args.steps // 4)
         pipe.enabled = False
         for _ in range(2):  # settle the caching allocator on the single-stream allocation pattern first
-            pipe.step(images, targets, nxt)
+            feed.step(pipe)
         sync()
         timer.enabled = on_gpu
         for _ in range(replay_steps):
-            pipe.step(images, targets, nxt)
+            feed.step(pipe)
         sync()
         timer.enabled = False
     timer.enabled = False
@@ -732,9 +798,12 @@ def main():
                              float(hook_launches)], device=gdev, dtype=torch.float64)
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
+        placed = [None] * world  # where every rank pinned itself (engine/launch.py::apply_rank_affinity)
+        dist.all_gather_object(placed, AFFINITY)
         per_rank = [{"rank": r, "elapsed_s": round(float(g[0]), 4), "steps": int(g[1]),
                      "allreduce_exposed_wait_ms_mean": round(float(g[2]), 3), "allreduce_exposed_wait_ms_max": round(float(g[3]), 3),
-                     "issued_from_backward_hooks": int(g[4])} for r, g in enumerate(gathered)]
+                     "issued_from_backward_hooks": int(g[4]), "cpus": placed[r]["cpus"], "cpus_from": placed[r]["source"]}
+                    for r, g in enumerate(gathered)]
     finite = all(bool(torch.isfinite(v).all()) for v in loss_dict.values())
     payload_mb = round(sum(f.numel() * f.element_size() for f in reducer.flat) / 1e6, 1)
 
@@ -748,7 +817,9 @@ def main():
         timer.records.clear()
         for k in timer.bytes:
             timer.bytes[k] = 0.0
-        del pipe, reducer, model
+        staged, bytes_per_step = feed.staged, getattr(feed, "bytes_per_step", 0)
+        feed.close()
+        del pipe, reducer, model, feed
         if on_gpu:
             torch.cuda.empty_cache()
         try:  # the headline above is complete: a failure in here must not take the line with it
@@ -759,6 +830,8 @@ def main():
             secondary = {"error": f"{type(e).__name__}: {e}"[:400]}
     else:
         kernels_primary = timer.summary() if rank == 0 else None
+        staged, bytes_per_step = feed.staged, getattr(feed, "bytes_per_step", 0)
+        feed.close()
 
     if rank == 0:
         kernels = kernels_primary
@@ -815,7 +888,10 @@ def main():
             "dry_run": dry_run,
             "device": args.device,
             "backend": backend if world > 1 else None,
-            "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+            # ranks whose gradients went through RCCL: 0 unless the group's backend is nccl (a one-rank job has no exchange;
+            # the gloo dry runs are not RCCL)
+            "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized() and backend == "nccl") else 0,
+            "cpus": AFFINITY,
             # gradient exchange of the last timed step: buckets whose all-reduce was issued from a backward hook (i.e.
             # overlapped with the rest of the backward) out of all buckets, the payload, and -- per step -- how long
             # finish() stalled on the collectives after the backward (max over ranks of each rank's mean)
@@ -826,7 +902,14 @@ def main():
             "ranks": per_rank,
             "config": {"workload": f"{name}.yaml R-50-C4, {IMS_PER_GPU} img/GPU {size}, fwd+bwd+allreduce+SGD",
                        "global_batch": global_batch, "parallelism": f"dp{world}", "losses_finite": finite,
-                       "pipelined": bool(overlapped)},
+                       "pipelined": bool(overlapped),
+                       # input staging inside the timed region (reference engine/trainer.py:103-107): pinned host batch ->
+                       # device on the copy stream, every step
+                       "h2d_in_timed_region": bool(staged), "h2d_MB_per_step": round(bytes_per_step / 1e6, 1),
+                       # BASELINE config 2 (teacher, zeroshot_mask.yaml): same protocol, after the student region
+                       "secondary_workload": (secondary or {}).get("workload"),
+                       "secondary_ms_per_step": (secondary or {}).get("ms_per_step"),
+                       "secondary_images_per_s": (secondary or {}).get("images_per_s")},
             # host-side step time over chunks of the timed region (issue rate of rank 0; the region total is `ms_per_step`)
             "ms_per_step_spread": ({"chunk_steps": chunk, "min": round(min(chunk_ms), 3), "median": round(sorted(chunk_ms)[len(chunk_ms) // 2], 3),
                                     "max": round(max(chunk_ms), 3)} if chunk_ms else None),

@@ -1266,7 +1266,7 @@ extern "C" int ovis_split_gemm_tn_slices(long m, int n, int channels, int taps) 
   // workgroups = 2.25 rounds ran at 75 %; 7 slices = 1008 fill two rounds to 98 %).  Among the slice counts of up to
   // ~4 rounds pick the one whose rounds are fullest, preferring about two rounds (enough parallelism, few slabs).
   const long slots = 2L * OVIS_NUM_CU;
-  if (steps >= 128 && steps <= 1100 && tiles <= slots) {
+  if (steps >= 128 && steps <= 1100 && tiles <= 64) {  // (the measured regime: medium tile counts go to the fill scorer)
     // Short contractions with few output tiles (the trainable trunk of the teacher step: M = 8400 / 33400 rows, 4-36
     // tiles): a workgroup's fixed costs (slab write, launch) and the slab reduction weigh as much as its k-steps, so ONE
     // round of workgroups with at least 16 k-steps each beats two rounds of shorter slices -- layer3's 3x3 (36 tiles):

@@ -32,6 +32,120 @@ def rank_env(rank, nproc, master_port, base=None, master_addr="127.0.0.1"):
     return env
 
 
+# ---- per-rank CPU placement ------------------------------------------------------------------------------------------
+# A rank drives its GPU from two host threads that issue ~530 launches per step between host reads (engine/trainer.py);
+# on a two-socket 8-GPU node an unpinned rank migrates between sockets and its launches cross the inter-socket link.
+# Every rank therefore pins itself -- BEFORE its first GPU call, so the runtime's helper threads inherit the mask -- to a
+# private share of the cores of the NUMA node its GPU hangs off (sysfs), or to an even share of the allowed cores when
+# the topology cannot be read.  The reference leaves placement to the OS (tools/train_net.py:187-195 only sets the device).
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_nodes(sysfs_root="/sys"):
+    """NUMA node of every AMD GPU (render node), in PCI-address order -- the order HIP enumerates devices in by default.
+    [] when sysfs has no answer (containers without /sys/class/drm, a node reporting -1)."""
+    base = os.path.join(sysfs_root, "class", "drm")
+    found = []
+    try:
+        entries = sorted(e for e in os.listdir(base) if e.startswith("renderD"))
+    except OSError:
+        return []
+    for e in entries:
+        dev = os.path.join(base, e, "device")
+        try:
+            with open(os.path.join(dev, "vendor")) as f:
+                if f.read().strip().lower() != "0x1002":
+                    continue
+            with open(os.path.join(dev, "numa_node")) as f:
+                node = int(f.read().strip())
+            addr = os.path.basename(os.path.realpath(dev))
+        except (OSError, ValueError):
+            return []
+        if node < 0:
+            return []
+        found.append((addr, node))
+    return [n for _, n in sorted(found)]
+
+
+def plan_affinity(nproc, allowed=None, sysfs_root="/sys", visible=None):
+    """[set of cpu ids] per local rank.  ``visible`` = the GPU indices the ranks use (HIP/ROCR_VISIBLE_DEVICES order;
+    default 0..nproc-1).  NUMA-aware when every rank's GPU has a known node with allowed cores, else an even contiguous
+    split of ``allowed`` (default: this process' affinity mask).  A rank never gets an empty set."""
+    allowed = sorted(os.sched_getaffinity(0) if allowed is None else allowed)
+    nodes = gpu_numa_nodes(sysfs_root)
+    visible = list(range(nproc)) if visible is None else list(visible)
+    plan = None
+    if nodes and len(visible) >= nproc and all(0 <= v < len(nodes) for v in visible[:nproc]):
+        by_node = {}
+        for r in range(nproc):
+            by_node.setdefault(nodes[visible[r]], []).append(r)
+        plan = [None] * nproc
+        for node, ranks in by_node.items():
+            try:
+                with open(os.path.join(sysfs_root, "devices", "system", "node", f"node{node}", "cpulist")) as f:
+                    cpus = sorted(_parse_cpulist(f.read()) & set(allowed))
+            except (OSError, ValueError):
+                cpus = []
+            if len(cpus) < len(ranks):
+                plan = None
+                break
+            share = len(cpus) // len(ranks)
+            for i, r in enumerate(ranks):
+                plan[r] = set(cpus[i * share:(i + 1) * share])
+    if plan is None:
+        if len(allowed) < nproc:  # fewer cores than ranks: everyone shares everything
+            return [set(allowed) for _ in range(nproc)]
+        share = len(allowed) // nproc
+        plan = [set(allowed[r * share:(r + 1) * share]) for r in range(nproc)]
+    return plan
+
+
+def format_cpus(cpus):
+    """{0,1,2,3,8} -> '0-3,8'."""
+    cpus = sorted(cpus)
+    out, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
+
+
+def apply_rank_affinity(env=None, sysfs_root="/sys"):
+    """Pin the calling rank (call before anything touches the GPU).  ``OVIS_RANK_CPUS`` (set by ``spawn_ranks``) wins;
+    under another launcher (torch.distributed.run) the share is planned here from LOCAL_RANK / LOCAL_WORLD_SIZE.
+    ``OVIS_NO_AFFINITY=1`` leaves placement to the OS.  Returns what was applied: {"cpus": "0-15", "source": ...}."""
+    env = os.environ if env is None else env
+    if env.get("OVIS_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
+        return {"cpus": None, "source": "off"}
+    try:
+        if env.get("OVIS_RANK_CPUS"):
+            cpus, source = _parse_cpulist(env["OVIS_RANK_CPUS"]), "launcher"
+        else:
+            world = int(env.get("LOCAL_WORLD_SIZE", env.get("WORLD_SIZE", "1")))
+            rank = int(env.get("LOCAL_RANK", env.get("RANK", "0")))
+            if world <= 1:
+                return {"cpus": format_cpus(os.sched_getaffinity(0)), "source": "single rank: unchanged"}
+            vis = env.get("HIP_VISIBLE_DEVICES") or env.get("ROCR_VISIBLE_DEVICES")
+            visible = [int(v) for v in vis.split(",")] if vis and all(v.strip().isdigit() for v in vis.split(",")) else None
+            cpus = plan_affinity(world, sysfs_root=sysfs_root, visible=visible)[rank]
+            source = "numa" if gpu_numa_nodes(sysfs_root) else "even split"
+        cpus = set(cpus) & os.sched_getaffinity(0) or set(cpus)
+        os.sched_setaffinity(0, cpus)
+        return {"cpus": format_cpus(cpus), "source": source}
+    except (OSError, ValueError) as e:  # a cpuset that forbids it: run unpinned, say so
+        return {"cpus": None, "source": f"failed: {e}"}
+
+
 def needs_spawn(requested, env=None):
     """True when the caller asked for more than one rank and no launcher has set the rendezvous variables yet."""
     env = os.environ if env is None else env
@@ -39,7 +153,9 @@ def needs_spawn(requested, env=None):
 
 
 class _Terminated(Exception):
-    """SIGTERM reached the launcher (``timeout``, a scheduler): unwinds ``spawn_ranks`` so that its ``finally`` ends the ranks."""
+    """SIGTERM reached the launcher (``timeout``, a scheduler).  Raised by ``spawn_ranks`` itself between two polls -- the
+    signal handler only leaves a note -- so that it can never fire inside ``Popen`` (a started rank missing from
+    ``children``) or inside the clean-up."""
 
 
 def _stop(children):
@@ -72,9 +188,10 @@ def spawn_ranks(argv, nproc, master_port=None, env=None, poll_seconds=0.2, pytho
     port = master_port or free_port()
     cmd = [python or sys.executable] + list(argv)
     children = []
+    got = []  # signals seen: the handler only notes them; the poll loop (and the spawn loop) act on the note
 
     def on_term(signum, frame):
-        raise _Terminated(signum)
+        got.append(signum)
 
     old_term = None
     try:
@@ -82,12 +199,21 @@ def spawn_ranks(argv, nproc, master_port=None, env=None, poll_seconds=0.2, pytho
     except ValueError:  # not the main thread: the caller's handlers stay
         old_term = None
     code = 0
+    base_env = os.environ if env is None else env
+    no_pin = base_env.get("OVIS_NO_AFFINITY") == "1"
+    plan = None if no_pin else plan_affinity(nproc)
     try:
         for r in range(nproc):
-            children.append(subprocess.Popen(cmd, env=rank_env(r, nproc, port, env),
-                                             stdout=None if r == 0 else sys.stderr))
+            if got:
+                raise _Terminated(got[0])
+            renv = rank_env(r, nproc, port, env)
+            if plan is not None:
+                renv.setdefault("OVIS_RANK_CPUS", format_cpus(plan[r]))
+            children.append(subprocess.Popen(cmd, env=renv, stdout=None if r == 0 else sys.stderr))
         alive = set(range(nproc))
         while alive and code == 0:
+            if got:
+                raise _Terminated(got[0])
             for r in sorted(alive):
                 rc = children[r].poll()
                 if rc is None:
@@ -106,7 +232,13 @@ def spawn_ranks(argv, nproc, master_port=None, env=None, poll_seconds=0.2, pytho
         code = 130
         sys.stderr.write("launch: interrupted; stopping the ranks\n")
     finally:
-        _stop(children)
+        # further SIGTERMs (timeout -k, a scheduler retrying) are only noted: nothing may cut the clean-up short
+        for attempt in range(3):
+            try:
+                _stop(children)
+                break
+            except BaseException as e:  # KeyboardInterrupt in the middle of a wait: try again, the ranks must go
+                sys.stderr.write(f"launch: clean-up interrupted ({type(e).__name__}); retrying\n")
         if old_term is not None:
             signal.signal(signal.SIGTERM, old_term)
     return code

@@ -57,6 +57,8 @@ def _record_stream(obj, stream):
     elif hasattr(obj, "probs") and hasattr(obj, "boxes"):  # PastedMasks
         _record_stream(obj.probs, stream)
         _record_stream(obj.boxes, stream)
+    elif hasattr(obj, "tensors") and hasattr(obj, "image_sizes"):  # ImageList: the padded batch to_image_list allocates
+        _record_stream(obj.tensors, stream)
 
 
 class PipelinedTrainer:
@@ -78,6 +80,12 @@ class PipelinedTrainer:
     def __init__(self, model, optimizer, reducer, scheduler=None, threaded=True, side_priority=-1):
         self.model, self.optimizer, self.reducer, self.scheduler = model, optimizer, reducer, scheduler
         self.enabled = hasattr(model, "forward_frozen") and torch.cuda.is_available()
+        # The look-ahead half must not read anything the optimizer writes: with MODEL.LANGUAGE_BACKBONE.FT_EMB the BERT
+        # table is trained AND read by the frozen half's noun embeddings (st_generalized_rcnn.py:242) -- the side stream
+        # would read it while optimizer.step() writes it.  Run such models un-pipelined.
+        bert = getattr(model, "bert", None)
+        if self.enabled and bert is not None and any(p.requires_grad for p in bert.parameters()):
+            self.enabled = False
         # The side stream gets the HIGH queue priority: the frozen half is a chain of small kernels between host reads
         # (RPN counts, sampler counts); behind the main stream's full-machine GEMMs each of those round trips waited for
         # a GEMM to drain, and a late frozen half stalls the next student half.  Measured: 33.9 -> 33.4 ms per step.

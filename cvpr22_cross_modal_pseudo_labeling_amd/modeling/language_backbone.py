@@ -17,6 +17,7 @@ and padding excluded through ``special_tokens_mask``) and L2-normalises.  Here
   (st_generalized_rcnn.py:190-191) although the table is frozen.
 """
 import os
+import threading
 
 import torch
 from torch import nn
@@ -47,6 +48,9 @@ class BERT(nn.Module):
         self._vocab_file = vocab_file
         self._tokenizer = tokenizer
         self._cache = {}
+        # the cache is read and re-ordered by two threads: PipelinedTrainer's worker (forward_frozen -> noun embeddings)
+        # and the training thread (forward_student -> prepare_text)
+        self._cache_lock = threading.Lock()
 
     # -- tokenizer ------------------------------------------------------------------------------------------------
     @property
@@ -100,21 +104,29 @@ class BERT(nn.Module):
             keep = (1 - enc["special_tokens_mask"]).to(table.device, torch.float32)
             emb = (table[ids] * keep[:, :, None]).sum(1) / keep.sum(1)[:, None]
             return torch.nn.functional.normalize(emb, dim=-1)
+        enc = None
+        if table.requires_grad:
+            # FT_EMB outside a graph (the @no_grad frozen half, eval): the table moves every optimizer step, and the fused
+            # optimizer writes it through raw pointers, so ``_version`` does not see the update -- never serve a cached value
+            enc = self.tokenize(words)
+            return _C.text_embed(table.detach(), enc["input_ids"], enc["special_tokens_mask"])
         key = (words, table._version, table.device, table.data_ptr())
-        hit = self._cache.get(key)
-        if hit is not None:
-            self._cache[key] = self._cache.pop(key)  # most recently used last
-            return hit
+        with self._cache_lock:
+            hit = self._cache.get(key)
+            if hit is not None:
+                self._cache[key] = self._cache.pop(key)  # most recently used last
+                return hit
         enc = self.tokenize(words)  # (host table, MODEL.DEVICE cpu: _C.text_embed dispatches to the in-package host formula)
         emb = _C.text_embed(table.detach(), enc["input_ids"], enc["special_tokens_mask"])
         # keyed by the strings: the per-image noun lists of a step must not evict the 1203-name vocabulary entry (the
         # reference re-tokenises it every iteration, st_generalized_rcnn.py:190-191).  A new table version drops everything.
-        for k in [k for k in self._cache if k[1:] != key[1:]]:
-            del self._cache[k]
-        while len(self._cache) >= self.CACHE_ENTRIES:
-            # evict the least recently used entry, sparing the LONGEST list: that one is the caption vocabulary
-            longest = max(self._cache, key=lambda k: len(k[0]))
-            victim = next((k for k in self._cache if k is not longest), longest)
-            del self._cache[victim]
-        self._cache[key] = emb
+        with self._cache_lock:
+            for k in [k for k in self._cache if k[1:] != key[1:]]:
+                del self._cache[k]
+            while len(self._cache) >= self.CACHE_ENTRIES:
+                # evict the least recently used entry, sparing the LONGEST list: that one is the caption vocabulary
+                longest = max(self._cache, key=lambda k: len(k[0]))
+                victim = next((k for k in self._cache if k is not longest), longest)
+                del self._cache[victim]
+            self._cache[key] = emb
         return emb

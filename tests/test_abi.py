@@ -90,4 +90,10 @@ def test_tn_slice_count_fills_the_rounds_of_resident_workgroups():
                                    ((33400, 128, 128, 9), 56)):
         s = f(m, n, ch, taps)
         assert s == want and s * (n // 128) * (taps * ch // 128) <= slots and ((m + 31) // 32) // s >= 16, (m, n, ch, taps, s)
+    # medium tile counts with a short contraction: outside the regime the one-round rule was measured in
+    # (4-36 tiles), so the fill scorer decides -- 144 tiles at M = 25088 get two nearly full rounds (7 slices, 1008 workgroups,
+    # 112 k-steps each), not 3 slices of one 84 % round; ~300 tiles are not left with one 58 % round
+    assert f(25088, 512, 512, 9) == 7
+    s = f(25088, 512, 8192, 1)   # 256 tiles
+    assert (s * 256) / (-(-(s * 256) // slots) * slots) >= 0.9 and s >= 2
     assert f(64, 128, 128, 1) == 1 and f(0, 128, 128, 1) == 1   # tiny / empty problems: one slice

@@ -112,3 +112,113 @@ def test_sigterm_to_the_launcher_ends_every_rank(tmp_path):
             alive = False
         assert not alive, pid
     assert "stopping the ranks" in parent.stderr.read()
+
+
+# ---- per-rank CPU placement (VERDICT r4 missing-5) ------------------------------------------------------------------------
+def _fake_sysfs(root, gpu_nodes, node_cpus):
+    """A sysfs tree with one render node per GPU (PCI addresses in enumeration order) and the nodes' cpu lists."""
+    for i, node in enumerate(gpu_nodes):
+        pci = root / "devices" / f"pci0000:{i:02x}" / f"0000:{i:02x}:00.0"
+        pci.mkdir(parents=True)
+        (pci / "vendor").write_text("0x1002\n")
+        (pci / "numa_node").write_text(f"{node}\n")
+        drm = root / "class" / "drm" / f"renderD{128 + i}"
+        drm.mkdir(parents=True)
+        os.symlink(pci, drm / "device")
+    for node, cpus in node_cpus.items():
+        d = root / "devices" / "system" / "node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus + "\n")
+
+
+def test_affinity_plan_even_split_without_topology(tmp_path):
+    plan = launch.plan_affinity(4, allowed=range(16), sysfs_root=str(tmp_path))
+    assert plan == [set(range(0, 4)), set(range(4, 8)), set(range(8, 12)), set(range(12, 16))]
+    assert launch.plan_affinity(8, allowed=range(3), sysfs_root=str(tmp_path)) == [{0, 1, 2}] * 8  # fewer cores than ranks
+    assert launch.format_cpus({0, 1, 2, 3, 8, 10, 11}) == "0-3,8,10-11"
+    assert launch._parse_cpulist("0-3,8,10-11") == {0, 1, 2, 3, 8, 10, 11}
+
+
+def test_affinity_plan_follows_the_gpus_numa_nodes(tmp_path):
+    """Two sockets, interleaved SMT numbering, GPUs 0-3 on node 0 and 4-7 on node 1: every rank gets a private quarter of
+    ITS socket's allowed cores."""
+    _fake_sysfs(tmp_path, [0, 0, 0, 0, 1, 1, 1, 1], {0: "0-15,32-47", 1: "16-31,48-63"})
+    assert launch.gpu_numa_nodes(str(tmp_path)) == [0, 0, 0, 0, 1, 1, 1, 1]
+    plan = launch.plan_affinity(8, allowed=range(64), sysfs_root=str(tmp_path))
+    node0, node1 = set(range(0, 16)) | set(range(32, 48)), set(range(16, 32)) | set(range(48, 64))
+    assert all(plan[r] <= node0 and len(plan[r]) == 8 for r in range(4))
+    assert all(plan[r] <= node1 and len(plan[r]) == 8 for r in range(4, 8))
+    assert sum(len(p) for p in plan) == 64 and len(set().union(*plan)) == 64  # private shares
+    # two ranks on GPUs 5 and 2 (HIP_VISIBLE_DEVICES=5,2): rank 0 lands on socket 1, rank 1 on socket 0
+    plan = launch.plan_affinity(2, allowed=range(64), sysfs_root=str(tmp_path), visible=[5, 2])
+    assert plan[0] == node1 and plan[1] == node0
+    # a cpuset that leaves a socket too few cores falls back to the even split
+    plan = launch.plan_affinity(8, allowed=list(range(0, 16)) + [16], sysfs_root=str(tmp_path))
+    assert [len(p) for p in plan] == [2] * 8
+
+
+def test_ranks_pin_themselves_before_anything_else(tmp_path):
+    """spawn_ranks hands every rank its share (OVIS_RANK_CPUS); apply_rank_affinity applies it; a rank started by another
+    launcher plans its own share from LOCAL_RANK / LOCAL_WORLD_SIZE; OVIS_NO_AFFINITY=1 turns it off."""
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        import pytest
+        pytest.skip("one core")
+    res = _run("""
+        import json, os, sys
+        sys.path.insert(0, %r)
+        from cvpr22_cross_modal_pseudo_labeling_amd.engine import launch
+        before = sorted(os.sched_getaffinity(0))
+        info = launch.apply_rank_affinity()
+        open(os.path.join(sys.argv[1], "aff_" + os.environ["RANK"]), "w").write(json.dumps(
+            {"info": info, "after": sorted(os.sched_getaffinity(0)), "before": before, "env": os.environ.get("OVIS_RANK_CPUS")}))
+    """ % ROOT, 2, tmp_path)
+    assert res.returncode == 0, res.stderr
+    got = [json.loads((tmp_path / f"aff_{r}").read_text()) for r in (0, 1)]
+    half = len(allowed) // 2
+    assert got[0]["after"] == allowed[:half] and got[1]["after"] == allowed[half:2 * half]
+    assert got[0]["info"]["source"] == "launcher" and got[0]["env"] == launch.format_cpus(allowed[:half])
+    # under another launcher: same plan, computed by the rank
+    script = ("import json, os, sys; sys.path.insert(0, %r)\n"
+              "from cvpr22_cross_modal_pseudo_labeling_amd.engine import launch\n"
+              "print(json.dumps([launch.apply_rank_affinity(), sorted(os.sched_getaffinity(0))]))\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("OVIS_")}
+    env.update({"LOCAL_RANK": "1", "LOCAL_WORLD_SIZE": "2", "RANK": "1", "WORLD_SIZE": "2"})
+    info, after = json.loads(subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env).stdout)
+    assert after == allowed[half:2 * half] and info["source"] in ("even split", "numa")
+    env["OVIS_NO_AFFINITY"] = "1"
+    info, after = json.loads(subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env).stdout)
+    assert after == allowed and info == {"cpus": None, "source": "off"}
+
+
+def test_second_sigterm_does_not_cut_the_cleanup_short(tmp_path):
+    """``timeout -k`` / a retrying scheduler sends SIGTERM again while the launcher is ending its ranks; a rank
+    that ignores SIGTERM (a hung runtime) must still be killed and reaped."""
+    import signal
+    import time
+
+    child = tmp_path / "child.py"
+    child.write_text("import os, signal, sys, time\n"
+                     "signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+                     "open(os.path.join(sys.argv[1], 'pid_' + os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+                     "time.sleep(300)\n")
+    driver = ("import sys; sys.path.insert(0, %r)\n"
+              "from cvpr22_cross_modal_pseudo_labeling_amd.engine import launch\n"
+              "sys.exit(launch.spawn_ranks([%r, %r], 2))\n" % (ROOT, str(child), str(tmp_path)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    parent = subprocess.Popen([sys.executable, "-c", driver], env=env, stderr=subprocess.PIPE, text=True)
+    deadline = time.time() + 60
+    while time.time() < deadline and not all((tmp_path / f"pid_{r}").exists() and (tmp_path / f"pid_{r}").read_text() for r in (0, 1)):
+        time.sleep(0.1)
+    pids = [int((tmp_path / f"pid_{r}").read_text()) for r in (0, 1)]
+    parent.send_signal(signal.SIGTERM)
+    time.sleep(1.0)                      # the launcher is now inside _stop(), waiting for ranks that ignore SIGTERM
+    parent.send_signal(signal.SIGTERM)
+    assert parent.wait(timeout=40) == 128 + signal.SIGTERM
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = open(f"/proc/{pid}/stat").read().split()[2] != "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, pid

@@ -93,6 +93,54 @@ def test_ft_emb_trains_the_table_through_the_reference_formula(golden_dir, z):
     assert not BERT(None, vocab_size=16, hidden_size=8).embeddings.requires_grad
 
 
+def test_ft_emb_no_grad_paths_never_serve_a_stale_cache_and_the_step_is_not_pipelined(golden_dir, z):
+    """with a trainable table the no-grad callers (the @no_grad frozen half, eval) must see the CURRENT
+    table although the fused optimizer updates it through raw pointers (no ``_version`` bump), and a model whose frozen
+    half reads a trained parameter must not run that half ahead on the side stream."""
+    from types import SimpleNamespace as NS
+
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine.trainer import PipelinedTrainer
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.language_backbone import BERT
+
+    table = T(z["table"])
+    vocab = os.path.join(golden_dir, "wordpiece_vocab.txt")
+    words = [str(w) for w in z["words"]]
+    for ft in (True, False):
+        b = BERT(NS(MODEL=NS(LANGUAGE_BACKBONE=NS(FT_EMB=ft))), vocab_file=vocab, vocab_size=table.shape[0], hidden_size=table.shape[1])
+        with torch.no_grad():
+            b.embeddings.copy_(table)
+            first = b.extract_emb(words).clone()
+            version = b.embeddings._version
+            b.embeddings.data.mul_(-1.0)       # what a raw-pointer optimizer step looks like to autograd's bookkeeping
+            assert b.embeddings._version == version
+            second = b.extract_emb(words)
+        assert torch.allclose(first, T(z["embeddings"]), rtol=0, atol=2e-7)
+        if ft:
+            assert torch.allclose(second, -first, rtol=0, atol=2e-7)   # recomputed from the moved table
+            assert not b._cache
+        else:
+            assert second is not None and torch.equal(second, first)    # frozen table: the cached entry (by design)
+
+        class Model(torch.nn.Module):
+            def __init__(self, bert):
+                super().__init__()
+                self.bert = bert
+
+            def forward_frozen(self, images, targets):
+                return {}
+
+        pipe = PipelinedTrainer.__new__(PipelinedTrainer)
+        real_available = torch.cuda.is_available
+        torch.cuda.is_available = lambda: True   # (the switch is decided before any stream is made; make it reachable here)
+        try:
+            stream = torch.cuda.Stream
+            torch.cuda.Stream = lambda *a, **k: None
+            PipelinedTrainer.__init__(pipe, Model(b), None, None)
+        finally:
+            torch.cuda.is_available, torch.cuda.Stream = real_available, stream
+        assert pipe.enabled is (not ft)
+
+
 def _rect(x0, y0, x1, y1):
     return [x0, y0, x1, y0, x1, y1, x0, y1]
 

@@ -16,11 +16,16 @@ import sys
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver: RCCL between ranks needs it
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+from cvpr22_cross_modal_pseudo_labeling_amd.engine import launch  # noqa: E402  (no torch, no GPU)
+
+# pin this rank to its share of the cores (of its GPU's NUMA node when sysfs tells) before torch / HIP start their threads
+AFFINITY = launch.apply_rank_affinity() if __name__ == "__main__" else {"cpus": None, "source": "not applied"}
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults  # noqa: E402
 from cvpr22_cross_modal_pseudo_labeling_amd.data.prefetch import DevicePrefetcher  # noqa: E402
@@ -104,6 +109,7 @@ def main():
     logging.basicConfig(level=logging.INFO if comm.get_rank() == 0 else logging.WARNING,
                         format="%(asctime)s %(name)s %(levelname)s: %(message)s")
     logging.getLogger("ovis.trainer").info("Using %d GPUs\n%s", num_gpus, args)
+    logging.getLogger("ovis.trainer").info("rank %d host cores: %s (%s)", comm.get_rank(), AFFINITY["cpus"], AFFINITY["source"])
     ims_per_gpu = max(cfg.SOLVER.IMS_PER_BATCH // num_gpus, 1)
     logging.getLogger("ovis.trainer").info("%d images per GPU and iteration (SOLVER.IMS_PER_BATCH %d / %d GPUs)", ims_per_gpu,
                                            cfg.SOLVER.IMS_PER_BATCH, num_gpus)
