@@ -535,7 +535,7 @@ class Feed:
     ground-truth masks 15 MB per step at 2 x 3 x 800 x 1333) -- what engine/trainer.py:103-107 of the reference does inside
     its loop, off the training thread.  Resident (``--resident-input``): the same device batch every step."""
 
-    def __init__(self, args, dev, rank, batch_kw):
+    def __init__(self, args, dev, rank, batch_kw, warmup):
         from cvpr22_cross_modal_pseudo_labeling_amd.data.prefetch import DevicePrefetcher, _map
         from cvpr22_cross_modal_pseudo_labeling_amd.data.synthetic import make_batch
         self.staged = not args.resident_input
@@ -545,8 +545,12 @@ class Feed:
             self.first_images = self.cur[0]
             return
         pin = (lambda t: t.pin_memory()) if dev.type == "cuda" else (lambda t: t)
+        # every distinct batch passes through the warm-up steps once (its RoI counts size the caching allocator's blocks:
+        # a batch first seen inside the timed region costs hipMallocs there -- 31 vs 22.5 ms per teacher step over 10 steps)
+        n_pool = max(1, min(args.host_batches, warmup - 1))
         pool = [_map(make_batch(IMS_PER_GPU, device="cpu", seed=1234 + rank + 1000 * i, **batch_kw), pin)
-                for i in range(max(1, args.host_batches))]
+                for i in range(n_pool)]
+        self.pool_size = n_pool
         self.bytes_per_step = sum(t.numel() * t.element_size() for b in pool[:1] for t in self._tensors(b))
 
         def cycle():
@@ -584,7 +588,7 @@ class Feed:
             self.prefetcher.close()
 
 
-def build_workload(args, workload, dev, world, rank):
+def build_workload(args, workload, dev, world, rank, warmup):
     from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
     from cvpr22_cross_modal_pseudo_labeling_amd.data.synthetic import calibrate_stem_bn, make_embeddings
     from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm, solver, trainer
@@ -605,7 +609,7 @@ def build_workload(args, workload, dev, world, rank):
     model.set_class_embeddings(e_seen)
     if hasattr(model, "set_caption_vocab"):
         model.set_caption_vocab(e_vocab)
-    feed = Feed(args, dev, rank, batch_kw)
+    feed = Feed(args, dev, rank, batch_kw, warmup)
     calibrate_stem_bn(model, feed.first_images)
     comm.broadcast_parameters(model)
     model.train()
@@ -623,9 +627,10 @@ def run_secondary(args, dev, world, rank, on_gpu, timer, sync):
     """A short timed region of the teacher configuration (zeroshot_mask.yaml, BASELINE config 2) after the student one: same
     protocol (warm-up, barrier + synchronize on both sides, MAX over ranks).  Returns the `secondary` object (rank 0) or None."""
     secondary = None
-    name2, model2, feed2, reducer2, pipe2 = build_workload(args, "teacher", dev, world, rank)
+    warm2 = 6
+    name2, model2, feed2, reducer2, pipe2 = build_workload(args, "teacher", dev, world, rank, warm2)
     # (the teacher step runs its frozen trunk prefix -- stem + layer1 -- of the next batch ahead)
-    for _ in range(3):
+    for _ in range(warm2):
         feed2.step(pipe2)
     sync()
     overlapped2 = pipe2.enabled
@@ -657,7 +662,7 @@ def run_secondary(args, dev, world, rank, on_gpu, timer, sync):
         k2 = timer.summary()
         secondary = {"workload": (f"{name2}.yaml R-50-C4 teacher, {IMS_PER_GPU} img/GPU "
                                   f"{'3x128x160 TINY' if args.tiny else '3x800x1333'}, fwd+bwd+allreduce+SGD"),
-                     "steps": args.secondary_steps, "warmup": 3, "pipelined": overlapped2, "replay_steps": replay2,
+                     "steps": args.secondary_steps, "warmup": warm2, "pipelined": overlapped2, "replay_steps": replay2,
                      "ms_per_step": round(1e3 * el2 / args.secondary_steps, 3),
                      "images_per_s": round(IMS_PER_GPU * world * args.secondary_steps / el2, 3),
                      "losses_finite": all(bool(torch.isfinite(v).all()) for v in loss2.values()),
@@ -709,7 +714,7 @@ def main():
 
     from cvpr22_cross_modal_pseudo_labeling_amd import _C
 
-    name, model, feed, reducer, pipe = build_workload(args, args.workload, dev, world, rank)
+    name, model, feed, reducer, pipe = build_workload(args, args.workload, dev, world, rank, args.warmup)
     timer = OpTimer(_C)
     if on_gpu:
         timer.install()
@@ -817,7 +822,7 @@ def main():
         timer.records.clear()
         for k in timer.bytes:
             timer.bytes[k] = 0.0
-        staged, bytes_per_step = feed.staged, getattr(feed, "bytes_per_step", 0)
+        staged, bytes_per_step, pool_size = feed.staged, getattr(feed, "bytes_per_step", 0), getattr(feed, "pool_size", 0)
         feed.close()
         del pipe, reducer, model, feed
         if on_gpu:
@@ -830,7 +835,7 @@ def main():
             secondary = {"error": f"{type(e).__name__}: {e}"[:400]}
     else:
         kernels_primary = timer.summary() if rank == 0 else None
-        staged, bytes_per_step = feed.staged, getattr(feed, "bytes_per_step", 0)
+        staged, bytes_per_step, pool_size = feed.staged, getattr(feed, "bytes_per_step", 0), getattr(feed, "pool_size", 0)
         feed.close()
 
     if rank == 0:
@@ -906,6 +911,7 @@ def main():
                        # input staging inside the timed region (reference engine/trainer.py:103-107): pinned host batch ->
                        # device on the copy stream, every step
                        "h2d_in_timed_region": bool(staged), "h2d_MB_per_step": round(bytes_per_step / 1e6, 1),
+                       "distinct_host_batches": pool_size,
                        # BASELINE config 2 (teacher, zeroshot_mask.yaml): same protocol, after the student region
                        "secondary_workload": (secondary or {}).get("workload"),
                        "secondary_ms_per_step": (secondary or {}).get("ms_per_step"),

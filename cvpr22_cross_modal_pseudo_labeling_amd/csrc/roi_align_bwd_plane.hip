@@ -32,20 +32,14 @@
 namespace {
 using namespace ovis_roi;
 
-#ifndef OVIS_ROI_KRI
-#define OVIS_ROI_KRI 4
-#endif
-#ifndef OVIS_ROI_KRING
-#define OVIS_ROI_KRING 3
-#endif
 // Round geometry.  A round = kRI items between two workgroup barriers; its table blocks (2 KB per item) sit in one slot of a
 // ring of kRing rounds in the 24 KB the planes leave of the CU's LDS: three slots of four items (tables requested two rounds
-// ahead).  Two slots of six (-DOVIS_ROI_KRI=6 -DOVIS_ROI_KRING=2: a round's tables requested when the previous round
+// ahead).  Two slots of six (kRI = 6, kRing = 2: a round's tables requested when the previous round
 // starts, a third fewer barriers) measured 1 % faster at twelve G tiles / origins in flight, which costs scalar-register
-// spills once anything else is added -- kept as a build option.
-constexpr int kRI = OVIS_ROI_KRI;        // items per round (one barrier per round)
+// spills once anything else is added -- tools/experiments/patches/roi_bwd_probes.patch restores it as a build option.
+constexpr int kRI = 4;        // items per round (one barrier per round)
 constexpr int kGDepth = 2 * kRI;         // G tiles in flight per wave = two rounds
-constexpr int kRing = OVIS_ROI_KRING;    // table ring depth in rounds
+constexpr int kRing = 3;    // table ring depth in rounds
 constexpr int kAhead = kRing - 1;        // a round's tables are requested this many rounds before it is consumed
 constexpr int kRoundBytes = 2 * kRI * 1024;  // kRI tx blocks + kRI ty blocks
 static_assert(kRing == 2 || kRing == 3, "ring depth");
@@ -297,32 +291,15 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
   bool on_prev = false;  // masked form only: does the lane own a column of the previous footprint
   unsigned slot = 0;     // ring slot of the round being consumed
 
-#if defined(OVIS_ROI_PROBE_TIME) || defined(OVIS_ROI_PROBE_ITEM)  /* timing probes (wrong output): shader-clock stamps summed per wave */
-  unsigned long long pt_a = 0, pt_b = 0, pt_c = 0, pt_d = 0, acc_ab = 0, acc_bc = 0, acc_cd = 0, acc_da = 0, pt_prev_d = 0;
-  unsigned long long it_a = 0, it_b = 0, it_c = 0, it_prev = 0;
-#define OVIS_PROBE_OUT 1
-#endif
-#ifdef OVIS_ROI_PROBE_TIME   /* stamps at the round's seams */
-#define OVIS_STAMP(x) asm volatile("s_memtime %0" : "=s"(x)::"memory")
-#else
-#define OVIS_STAMP(x)
-#endif
-#ifdef OVIS_ROI_PROBE_ITEM   /* stamps inside every item */
-#define OVIS_STAMP2(x) asm volatile("s_memtime %0" : "=s"(x)::"memory")
-#else
-#define OVIS_STAMP2(x)
-#endif
   // cnt is a multiple of kGDepth; the list runs kListPad zero-contribution items past it
   for (int k0 = 0; k0 < cnt; k0 += kGDepth) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       {
-        OVIS_STAMP(pt_a);
         __builtin_amdgcn_sched_barrier(0);
         const unsigned slot2 = slot + kAhead >= kRing ? slot + kAhead - kRing : slot + kAhead;
         dma_round(k0 / kRI + half + kAhead, slot2);
         __builtin_amdgcn_sched_barrier(0);
-        OVIS_STAMP(pt_b);
         __builtin_amdgcn_sched_barrier(0);
       }
       const char* tab = smem + ring_base + slot * kRoundBytes + lane * 16;
@@ -341,9 +318,7 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
         const u4 bx = *(const u4*)(tab + i * 1024);
         const u4 ay = *(const u4*)(tab + (kRI + i) * 1024);
         __builtin_amdgcn_sched_barrier(0);
-        OVIS_STAMP2(it_a);
         OVIS_WAIT1(kGDepth - 1 + 2 * P, rg[d]);  // G(k) has landed
-        OVIS_STAMP2(it_b);
         __builtin_amdgcn_sched_barrier(0);
         // stage 1: T[i][x] = sum_j G[i][j] Ax[j][x], then its hi/lo split (T's accumulator layout -- col = lane & 15,
         // row = 4s + e -- is the B-operand layout of stage 2) -- unless the previous item (same RoI, same xb) left this
@@ -374,32 +349,14 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
         OVIS_FETCH(d, epre);
         __builtin_amdgcn_sched_barrier(0);
         epre = ent[i + 1];
-#ifdef OVIS_ROI_PROBE_ITEM
-        OVIS_STAMP2(it_c);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(it_a), "+s"(it_b), "+s"(it_c)::"memory");
-        acc_ab += it_b - it_a;   /* clocks in the wait for the G tile */
-        acc_bc += it_c - it_b;   /* the rest of the item */
-        if (it_prev) acc_cd += it_a - it_prev;  /* previous item's end -> the wait (plane / table reads issued) */
-        it_prev = it_c;
-#endif
       }
       // the wave's DMAs for the next round have landed (nothing younger than G(k+1) is forced); all waves have
       // finished reading this round's slot once they pass the barrier
       __builtin_amdgcn_sched_barrier(0);
-      OVIS_STAMP(pt_c);
       // the tables of the next round were requested kAhead round starts ago: what may still be in flight behind them are
       // the G refills since (kRI per round) and the table requests of the round starts after theirs
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(kRI * kAhead + (kAhead - 1) * P) : "memory");
-      OVIS_STAMP(pt_d);
       __builtin_amdgcn_sched_barrier(0);
-#ifdef OVIS_ROI_PROBE_TIME
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pt_a), "+s"(pt_b), "+s"(pt_c), "+s"(pt_d)::"memory");
-      acc_ab += pt_b - pt_a;
-      acc_bc += pt_c - pt_b;
-      acc_cd += pt_d - pt_c;
-      if (pt_prev_d) acc_da += pt_a - pt_prev_d;
-      pt_prev_d = pt_d;
-#endif
       slot = slot + 1 >= kRing ? 0 : slot + 1;
     }
   }
@@ -425,11 +382,6 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
   if (live) {
     float* dst = gin + ((long)n * C + c) * HW;
     for (int i = lane; i < HW; i += 64) dst[i] = plane[i];
-#ifdef OVIS_PROBE_OUT
-    if (lane == 0) {
-      dst[0] = (float)acc_ab; dst[1] = (float)acc_bc; dst[2] = (float)acc_cd; dst[3] = (float)acc_da; dst[4] = (float)cnt;
-    }
-#endif
   }
 }
 
@@ -451,9 +403,7 @@ extern "C" size_t ovis_roi_align_backward_workspace_bytes(int num_rois, int batc
 static int plane_waves(int height, int width) {
   const size_t stride = align_up((size_t)height * width * sizeof(float), 16);
   const size_t room = 160 * 1024 - (size_t)kRing * kRoundBytes;
-#ifndef OVIS_ROI_PROBE_NW4  /* timing probe: four waves (one per SIMD) per workgroup where eight would fit */
   if (8 * stride <= room) return 8;
-#endif
   if (4 * stride <= room) return 4;
   return 0;
 }

@@ -43,9 +43,7 @@
 #include <stdlib.h>
 
 #include "ovis_common.h"
-#ifndef OVIS_SG_GW
-#define OVIS_SG_GW 4   // column tiles per group of the tile order (A/B builds: -DOVIS_SG_GW=16, profiles/r4_column_group_ab.txt)
-#endif
+constexpr int kGroupWidth = 4;   // column tiles per group of the tile order (16 measured slower, profiles/r4_column_group_ab.txt)
 
 namespace {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -537,13 +535,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void split_gemm_kernel(SplitGemm
   // pieces of 2 rows, double-buffered: 8 pieces per lane
   // NBUF - 1 pieces are in flight ahead of the one being stored; with two ahead the wait for a piece's operands no longer
   // includes the previous piece's stores (vmcnt retires in order).  The single-stage SHIFTED form has no registers for it.
-#ifndef OVIS_EPI_NBUF   // experiment knobs (tools/experiments/build_variants.sh); 3 / 2 are the shipped depths
-#define OVIS_EPI_NBUF 3
-#endif
-#ifndef OVIS_EPI_NBUF_DUAL
-#define OVIS_EPI_NBUF_DUAL 2
-#endif
-  constexpr int NBUF = DUAL ? OVIS_EPI_NBUF_DUAL : ((MODE == SHIFTED && NS == 1) ? 2 : OVIS_EPI_NBUF);
+  constexpr int NBUF = DUAL ? 2 : ((MODE == SHIFTED && NS == 1) ? 2 : 3);  // (deeper: no gain, tools/experiments/patches)
   EpilogueOperands ops[NBUF][2];
   uint2 gates[NBUF][2];  // DUAL only
   // The fetches are UNCONDITIONAL straight-line loads (rows / columns outside the problem re-read its last row / first
@@ -717,9 +709,6 @@ __global__ __launch_bounds__(256, 2) void split_gemm_tn_kernel(SplitGemmTnArgs p
     tdy = tap / p.KW - p.KH / 2;
     tdx = tap % p.KW - p.KW / 2;
     off_rows = tdy * p.W + tdx;
-#ifdef OVIS_TN_ABL_NOSHIFT   // ablation (wrong results): every tap reads the un-shifted rows
-    off_rows = 0;
-#endif
   }
   const long step0 = (long)slice * p.steps_per_slice;
   const long steps_total = (p.M + 31) >> 5;
@@ -765,11 +754,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_tn_kernel(SplitGemmTnArgs p
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       x_ok[i] = m_row[i] < Mi;
-#ifdef OVIS_TN_ABL_NOMASK     // ablation (wrong results): no tap masks
-      if (false) {
-#else
       if (CONV && SMALL) {
-#endif
         x_ok[i] = x_ok[i] && ((tap_mask >> x_x[i]) & 1ull) != 0ull;
         int q = x_x[i] + step_q;
         if (q >= HW) q -= HW;
@@ -1461,13 +1446,7 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
   p.M = m; p.N = n; p.ch = channels; p.ch2 = channels2; p.T = T; p.H = height; p.W = width; p.KH = taps_h; p.KW = taps_w;
   p.flip = flip; p.relu = relu;
   p.kslices = q.kslices; p.steps_per_slice = q.steps_per_slice;
-  p.gw = (q.tiles_n % OVIS_SG_GW == 0) ? OVIS_SG_GW : (q.tiles_n % 4 == 0) ? 4 : q.tiles_n;   // column groups of 4 weight tiles (2 MB) stay in an XCD's L2
-#ifdef OVIS_SG_GW_SHORTK   // experiment knobs: other group widths for short / long K (the group's weight bytes follow K)
-  if (T * channels + channels2 <= 512 && q.tiles_n % OVIS_SG_GW_SHORTK == 0) p.gw = OVIS_SG_GW_SHORTK;
-#endif
-#ifdef OVIS_SG_GW_LONGK
-  if (T * channels + channels2 >= 2048 && q.mode != HALO && q.tiles_n % OVIS_SG_GW_LONGK == 0) p.gw = OVIS_SG_GW_LONGK;
-#endif
+  p.gw = (q.tiles_n % kGroupWidth == 0) ? kGroupWidth : (q.tiles_n % 4 == 0) ? 4 : q.tiles_n;   // column groups of 4 weight tiles (2 MB) stay in an XCD's L2
   const long ntiles = (long)q.tiles_m * q.tiles_n;
   const long nblocks = ntiles * q.kslices;
   if (nblocks > 0x7fffffffL) return OVIS_ERANGE;
@@ -1636,7 +1615,7 @@ extern "C" int ovis_deform_conv_implicit_f32(const float* input_nhwc, const floa
   p.Ho = out_h; p.Wo = out_w; p.sh = stride_h; p.sw = stride_w; p.ph = pad_h; p.pw = pad_w; p.dlh = dil_h; p.dlw = dil_w;
   p.dg = deformable_group;
   const int tiles_m = (int)((m + 127) / 128), tiles_n = (out_channels + 127) / 128;
-  p.gw = (tiles_n % OVIS_SG_GW == 0) ? OVIS_SG_GW : (tiles_n % 4 == 0) ? 4 : tiles_n;
+  p.gw = (tiles_n % kGroupWidth == 0) ? kGroupWidth : (tiles_n % 4 == 0) ? 4 : tiles_n;
   const long ntiles = (long)tiles_m * tiles_n;
   if (ntiles > 0x7fffffffL) return OVIS_ERANGE;
   constexpr int lds = 128 * 128 + 128 * 128;

@@ -33,6 +33,12 @@ def normalize_class_names(names):
     return out
 
 
+# The extract_emb cache is read and re-ordered by two threads: PipelinedTrainer's worker (forward_frozen -> noun embeddings)
+# and the training thread (forward_student -> prepare_text).  One module-level lock (an instance attribute would make the
+# module un-deepcopy-able; the critical sections are a few dictionary operations).
+_CACHE_LOCK = threading.Lock()
+
+
 class BERT(nn.Module):
     VOCAB_SIZE, HIDDEN_SIZE = 30522, 768  # bert-base-uncased (BertConfig.from_pretrained, transformers.py:11)
     CACHE_ENTRIES = 64  # extract_emb results kept: the vocabulary names + the recent per-image noun lists
@@ -48,9 +54,6 @@ class BERT(nn.Module):
         self._vocab_file = vocab_file
         self._tokenizer = tokenizer
         self._cache = {}
-        # the cache is read and re-ordered by two threads: PipelinedTrainer's worker (forward_frozen -> noun embeddings)
-        # and the training thread (forward_student -> prepare_text)
-        self._cache_lock = threading.Lock()
 
     # -- tokenizer ------------------------------------------------------------------------------------------------
     @property
@@ -111,7 +114,7 @@ class BERT(nn.Module):
             enc = self.tokenize(words)
             return _C.text_embed(table.detach(), enc["input_ids"], enc["special_tokens_mask"])
         key = (words, table._version, table.device, table.data_ptr())
-        with self._cache_lock:
+        with _CACHE_LOCK:
             hit = self._cache.get(key)
             if hit is not None:
                 self._cache[key] = self._cache.pop(key)  # most recently used last
@@ -120,7 +123,7 @@ class BERT(nn.Module):
         emb = _C.text_embed(table.detach(), enc["input_ids"], enc["special_tokens_mask"])
         # keyed by the strings: the per-image noun lists of a step must not evict the 1203-name vocabulary entry (the
         # reference re-tokenises it every iteration, st_generalized_rcnn.py:190-191).  A new table version drops everything.
-        with self._cache_lock:
+        with _CACHE_LOCK:
             for k in [k for k in self._cache if k[1:] != key[1:]]:
                 del self._cache[k]
             while len(self._cache) >= self.CACHE_ENTRIES:

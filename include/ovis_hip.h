@@ -29,8 +29,10 @@ extern "C" {
 #define OVIS_ENOSPC (-2)    /* caller workspace too small                  */
 #define OVIS_ERANGE (-3)    /* problem exceeds what the kernel supports    */
 
-/* Library / build identification. Returns a static NUL-terminated string such as
- * "ovis_hip 0.1 gfx950". */
+/* Library / build identification.  Returns a static NUL-terminated string
+ * "ovis_hip <version> gfx950 flags: <the compiler flags of every object>".  The kernel sources have no compile-time
+ * switch and a product build carries no -D; experiment variants live in their own libraries
+ * (tools/experiments/build_variants.sh). */
 const char* ovis_version(void);
 
 /* ------------------------------------------------------------------------------------

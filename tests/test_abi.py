@@ -31,6 +31,29 @@ def test_header_symbols_exported_and_bound():
     assert _lib.load().ovis_version().startswith(b"ovis_hip")
 
 
+def test_shipped_library_is_a_product_build_without_experiment_switches():
+    """wrong-output probe variants used to live behind ``#ifdef``s in the product kernels, one stray
+    ``-D`` away from shipping wrong gradients.  Now (a) the kernel sources have NO preprocessor conditional at all (probes and
+    knobs are patches under tools/experiments/patches, built into separate libraries), and (b) ``ovis_version()`` reports
+    the compile flags of the library that is actually loaded: no ``-D`` among them."""
+    import glob
+
+    from cvpr22_cross_modal_pseudo_labeling_amd import _lib
+
+    csrc = os.path.join(ROOT, "cvpr22_cross_modal_pseudo_labeling_amd", "csrc")
+    cond = re.compile(r"^\s*#\s*(if|ifdef|ifndef|elif)\b", flags=re.M)
+    offenders = [os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))
+                 if cond.search(open(f).read())]
+    assert not offenders, offenders
+    version = _lib.load().ovis_version().decode()
+    assert version.startswith("ovis_hip ") and " flags: " in version and "--offload-arch=gfx950" in version
+    flags = version.split(" flags: ", 1)[1].split()
+    assert not [f for f in flags if f.startswith("-D") or f.startswith("-U")], version
+    assert "-ffp-contract=off" in flags   # RoIAlign forward / NMS follow the reference's IEEE op sequence
+    for patch in glob.glob(os.path.join(ROOT, "tools", "experiments", "patches", "*.patch")):
+        assert "#if" in open(patch).read()     # the probes still exist -- as patches
+
+
 def test_every_declaration_cites_the_reference():
     text = open(HEADER).read()
     assert text.count("mb/csrc/") >= 6

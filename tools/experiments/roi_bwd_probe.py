@@ -1,4 +1,4 @@
-"""RoIAlign backward micro-benchmark over experiment builds (tools/experiments/roi_bwd_variants.sh):
+"""RoIAlign backward micro-benchmark over experiment builds (tools/experiments/build_variants.sh roi_align_bwd_plane:<name>:"flags"):
 
     python tools/experiments/roi_bwd_probe.py [variant ...]       ("base" = the regular library)
 
