@@ -627,7 +627,7 @@ def run_secondary(args, dev, world, rank, on_gpu, timer, sync):
     """A short timed region of the teacher configuration (zeroshot_mask.yaml, BASELINE config 2) after the student one: same
     protocol (warm-up, barrier + synchronize on both sides, MAX over ranks).  Returns the `secondary` object (rank 0) or None."""
     secondary = None
-    warm2 = 6
+    warm2 = 8  # the student model was just released and the allocator emptied: a few more steps than the pool of distinct batches
     name2, model2, feed2, reducer2, pipe2 = build_workload(args, "teacher", dev, world, rank, warm2)
     # (the teacher step runs its frozen trunk prefix -- stem + layer1 -- of the next batch ahead)
     for _ in range(warm2):
@@ -636,8 +636,10 @@ def run_secondary(args, dev, world, rank, on_gpu, timer, sync):
     overlapped2 = pipe2.enabled
     timer.enabled = on_gpu and not overlapped2
     t0 = time.perf_counter()
+    marks2 = []
     for _ in range(args.secondary_steps):
         loss2 = feed2.step(pipe2)
+        marks2.append(time.perf_counter())
     sync()
     el2 = time.perf_counter() - t0
     timer.enabled = False
@@ -664,6 +666,7 @@ def run_secondary(args, dev, world, rank, on_gpu, timer, sync):
                                   f"{'3x128x160 TINY' if args.tiny else '3x800x1333'}, fwd+bwd+allreduce+SGD"),
                      "steps": args.secondary_steps, "warmup": warm2, "pipelined": overlapped2, "replay_steps": replay2,
                      "ms_per_step": round(1e3 * el2 / args.secondary_steps, 3),
+                     "host_issue_ms": [round(1e3 * (b - a), 2) for a, b in zip([t0] + marks2[:-1], marks2)],
                      "images_per_s": round(IMS_PER_GPU * world * args.secondary_steps / el2, 3),
                      "losses_finite": all(bool(torch.isfinite(v).all()) for v in loss2.values()),
                      "allreduce_payload_MB": round(sum(f.numel() * f.element_size() for f in reducer2.flat) / 1e6, 1),

@@ -61,6 +61,18 @@ def _record_stream(obj, stream):
         _record_stream(obj.tensors, stream)
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(priority):
+    """ONE side stream per (device, priority) and process: streams share a few hardware queues, so a process must not grow a
+    new one per trainer object (data/prefetch.py::copy_stream has the measurement)."""
+    key = (torch.cuda.current_device(), priority)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(priority=priority)
+    return _SIDE_STREAMS[key]
+
+
 class PipelinedTrainer:
     """Student-teacher step, software-pipelined across iterations on two HIP streams.
 
@@ -89,7 +101,7 @@ class PipelinedTrainer:
         # The side stream gets the HIGH queue priority: the frozen half is a chain of small kernels between host reads
         # (RPN counts, sampler counts); behind the main stream's full-machine GEMMs each of those round trips waited for
         # a GEMM to drain, and a late frozen half stalls the next student half.  Measured: 33.9 -> 33.4 ms per step.
-        self.side = torch.cuda.Stream(priority=side_priority) if self.enabled else None
+        self.side = side_stream(side_priority) if self.enabled else None
         self.pending = None  # (key, frozen outputs, event recorded on the side stream)
         # threaded: the frozen half of the next batch is ISSUED by a worker thread concurrently with the student half
         # (both halves are host-bound between their own host syncs, which release the GIL), not after it

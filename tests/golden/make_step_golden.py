@@ -165,6 +165,16 @@ def gen_student():
         c = case.image_case(img_index, model.cap_vocab)
         target = make_target(BoxList, SegmentationMask, c, True)
         key = f"img{img_index}_"
+        # ---- evaluation branch (st_generalized_rcnn.py:409-418) on a FRESH model: the student heads still hold their own
+        # weights (the training branch copies the teacher's into them at iteration 0), so a product that evaluated with the
+        # teacher heads, or with the caption vocabulary left in the predictor, would not reproduce these detections
+        model.eval()
+        with torch.no_grad():
+            det = model(c["image"][None])[0]
+        out[key + "eval_bbox"] = det.bbox.numpy()
+        for f in ("scores", "labels", "mask"):
+            out[key + "eval_" + f] = det.get_field(f).numpy()
+        model.train()
         with Capture(BalancedPositiveNegativeSampler) as cap:
             losses = model(c["image"][None], [target])
             # the frozen half again, piece by piece, for the intermediate values (same modules, same state)
@@ -213,7 +223,7 @@ def gen_student():
             out[key + k] = np.float64(v.item())
         put_grads(out, model, key + "grad")
         print(key, {k: round(v.item(), 6) for k, v in losses.items()}, "lamb", float(model.adaptive_lamb),
-              "margin", out[key + "aligned_margin"])
+              "margin", out[key + "aligned_margin"], "eval detections", len(det), "classes", len(set(det.get_field("labels").tolist())))
     out["state_names"] = np.array([n for n, _, _ in names])
     out["state_shapes"] = np.array([",".join(map(str, s)) for _, s, _ in names])
     out["state_seeded_as"] = np.array([c for _, _, c in names])
@@ -254,6 +264,14 @@ def gen_teacher():
     targets = [make_target(BoxList, SegmentationMask, c, False) for c in cases]
     images = torch.stack([c["image"] for c in cases])
     out = {}
+    model.eval()   # evaluation branch (generalized_rcnn.py:56-73): detections of the two-image batch
+    with torch.no_grad():
+        dets = model(images)
+    for i, det in enumerate(dets):
+        out[f"eval{i}_bbox"] = det.bbox.numpy()
+        for f in ("scores", "labels", "mask"):
+            out[f"eval{i}_{f}"] = det.get_field(f).numpy()
+    model.train()
     with Capture(BalancedPositiveNegativeSampler) as cap:
         losses = model(images, targets)
     sum(losses.values()).backward()

@@ -330,6 +330,27 @@ def test_device_prefetcher_stages_batches_on_a_copy_stream():
     assert len(sums) == 6 and all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(sums, want))
 
 
+def test_streams_are_shared_per_process_not_grown_per_object():
+    """HIP multiplexes streams onto a few hardware queues: a process that made a NEW copy / side stream for every prefetcher /
+    trainer put its fifth stream on the compute stream's queue (the teacher step as second workload of bench.py: 31 ms instead
+    of 22.5).  Every prefetcher of a device shares one copy stream, every trainer one side stream per priority -- and a second
+    prefetcher opened after the first was closed still delivers its batches."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.data.prefetch import DevicePrefetcher
+    from cvpr22_cross_modal_pseudo_labeling_amd.data.synthetic import make_batch
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import trainer
+
+    host = [make_batch(1, seed=i, height=64, width=96, num_gt=2, num_nouns=2) for i in range(3)]
+    a = DevicePrefetcher(iter(host), "cuda", depth=2)
+    first = [im.sum().item() for im, _ in a]
+    a.close()
+    b = DevicePrefetcher(iter(host), "cuda", depth=2)
+    assert b.stream is a.stream and b.stream != torch.cuda.current_stream()
+    assert [im.sum().item() for im, _ in b] == first
+    b.close()
+    s1, s2 = trainer.side_stream(-1), trainer.side_stream(-1)
+    assert s1 is s2 and s1 != torch.cuda.current_stream() and trainer.side_stream(0) is not s1
+
+
 def test_student_step_with_text_vocabulary_and_polygon_ground_truth(golden_dir):
     """The round-3 input forms inside the real step: (a) the caption vocabulary given as STRINGS and embedded through the
     BERT word-embedding table (tokenizer over the golden WordPiece vocabulary; per-image nouns from the ``nn_caption``
