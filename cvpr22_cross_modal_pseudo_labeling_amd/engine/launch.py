@@ -38,6 +38,9 @@ def rank_env(rank, nproc, master_port, base=None, master_addr="127.0.0.1"):
 # Every rank therefore pins itself -- BEFORE its first GPU call, so the runtime's helper threads inherit the mask -- to a
 # private share of the cores of the NUMA node its GPU hangs off (sysfs), or to an even share of the allowed cores when
 # the topology cannot be read.  The reference leaves placement to the OS (tools/train_net.py:187-195 only sets the device).
+MIN_CORES_PER_RANK = 4
+
+
 def _parse_cpulist(text):
     cpus = set()
     for part in text.strip().split(","):
@@ -140,6 +143,10 @@ def apply_rank_affinity(env=None, sysfs_root="/sys"):
             cpus = plan_affinity(world, sysfs_root=sysfs_root, visible=visible)[rank]
             source = "numa" if gpu_numa_nodes(sysfs_root) else "even split"
         cpus = set(cpus) & os.sched_getaffinity(0) or set(cpus)
+        if len(cpus) < MIN_CORES_PER_RANK and len(cpus) < len(os.sched_getaffinity(0)):
+            # a rank runs its training thread, the frozen-half worker, the staging thread and RCCL's proxy threads: squeezing
+            # them onto one or two cores (an 8-core container shared by 8 ranks) costs more than migration does
+            return {"cpus": format_cpus(os.sched_getaffinity(0)), "source": f"unpinned: a share of {len(cpus)} core(s) is too small"}
         os.sched_setaffinity(0, cpus)
         return {"cpus": format_cpus(cpus), "source": source}
     except (OSError, ValueError) as e:  # a cpuset that forbids it: run unpinned, say so

@@ -84,8 +84,10 @@ def test_bench_eight_ranks_dry_run():
     assert abs(d["value"] - 16 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) <= 1e-6 * d["value"]
     shares = [launch._parse_cpulist(r["cpus"]) for r in d["ranks"]]
     assert all(shares)
-    if len(os.sched_getaffinity(0)) >= 8:
+    if len(os.sched_getaffinity(0)) >= 8 * launch.MIN_CORES_PER_RANK:
         assert sum(len(s) for s in shares) == len(set().union(*shares))  # private shares
+    else:  # too few cores for eight private shares of a useful size: the ranks say so and stay unpinned
+        assert all(r["cpus_from"].startswith("unpinned") for r in d["ranks"])
 
 
 def test_bench_under_torch_distributed_run_as_the_driver_launches_it():

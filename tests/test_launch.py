@@ -191,6 +191,22 @@ def test_ranks_pin_themselves_before_anything_else(tmp_path):
     assert after == allowed and info == {"cpus": None, "source": "off"}
 
 
+def test_a_share_of_one_or_two_cores_is_not_applied():
+    """Eight ranks in an eight-core container: one core per rank would put the training thread, the frozen-half worker, the
+    staging thread and the collective's proxy threads on it -- the rank stays unpinned and reports why."""
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        import pytest
+        pytest.skip("one core")
+    script = ("import json, os, sys; sys.path.insert(0, %r)\n"
+              "from cvpr22_cross_modal_pseudo_labeling_amd.engine import launch\n"
+              "print(json.dumps([launch.apply_rank_affinity(), sorted(os.sched_getaffinity(0))]))\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("OVIS_")}
+    env["OVIS_RANK_CPUS"] = str(allowed[0])
+    info, after = json.loads(subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env).stdout)
+    assert after == allowed and info["source"].startswith("unpinned") and info["cpus"] == launch.format_cpus(allowed)
+
+
 def test_second_sigterm_does_not_cut_the_cleanup_short(tmp_path):
     """``timeout -k`` / a retrying scheduler sends SIGTERM again while the launcher is ending its ranks; a rank
     that ignores SIGTERM (a hung runtime) must still be killed and reaped."""
