@@ -38,6 +38,12 @@ class GeneralizedRCNN(nn.Module):
         self.backbone = Backbone(cfg)
         self.rpn = RPNModule(cfg, self.backbone.out_channels)
         self.roi_heads = CombinedROIHeads(cfg, self.backbone.out_channels)
+        # generalized_rcnn.py:32-35,53-54: MODEL.RPN.DONT_TRAIN freezes the RPN and keeps it in eval mode inside a training
+        # step -- test-mode proposal selection (no ground-truth boxes appended), no RPN losses
+        self.fix_rpn = bool(cfg.MODEL.RPN.DONT_TRAIN)
+        if self.fix_rpn:
+            for p in self.rpn.parameters():
+                p.requires_grad = False
 
     def set_class_embeddings(self, embs):
         self.roi_heads["box"].predictor.set_class_embeddings(embs)
@@ -55,6 +61,8 @@ class GeneralizedRCNN(nn.Module):
     def forward(self, images, targets=None, prefix=None):
         if self.training and targets is None:
             raise ValueError("In training mode, targets should be passed")
+        if self.fix_rpn:
+            self.rpn.eval()
         images = to_image_list(images)
         features = self.backbone(images.tensors) if prefix is None else self.backbone.body(images.tensors, prefix=prefix)
         proposals, proposal_losses = self.rpn(images, features, targets)

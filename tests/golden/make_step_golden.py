@@ -232,6 +232,50 @@ def gen_student():
     np.savez_compressed(os.path.join(HERE, "step_student.npz"), **out)
 
 
+VARIANTS = {  # configuration switches of STGeneralizedRCNN.forward's loss composition (st_generalized_rcnn.py:332-361)
+    "no_reweight": ["MODEL.REWEIGHT", False],                        # pseudo losses x LAMBDA_PSEUDO_LABEL (0.1), mask too
+    "no_pseudo_mask": ["MODEL.NO_PSEUDO_MASK", True],                # loss_mask_pseudo x 0
+    "no_uncertainty": ["MODEL.UNCERTAINTY", False],                  # no sigma branch, no noise; x LAMBDA_PSEUDO_LABEL
+    "lambda_half": ["MODEL.REWEIGHT", False, "MODEL.LAMBDA_PSEUDO_LABEL", 0.5],
+}
+
+
+def gen_student_variants():
+    """The same image-0 step under the switches above: the six losses (and what the product needs to replay the run) ->
+    tests/golden/step_student_variants.npz."""
+    from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+    from maskrcnn_benchmark.modeling.detector import st_generalized_rcnn as st_mod
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.segmentation_mask import SegmentationMask
+
+    out = {}
+    for name, opts in VARIANTS.items():
+        cfg = ref_import.reference_cfg("student_teacher_mask_rcnn_uncertainty.yaml", list(case.COMMON_OPTS) + opts)
+        model = st_mod.STGeneralizedRCNN(cfg)
+        load_seeded(model)
+        model.class_names = list(case.SEEN_NAMES)
+        model.roi_heads["box"].predictor.set_class_embeddings(case.text_embeddings())
+        model.train()
+        c = case.image_case(0, model.cap_vocab)
+        target = make_target(BoxList, SegmentationMask, c, True)
+        with Capture(BalancedPositiveNegativeSampler) as cap:
+            losses = model(c["image"][None], [target])
+        sum(losses.values()).backward()
+        key = name + "_"
+        put_samples(out, key + "roi_sample", cap, cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE)
+        assert out[key + "roi_sample_count"] == 2
+        eps = [r for r in cap.randn if r.dim() == 5]
+        assert len(eps) == (1 if cfg.MODEL.UNCERTAINTY else 0)
+        if eps:
+            out[key + "mask_eps"] = eps[0].numpy()
+        for k, v in losses.items():
+            out[key + k] = np.float64(v.item())
+        put_grads(out, model, key + "grad")
+        out[key + "opts"] = np.array([str(o) for o in opts])
+        print(name, {k: round(v.item(), 6) for k, v in losses.items()})
+    np.savez_compressed(os.path.join(HERE, "step_student_variants.npz"), **out)
+
+
 def gen_teacher():
     from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
     from maskrcnn_benchmark.modeling.detector.generalized_rcnn import GeneralizedRCNN
@@ -298,14 +342,57 @@ def gen_teacher():
     np.savez_compressed(os.path.join(HERE, "step_teacher.npz"), **out)
 
 
+def gen_teacher_fixed_rpn():
+    """GeneralizedRCNN with MODEL.RPN.DONT_TRAIN True (generalized_rcnn.py:32-35,53-54): the RPN frozen and in eval mode
+    inside the training step -- test-mode proposals, three losses -> tests/golden/step_teacher_fixed_rpn.npz."""
+    from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+    from maskrcnn_benchmark.modeling.detector.generalized_rcnn import GeneralizedRCNN
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.segmentation_mask import SegmentationMask
+
+    cfg = ref_import.reference_cfg("zeroshot_mask.yaml", list(case.COMMON_OPTS) + ["MODEL.RPN.DONT_TRAIN", True])
+    model = GeneralizedRCNN(cfg)
+    names = load_seeded(model)
+    model.roi_heads["box"].predictor.set_class_embeddings(case.text_embeddings())
+    model.train()
+    # The eval-mode RPN selects its boxes OUTSIDE no_grad (rpn/rpn.py:175-192) on features that require grad here; its in-place
+    # clip (structures/bounding_box.py:216) on a view of the decoded boxes was a deprecation warning in the reference's
+    # torch 1.7 and is an error today.  Box coordinates carry no gradient into the heads (RoIAlign does not differentiate its
+    # rois), so running the frozen RPN under no_grad changes nothing but makes the step runnable.
+    model.rpn.forward = torch.no_grad()(model.rpn.forward)
+    cases = [case.image_case(i, ["-"] * 1203) for i in range(2)]
+    targets = [make_target(BoxList, SegmentationMask, c, False) for c in cases]
+    images = torch.stack([c["image"] for c in cases])
+    out = {}
+    with Capture(BalancedPositiveNegativeSampler) as cap:
+        losses = model(images, targets)
+    sum(losses.values()).backward()
+    assert set(losses) == {"loss_box_reg", "loss_classifier", "loss_mask"}
+    assert not any(p.requires_grad for p in model.rpn.parameters())
+    put_samples(out, "roi_sample", cap, cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE)
+    assert out["roi_sample_count"] == 2 and len(cap.samples) == 1  # the RPN's own sampler never ran
+    for i in range(2):
+        out[f"proposal_count{i}"] = np.int64(out[f"roi_sample{i}_pos"].shape[0])
+    for k, v in losses.items():
+        out[k] = np.float64(v.item())
+    put_grads(out, model)
+    out["state_names"] = np.array([n for n, _, _ in names])
+    out["state_shapes"] = np.array([",".join(map(str, s)) for _, s, _ in names])
+    out["state_seeded_as"] = np.array([c for _, _, c in names])
+    print("teacher, fixed RPN", {k: round(v.item(), 6) for k, v in losses.items()}, [int(out[f"proposal_count{i}"]) for i in range(2)])
+    np.savez_compressed(os.path.join(HERE, "step_teacher_fixed_rpn.npz"), **out)
+
+
 def main():
     torch.set_num_threads(1)
     torch.manual_seed(20260101)
     ref_import.install()
     torch.Tensor.cuda = lambda self, *a, **k: self  # box_head/loss.py:42,173, language_backbone/transformers.py:60
     gen_student()
+    gen_student_variants()
     gen_teacher()
-    for f in ("step_student.npz", "step_teacher.npz"):
+    gen_teacher_fixed_rpn()
+    for f in ("step_student.npz", "step_student_variants.npz", "step_teacher.npz", "step_teacher_fixed_rpn.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 

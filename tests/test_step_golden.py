@@ -35,14 +35,14 @@ def _fixture(name):
     return np.load(os.path.join(GOLDEN, name))
 
 
-def _cfg(yaml_name, device):
+def _cfg(yaml_name, device, extra=()):
     from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
 
     cfg = get_defaults()
     cfg.merge_from_file(os.path.join(ROOT, "configs", "coco_cap_det", yaml_name))
     opts = list(case.COMMON_OPTS)
     opts[opts.index("MODEL.DEVICE") + 1] = device
-    cfg.merge_from_list(opts)
+    cfg.merge_from_list(opts + list(extra))
     cfg.freeze()
     return cfg
 
@@ -51,16 +51,19 @@ def _load_seeded(model, d):
     state = {}
     for n, s, seeded_as in zip(d["state_names"], d["state_shapes"], d["state_seeded_as"]):
         state[str(n)] = case.seeded_tensor(str(seeded_as), tuple(int(x) for x in s.split(",")) if s else ())
-    missing, unexpected = model.load_state_dict(state, strict=False)
+    own = set(model.state_dict())
+    dropped = [k for k in state if k not in own]
+    assert all("uncertain_pred" in k for k in dropped), dropped  # (MODEL.UNCERTAINTY False builds no sigma branch)
+    missing, unexpected = model.load_state_dict({k: v for k, v in state.items() if k in own}, strict=False)
     assert not unexpected and all("anchor_generator" in k for k in missing), (missing, unexpected)
 
 
-def build_student(device):
+def build_student(device, extra=()):
     from cvpr22_cross_modal_pseudo_labeling_amd.modeling.detector import build_detection_model
     from cvpr22_cross_modal_pseudo_labeling_amd.modeling.language_backbone import BERT
 
     d = _fixture("step_student.npz")
-    cfg = _cfg("student_teacher_mask_rcnn_uncertainty.yaml", device)
+    cfg = _cfg("student_teacher_mask_rcnn_uncertainty.yaml", device, extra)
     model = build_detection_model(cfg)
     model.bert = BERT(cfg, vocab_file=os.path.join(GOLDEN, "step_wordpiece_vocab.txt"), vocab_size=len(case.WORDPIECES))
     _load_seeded(model, d)
@@ -71,11 +74,11 @@ def build_student(device):
     return model, d, cfg
 
 
-def build_teacher(device):
+def build_teacher(device, fixed_rpn=False):
     from cvpr22_cross_modal_pseudo_labeling_amd.modeling.detector import build_detection_model
 
-    d = _fixture("step_teacher.npz")
-    cfg = _cfg("zeroshot_mask.yaml", device)
+    d = _fixture("step_teacher_fixed_rpn.npz" if fixed_rpn else "step_teacher.npz")
+    cfg = _cfg("zeroshot_mask.yaml", device, ["MODEL.RPN.DONT_TRAIN", True] if fixed_rpn else [])
     model = build_detection_model(cfg)
     _load_seeded(model, d)
     model = model.to(device)
@@ -495,3 +498,76 @@ def test_teacher_step_cpu_vs_reference_fixture(staged):
 @pytest.mark.gpu
 def test_teacher_step_hip_vs_reference_fixture():
     print(run_teacher("cuda", 2e-4, 5e-3, True))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# MODEL.RPN.DONT_TRAIN on the teacher (generalized_rcnn.py:32-35,53-54): frozen RPN in eval mode inside the training step
+# ------------------------------------------------------------------------------------------------------------------
+def run_teacher_fixed_rpn(device, tol_grad):
+    model, d, cfg = build_teacher(device, fixed_rpn=True)
+    assert not any(p.requires_grad for p in model.rpn.parameters())
+    cs = [case.image_case(i, ["-"] * 1203) for i in range(2)]
+    images = torch.stack([c["image"] for c in cs]).to(device)
+    targets = [make_target(c, device, caption=False) for c in cs]
+    _replay(model.roi_heads["box"].loss_evaluator, d, "roi_sample", (0, 1))   # fits only test-mode proposal lists (60 per
+    with _ops(device):                                                        # image, no ground-truth boxes appended)
+        losses = model(images, targets)
+        sum(losses.values()).backward()
+    assert set(losses) == {"loss_classifier", "loss_box_reg", "loss_mask"}      # no RPN losses
+    for k in losses:
+        assert _rel(losses[k], d[k]) <= 1e-3, (k, float(losses[k]), float(d[k]))
+    assert all(p.grad is None for p in model.rpn.parameters())
+    return check_grads(model, d, "grad", tol_grad)
+
+
+def test_teacher_step_with_frozen_rpn_cpu_vs_reference_fixture():
+    print(run_teacher_fixed_rpn("cpu", 5e-3))
+
+
+@pytest.mark.gpu
+def test_teacher_step_with_frozen_rpn_hip_vs_reference_fixture():
+    print(run_teacher_fixed_rpn("cuda", 5e-3))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the switches of the loss composition (st_generalized_rcnn.py:332-361): MODEL.REWEIGHT / LAMBDA_PSEUDO_LABEL /
+# NO_PSEUDO_MASK / UNCERTAINTY, each against a run of the reference under the same switch
+# ------------------------------------------------------------------------------------------------------------------
+VARIANTS = ("no_reweight", "no_pseudo_mask", "no_uncertainty", "lambda_half")
+
+
+def _typed(opts):
+    out = []
+    for k, v in zip(opts[0::2], opts[1::2]):
+        out += [str(k), {"True": True, "False": False}.get(str(v), float(v) if str(v).replace(".", "", 1).isdigit() else str(v))]
+    return out
+
+
+def run_variant(device, name):
+    v = _fixture("step_student_variants.npz")
+    key = name + "_"
+    model, d, cfg = build_student(device, _typed([str(o) for o in v[key + "opts"]]))
+    c = case.image_case(0, [str(n) for n in d["cap_vocab"]])
+    _replay(model.roi_heads_student["box"].loss_evaluator, v, key + "roi_sample", (0, 1))
+    eps = torch.from_numpy(v[key + "mask_eps"]).to(device) if (key + "mask_eps") in v.files else None
+    with _ops(device):
+        losses = model(c["image"][None].to(device), [make_target(c, device)], eps=eps)
+        sum(losses.values()).backward()
+    for k in PSEUDO + SEEN:
+        want = float(v[key + k])
+        if want == 0.0:
+            assert float(losses[k]) == 0.0, k
+        else:
+            assert _rel(losses[k], want) <= 1e-3, (name, k, float(losses[k]), want)
+    check_grads(model, v, key + "grad", 5e-3)
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_loss_composition_switches_cpu_vs_reference_fixture(name):
+    run_variant("cpu", name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", VARIANTS)
+def test_loss_composition_switches_hip_vs_reference_fixture(name):
+    run_variant("cuda", name)
