@@ -556,7 +556,7 @@ def run_variant(device, name):
     for k in PSEUDO + SEEN:
         want = float(v[key + k])
         if want == 0.0:
-            assert float(losses[k]) == 0.0, k
+            assert float(losses[k].detach()) == 0.0, k
         else:
             assert _rel(losses[k], want) <= 1e-3, (name, k, float(losses[k]), want)
     check_grads(model, v, key + "grad", 5e-3)
