@@ -135,12 +135,16 @@ class BucketedGradReducer:
             op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
             self.handles[bi] = dist.all_reduce(self.flat[bi], op=op, async_op=True)
 
-    def zero_grad(self):
-        """Replaces optimizer.zero_grad(): grads stay views of the flat buffers."""
+    def zero_grad(self, set_to_zero=True):
+        """Replaces optimizer.zero_grad(): grads stay views of the flat buffers.  ``set_to_zero=False`` starts the next
+        micro-step of a gradient accumulation (SOLVER.GRADIENT_ACCUMULATION_STEPS, engine/trainer.py:117,135-141): the hook
+        bookkeeping is reset, the buffers keep what the earlier micro-steps left -- values every rank holds identically after
+        their all-reduce, so reducing the buffer again after this micro-step's backward adds exactly its averaged gradient."""
         self._next = 0
         self.hook_launches = 0
         for bi, (flat, bucket) in enumerate(zip(self.flat, self.buckets)):
-            flat.zero_()
+            if set_to_zero:
+                flat.zero_()
             self.pending[bi] = self._expected(bucket)
             self.handles[bi] = None
             self.launched[bi] = False
@@ -178,6 +182,17 @@ class BucketedGradReducer:
             if not self._avg_in_collective:
                 for flat in self.flat:
                     flat.div_(self.world)
+
+    def clip_grad_norm_(self, max_norm):
+        """``torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)`` (engine/trainer.py:136-138) on the flat buckets:
+        total L2 norm over all gradients, every gradient scaled by min(1, max_norm / (norm + 1e-6)) -- no host read."""
+        if not self.flat:
+            return None
+        total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(f.float()) for f in self.flat]))
+        coef = (float(max_norm) / (total + 1e-6)).clamp(max=1.0)
+        for f in self.flat:
+            f.mul_(coef.to(f.dtype))
+        return total
 
     def exposed_wait_ms(self, clear=True):
         """Per-step stall of finish() on the collectives, in ms (list; needs ``measure_wait``; device events must have

@@ -23,17 +23,59 @@ def total_loss(loss_dict):
     return torch.stack([t.reshape(()) for t in terms]).sum()
 
 
-def train_step(model, optimizer, reducer, images, targets, scheduler=None):
-    """One optimisation step; returns the (un-reduced) loss dict of this rank."""
-    reducer.zero_grad()
+class StepPolicy:
+    """SOLVER.GRADIENT_ACCUMULATION_STEPS and SOLVER.CLIP_GRAD_NORM_AT of the reference loop (engine/trainer.py:117,
+    135-141): the summed loss is divided by the accumulation count, the optimizer (and the LR schedule) steps every k-th
+    iteration on the accumulated gradients, clipped to a total L2 norm first when the threshold is positive."""
+
+    def __init__(self, accumulation_steps=1, clip_grad_norm_at=-1.0):
+        self.accumulation_steps = max(int(accumulation_steps), 1)
+        self.clip_grad_norm_at = float(clip_grad_norm_at)
+        self.micro = 0  # micro-steps since the last optimizer step
+
+    @classmethod
+    def from_cfg(cls, cfg):
+        return cls(cfg.SOLVER.GRADIENT_ACCUMULATION_STEPS, cfg.SOLVER.CLIP_GRAD_NORM_AT)
+
+    def begin(self, reducer):
+        reducer.zero_grad(set_to_zero=self.micro == 0)
+
+    def scale(self, losses):
+        return losses / float(self.accumulation_steps) if self.accumulation_steps > 1 else losses
+
+    def end(self, reducer, optimizer, scheduler):
+        """After backward(): reduce, and -- on the last micro-step -- clip, step, advance the schedule."""
+        reducer.finish()
+        self.micro += 1
+        if self.micro < self.accumulation_steps:
+            return False
+        self.micro = 0
+        if self.clip_grad_norm_at > 0:
+            reducer.clip_grad_norm_(self.clip_grad_norm_at)
+        optimizer.step()
+        if scheduler is not None:
+            scheduler.step()
+        return True
+
+
+def train_step(model, optimizer, reducer, images, targets, scheduler=None, policy=None):
+    """One iteration of the loop (an optimisation step unless ``policy`` accumulates); returns the (un-reduced) loss dict
+    of this rank."""
+    policy = policy or _default_policy(reducer)
+    policy.begin(reducer)
     loss_dict = model(images, targets)
-    losses = total_loss(loss_dict)
+    losses = policy.scale(total_loss(loss_dict))
     losses.backward()
-    reducer.finish()
-    optimizer.step()
-    if scheduler is not None:
-        scheduler.step()
+    policy.end(reducer, optimizer, scheduler)
     return loss_dict
+
+
+def _default_policy(reducer):
+    """One policy object per reducer when the caller passes none (plain step: no accumulation, no clipping)."""
+    pol = getattr(reducer, "_step_policy", None)
+    if pol is None:
+        pol = reducer._step_policy = StepPolicy()
+    return pol
 
 
 def _record_stream(obj, stream):
@@ -89,8 +131,9 @@ class PipelinedTrainer:
     step: its ~1.1 ms of GEMMs fill the under-filled launches of the backward); models without ``forward_frozen`` /
     ``forward_student`` fall back to ``train_step``."""
 
-    def __init__(self, model, optimizer, reducer, scheduler=None, threaded=True, side_priority=-1):
+    def __init__(self, model, optimizer, reducer, scheduler=None, threaded=True, side_priority=-1, policy=None):
         self.model, self.optimizer, self.reducer, self.scheduler = model, optimizer, reducer, scheduler
+        self.policy = policy or StepPolicy()
         self.enabled = hasattr(model, "forward_frozen") and torch.cuda.is_available()
         # The look-ahead half must not read anything the optimizer writes: with MODEL.LANGUAGE_BACKBONE.FT_EMB the BERT
         # table is trained AND read by the frozen half's noun embeddings (st_generalized_rcnn.py:242) -- the side stream
@@ -144,7 +187,7 @@ class PipelinedTrainer:
         """One optimisation step on (images, targets); ``next_batch`` = the (images, targets) of the following call
         (already resident on the device), whose frozen half is started before this call returns."""
         if not self.enabled:
-            return train_step(self.model, self.optimizer, self.reducer, images, targets, self.scheduler)
+            return train_step(self.model, self.optimizer, self.reducer, images, targets, self.scheduler, self.policy)
         main = torch.cuda.current_stream()
         inputs_ready = torch.cuda.Event()
         inputs_ready.record(main)  # uploads of this and the next batch precede this point on the main stream
@@ -157,14 +200,11 @@ class PipelinedTrainer:
         _record_stream(frozen, main)
         if next_batch is not None and self.threaded:
             self._launch_frozen(next_batch[0], next_batch[1], inputs_ready, threaded=True)
-        self.reducer.zero_grad()
+        self.policy.begin(self.reducer)
         loss_dict = self.model.forward_student(frozen, targets)
-        losses = total_loss(loss_dict)
+        losses = self.policy.scale(total_loss(loss_dict))
         losses.backward()
-        self.reducer.finish()
-        self.optimizer.step()
-        if self.scheduler is not None:
-            self.scheduler.step()
+        self.policy.end(self.reducer, self.optimizer, self.scheduler)
         if next_batch is not None and not self.threaded:
             # the GPU now has the whole backward queued: overlap the next frozen half with it
             self._launch_frozen(next_batch[0], next_batch[1], inputs_ready)
@@ -186,7 +226,8 @@ def do_train(cfg, model, data_iter, optimizer, scheduler, max_iter, start_iter=0
     log_period = log_period or cfg.SOLVER.LOG_PERIOD
     model.train()
     reducer = comm.BucketedGradReducer(model)
-    pipe = PipelinedTrainer(model, optimizer, reducer, scheduler)  # plain train_step for models without a frozen half
+    # (plain train_step for models without a frozen half; gradient accumulation / clipping as the config says)
+    pipe = PipelinedTrainer(model, optimizer, reducer, scheduler, policy=StepPolicy.from_cfg(cfg))
     start = time.time()
     last = start
     history = []

@@ -232,12 +232,31 @@ def gen_student():
     np.savez_compressed(os.path.join(HERE, "step_student.npz"), **out)
 
 
-VARIANTS = {  # configuration switches of STGeneralizedRCNN.forward's loss composition (st_generalized_rcnn.py:332-361)
+VARIANTS = {  # configuration switches of STGeneralizedRCNN.forward's loss composition (st_generalized_rcnn.py:332-361) ...
     "no_reweight": ["MODEL.REWEIGHT", False],                        # pseudo losses x LAMBDA_PSEUDO_LABEL (0.1), mask too
     "no_pseudo_mask": ["MODEL.NO_PSEUDO_MASK", True],                # loss_mask_pseudo x 0
     "no_uncertainty": ["MODEL.UNCERTAINTY", False],                  # no sigma branch, no noise; x LAMBDA_PSEUDO_LABEL
     "lambda_half": ["MODEL.REWEIGHT", False, "MODEL.LAMBDA_PSEUDO_LABEL", 0.5],
+    # ... and of the optimisation step around it (engine/trainer.py:117,135-141; solver/build.py:8-37)
+    "sigma_lr": ["SOLVER.UNCERTAINTY_LR_FACTOR", 0.25],              # uncertain_pred's own learning-rate factor
+    "clip_grad": ["SOLVER.CLIP_GRAD_NORM_AT", 5.0],                  # total gradient norm here is ~40: the clip is active
+    "accumulate2": ["SOLVER.GRADIENT_ACCUMULATION_STEPS", 2],        # two micro-steps, losses / 2, one optimizer step
 }
+
+
+def reference_iteration(cfg, model, optimizer, scheduler, run_forward, iteration):
+    """One pass of the reference's loop body, engine/trainer.py:110-141 (amp at O0 is the identity)."""
+    loss_dict = run_forward()
+    losses = sum(loss for loss in loss_dict.values())
+    losses = losses / float(cfg.SOLVER.GRADIENT_ACCUMULATION_STEPS)
+    losses.backward()
+    if iteration % cfg.SOLVER.GRADIENT_ACCUMULATION_STEPS == 0:
+        if cfg.SOLVER.CLIP_GRAD_NORM_AT > 0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.SOLVER.CLIP_GRAD_NORM_AT)
+        optimizer.step()
+        scheduler.step()
+        optimizer.zero_grad()
+    return loss_dict
 
 
 def gen_student_variants():
@@ -256,23 +275,69 @@ def gen_student_variants():
         model.class_names = list(case.SEEN_NAMES)
         model.roi_heads["box"].predictor.set_class_embeddings(case.text_embeddings())
         model.train()
+        from maskrcnn_benchmark.solver import make_lr_scheduler, make_optimizer
         c = case.image_case(0, model.cap_vocab)
         target = make_target(BoxList, SegmentationMask, c, True)
-        with Capture(BalancedPositiveNegativeSampler) as cap:
-            losses = model(c["image"][None], [target])
-        sum(losses.values()).backward()
+        optimizer = make_optimizer(cfg, model)            # tools/train_net.py:58-59
+        scheduler = make_lr_scheduler(cfg, optimizer)
+        by_id = {id(p): n for n, p in model.named_parameters()}
         key = name + "_"
+        out[key + "group_names"] = np.array([by_id[id(g["params"][0])] for g in optimizer.param_groups])
+        out[key + "group_lr_wd"] = np.array([[g["initial_lr"], g["weight_decay"]] for g in optimizer.param_groups])
+        k_acc = cfg.SOLVER.GRADIENT_ACCUMULATION_STEPS
+        before, grads = None, {}
+        with Capture(BalancedPositiveNegativeSampler) as cap:
+            for it in range(1, k_acc + 1):
+                if it == k_acc:  # keep the gradients the optimizer is about to consume (zero_grad follows the step)
+                    step, zero = optimizer.step, optimizer.zero_grad
+
+                    def recording_step():
+                        for n, p in model.named_parameters():
+                            if p.grad is not None:
+                                grads[n] = p.grad.detach().clone()
+                        return step()
+
+                    optimizer.step = recording_step
+                losses = reference_iteration(cfg, model, optimizer, scheduler, lambda: model(c["image"][None], [target]), it)
+                if before is None:  # the student heads as the first forward left them (teacher copy at iteration 0)
+                    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+                    if k_acc == 1:   # (the step already happened: undo is not possible -- recompute "before" from the teacher)
+                        before = None
+        if before is None:
+            teacher = dict(model.roi_heads.named_parameters())
+            before = {n: (teacher[n[len("roi_heads_student."):]] if n.startswith("roi_heads_student.") else p).detach().clone()
+                      for n, p in model.named_parameters()}
         put_samples(out, key + "roi_sample", cap, cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE)
-        assert out[key + "roi_sample_count"] == 2
+        assert out[key + "roi_sample_count"] == 2 * k_acc
         eps = [r for r in cap.randn if r.dim() == 5]
-        assert len(eps) == (1 if cfg.MODEL.UNCERTAINTY else 0)
-        if eps:
-            out[key + "mask_eps"] = eps[0].numpy()
-        for k, v in losses.items():
+        assert len(eps) == (k_acc if cfg.MODEL.UNCERTAINTY else 0)
+        for i, e in enumerate(eps):
+            out[key + f"mask_eps{i}"] = e.numpy()
+        for k, v in losses.items():   # of the last micro-step
             out[key + k] = np.float64(v.item())
-        put_grads(out, model, key + "grad")
+        names = []
+        for n, g in grads.items():    # what optimizer.step() consumed (accumulated and clipped)
+            dg = case.grad_digest(n, g, n=case.VARIANT_DIGEST)
+            out[f"{key}grad:{n}:values"], out[f"{key}grad:{n}:norm_sum"] = dg["values"], np.array([dg["norm"], dg["sum"]])
+            names.append(n)
+        out[key + "grad_names"] = np.array(names)
+        for n, p in model.named_parameters():   # the update itself: parameter after the step minus before
+            if n in grads:
+                dd = case.grad_digest(n, p.detach() - before[n], n=case.VARIANT_DIGEST)
+                out[f"{key}delta:{n}:values"], out[f"{key}delta:{n}:norm_sum"] = dd["values"], np.array([dd["norm"], dd["sum"]])
+        out[key + "delta_names"] = np.array(names)
+        out[key + "lr_after"] = np.array([g["lr"] for g in optimizer.param_groups])
         out[key + "opts"] = np.array([str(o) for o in opts])
-        print(name, {k: round(v.item(), 6) for k, v in losses.items()})
+        print(name, {k: round(v.item(), 6) for k, v in losses.items()}, "lr", optimizer.param_groups[0]["lr"])
+    # the schedule itself (solver/lr_scheduler.py:10-52) at a few iterations of the shipped student configuration
+    probe = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=cfg.SOLVER.BASE_LR)
+    sched = make_lr_scheduler(cfg, probe)
+    its = [0, 1, 2, 100, 499, 500, 501, 19999, 20000, 20001, 49999, 50000, 69999]
+    lrs = []
+    for it in its:
+        sched.last_epoch = it
+        lrs.append(sched.get_lr()[0])
+    out["schedule_iterations"], out["schedule_lr"] = np.array(its), np.array(lrs)
     np.savez_compressed(os.path.join(HERE, "step_student_variants.npz"), **out)
 
 

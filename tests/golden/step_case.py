@@ -132,6 +132,9 @@ def image_case(index, vocab_names, seed=0):
     }
 
 
+VARIANT_DIGEST = 256  # entries per tensor kept by the configuration-variant fixtures (seven runs: keep them small)
+
+
 def grad_digest(name, grad, n=2048, seed=0):
     """What the fixtures keep of one gradient tensor: its L2 norm, its sum and the entries at ``n`` seeded positions (all
     of them when the tensor is smaller)."""

@@ -110,6 +110,56 @@ def test_pipelined_trainer_matches_plain_steps():
                 assert abs(a[k] - b[k]) <= 1e-6 * max(abs(b[k]), 1e-3), (kind, k, a[k], b[k])
 
 
+def test_pipelined_trainer_with_accumulation_and_clipping_matches_plain_steps():
+    """SOLVER.GRADIENT_ACCUMULATION_STEPS 2 + SOLVER.CLIP_GRAD_NORM_AT through the two-stream trainer (``StepPolicy``): the
+    optimizer steps every second iteration on the accumulated, clipped gradients -- losses step by step and the weights after
+    four iterations (two optimizer steps) equal those of the plain sequential loop."""
+    import copy
+
+    from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm, solver, trainer
+
+    model, e_vocab, e_seen, images, targets = _build("student_teacher_mask_rcnn_uncertainty")
+    cfg = get_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, "configs/coco_cap_det/student_teacher_mask_rcnn_uncertainty.yaml"))
+    cfg.merge_from_list(["SOLVER.BASE_LR", 1e-4, "SOLVER.GRADIENT_ACCUMULATION_STEPS", 2, "SOLVER.CLIP_GRAD_NORM_AT", 1.0])
+    cfg.freeze()
+    images = images.cuda()
+    tg = [t.to("cuda") for t in targets]
+
+    def run(pipelined):
+        m = copy.deepcopy(model).cuda()
+        m.iter = model.iter
+        m.set_class_embeddings(e_seen.cuda())
+        m.set_caption_vocab(e_vocab.cuda())
+        m.train()
+        opt = solver.make_optimizer(cfg, m)
+        sched = solver.make_lr_scheduler(cfg, opt)
+        red = comm.BucketedGradReducer(m)
+        pipe = trainer.PipelinedTrainer(m, opt, red, sched, policy=trainer.StepPolicy.from_cfg(cfg))
+        pipe.enabled = pipelined
+        out, stepped = [], []
+        for i in range(4):
+            torch.manual_seed(100 + i)
+            w = m.roi_heads_student["box"].predictor.bbox_pred.weight
+            before = w.detach().clone()
+            out.append({k: float(v) for k, v in pipe.step(images, tg, (images, tg)).items()})
+            stepped.append(not torch.equal(before, w.detach()))
+        pipe.drain()
+        red.remove()
+        return out, stepped, {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}, opt.param_groups[0]["lr"]
+
+    plain, stepped_p, w_plain, lr_plain = run(False)
+    got, stepped_g, w_got, lr_got = run(True)
+    assert stepped_p == stepped_g == [False, True, False, True]   # the weights move on every second iteration only
+    assert lr_plain == lr_got
+    for a, b in zip(got, plain):
+        for k in b:
+            assert abs(a[k] - b[k]) <= 1e-6 * max(abs(b[k]), 1e-3), (k, a[k], b[k])
+    for n in w_plain:
+        assert torch.allclose(w_got[n], w_plain[n], rtol=1e-5, atol=1e-7), n
+
+
 def test_pipelined_trainer_runs_the_teacher_steps_frozen_trunk_prefix_ahead():
     """Teacher training (zeroshot_mask.yaml, FREEZE_CONV_BODY_AT 2): stem + layer1 of batch k+1 run on the side stream beside
     the backward of batch k (``GeneralizedRCNN.forward_frozen`` / ``forward_student``).  The split chain hands on what the

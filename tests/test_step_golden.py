@@ -153,6 +153,24 @@ def _rel(a, b):
     return abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
 
 
+def check_digests(values, d, prefix, tol, n_digest=2048):
+    """{name: tensor} against the fixture's digests ``prefix:name:{values,norm_sum}``."""
+    worst = ("", 0.0)
+    for n in [str(x) for x in d[f"{prefix}_names"]]:
+        want = torch.from_numpy(d[f"{prefix}:{n}:values"]).double()
+        norm = float(d[f"{prefix}:{n}:norm_sum"][0])
+        g = values[n].detach().double().cpu().reshape(-1)
+        got = g[case.digest_index(n, g.numel(), n_digest)]
+        if norm == 0.0:
+            assert float(g.norm()) == 0.0, n
+            continue
+        err = float((got - want).norm() / max(float(want.norm()), 1e-30))
+        worst = max(worst, (n, err), key=lambda t: t[1])
+        assert err <= tol, (prefix, n, err)
+        assert abs(float(g.norm()) - norm) <= tol * norm, (prefix, n, float(g.norm()), norm)
+    return worst
+
+
 def check_grads(model, d, prefix, tol):
     names = [str(n) for n in d[f"{prefix}_names"]]
     have = {n: p for n, p in model.named_parameters() if p.grad is not None}
@@ -533,41 +551,96 @@ def test_teacher_step_with_frozen_rpn_hip_vs_reference_fixture():
 # the switches of the loss composition (st_generalized_rcnn.py:332-361): MODEL.REWEIGHT / LAMBDA_PSEUDO_LABEL /
 # NO_PSEUDO_MASK / UNCERTAINTY, each against a run of the reference under the same switch
 # ------------------------------------------------------------------------------------------------------------------
-VARIANTS = ("no_reweight", "no_pseudo_mask", "no_uncertainty", "lambda_half")
+VARIANTS = ("no_reweight", "no_pseudo_mask", "no_uncertainty", "lambda_half", "sigma_lr", "clip_grad", "accumulate2")
 
 
 def _typed(opts):
     out = []
     for k, v in zip(opts[0::2], opts[1::2]):
-        out += [str(k), {"True": True, "False": False}.get(str(v), float(v) if str(v).replace(".", "", 1).isdigit() else str(v))]
+        v = str(v)
+        out += [str(k), {"True": True, "False": False}.get(v, int(v) if v.isdigit() else float(v) if v.replace(".", "", 1).isdigit() else v)]
     return out
 
 
 def run_variant(device, name):
+    """The reference's loop body (engine/trainer.py:110-141) under one switch, through the PRODUCT's trainer: ``train_step`` with
+    its ``StepPolicy`` (accumulation, clipping), ``BucketedGradReducer``, ``make_optimizer`` / ``make_lr_scheduler`` /
+    ``GroupFusedSGD`` -- losses of the last micro-step, the gradients the optimizer consumed, the parameter update and the
+    learning rates after it."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm, solver, trainer
+
     v = _fixture("step_student_variants.npz")
     key = name + "_"
     model, d, cfg = build_student(device, _typed([str(o) for o in v[key + "opts"]]))
+    k_acc = cfg.SOLVER.GRADIENT_ACCUMULATION_STEPS
     c = case.image_case(0, [str(n) for n in d["cap_vocab"]])
-    _replay(model.roi_heads_student["box"].loss_evaluator, v, key + "roi_sample", (0, 1))
-    eps = torch.from_numpy(v[key + "mask_eps"]).to(device) if (key + "mask_eps") in v.files else None
+    images, targets = c["image"][None].to(device), [make_target(c, device)]
+    _replay(model.roi_heads_student["box"].loss_evaluator, v, key + "roi_sample", tuple(range(2 * k_acc)))
+    eps = [torch.from_numpy(v[key + f"mask_eps{i}"]).to(device) for i in range(k_acc) if (key + f"mask_eps{i}") in v.files]
+    forward = model.forward
+    model.forward = lambda im, tg: forward(im, tg, eps=eps.pop(0) if eps else None)   # the noise the reference drew
+    optimizer = solver.make_optimizer(cfg, model)
+    scheduler = solver.make_lr_scheduler(cfg, optimizer)
+    # solver/build.py:8-37: one group per trainable parameter, bias lr x 2 / no decay, uncertain_pred's own factor
+    by_id = {id(p): n for n, p in model.named_parameters()}
+    assert [by_id[id(g["params"][0])] for g in optimizer.param_groups] == [str(n) for n in v[key + "group_names"]]
+    got_lr_wd = torch.tensor([[g.get("initial_lr", g["lr"]), g["weight_decay"]] for g in optimizer.param_groups], dtype=torch.float64)
+    assert torch.allclose(got_lr_wd, torch.from_numpy(v[key + "group_lr_wd"]), rtol=1e-12, atol=0)
+    reducer = comm.BucketedGradReducer(model)
+    policy = trainer.StepPolicy.from_cfg(cfg)
     with _ops(device):
-        losses = model(c["image"][None].to(device), [make_target(c, device)], eps=eps)
-        sum(losses.values()).backward()
+        model.prepare_model()                      # the teacher -> student copy of iteration 0: the update is measured from it
+        before = {n: p.detach().clone() for n, p in model.named_parameters()}
+        consumed = {}
+        step = optimizer.step
+
+        def recording_step(*a, **k):
+            for n, p in model.named_parameters():
+                if p.grad is not None and p.requires_grad:
+                    consumed[n] = p.grad.detach().clone()
+            return step(*a, **k)
+
+        optimizer.step = recording_step
+        for _ in range(k_acc):
+            losses = trainer.train_step(model, optimizer, reducer, images, targets, scheduler, policy)
+    assert policy.micro == 0 and consumed
     for k in PSEUDO + SEEN:
         want = float(v[key + k])
         if want == 0.0:
             assert float(losses[k].detach()) == 0.0, k
         else:
             assert _rel(losses[k], want) <= 1e-3, (name, k, float(losses[k]), want)
-    check_grads(model, v, key + "grad", 5e-3)
+    names = [str(n) for n in v[key + "grad_names"]]
+    assert set(names) - {"lambda_exemplar"} <= set(consumed)
+    consumed.setdefault("lambda_exemplar", torch.zeros(1))
+    check_digests(consumed, v, key + "grad", 5e-3, case.VARIANT_DIGEST)
+    after = dict(model.named_parameters())
+    check_digests({n: after[n].detach() - before[n] for n in names}, v, key + "delta", 5e-3, case.VARIANT_DIGEST)
+    got_lr = torch.tensor([g["lr"] for g in optimizer.param_groups], dtype=torch.float64)
+    assert torch.allclose(got_lr, torch.from_numpy(v[key + "lr_after"]), rtol=1e-9, atol=0)
+    reducer.remove()
 
 
 @pytest.mark.parametrize("name", VARIANTS)
-def test_loss_composition_switches_cpu_vs_reference_fixture(name):
+def test_step_switches_through_the_trainer_cpu_vs_reference_fixture(name):
     run_variant("cpu", name)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", VARIANTS)
-def test_loss_composition_switches_hip_vs_reference_fixture(name):
+def test_step_switches_through_the_trainer_hip_vs_reference_fixture(name):
     run_variant("cuda", name)
+
+
+def test_lr_schedule_vs_reference_fixture():
+    """WarmupMultiStepLR (solver/lr_scheduler.py:10-52) of the shipped student configuration at the iterations around the
+    warm-up end and the two milestones."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import solver
+
+    v = _fixture("step_student_variants.npz")
+    cfg = _cfg("student_teacher_mask_rcnn_uncertainty.yaml", "cpu")
+    probe = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=cfg.SOLVER.BASE_LR)
+    sched = solver.make_lr_scheduler(cfg, probe)
+    for it, want in zip(v["schedule_iterations"].tolist(), v["schedule_lr"].tolist()):
+        sched.last_epoch = it
+        assert abs(sched.get_lr()[0] - want) <= 1e-12 * want, (it, sched.get_lr()[0], want)
