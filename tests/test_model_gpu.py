@@ -138,6 +138,7 @@ def test_pipelined_trainer_with_accumulation_and_clipping_matches_plain_steps():
         red = comm.BucketedGradReducer(m)
         pipe = trainer.PipelinedTrainer(m, opt, red, sched, policy=trainer.StepPolicy.from_cfg(cfg))
         pipe.enabled = pipelined
+        m.prepare_model()   # the teacher -> student copy of iteration 0 happens here, not inside the first timed comparison
         out, stepped = [], []
         for i in range(4):
             torch.manual_seed(100 + i)
