@@ -50,8 +50,8 @@ def test_shipped_library_is_a_product_build_without_experiment_switches():
     flags = version.split(" flags: ", 1)[1].split()
     assert not [f for f in flags if f.startswith("-D") or f.startswith("-U")], version
     assert "-ffp-contract=off" in flags   # RoIAlign forward / NMS follow the reference's IEEE op sequence
-    for patch in glob.glob(os.path.join(ROOT, "tools", "experiments", "patches", "*.patch")):
-        assert "#if" in open(patch).read()     # the probes still exist -- as patches
+    for name in ("roi_bwd_probes.patch", "split_gemm_knobs.patch"):   # the probes still exist -- as patches
+        assert "#if" in open(os.path.join(ROOT, "tools", "experiments", "patches", name)).read()
 
 
 def test_every_declaration_cites_the_reference():
