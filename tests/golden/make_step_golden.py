@@ -19,6 +19,7 @@ proposals of both RPN modes, the pseudo labels, and after ``sum(losses).backward
 """
 import os
 import sys
+import types
 
 import numpy as np
 import torch
@@ -448,6 +449,67 @@ def gen_teacher_fixed_rpn():
     np.savez_compressed(os.path.join(HERE, "step_teacher_fixed_rpn.npz"), **out)
 
 
+def pretraining_checkpoint_keys(model_state):
+    """A synthetic caption-pretraining checkpoint for ``model_state`` (name -> shape): what the README's pretrained OVR-CNN
+    weights look like from the loader's side -- a DistributedDataParallel-wrapped model (``module.``) with a ResNet-50 body
+    INCLUDING layer4 (the res5 heads take their weights from it by suffix match), the grounding head's vision-to-language
+    projection (-> ``emb_pred``), and pieces no detector key matches.  {checkpoint key: shape}."""
+    ck = {}
+    for k, shape in model_state.items():
+        if k.startswith("backbone.body."):
+            ck["module." + k] = shape
+        elif k.startswith("roi_heads.box.feature_extractor.head.layer4."):
+            ck["module.backbone.body." + k[len("roi_heads.box.feature_extractor.head."):]] = shape
+        elif k.startswith("roi_heads.box.predictor.emb_pred."):
+            ck["module.mmss_heads.GroundingHead.v2l_projection." + k.rsplit(".", 1)[1]] = shape
+    ck["module.mmss_heads.TransformerHead.heads.cls.weight"] = (7, 5)
+    ck["module.mmss_heads.GroundingHead.t2v_unused.bias"] = (3,)
+    return ck
+
+
+def gen_checkpoint_map():
+    """Which checkpoint tensor the reference's ``DetectronCheckpointer`` (utils/checkpoint.py:103-131: prefix strip, key
+    rewrites; utils/model_serialization.py:10-89: longest-suffix match) puts into which model tensor, built exactly as
+    tools/train_net.py:78-86 builds it from the shipped yaml files -> tests/golden/step_checkpoint_map.json."""
+    import json
+
+    import torch.hub
+    if not hasattr(torch.hub, "_download_url_to_file"):   # utils/model_zoo.py:5-12 imports the private name of torch < 1.12;
+        torch.hub._download_url_to_file = torch.hub.download_url_to_file  # the download path is never taken here
+    from maskrcnn_benchmark.modeling.detector import st_generalized_rcnn as st_mod
+    from maskrcnn_benchmark.modeling.detector.generalized_rcnn import GeneralizedRCNN
+    from maskrcnn_benchmark.utils.checkpoint import DetectronCheckpointer
+
+    out = {}
+    for name, yaml_name, cls in (("student", "student_teacher_mask_rcnn_uncertainty.yaml", st_mod.STGeneralizedRCNN),
+                                 ("teacher", "zeroshot_mask.yaml", GeneralizedRCNN)):
+        cfg = ref_import.reference_cfg(yaml_name, case.COMMON_OPTS)
+        model = cls(cfg)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        ck = pretraining_checkpoint_keys(shapes)
+        with torch.no_grad():
+            for v in model.state_dict().values():
+                v.fill_(-1)
+        loaded = {k: torch.full(shape, float(i)) for i, (k, shape) in enumerate(ck.items())}
+        chk = DetectronCheckpointer(cfg, model, None, None, "", False, backbone_prefix=cfg.MODEL.BACKBONE_PREFIX,
+                                    load_emb_pred_from=(cfg.MODEL.MMSS_HEAD.DEFAULT_HEAD if cfg.MODEL.LOAD_EMB_PRED_FROM_MMSS_HEAD
+                                                        else None), load_classifier=cfg.MODEL.LOAD_CLASSIFIER,
+                                    replace_substr_dict={})
+        chk._load_model({"model": loaded})
+        keys = list(ck)
+        mapping = {}
+        for k, v in model.state_dict().items():
+            val = float(v.reshape(-1)[0])
+            assert bool((v == val).all())
+            mapping[k] = keys[int(val)] if val >= 0 else None
+        out[name] = {"checkpoint": {k: list(s) for k, s in ck.items()}, "loaded_from": mapping,
+                     "backbone_prefix": cfg.MODEL.BACKBONE_PREFIX, "default_head": cfg.MODEL.MMSS_HEAD.DEFAULT_HEAD}
+        n_hit = sum(1 for v in mapping.values() if v is not None)
+        print("checkpoint map", name, len(ck), "checkpoint keys ->", n_hit, "of", len(mapping), "model tensors")
+    with open(os.path.join(HERE, "step_checkpoint_map.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+
+
 def main():
     torch.set_num_threads(1)
     torch.manual_seed(20260101)
@@ -457,6 +519,7 @@ def main():
     gen_student_variants()
     gen_teacher()
     gen_teacher_fixed_rpn()
+    gen_checkpoint_map()
     for f in ("step_student.npz", "step_student_variants.npz", "step_teacher.npz", "step_teacher_fixed_rpn.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 

@@ -644,3 +644,51 @@ def test_lr_schedule_vs_reference_fixture():
     for it, want in zip(v["schedule_iterations"].tolist(), v["schedule_lr"].tolist()):
         sched.last_epoch = it
         assert abs(sched.get_lr()[0] - want) <= 1e-12 * want, (it, sched.get_lr()[0], want)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# wire format: which tensor of a caption-pretraining checkpoint lands in which model tensor (utils/checkpoint.py:103-131,
+# utils/model_serialization.py:10-89), against the reference's own DetectronCheckpointer built as tools/train_net.py:78-86
+# builds it -- "module." strip, BACKBONE_PREFIX rewrite, the grounding head's v2l_projection -> emb_pred, the res5 heads of
+# BOTH the teacher and the student fed from the body's layer4 by longest-suffix match, unmatched keys left alone
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["student", "teacher"])
+def test_pretraining_checkpoint_lands_where_the_reference_puts_it(name, tmp_path):
+    import json
+
+    from cvpr22_cross_modal_pseudo_labeling_amd.utils.checkpoint import DetectronCheckpointer
+
+    with open(os.path.join(GOLDEN, "step_checkpoint_map.json")) as f:
+        want = json.load(f)[name]
+    model, _, cfg = build_student("cpu") if name == "student" else build_teacher("cpu")
+    assert cfg.MODEL.BACKBONE_PREFIX == want["backbone_prefix"] and cfg.MODEL.MMSS_HEAD.DEFAULT_HEAD == want["default_head"]
+    with torch.no_grad():
+        for v in model.state_dict().values():
+            v.fill_(-1)
+    keys = list(want["checkpoint"])
+    loaded = {k: torch.full(tuple(want["checkpoint"][k]), float(i)) for i, k in enumerate(keys)}
+    chk = DetectronCheckpointer(cfg, model, None, None, "", False, backbone_prefix=cfg.MODEL.BACKBONE_PREFIX,
+                                load_emb_pred_from=(cfg.MODEL.MMSS_HEAD.DEFAULT_HEAD if cfg.MODEL.LOAD_EMB_PRED_FROM_MMSS_HEAD else None),
+                                load_classifier=cfg.MODEL.LOAD_CLASSIFIER)
+    path = str(tmp_path / "pretrained.pth")
+    torch.save({"model": loaded, "iteration": 120000}, path)          # the reference's file format (utils/checkpoint.py:34-52)
+    extra = chk.load(path, use_latest=False, load_trainer_state=cfg.MODEL.LOAD_TRAINER_STATE)
+    assert extra.get("iteration") == 120000
+    got = {}
+    for k, v in model.state_dict().items():
+        if k == "bert.embeddings":
+            continue   # (the fixture's model carried the case's 187-row table, the product test's too: not part of the map)
+        val = float(v.reshape(-1)[0])
+        assert bool((v == val).all()), k
+        got[k] = keys[int(val)] if val >= 0 else None
+    # (the reference registers its anchor table as a buffer, rpn/anchor_generator.py:18-30; the product computes anchors in
+    # its decode kernel and has no such entry -- the suffix-matching loader of either side ignores the difference)
+    ref = {k: v for k, v in want["loaded_from"].items() if k != "bert.embeddings" and "anchor_generator" not in k}
+    assert got.keys() == ref.keys()
+    wrong = {k: (got[k], ref[k]) for k in ref if got[k] != ref[k]}
+    assert not wrong, list(wrong.items())[:5]
+    assert sum(v is not None for v in got.values()) >= 300 and any(v is None for v in got.values())
+    # the student's res5 head is fed by the same body.layer4 tensors as the teacher's
+    if name == "student":
+        k = "roi_heads_student.box.feature_extractor.head.layer4.0.conv1.weight"
+        assert got[k] == got[k.replace("roi_heads_student", "roi_heads")] == "module.backbone.body.layer4.0.conv1.weight"
