@@ -123,6 +123,15 @@ def format_cpus(cpus):
     return ",".join(out)
 
 
+def _visible_devices(env):
+    """GPU indices behind local ranks 0, 1, ... when HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES re-orders or restricts them
+    (None: rank r uses GPU r)."""
+    vis = env.get("HIP_VISIBLE_DEVICES") or env.get("ROCR_VISIBLE_DEVICES")
+    if vis and all(v.strip().isdigit() for v in vis.split(",")):
+        return [int(v) for v in vis.split(",")]
+    return None
+
+
 def apply_rank_affinity(env=None, sysfs_root="/sys"):
     """Pin the calling rank (call before anything touches the GPU).  ``OVIS_RANK_CPUS`` (set by ``spawn_ranks``) wins;
     under another launcher (torch.distributed.run) the share is planned here from LOCAL_RANK / LOCAL_WORLD_SIZE.
@@ -138,9 +147,7 @@ def apply_rank_affinity(env=None, sysfs_root="/sys"):
             rank = int(env.get("LOCAL_RANK", env.get("RANK", "0")))
             if world <= 1:
                 return {"cpus": format_cpus(os.sched_getaffinity(0)), "source": "single rank: unchanged"}
-            vis = env.get("HIP_VISIBLE_DEVICES") or env.get("ROCR_VISIBLE_DEVICES")
-            visible = [int(v) for v in vis.split(",")] if vis and all(v.strip().isdigit() for v in vis.split(",")) else None
-            cpus = plan_affinity(world, sysfs_root=sysfs_root, visible=visible)[rank]
+            cpus = plan_affinity(world, sysfs_root=sysfs_root, visible=_visible_devices(env))[rank]
             source = "numa" if gpu_numa_nodes(sysfs_root) else "even split"
         cpus = set(cpus) & os.sched_getaffinity(0) or set(cpus)
         if len(cpus) < MIN_CORES_PER_RANK and len(cpus) < len(os.sched_getaffinity(0)):
@@ -208,7 +215,7 @@ def spawn_ranks(argv, nproc, master_port=None, env=None, poll_seconds=0.2, pytho
     code = 0
     base_env = os.environ if env is None else env
     no_pin = base_env.get("OVIS_NO_AFFINITY") == "1"
-    plan = None if no_pin else plan_affinity(nproc)
+    plan = None if no_pin else plan_affinity(nproc, visible=_visible_devices(base_env))
     try:
         for r in range(nproc):
             if got:
