@@ -20,6 +20,7 @@ proposals of both RPN modes, the pseudo labels, and after ``sum(losses).backward
 import os
 import sys
 import types
+import zlib
 
 import numpy as np
 import torch
@@ -231,6 +232,159 @@ def gen_student():
     out["cap_vocab"] = np.array(model.cap_vocab)
     out["opts"] = np.array([str(o) for o in case.COMMON_OPTS])
     np.savez_compressed(os.path.join(HERE, "step_student.npz"), **out)
+
+
+FULL_OPTS = ["MODEL.DEVICE", "cpu"]   # the shipped configuration itself: full R-50-C4, 6000 -> 1000 / 12000 -> 2000 proposals, 512 RoIs
+
+
+def gen_student_full():
+    """ONE image at BASELINE size (3 x 800 x 1333) through the reference's STGeneralizedRCNN with the SHIPPED configuration
+    (full R-50-C4 -- 55 M seeded weights --, 1000 test-mode / 2000 train-mode proposals, 512 sampled RoIs per branch):
+    proposals, aligned regions + margins, pseudo labels, sampler draws, mask noise, losses, gradient digests ->
+    tests/golden/step_student_full.npz.  About a minute on 8 cores."""
+    from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+    from maskrcnn_benchmark.modeling.detector import st_generalized_rcnn as st_mod
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.image_list import to_image_list
+    from maskrcnn_benchmark.structures.segmentation_mask import SegmentationMask
+
+    torch.set_num_threads(os.cpu_count())
+    cfg = ref_import.reference_cfg("student_teacher_mask_rcnn_uncertainty.yaml", FULL_OPTS)
+    model = st_mod.STGeneralizedRCNN(cfg)
+    names = load_seeded(model)
+    model.class_names = list(case.SEEN_NAMES)
+    model.roi_heads["box"].predictor.set_class_embeddings(case.text_embeddings())
+    model.train()
+    c = case.image_case(0, model.cap_vocab, size=(case.FULL_H, case.FULL_W), n_gt=7, n_nouns=5)
+    t = BoxList(c["boxes"].clone(), (case.FULL_W, case.FULL_H), mode="xyxy")
+    t.add_field("labels", c["labels"].clone())
+    t.add_field("masks", SegmentationMask(c["masks"].clone(), (case.FULL_W, case.FULL_H), mode="mask"))
+    t.add_field("nn_caption", c["nn_caption"])
+    t.add_field("ids_cap", c["ids_cap"].clone())
+    t.add_field("is_det", "Yes")
+    out, key = {}, "img0_"
+    with Capture(BalancedPositiveNegativeSampler) as cap:
+        losses = model(c["image"][None], [t])
+        with torch.no_grad():
+            images = to_image_list(c["image"][None])
+            feats = model.backbone(images.tensors)
+            model.rpn.eval()
+            props_test, _ = model.rpn(images, feats, None)
+            n_einsum = len(cap.einsum)
+            pseudo = model.generate_pseudo_label([feats[0]], props_test, [t.get_field("nn_caption").split("/")], [t])
+            scores_pw = [o for eq, o in cap.einsum[n_einsum:] if eq == "pd,wd->pw"][0]
+            model.rpn.train()
+            props_train, _ = model.rpn(images, feats, [t])
+    sum(losses.values()).backward()
+    f = feats[0]
+    out[key + "feature_stats"] = np.array([float(f.mean()), float(f.std()), float(f.abs().max())])
+    idx = torch.from_numpy(_rng_index("full_features", f.numel(), 4096))
+    out[key + "feature_samples"] = f.reshape(-1)[idx].numpy()
+    put_boxes(out, key + "proposals_test", props_test, ("objectness",))
+    put_boxes(out, key + "proposals_train", props_train)
+    out[key + "aligned_idx"] = scores_pw.argmax(0).numpy()
+    top2 = scores_pw.topk(2, dim=0).values
+    out[key + "aligned_margin"] = (top2[0] - top2[1]).numpy()
+    out[key + "aligned_scores"] = top2[0].numpy()
+    pl = pseudo[0]
+    out[key + "pseudo_bbox"] = pl.bbox.numpy()
+    for fld in ("labels", "scores", "consistencies", "embs"):
+        out[key + "pseudo_" + fld] = pl.get_field(fld).numpy()
+    pm = pl.get_field("masks").get_mask_tensor()
+    out[key + "pseudo_masks_packed"] = np.packbits((pm[None] if pm.dim() == 2 else pm).numpy().astype(np.bool_), axis=-1)
+    put_samples(out, key + "roi_sample", cap, cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE)
+    assert out[key + "roi_sample_count"] == 2
+    eps = [r for r in cap.randn if r.dim() == 5]
+    assert len(eps) == 1
+    out[key + "mask_eps"] = eps[0].numpy()
+    out[key + "avg_uncertain"] = np.float64(model.roi_heads_student["mask"].avg_uncertain.item())
+    out[key + "adaptive_lamb"] = np.float64(float(model.adaptive_lamb))
+    for k, v in losses.items():
+        out[key + k] = np.float64(v.item())
+    put_grads(out, model, key + "grad")
+    out["state_names"] = np.array([n for n, _, _ in names])
+    out["state_shapes"] = np.array([",".join(map(str, s)) for _, s, _ in names])
+    out["state_seeded_as"] = np.array([c_ for _, _, c_ in names])
+    print("full size", {k: round(v.item(), 6) for k, v in losses.items()}, "proposals", len(props_test[0]), len(props_train[0]),
+          "positives", [int(out[key + f"roi_sample{b}_pos"].sum()) for b in (0, 1)], "margins", out[key + "aligned_margin"],
+          "features mean/std/max", out[key + "feature_stats"])
+    np.savez_compressed(os.path.join(HERE, "step_student_full.npz"), **out)
+    torch.set_num_threads(1)
+
+
+def gen_teacher_full():
+    """The two-image batch at BASELINE size through the reference's GeneralizedRCNN with the SHIPPED zeroshot_mask.yaml (trunk
+    trainable from layer2, RPN trained: 12000 -> 2000 train-mode proposals, 256 RPN / 512 RoI samples per image): sampler
+    draws, proposals, the five losses, gradient digests -> tests/golden/step_teacher_full.npz.  RoIAlign backward = the oracle's
+    (see gen_teacher).  A few minutes on 8 cores."""
+    import oracle
+    from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+    from maskrcnn_benchmark.modeling.detector.generalized_rcnn import GeneralizedRCNN
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.image_list import to_image_list
+    from maskrcnn_benchmark.structures.segmentation_mask import SegmentationMask
+    import maskrcnn_benchmark.layers  # noqa: F401
+
+    ref_roi_align = sys.modules["maskrcnn_benchmark.layers.roi_align"]
+
+    class _CWithBackward:
+        def __getattr__(self, name):
+            return getattr(sys.modules["maskrcnn_benchmark._C"], name)
+
+        @staticmethod
+        def roi_align_backward(grad, rois, scale, ph, pw, n, c, h, w, sampling_ratio):
+            return oracle.roi_align_backward(grad, rois, scale, ph, pw, n, c, h, w, sampling_ratio)
+
+    ref_roi_align._C = _CWithBackward()
+    torch.set_num_threads(os.cpu_count())
+    cfg = ref_import.reference_cfg("zeroshot_mask.yaml", FULL_OPTS)
+    model = GeneralizedRCNN(cfg)
+    names = load_seeded(model)
+    model.roi_heads["box"].predictor.set_class_embeddings(case.text_embeddings())
+    model.train()
+    cases = [case.image_case(i, ["-"] * 1203, size=(case.FULL_H, case.FULL_W), n_gt=7, n_nouns=5) for i in range(2)]
+    targets = []
+    for c in cases:
+        t = BoxList(c["boxes"].clone(), (case.FULL_W, case.FULL_H), mode="xyxy")
+        t.add_field("labels", c["labels"].clone())
+        t.add_field("masks", SegmentationMask(c["masks"].clone(), (case.FULL_W, case.FULL_H), mode="mask"))
+        targets.append(t)
+    images = torch.stack([c["image"] for c in cases])
+    out = {}
+    with Capture(BalancedPositiveNegativeSampler) as cap:
+        losses = model(images, targets)
+    sum(losses.values()).backward()
+    put_samples(out, "rpn_sample", cap, cfg.MODEL.RPN.BATCH_SIZE_PER_IMAGE)
+    put_samples(out, "roi_sample", cap, cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE)
+    assert out["rpn_sample_count"] == 2 and out["roi_sample_count"] == 2
+    for i in range(2):   # 63 000 anchors per image: store the drawn indices, not the masks
+        for kind in ("pos", "neg"):
+            m = out.pop(f"rpn_sample{i}_{kind}")
+            out[f"rpn_sample{i}_{kind}_index"] = np.nonzero(m)[0].astype(np.int32)
+        out[f"rpn_sample{i}_anchors"] = np.int64(m.shape[0])
+    with torch.no_grad():
+        il = to_image_list(images)
+        feats = model.backbone(il.tensors)
+        with Capture(BalancedPositiveNegativeSampler):
+            props, _ = model.rpn(il, feats, targets)
+    f = feats[0]
+    out["feature_stats"] = np.array([float(f.mean()), float(f.std()), float(f.abs().max())])
+    out["feature_samples"] = f.reshape(-1)[torch.from_numpy(_rng_index("full_features", f.numel(), 4096))].numpy()
+    put_boxes(out, "proposals_train", props)
+    for k, v in losses.items():
+        out[k] = np.float64(v.item())
+    put_grads(out, model)
+    out["state_names"] = np.array([n for n, _, _ in names])
+    out["state_shapes"] = np.array([",".join(map(str, s)) for _, s, _ in names])
+    out["state_seeded_as"] = np.array([c_ for _, _, c_ in names])
+    print("teacher, full size", {k: round(v.item(), 6) for k, v in losses.items()}, "proposals", [len(p) for p in props],
+          "positives", [int(out[f"roi_sample{b}_pos"].sum()) for b in (0, 1)], [len(out[f"rpn_sample{b}_pos_index"]) for b in (0, 1)])
+    np.savez_compressed(os.path.join(HERE, "step_teacher_full.npz"), **out)
+    torch.set_num_threads(1)
+
+
+def _rng_index(name, numel, n):
+    return np.sort(np.random.default_rng([zlib.crc32(name.encode()), 0]).choice(numel, n, replace=False)).astype(np.int64)
 
 
 VARIANTS = {  # configuration switches of STGeneralizedRCNN.forward's loss composition (st_generalized_rcnn.py:332-361) ...
@@ -520,7 +674,10 @@ def main():
     gen_teacher()
     gen_teacher_fixed_rpn()
     gen_checkpoint_map()
-    for f in ("step_student.npz", "step_student_variants.npz", "step_teacher.npz", "step_teacher_fixed_rpn.npz"):
+    gen_student_full()
+    gen_teacher_full()
+    for f in ("step_student.npz", "step_student_variants.npz", "step_teacher.npz", "step_teacher_fixed_rpn.npz", "step_student_full.npz",
+              "step_teacher_full.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 

@@ -95,28 +95,34 @@ def text_embeddings(seed=0):
     return torch.from_numpy(e.astype(np.float32))
 
 
-def image_case(index, vocab_names, seed=0):
+FULL_H, FULL_W = 800, 1333   # the BASELINE image size (full-size fixture: step_student_full.npz)
+
+
+def image_case(index, vocab_names, seed=0, size=None, n_gt=3, n_nouns=3):
     """One image of the case: pixels, ground-truth boxes (xyxy) / labels / rectangular binary masks, caption nouns (names of
-    the caption vocabulary and their 0-based ids).  ``vocab_names`` = the normalised caption vocabulary."""
-    g = _rng(f"image{index}", seed)
+    the caption vocabulary and their 0-based ids).  ``vocab_names`` = the normalised caption vocabulary.  ``size`` = (H, W),
+    default the small case's 128 x 160 (its random stream is unchanged by the other arguments' defaults)."""
+    IMAGE_H, IMAGE_W = size or (globals()["IMAGE_H"], globals()["IMAGE_W"])
+    big = size is not None
+    g = _rng(f"image{index}" + (f"@{IMAGE_H}x{IMAGE_W}" if big else ""), seed)
     img = (g.uniform(0, 255, (3, IMAGE_H, IMAGE_W)) - np.array([102.9801, 115.9465, 122.7717])[:, None, None])
     # smooth structure so that features differ across the map (pure noise averages out in the strided stem)
     yy, xx = np.mgrid[0:IMAGE_H, 0:IMAGE_W]
-    for _ in range(6):
-        cx, cy, r = g.uniform(0, IMAGE_W), g.uniform(0, IMAGE_H), g.uniform(10, 50)
+    for _ in range(24 if big else 6):
+        cx, cy, r = g.uniform(0, IMAGE_W), g.uniform(0, IMAGE_H), g.uniform(10, 50) * (5 if big else 1)
         img += (g.uniform(-120, 120, (3, 1, 1)) * (((xx - cx) ** 2 + (yy - cy) ** 2) < r * r))
-    n_gt = 3
-    x1 = g.uniform(0, IMAGE_W - 60, n_gt)
-    y1 = g.uniform(0, IMAGE_H - 60, n_gt)
-    w = g.uniform(24, 90, n_gt)
-    h = g.uniform(24, 80, n_gt)
+    k = 5 if big else 1
+    x1 = g.uniform(0, IMAGE_W - 60 * k, n_gt)
+    y1 = g.uniform(0, IMAGE_H - 60 * k, n_gt)
+    w = g.uniform(24, 90, n_gt) * k
+    h = g.uniform(24, 80, n_gt) * k
     boxes = np.stack([x1, y1, np.minimum(x1 + w, IMAGE_W - 1), np.minimum(y1 + h, IMAGE_H - 1)], 1).round()
     labels = g.integers(1, N_SEEN, n_gt)
     masks = np.zeros((n_gt, IMAGE_H, IMAGE_W), np.uint8)
     for i, (bx1, by1, bx2, by2) in enumerate(boxes.astype(int)):
         dx, dy = (bx2 - bx1) // 6, (by2 - by1) // 6
         masks[i, by1 + dy:by2 - dy + 1, bx1 + dx:bx2 - dx + 1] = 1
-    ids_cap = np.sort(g.choice(len(vocab_names), 3, replace=False))
+    ids_cap = np.sort(g.choice(len(vocab_names), n_nouns, replace=False))
     return {
         "image": torch.from_numpy(img.astype(np.float32)),
         "boxes": torch.from_numpy(boxes.astype(np.float32)),

@@ -692,3 +692,145 @@ def test_pretraining_checkpoint_lands_where_the_reference_puts_it(name, tmp_path
     if name == "student":
         k = "roi_heads_student.box.feature_extractor.head.layer4.0.conv1.weight"
         assert got[k] == got[k.replace("roi_heads_student", "roi_heads")] == "module.backbone.body.layer4.0.conv1.weight"
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE size: one 3 x 800 x 1333 image through the SHIPPED configuration (full R-50-C4, 1000 / 2007 proposals, 512 sampled
+# RoIs per branch) against the reference's own run of it (tests/golden/step_student_full.npz) -- HIP path only (the CPU path is
+# pinned at the small size above and would take a minute here)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_student_step_at_baseline_size_hip_vs_reference_fixture():
+    from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.detector import build_detection_model
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.language_backbone import BERT
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.structures import BoxList
+
+    d = _fixture("step_student_full.npz")
+    small = _fixture("step_student.npz")
+    device, key = "cuda", "img0_"
+    cfg = get_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "coco_cap_det", "student_teacher_mask_rcnn_uncertainty.yaml"))
+    cfg.freeze()                                                        # the shipped configuration, nothing overridden
+    model = build_detection_model(cfg)
+    model.bert = BERT(cfg, vocab_file=os.path.join(GOLDEN, "step_wordpiece_vocab.txt"), vocab_size=len(case.WORDPIECES))
+    _load_seeded(model, d)
+    model = model.to(device)
+    model.set_class_embeddings(case.text_embeddings().to(device))
+    vocab = [str(n) for n in small["cap_vocab"]]
+    model.set_caption_vocab_names(vocab)
+    model.train()
+    size = (case.FULL_W, case.FULL_H)
+    c = case.image_case(0, vocab, size=(case.FULL_H, case.FULL_W), n_gt=7, n_nouns=5)
+    t = BoxList(c["boxes"].clone(), size)
+    for f in ("labels", "masks", "ids_cap"):
+        t.add_field(f, c[f].clone())
+    t.add_field("nn_caption", c["nn_caption"])
+    t.add_field("is_det", "Yes")
+    target = t.to(device)
+    images = c["image"][None].to(device)
+    # ---- frozen half: features (4096 seeded samples of the 50 x 84 x 1024 map), both proposal sets
+    with torch.no_grad():
+        fz = model.forward_frozen(images, [target])
+    feat = fz["feat"].float()
+    assert feat.shape == (1, 1024, 50, 84)
+    idx = torch.from_numpy(np.sort(np.random.default_rng([__import__("zlib").crc32(b"full_features"), 0]).choice(feat.numel(), 4096, replace=False)))
+    got = feat.permute(0, 1, 2, 3).contiguous().reshape(-1)[idx.to(device)].cpu()
+    want = torch.from_numpy(d[key + "feature_samples"])
+    assert float((got - want).abs().max()) <= 2e-4 * float(d[key + "feature_stats"][2]), float((got - want).abs().max())
+    assert boxes_match(fz["cap_proposals"][0].bbox, torch.from_numpy(d[key + "proposals_test0_bbox"]), 0.95)
+    assert boxes_match(fz["gt_proposals"][0].bbox, torch.from_numpy(d[key + "proposals_train0_bbox"]), 0.95)
+    # ---- generate_pseudo_label on the fixture's 1000 test-mode proposals
+    props = BoxList(torch.from_numpy(d[key + "proposals_test0_bbox"]).to(device), size)
+    props.add_field("objectness", torch.from_numpy(d[key + "proposals_test0_objectness"]).to(device))
+    with torch.no_grad():
+        pseudo = model.generate_pseudo_label([fz["feat"]], [props], [model._noun_embs(target)], [target])[0]
+    decided = torch.from_numpy(d[key + "aligned_margin"]) > 5e-3      # a top-2 margin below the arithmetic's noise may go either way
+    assert int(decided.sum()) >= 4
+    assert torch.equal(pseudo.get_field("labels").cpu(), c["ids_cap"])
+    assert torch.allclose(pseudo.bbox.cpu()[decided], torch.from_numpy(d[key + "pseudo_bbox"])[decided], atol=5e-2, rtol=0)
+    assert torch.allclose(pseudo.get_field("scores").cpu(), torch.from_numpy(d[key + "pseudo_scores"]), rtol=1e-3, atol=1e-4)
+    # ---- student half on the fixture's frozen outputs, the reference samplers' draws (512 per branch) and its mask noise
+    want_m = torch.from_numpy(np.unpackbits(d[key + "pseudo_masks_packed"], axis=-1)[..., : case.FULL_W]).bool()
+    ref_pseudo = BoxList(torch.from_numpy(d[key + "pseudo_bbox"]).to(device), size)
+    for f in ("labels", "scores", "consistencies", "embs"):
+        ref_pseudo.add_field(f, torch.from_numpy(d[key + "pseudo_" + f]).to(device))
+    ref_pseudo.add_field("masks", want_m.to(device))
+    gt_props = BoxList(torch.from_numpy(d[key + "proposals_train0_bbox"]).to(device), size)
+    frozen = dict(fz, cap_proposals=[props], pseudo_targets=[ref_pseudo], gt_proposals=[gt_props])
+    _replay(model.roi_heads_student["box"].loss_evaluator, d, key + "roi_sample", (0, 1))
+    losses = model.forward_student(frozen, [target], eps=torch.from_numpy(d[key + "mask_eps"]).to(device))
+    sum(losses.values()).backward()
+    for k in PSEUDO + SEEN:
+        want_k = float(d[key + k])
+        assert abs(float(losses[k].detach()) - want_k) <= 1e-3 * max(abs(want_k), 1e-3), (k, float(losses[k]), want_k)
+    assert _rel(model.adaptive_lamb, d[key + "adaptive_lamb"]) <= 1e-3
+    print(check_grads(model, d, key + "grad", 5e-3))
+
+
+@pytest.mark.gpu
+def test_teacher_step_at_baseline_size_hip_vs_reference_fixture():
+    """Two 3 x 800 x 1333 images through the SHIPPED zeroshot_mask.yaml (trunk trainable from layer2, RPN trained) against the
+    reference's own GeneralizedRCNN run: features, train-mode proposals, the five losses with the reference samplers' draws
+    replayed (256 of 63 000 anchors, 512 of 2007 proposals per image), gradients of every trainable tensor -- the ten-bottleneck
+    trunk included, 5e-3 per tensor."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.detector import build_detection_model
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.structures import BoxList
+
+    d = _fixture("step_teacher_full.npz")
+    device = "cuda"
+    cfg = get_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "coco_cap_det", "zeroshot_mask.yaml"))
+    cfg.freeze()
+    model = build_detection_model(cfg)
+    _load_seeded(model, d)
+    model = model.to(device)
+    model.set_class_embeddings(case.text_embeddings().to(device))
+    model.train()
+    size = (case.FULL_W, case.FULL_H)
+    cs = [case.image_case(i, ["-"] * 1203, size=(case.FULL_H, case.FULL_W), n_gt=7, n_nouns=5) for i in range(2)]
+    targets = []
+    for c in cs:
+        t = BoxList(c["boxes"].clone(), size)
+        t.add_field("labels", c["labels"].clone())
+        t.add_field("masks", c["masks"].clone())
+        targets.append(t.to(device))
+    images = torch.stack([c["image"] for c in cs]).to(device)
+    # the RPN sampler's draws come as index lists (63 000 anchors per image)
+    rpn_draws = []
+    for i in range(2):
+        n = int(d[f"rpn_sample{i}_anchors"])
+        pos, neg = torch.zeros(n, dtype=torch.bool), torch.zeros(n, dtype=torch.bool)
+        pos[torch.from_numpy(d[f"rpn_sample{i}_pos_index"]).long()] = True
+        neg[torch.from_numpy(d[f"rpn_sample{i}_neg_index"]).long()] = True
+        rpn_draws.append((pos, neg))
+    ev = model.rpn.loss_evaluator
+    s_rpn = ev.sampler if hasattr(ev, "sampler") else ev.fg_bg_sampler
+    rep = ReplaySampler(s_rpn.batch_size_per_image, s_rpn.positive_fraction, rpn_draws)
+    if hasattr(ev, "sampler"):
+        ev.sampler = rep
+    else:
+        ev.fg_bg_sampler = rep
+    _replay(model.roi_heads["box"].loss_evaluator, d, "roi_sample", (0, 1))
+    rpn_forward = model.rpn.forward
+
+    def forward(*a, **k):   # the RoI heads run on the FIXTURE's proposals (2007 per image: 2000 + the 7 ground-truth boxes)
+        props, losses = rpn_forward(*a, **k)
+        for i, p in enumerate(props):
+            assert boxes_match(p.bbox, torch.from_numpy(d[f"proposals_train{i}_bbox"]), 0.95)
+        return [BoxList(torch.from_numpy(d[f"proposals_train{i}_bbox"]).to(device), size) for i in range(2)], losses
+
+    model.rpn.forward = forward
+    losses = model(images, targets)
+    sum(losses.values()).backward()
+    with torch.no_grad():
+        feat = model.backbone(images)[0].float()
+    idx = torch.from_numpy(np.sort(np.random.default_rng([__import__("zlib").crc32(b"full_features"), 0]).choice(feat.numel(), 4096, replace=False)))
+    got = feat.contiguous().reshape(-1)[idx.to(device)].cpu()
+    want = torch.from_numpy(d["feature_samples"])
+    assert float((got - want).abs().max()) <= 2e-4 * float(d["feature_stats"][2])
+    assert set(losses) == set(TEACHER)
+    for k in TEACHER:
+        assert _rel(losses[k], d[k]) <= 1e-3, (k, float(losses[k]), float(d[k]))
+    print(check_grads(model, d, "grad", 5e-3))   # worst seen: 1.2e-3 (layer2); the product-vs-own-CPU test allows 2e-2
