@@ -562,6 +562,66 @@ def gen_teacher():
     np.savez_compressed(os.path.join(HERE, "step_teacher.npz"), **out)
 
 
+TEACHER_VARIANTS = {  # head configurations of the reference's GeneralizedRCNN other than the shipped one
+    # a plain Mask R-CNN: linear classifier, per-class box regression, one mask per class
+    # (roi_box_predictors.py:33-40,70-72; box_head/loss.py:156-160; mask_head/loss.py:131-141)
+    "plain_mask_rcnn": ["MODEL.ROI_BOX_HEAD.EMBEDDING_BASED", False, "MODEL.CLS_AGNOSTIC_BBOX_REG", False,
+                        "MODEL.CLS_AGNOSTIC_MASK", False],
+    # the mask head pooling for itself instead of re-using the box head's res5 features (roi_heads.py:21-22,57-64)
+    "own_mask_extractor": ["MODEL.ROI_MASK_HEAD.SHARE_BOX_FEATURE_EXTRACTOR", False],
+    # trainable emb_pred (the shipped teacher freezes it, roi_box_predictors.py:52-56)
+    "train_emb_pred": ["MODEL.ROI_BOX_HEAD.FREEZE_EMB_PRED", False],
+}
+
+
+def gen_teacher_variants():
+    """The small two-image teacher step under the head configurations above -> tests/golden/step_teacher_variants.npz."""
+    import oracle
+    from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+    from maskrcnn_benchmark.modeling.detector.generalized_rcnn import GeneralizedRCNN
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.segmentation_mask import SegmentationMask
+
+    out = {}
+    for name, opts in TEACHER_VARIANTS.items():
+        cfg = ref_import.reference_cfg("zeroshot_mask.yaml", list(case.COMMON_OPTS) + opts)
+        model = GeneralizedRCNN(cfg)
+        names = load_seeded(model)
+        if cfg.MODEL.ROI_BOX_HEAD.EMBEDDING_BASED:
+            model.roi_heads["box"].predictor.set_class_embeddings(case.text_embeddings())
+        model.train()
+        cases = [case.image_case(i, ["-"] * 1203) for i in range(2)]
+        targets = [make_target(BoxList, SegmentationMask, c, False) for c in cases]
+        images = torch.stack([c["image"] for c in cases])
+        key = name + "_"
+        with Capture(BalancedPositiveNegativeSampler) as cap:
+            losses = model(images, targets)
+        sum(losses.values()).backward()
+        put_samples(out, key + "rpn_sample", cap, cfg.MODEL.RPN.BATCH_SIZE_PER_IMAGE)
+        put_samples(out, key + "roi_sample", cap, cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE)
+        with torch.no_grad():
+            from maskrcnn_benchmark.structures.image_list import to_image_list
+            il = to_image_list(images)
+            with Capture(BalancedPositiveNegativeSampler):
+                props, _ = model.rpn(il, model.backbone(il.tensors), targets)
+        put_boxes(out, key + "proposals_train", props)
+        for k, v in losses.items():
+            out[key + k] = np.float64(v.item())
+        gnames = []
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                dg = case.grad_digest(n, p.grad, n=case.VARIANT_DIGEST)
+                out[f"{key}grad:{n}:values"], out[f"{key}grad:{n}:norm_sum"] = dg["values"], np.array([dg["norm"], dg["sum"]])
+                gnames.append(n)
+        out[key + "grad_names"] = np.array(gnames)
+        out[key + "state_names"] = np.array([n for n, _, _ in names])
+        out[key + "state_shapes"] = np.array([",".join(map(str, s)) for _, s, _ in names])
+        out[key + "state_seeded_as"] = np.array([c_ for _, _, c_ in names])
+        out[key + "opts"] = np.array([str(o) for o in opts])
+        print("teacher variant", name, {k: round(v.item(), 6) for k, v in losses.items()}, len(gnames), "gradients")
+    np.savez_compressed(os.path.join(HERE, "step_teacher_variants.npz"), **out)
+
+
 def gen_teacher_fixed_rpn():
     """GeneralizedRCNN with MODEL.RPN.DONT_TRAIN True (generalized_rcnn.py:32-35,53-54): the RPN frozen and in eval mode
     inside the training step -- test-mode proposals, three losses -> tests/golden/step_teacher_fixed_rpn.npz."""
@@ -672,12 +732,13 @@ def main():
     gen_student()
     gen_student_variants()
     gen_teacher()
+    gen_teacher_variants()
     gen_teacher_fixed_rpn()
     gen_checkpoint_map()
     gen_student_full()
     gen_teacher_full()
     for f in ("step_student.npz", "step_student_variants.npz", "step_teacher.npz", "step_teacher_fixed_rpn.npz", "step_student_full.npz",
-              "step_teacher_full.npz"):
+              "step_teacher_full.npz", "step_teacher_variants.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 

@@ -834,3 +834,63 @@ def test_teacher_step_at_baseline_size_hip_vs_reference_fixture():
     for k in TEACHER:
         assert _rel(losses[k], d[k]) <= 1e-3, (k, float(losses[k]), float(d[k]))
     print(check_grads(model, d, "grad", 5e-3))   # worst seen: 1.2e-3 (layer2); the product-vs-own-CPU test allows 2e-2
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# head configurations other than the shipped one, against the reference's GeneralizedRCNN under the same switches: a plain
+# Mask R-CNN (linear classifier, per-class box regression, per-class masks), the mask head with its own feature extractor,
+# a trainable emb_pred
+# ------------------------------------------------------------------------------------------------------------------
+TEACHER_VARIANTS = ("plain_mask_rcnn", "own_mask_extractor", "train_emb_pred")
+
+
+def run_teacher_variant(device, name):
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.detector import build_detection_model
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.structures import BoxList
+
+    v = _fixture("step_teacher_variants.npz")
+    key = name + "_"
+    cfg = _cfg("zeroshot_mask.yaml", device, _typed([str(o) for o in v[key + "opts"]]))
+    model = build_detection_model(cfg)
+    sub = {"state_names": v[key + "state_names"], "state_shapes": v[key + "state_shapes"], "state_seeded_as": v[key + "state_seeded_as"]}
+    _load_seeded(model, sub)
+    model = model.to(device)
+    if cfg.MODEL.ROI_BOX_HEAD.EMBEDDING_BASED:
+        model.set_class_embeddings(case.text_embeddings().to(device))
+    model.train()
+    cs = [case.image_case(i, ["-"] * 1203) for i in range(2)]
+    images = torch.stack([c["image"] for c in cs]).to(device)
+    targets = [make_target(c, device, caption=False) for c in cs]
+    _replay(model.rpn.loss_evaluator, v, key + "rpn_sample", (0, 1))
+    _replay(model.roi_heads["box"].loss_evaluator, v, key + "roi_sample", (0, 1))
+    rpn_forward = model.rpn.forward
+
+    def forward(*a, **k):
+        props, losses = rpn_forward(*a, **k)
+        for i, p in enumerate(props):
+            assert boxes_match(p.bbox, torch.from_numpy(v[f"{key}proposals_train{i}_bbox"]), 1.0 if device == "cpu" else 0.95)
+        return [BoxList(torch.from_numpy(v[f"{key}proposals_train{i}_bbox"]).to(device), (case.IMAGE_W, case.IMAGE_H))
+                for i in range(2)], losses
+
+    model.rpn.forward = forward
+    with _ops(device):
+        losses = model(images, targets)
+        sum(losses.values()).backward()
+    assert set(losses) == set(TEACHER)
+    for k in TEACHER:
+        assert _rel(losses[k], v[key + k]) <= 1e-3, (name, k, float(losses[k]), float(v[key + k]))
+    have = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    names = [str(n) for n in v[key + "grad_names"]]
+    assert set(names) <= set(have), sorted(set(names) - set(have))
+    return check_digests(have, v, key + "grad", 5e-3, case.VARIANT_DIGEST)
+
+
+@pytest.mark.parametrize("name", TEACHER_VARIANTS)
+def test_teacher_head_configurations_cpu_vs_reference_fixture(name):
+    print(run_teacher_variant("cpu", name))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", TEACHER_VARIANTS)
+def test_teacher_head_configurations_hip_vs_reference_fixture(name):
+    print(run_teacher_variant("cuda", name))
