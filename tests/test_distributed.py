@@ -305,3 +305,67 @@ def test_bucketed_allreduce_on_rccl_one_rank(tmp_path):
     mp.spawn(_nccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
     got = torch.load(out)
     assert got["ok"] and got["buckets"] > 1 and abs(got["loss"] - 3.0) < 1e-6
+
+
+# ---- gradient accumulation + clipping across ranks (engine/trainer.py::StepPolicy, reference engine/trainer.py:117,135-141) ----
+class _Det(nn.Module):
+    """Stands in for a detector: ``model(images, targets)`` returns a loss dict."""
+
+    def __init__(self):
+        super().__init__()
+        self.net = Tiny()
+
+    def forward(self, images, targets):
+        y = self.net(images)
+        return {"loss_a": y.pow(2).mean(), "loss_b": (y - targets).abs().mean()}
+
+
+def _worker_accumulate(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm, trainer
+
+    torch.manual_seed(5)
+    model = _Det()
+    comm.broadcast_parameters(model)
+    start = {n: p.detach().clone() for n, p in model.named_parameters()}
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.1, momentum=0.9)
+    reducer = comm.BucketedGradReducer(model, bucket_bytes=256)
+    policy = trainer.StepPolicy(accumulation_steps=3, clip_grad_norm_at=0.05)
+    g = torch.Generator().manual_seed(11)
+    x, t = torch.randn(2, 3, 4, 8, generator=g), torch.randn(2, 3, 4, 4, generator=g)   # [rank][micro-step]
+    stepped = []
+    for k in range(3):
+        before = model.net.a.weight.detach().clone()
+        trainer.train_step(model, opt, reducer, x[rank, k], t[rank, k], None, policy)
+        stepped.append(not torch.equal(before, model.net.a.weight.detach()))
+    if rank == 0:
+        torch.save({"start": start, "end": {n: p.detach().clone() for n, p in model.named_parameters()}, "stepped": stepped,
+                    "x": x, "t": t}, out)
+    dist.destroy_process_group()
+
+
+def test_accumulated_and_clipped_gradients_across_two_ranks(tmp_path):
+    """Three micro-steps on each of two ranks, one optimizer step: the update equals single-process SGD on the MEAN over ranks of
+    the per-rank sums of (loss / 3) gradients, clipped to the total norm -- the buffers are all-reduced after every micro-step
+    (as DistributedDataParallel does without no_sync) and never zeroed in between."""
+    out = str(tmp_path / "acc.pt")
+    mp.spawn(_worker_accumulate, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["stepped"] == [False, False, True]
+    model = _Det()
+    model.load_state_dict({k: v for k, v in got["start"].items()}, strict=False)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.1, momentum=0.9)
+    total = 0.0
+    for r in range(2):
+        for k in range(3):
+            ld = model(got["x"][r, k], got["t"][r, k])
+            total = total + sum(ld.values()) / 3.0 / 2.0
+    total.backward()
+    torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 0.05)
+    opt.step()
+    for n, p in model.named_parameters():
+        assert torch.allclose(got["end"][n], p.detach(), atol=1e-7, rtol=1e-5), n
+    moved = [n for n, p in model.named_parameters() if p.requires_grad and not torch.equal(p.detach(), got["start"][n])]
+    assert len(moved) >= 4
