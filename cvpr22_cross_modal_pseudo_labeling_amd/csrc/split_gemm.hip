@@ -657,6 +657,7 @@ struct SplitGemmTnArgs {
   const char* X; long x_rs;   // [M] pair rows of ch values
   float* C;                   // [slices][N][T*ch]
   long M; int N; int ch; int T; int H; int W; int KH; int KW; int slices; int steps_per_slice;
+  int g_major;                // tile order inside a row slice: G column tile major (else X column tile major), see the launcher
 };
 
 // The transpose reads are inline asm: hipcc treats the ds_read_tr builtin as possibly aliasing the in-flight LDS-DMA
@@ -698,7 +699,8 @@ __global__ __launch_bounds__(256, 2) void split_gemm_tn_kernel(SplitGemmTnArgs p
   const int per_slice = tiles_i * tiles_j;
   const int slice = id / per_slice;
   const int rem = id - slice * per_slice;
-  const int tile_j = rem / tiles_i, tile_i = rem - tile_j * tiles_i;
+  const int tile_j = p.g_major ? rem % tiles_j : rem / tiles_i;
+  const int tile_i = p.g_major ? rem / tiles_j : rem - tile_j * tiles_i;
   const int i0 = tile_i * 128, j0 = tile_j * 128;
   const int tap = CONV ? j0 / p.ch : 0, c0 = CONV ? j0 - tap * p.ch : j0;
   // tap of this workgroup's column tile: X rows are read shifted by (tdy, tdx); a row whose shifted pixel lies outside
@@ -1298,6 +1300,12 @@ extern "C" int ovis_split_gemm_pair_tn(const void* g_pair, long g_row_bytes, con
   const long steps = (m + 31) / 32;
   p.steps_per_slice = (int)((steps + slices - 1) / slices);
   const int tiles_i = n / 128, tiles_j = (int)((long)T * channels / 128);
+  // An XCD owns a contiguous run of 64 tile ids of a slice: the operand whose column tile is the MAJOR index is read for
+  // one or two of its column tiles per run, the other one whole.  Major = the operand with more DISTINCT column tiles
+  // (the taps of a 3x3 re-read the same X tiles).  Same-box A/B (profiles/r5_tn_tile_order_ab.txt): the 3x3 weight
+  // gradient fetches 27 % less from beyond L2 (2008 -> 1465 MB per launch, time unchanged: it is not fetch-bound), the
+  // N = 2048 / K = 512 one runs 3 % faster G-major, the N = 512 / K = 2048 one 2 % slower (it keeps X-major).
+  p.g_major = tiles_i >= channels / 128 ? 1 : 0;
   const long nblocks = (long)tiles_i * tiles_j * slices;
   if (nblocks > 0x7fffffffL) return OVIS_ERANGE;
   hipStream_t s = (hipStream_t)stream;
