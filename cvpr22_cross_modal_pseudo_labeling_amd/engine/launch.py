@@ -66,6 +66,9 @@ def gpu_numa_nodes(sysfs_root="/sys"):
             with open(os.path.join(dev, "vendor")) as f:
                 if f.read().strip().lower() != "0x1002":
                     continue
+        except OSError:
+            continue  # not a PCI function: the compute-partition render nodes (amdgpu_xcp_*) an MI300 / MI355X also lists
+        try:
             with open(os.path.join(dev, "numa_node")) as f:
                 node = int(f.read().strip())
             addr = os.path.basename(os.path.realpath(dev))
@@ -75,6 +78,19 @@ def gpu_numa_nodes(sysfs_root="/sys"):
             return []
         found.append((addr, node))
     return [n for _, n in sorted(found)]
+
+
+def _smt_order(cpus, sysfs_root="/sys"):
+    """``cpus`` ordered so that the hardware threads of one core are adjacent (key: the lowest sibling id): contiguous shares
+    then own whole cores instead of sharing them with the rank that got the sibling ids (node0 = "0-63,128-191" on the MI355X
+    hosts: 128-191 are the second threads of 0-63)."""
+    def key(c):
+        try:
+            with open(os.path.join(sysfs_root, "devices", "system", "cpu", f"cpu{c}", "topology", "thread_siblings_list")) as f:
+                return (min(_parse_cpulist(f.read())), c)
+        except (OSError, ValueError):
+            return (c, c)
+    return sorted(cpus, key=key)
 
 
 def plan_affinity(nproc, allowed=None, sysfs_root="/sys", visible=None):
@@ -93,7 +109,7 @@ def plan_affinity(nproc, allowed=None, sysfs_root="/sys", visible=None):
         for node, ranks in by_node.items():
             try:
                 with open(os.path.join(sysfs_root, "devices", "system", "node", f"node{node}", "cpulist")) as f:
-                    cpus = sorted(_parse_cpulist(f.read()) & set(allowed))
+                    cpus = _smt_order(_parse_cpulist(f.read()) & set(allowed), sysfs_root)
             except (OSError, ValueError):
                 cpus = []
             if len(cpus) < len(ranks):
@@ -106,7 +122,8 @@ def plan_affinity(nproc, allowed=None, sysfs_root="/sys", visible=None):
         if len(allowed) < nproc:  # fewer cores than ranks: everyone shares everything
             return [set(allowed) for _ in range(nproc)]
         share = len(allowed) // nproc
-        plan = [set(allowed[r * share:(r + 1) * share]) for r in range(nproc)]
+        ordered = _smt_order(allowed, sysfs_root)
+        plan = [set(ordered[r * share:(r + 1) * share]) for r in range(nproc)]
     return plan
 
 

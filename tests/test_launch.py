@@ -125,6 +125,12 @@ def _fake_sysfs(root, gpu_nodes, node_cpus):
         drm = root / "class" / "drm" / f"renderD{128 + i}"
         drm.mkdir(parents=True)
         os.symlink(pci, drm / "device")
+        for x in range(2):   # the compute-partition render nodes of the same GPU: platform devices without a vendor file
+            xcp = root / "devices" / "platform" / f"amdgpu_xcp_{2 * i + x}"
+            xcp.mkdir(parents=True)
+            part = root / "class" / "drm" / f"renderD{160 + 2 * i + x}"
+            part.mkdir(parents=True)
+            os.symlink(xcp, part / "device")
     for node, cpus in node_cpus.items():
         d = root / "devices" / "system" / "node" / f"node{node}"
         d.mkdir(parents=True)
@@ -155,6 +161,22 @@ def test_affinity_plan_follows_the_gpus_numa_nodes(tmp_path):
     # a cpuset that leaves a socket too few cores falls back to the even split
     plan = launch.plan_affinity(8, allowed=list(range(0, 16)) + [16], sysfs_root=str(tmp_path))
     assert [len(p) for p in plan] == [2] * 8
+
+
+def test_affinity_shares_keep_the_threads_of_a_core_together(tmp_path):
+    """The MI355X hosts number a socket's second hardware threads 128 higher (node0 = 0-63,128-191): a rank's share must be
+    whole cores -- 0-15 with 128-143 -- not the first threads of one set of cores and the second threads of another rank's."""
+    _fake_sysfs(tmp_path, [0, 0, 0, 0, 1, 1, 1, 1], {0: "0-63,128-191", 1: "64-127,192-255"})
+    for c in range(256):
+        d = tmp_path / "devices" / "system" / "cpu" / f"cpu{c}" / "topology"
+        d.mkdir(parents=True)
+        (d / "thread_siblings_list").write_text(f"{c % 128},{c % 128 + 128}\n")
+    plan = launch.plan_affinity(8, allowed=range(256), sysfs_root=str(tmp_path))
+    assert plan[0] == set(range(0, 16)) | set(range(128, 144)) and plan[3] == set(range(48, 64)) | set(range(176, 192))
+    assert plan[4] == set(range(64, 80)) | set(range(192, 208))
+    assert launch.format_cpus(plan[0]) == "0-15,128-143"
+    for share in plan:   # whole cores only
+        assert {c % 128 for c in share if c < 128} == {c % 128 for c in share if c >= 128}
 
 
 def test_ranks_pin_themselves_before_anything_else(tmp_path):
