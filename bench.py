@@ -377,6 +377,22 @@ def _median_ms(fn, reps=5):
     return ts[len(ts) // 2]
 
 
+def reference_cpu_step_record():
+    """The reference's OWN student-teacher training step timed on CPU cores -- measured in the BUILD CONTAINER (the reference
+    does not travel to the GPU box) by tests/golden/time_reference_cpu_step.py and committed under profiles/: quoted here, never
+    re-measured, so that the extrapolated estimate next to it can be read against a real run."""
+    import re
+    path = os.path.join(ROOT, "profiles", "r5_reference_cpu_step_build_container.txt")
+    try:
+        text = open(path).read()
+        m = re.search(r"=\s*([0-9.]+) s per image = ([0-9.]+) images/s", text)
+        t = re.search(r"(\d+) CPU threads", text)
+        return {"value": float(m.group(2)), "unit": "images/sec", "seconds_per_image": float(m.group(1)), "cores": int(t.group(1)),
+                "kind": "reference", "where": "build container, not this box", "source": "profiles/" + os.path.basename(path)}
+    except (OSError, AttributeError, ValueError):
+        return None
+
+
 def cpu_baseline(workload):
     """The reference's own CPU kernels (oracle/_ref; the C port when it was not built) on the native-op work of the step,
     on the host cores: median of 5 per op on a bounded sample (RoIAlign is linear in the RoI count: 512 RoIs are timed and
@@ -482,6 +498,7 @@ def cpu_baseline(workload):
             "all_cores": {"value": 1e3 / native_ms * speedup, "unit": "images/sec", "cores": threads, "kind": "port",
                           "sample": f"{threads} threads, one image sample (RoIAlign R={sample_r} + NMS K={nms_counts[0]}) each through "
                                     f"the C port; measured speed-up x{speedup:.1f} applied to the single-thread figure"},
+            "reference_own_step": reference_cpu_step_record(),
             "full_step_estimate": {"value": 1e3 / full_ms, "unit": "images/sec", "cores": threads,
                                    "method": (f"native ops on all cores + torch-CPU res5 head on all cores: {res5_fwd_rois} RoIs forward of "
                                               f"which {res5_bwd_rois} also backward per image ({fwd_per_roi:.1f} / {fb_per_roi:.1f} ms per RoI); "
