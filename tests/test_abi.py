@@ -52,6 +52,20 @@ def test_shipped_library_is_a_product_build_without_experiment_switches():
     assert "-ffp-contract=off" in flags   # RoIAlign forward / NMS follow the reference's IEEE op sequence
     for name in ("roi_bwd_probes.patch", "split_gemm_knobs.patch"):   # the probes still exist -- as patches
         assert "#if" in open(os.path.join(ROOT, "tools", "experiments", "patches", name)).read()
+    # ... that still apply to the sources they were cut from (tools/experiments/build_variants.sh patches a scratch copy)
+    import shutil
+    import subprocess
+    import tempfile
+    targets = {"roi_bwd_probes.patch": "roi_align_bwd_plane.hip", "split_gemm_knobs.patch": "split_gemm.hip",
+               "tn_tile_order.patch": "split_gemm.hip", "nms_wide_stores.patch": "nms.hip"}
+    assert sorted(targets) == sorted(os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "tools", "experiments", "patches", "*.patch")))
+    if shutil.which("patch"):
+        for name, src in targets.items():
+            with tempfile.TemporaryDirectory() as tmp:
+                shutil.copy(os.path.join(csrc, src), os.path.join(tmp, src))
+                r = subprocess.run(["patch", "--dry-run", "-s", os.path.join(tmp, src), os.path.join(ROOT, "tools", "experiments", "patches", name)],
+                                   capture_output=True, text=True)
+                assert r.returncode == 0, (name, r.stdout[-300:])
 
 
 def test_every_declaration_cites_the_reference():
