@@ -1,5 +1,5 @@
 """Weight-gradient GEMM (split_gemm_tn_kernel) tile order inside a row slice: shipped = X column
-tile (tap, channel block) major / G column tile minor; variant `tn_order` (tools/experiments/patches/tn_tile_order.patch) = G
+tile (tap, channel block) major / G column tile minor; variants `tn_gmajor` / `tn_xmajor` (tools/experiments/patches/tn_tile_order.patch with -DOVIS_TN_FORCE_GMAJOR=1 / 0) = G
 column tile major, so that an XCD's contiguous run of 64 workgroups covers 1-2 of G's four column tiles instead of all four.
 
     python tools/experiments/tn_order_ab.py                  # same-box alternation of the two libraries, three rounds
@@ -46,7 +46,7 @@ if __name__ == "__main__":
     else:
         env = dict(os.environ, TN_AB_ITERS="50")
         for i in range(3):
-            for v in sys.argv[1:] or ("shipped", "tn_order"):
+            for v in sys.argv[1:] or ("shipped", "tn_gmajor"):
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "child", v], capture_output=True, text=True, env=env)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 print(i, f"{v:9s}", line[-1] if line else r.stderr[-500:], flush=True)
