@@ -214,8 +214,11 @@ def boxes_match(got, want, frac=1.0, atol=2e-2):
 # ------------------------------------------------------------------------------------------------------------------
 # student-teacher step
 # ------------------------------------------------------------------------------------------------------------------
+HOST_BACKEND = "oracle"   # "host": host tensors served by the in-package host code instead (see the last section)
+
+
 def _ops(device):
-    if device == "cpu":
+    if device == "cpu" and HOST_BACKEND == "oracle":
         from tests.oracle_backend import oracle_ops
         return oracle_ops()
     import contextlib
@@ -894,3 +897,42 @@ def test_teacher_head_configurations_cpu_vs_reference_fixture(name):
 @pytest.mark.parametrize("name", TEACHER_VARIANTS)
 def test_teacher_head_configurations_hip_vs_reference_fixture(name):
     print(run_teacher_variant("cuda", name))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[0] (MODEL.DEVICE cpu): the same fixtures with host tensors served by the PRODUCT's own host code
+# (_cpu.py + libovis_cpu.so) -- no oracle anywhere in the run
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def host_backend():
+    global HOST_BACKEND
+    HOST_BACKEND = "host"
+    try:
+        yield
+    finally:
+        HOST_BACKEND = "oracle"
+
+
+def test_cpu_only_configuration_vs_reference_fixtures(host_backend):
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+    import oracle
+
+    calls = []
+    real = oracle.lib
+    oracle.lib = lambda: calls.append(1) or real()      # any use of the oracle library in here would be recorded
+    try:
+        for img in (0, 1):
+            r = run_student_staged("cpu", img, tol_feat=1e-5, tol_grad=5e-3, prop_frac=1.0)
+            assert r["mask_pixels_off"] == 0
+        run_teacher("cpu", 1e-5, 5e-3, True)
+        assert run_eval("cpu", 0, 1.0) == (100, 100)
+        matched, total = run_eval("cpu", 1, 1.0, teacher=True)
+        assert matched == total
+        run_two_image_batch("cpu", 1e-3)
+        run_teacher_fixed_rpn("cpu", 5e-3)
+        run_variant("cpu", "accumulate2")
+        run_variant("cpu", "clip_grad")
+        run_teacher_variant("cpu", "plain_mask_rcnn")
+    finally:
+        oracle.lib = real
+    assert not calls and _C is not None
