@@ -290,7 +290,26 @@ def _nccl_worker(rank, world, port, out):
     torch.cuda.synchronize()
     ok = all(torch.allclose(p.grad, want[n] / 2, rtol=1e-6, atol=1e-8) for n, p in model.named_parameters() if n in want)
     red = comm.reduce_loss_dict({"l": torch.tensor(3.0, device="cuda")})
-    torch.save({"ok": bool(ok), "loss": float(red["l"]), "buckets": len(reducer.buckets)}, out)
+    # the RCCL-specific calls of bench.py / the reducer that no gloo run executes, on the one-rank communicator: the average
+    # INSIDE the collective (ReduceOp.AVG on the fp32 buckets), MAX of a float64 device scalar (the elapsed time), the gather
+    # of float64 device rows (ranks[*]), the object gather (where every rank pinned itself), the barrier
+    reducer2 = comm.BucketedGradReducer(model, bucket_bytes=256)
+    reducer2.world, reducer2._avg_in_collective = 2, True
+    reducer2.zero_grad()
+    model(x).pow(2).mean().backward()
+    reducer2.finish()
+    torch.cuda.synchronize()
+    avg_ok = all(torch.allclose(p.grad, want[n], rtol=1e-6, atol=1e-8) for n, p in model.named_parameters() if n in want)
+    t = torch.tensor([1.25], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    mine = torch.tensor([0.5, 2.0, 3.0], device="cuda", dtype=torch.float64)
+    rows = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(rows, mine)
+    placed = [None] * world
+    dist.all_gather_object(placed, {"cpus": "0-15,128-143", "source": "numa"})
+    dist.barrier()
+    calls_ok = float(t) == 1.25 and torch.equal(rows[0], mine) and placed[0]["source"] == "numa"
+    torch.save({"ok": bool(ok and avg_ok and calls_ok), "loss": float(red["l"]), "buckets": len(reducer.buckets)}, out)
     dist.destroy_process_group()
 
 
