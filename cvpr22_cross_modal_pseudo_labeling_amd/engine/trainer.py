@@ -259,9 +259,11 @@ def do_train(cfg, model, data_iter, optimizer, scheduler, max_iter, start_iter=0
                 vals = {k: float(v) for k, v in reduced.items()}
                 now = time.time()
                 history.append((iteration + 1, vals))
-                logger.info("iter %d  loss %.4f  %s  lr %.6f  %.3f s/it", iteration + 1, sum(vals.values()),
+                # (engine/trainer.py:156-170 of the reference: iteration, meters, lr, max mem in MB)
+                mem = torch.cuda.max_memory_allocated() / 1024.0 / 1024.0 if torch.cuda.is_available() else 0.0
+                logger.info("iter %d  loss %.4f  %s  lr %.6f  %.3f s/it  max mem: %.0f", iteration + 1, sum(vals.values()),
                             "  ".join(f"{k} {v:.4f}" for k, v in vals.items()), optimizer.param_groups[0]["lr"],
-                            (now - last) / log_period)
+                            (now - last) / log_period, mem)
                 last = now
         if checkpointer is not None and checkpoint_period and (iteration + 1) % checkpoint_period == 0:
             pipe.drain()  # the look-ahead half holds no state, but the weights must be quiescent while they are read
