@@ -719,6 +719,10 @@ def main():
                              "of the multi-rank control flow on the CPU-only configuration, not a fallback)")
         index = local_rank % torch.cuda.device_count() if args.share_gpu else local_rank
         torch.cuda.set_device(index)
+        if "OMP_NUM_THREADS" not in os.environ:
+            # the GPU path does almost no CPU math, but a machine-wide OpenMP team spinning behind every small host op starves
+            # the staging thread / loader workers (tools/train_net.py); the CPU-baseline leg sets its own thread counts
+            torch.set_num_threads(max(1, min(8, len(os.sched_getaffinity(0)) // 4)))
         dev = torch.device("cuda", index)
     else:
         dev = torch.device("cpu")

@@ -102,6 +102,12 @@ def main():
     cfg.freeze()
     if cfg.MODEL.DEVICE == "cuda":
         torch.cuda.set_device(args.local_rank)
+        # The training process does almost no CPU math, but every multi-threaded host op (a staging memcpy, a reduction over a
+        # host tensor) wakes an OpenMP team as wide as the machine whose threads then SPIN for their blocktime -- on a
+        # 256-thread host that starved the data-loader workers: next(loader) 31 instead of 6 ms per 2-image batch, 58 instead
+        # of 33 ms per iteration (tools/experiments/loader_consume_probe.py).  A small team for the rank's core share.
+        if "OMP_NUM_THREADS" not in os.environ:
+            torch.set_num_threads(max(1, min(8, len(os.sched_getaffinity(0)) // 4)))
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl" if cfg.MODEL.DEVICE == "cuda" else "gloo", init_method="env://")
