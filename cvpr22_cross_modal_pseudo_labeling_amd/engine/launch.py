@@ -28,7 +28,9 @@ def rank_env(rank, nproc, master_port, base=None, master_addr="127.0.0.1"):
     env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(nproc), "LOCAL_WORLD_SIZE": str(nproc),
                 "MASTER_ADDR": master_addr, "MASTER_PORT": str(master_port)})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver: RCCL needs it
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(nproc, 1))))
+    # a SMALL OpenMP team per rank: the GPU path does almost no CPU math, and a team as wide as the rank's core share spins
+    # after every host op and starves the rank's own staging / loader threads (profiles/r5_cli_input_path.txt)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or 1) // max(nproc, 1) // 4))))
     return env
 
 
