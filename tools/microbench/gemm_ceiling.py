@@ -85,6 +85,23 @@ def main():
         lines.append(f"{tag} | {m} x {n} x {k} | {1e3 * ms_lib:.1f} us, {lib:.0f} | {1e3 * ms_split:.1f} us, {split:.0f} | "
                      f"{split / lib:.2f} | {split / 2500:.3f} | {lib / 2500:.3f}")
         del a, b, out, af, bf, ap_, bp_
+    # weight gradients: dW[N, K] = G[M, N]^T X[M, K], contraction over the M rows (split_gemm_tn_kernel)
+    lines.append("")
+    lines.append("weight gradients (contraction over M rows) | M x N x K | hipBLASLt bf16 (G^T X): us, TFLOP/s | split TN: us, TFLOP/s issued | split / library")
+    for tag, m, n, k, conv in [("res5 3x3 dW", 100352, 512, 4608, (7, 7, 3, 3)), ("res5 conv3 dW", 100352, 2048, 512, None),
+                               ("res5 conv1 dW", 100352, 512, 2048, None), ("res5 conv3 + shortcut dW", 100352, 2048, 1024, None)]:
+        gm = torch.randn(m, n, device=dev, generator=g).bfloat16()
+        xm = torch.randn(m, k, device=dev, generator=g).bfloat16()
+        out = torch.empty(n, k, device=dev, dtype=torch.bfloat16)
+        gt = gm.t()
+        ms_lib = timeit(lambda: torch.matmul(gt, xm, out=out), args.iters)
+        lib = 2.0 * m * n * k / ms_lib / 1e9
+        gp = _C.split_pair(torch.randn(m, n, device=dev, generator=g))
+        xp = _C.split_pair(torch.randn(m, k // 9 if conv else k, device=dev, generator=g))
+        ms_split = timeit((lambda: _C.split_gemm_pair_tn(gp, xp, conv)) if conv else (lambda: _C.split_gemm_pair_tn(gp, xp)), args.iters)
+        split = 6.0 * m * n * k / ms_split / 1e9
+        lines.append(f"{tag} | {m} x {n} x {k} | {1e3 * ms_lib:.1f} us, {lib:.0f} | {1e3 * ms_split:.1f} us, {split:.0f} | {split / lib:.2f}")
+        del gm, xm, out, gp, xp
     text = "\n".join(lines)
     print(text)
     if args.out:
