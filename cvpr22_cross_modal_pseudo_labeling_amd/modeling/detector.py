@@ -66,7 +66,7 @@ class GeneralizedRCNN(nn.Module):
         images = to_image_list(images)
         features = self.backbone(images.tensors) if prefix is None else self.backbone.body(images.tensors, prefix=prefix)
         proposals, proposal_losses = self.rpn(images, features, targets)
-        _, result, detector_losses = self.roi_heads(features, proposals, targets)
+        _, result, detector_losses = self.roi_heads(features, proposals, targets, is_eval_func=True)
         if self.training:
             losses = {}
             losses.update(detector_losses)
@@ -227,7 +227,7 @@ class STGeneralizedRCNN(nn.Module):
             self.rpn.eval()
             proposals, _ = self.rpn(images, features, None)
             student["box"].predictor.set_class_embeddings(self.combine_embs(self.roi_heads["box"].predictor.cls_score))
-            _, result, _ = student(features, proposals, targets)
+            _, result, _ = student(features, proposals, targets, is_eval_func=True)
             return result
 
         frozen = self.forward_frozen(images, targets, features=features)

@@ -309,10 +309,26 @@ class PostProcessor(nn.Module):
         self.box_coder = BoxCoder(weights=rh.BBOX_REG_WEIGHTS)
         self.cls_agnostic_bbox_reg = cfg.MODEL.CLS_AGNOSTIC_BBOX_REG
         self.is_teacher = is_teacher
+        # MODEL.GT_BOX_EVAL (inference.py:177-181): ground-truth boxes are the proposals of the evaluation pass, every one
+        # is kept (no score cut below 1, no suppression) and scored on its own class only
+        self.gt_box_eval = cfg.MODEL.GT_BOX_EVAL
+        if self.gt_box_eval:
+            self.score_thresh = self.nms = 1.0
 
     def forward(self, x, boxes):
         class_logits, box_regression = x
         class_prob = F.softmax(class_logits, -1)
+        if self.gt_box_eval and not self.is_teacher:  # inference.py:82-89: prob of the box's own class + 1.1, zero elsewhere
+            own = torch.zeros_like(class_prob)
+            rows = [i for i, b in enumerate(boxes) if b.has_field("labels")]
+            if rows:
+                offsets = [0]
+                for b in boxes:
+                    offsets.append(offsets[-1] + len(b))
+                r = _cat([torch.arange(offsets[i], offsets[i + 1], device=class_prob.device) for i in rows], 0)
+                c = _cat([boxes[i].get_field("labels").long() for i in rows], 0)
+                own[r, c] = class_prob[r, c] + 1.1
+            class_prob = own
         per_img = [len(b) for b in boxes]
         concat = _cat([b.bbox for b in boxes], 0)
         if self.cls_agnostic_bbox_reg:
@@ -839,9 +855,23 @@ class CombinedROIHeads(nn.ModuleDict):
                 off += k
         return out
 
-    def forward(self, features, proposals, targets=None, bbox_only=False, compute_uncertain=False, eps=None):
+    def forward(self, features, proposals, targets=None, bbox_only=False, compute_uncertain=False, eps=None,
+                is_eval_func=False):
         losses, package_x = {}, {}
+        # MODEL.GT_BOX_EVAL (roi_heads.py:31-49): the evaluation pass of a detector -- not the teacher's passes inside
+        # generate_pseudo_label, which leave ``is_eval_func`` False -- classifies and segments the ground-truth boxes
+        gt_boxes = self.cfg.MODEL.GT_BOX_EVAL and is_eval_func and not self.training
+        if gt_boxes:
+            device = features[0].device if isinstance(features, (list, tuple)) else features.device
+            proposals = []
+            for t in targets:
+                det = t.copy_with_fields(["labels"])
+                det.add_field("objectness", t.get_field("labels") * 0.0 + 1.0)
+                proposals.append(det.to(device))
         x, detections, loss_box = self.box(features, proposals, targets)
+        if gt_boxes:
+            for det, tar in zip(detections, targets):
+                assert len(det) == len(tar), "GT_BOX_EVAL keeps one detection per ground-truth box"
         package_x["bbox"] = x
         losses.update(loss_box)
         if self.mask_on and not bbox_only:

@@ -79,6 +79,8 @@ def make_bert_class(RefBERT):
             return {k: v for k, v in enc.items()}
 
     class LocalBERT(RefBERT):
+        _seeded_stand_in = True
+
         def __init__(self, cfg):
             torch.nn.Module.__init__(self)
             self.tokenizer, self.mlm = Tok302(), False
@@ -724,21 +726,69 @@ def gen_checkpoint_map():
         json.dump(out, f, indent=0, sort_keys=True)
 
 
+def gen_gt_box_eval():
+    """MODEL.GT_BOX_EVAL True (roi_heads.py:25-49, box_head/inference.py:82-89,177-181): the evaluation branch of both
+    detectors with the ground-truth boxes as the proposals of the heads -- one detection per ground-truth box, scored
+    ``prob[own class] + 1.1``, class-major order, masks of the own class."""
+    from maskrcnn_benchmark.modeling.language_backbone import transformers as ref_lb
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.segmentation_mask import SegmentationMask
+
+    ref_import._namespace_pkg("maskrcnn_benchmark.modeling.detector",
+                              os.path.join(ref_import.REF, "maskrcnn_benchmark/modeling/detector"))
+    if not getattr(ref_lb.BERT, "_seeded_stand_in", False):
+        ref_lb.BERT = make_bert_class(ref_lb.BERT)
+    from maskrcnn_benchmark.modeling.detector.generalized_rcnn import GeneralizedRCNN
+    from maskrcnn_benchmark.modeling.detector import st_generalized_rcnn as st_mod
+
+    opts = list(case.COMMON_OPTS) + ["MODEL.GT_BOX_EVAL", True]
+    out = {}
+    cfg = ref_import.reference_cfg("student_teacher_mask_rcnn_uncertainty.yaml", opts)
+    model = st_mod.STGeneralizedRCNN(cfg)
+    load_seeded(model)
+    model.class_names = list(case.SEEN_NAMES)
+    model.roi_heads["box"].predictor.set_class_embeddings(case.text_embeddings())
+    model.eval()
+    cases = [case.image_case(i, model.cap_vocab, n_gt=4) for i in range(2)]
+    targets = [make_target(BoxList, SegmentationMask, c, True) for c in cases]
+    with torch.no_grad():
+        dets = model(torch.stack([c["image"] for c in cases]), targets)
+    for i, det in enumerate(dets):
+        assert len(det) == len(targets[i])
+        out[f"student{i}_bbox"] = det.bbox.numpy()
+        for f in ("scores", "labels", "mask"):
+            out[f"student{i}_{f}"] = det.get_field(f).numpy()
+    cfg = ref_import.reference_cfg("zeroshot_mask.yaml", opts)
+    model = GeneralizedRCNN(cfg)
+    load_seeded(model)
+    model.roi_heads["box"].predictor.set_class_embeddings(case.text_embeddings())
+    model.eval()
+    cases = [case.image_case(i, ["-"] * 1203, n_gt=4) for i in range(2)]
+    targets = [make_target(BoxList, SegmentationMask, c, False) for c in cases]
+    with torch.no_grad():
+        dets = model(torch.stack([c["image"] for c in cases]), targets)
+    for i, det in enumerate(dets):
+        assert len(det) == len(targets[i])
+        out[f"teacher{i}_bbox"] = det.bbox.numpy()
+        for f in ("scores", "labels", "mask"):
+            out[f"teacher{i}_{f}"] = det.get_field(f).numpy()
+        print("gt_box_eval teacher", i, det.get_field("labels").tolist(), det.get_field("scores").tolist())
+    np.savez_compressed(os.path.join(HERE, "step_gt_box_eval.npz"), **out)
+
+
 def main():
     torch.set_num_threads(1)
     torch.manual_seed(20260101)
     ref_import.install()
     torch.Tensor.cuda = lambda self, *a, **k: self  # box_head/loss.py:42,173, language_backbone/transformers.py:60
-    gen_student()
-    gen_student_variants()
-    gen_teacher()
-    gen_teacher_variants()
-    gen_teacher_fixed_rpn()
-    gen_checkpoint_map()
-    gen_student_full()
-    gen_teacher_full()
+    gens = [gen_student, gen_student_variants, gen_teacher, gen_teacher_variants, gen_teacher_fixed_rpn, gen_checkpoint_map,
+            gen_student_full, gen_teacher_full, gen_gt_box_eval]
+    only = sys.argv[1:]  # e.g. ``make_step_golden.py gen_gt_box_eval``: that file alone (each generator builds its own models)
+    for g in gens:
+        if not only or g.__name__ in only:
+            g()
     for f in ("step_student.npz", "step_student_variants.npz", "step_teacher.npz", "step_teacher_fixed_rpn.npz", "step_student_full.npz",
-              "step_teacher_full.npz", "step_teacher_variants.npz"):
+              "step_teacher_full.npz", "step_teacher_variants.npz", "step_gt_box_eval.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 

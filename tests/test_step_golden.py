@@ -74,11 +74,11 @@ def build_student(device, extra=()):
     return model, d, cfg
 
 
-def build_teacher(device, fixed_rpn=False):
+def build_teacher(device, fixed_rpn=False, extra=()):
     from cvpr22_cross_modal_pseudo_labeling_amd.modeling.detector import build_detection_model
 
     d = _fixture("step_teacher_fixed_rpn.npz" if fixed_rpn else "step_teacher.npz")
-    cfg = _cfg("zeroshot_mask.yaml", device, ["MODEL.RPN.DONT_TRAIN", True] if fixed_rpn else [])
+    cfg = _cfg("zeroshot_mask.yaml", device, (["MODEL.RPN.DONT_TRAIN", True] if fixed_rpn else []) + list(extra))
     model = build_detection_model(cfg)
     _load_seeded(model, d)
     model = model.to(device)
@@ -400,6 +400,41 @@ def test_teacher_eval_detections_cpu_vs_reference_fixture(img):
 @pytest.mark.parametrize("img", [0, 1])
 def test_teacher_eval_detections_hip_vs_reference_fixture(img):
     print(run_eval("cuda", img, 0.95, teacher=True))
+
+
+def run_gt_box_eval(device, teacher):
+    """MODEL.GT_BOX_EVAL True (roi_heads.py:25-49, box_head/inference.py:82-89,177-181): the evaluation pass classifies and
+    segments the ground-truth boxes -- one detection per box, in the reference's order, scored prob[own class] + 1.1."""
+    g = _fixture("step_gt_box_eval.npz")
+    extra = ["MODEL.GT_BOX_EVAL", True]
+    if teacher:
+        model, d, cfg = build_teacher(device, extra=extra)
+        cs = [case.image_case(i, ["-"] * 1203, n_gt=4) for i in range(2)]
+    else:
+        model, d, cfg = build_student(device, extra)
+        cs = [case.image_case(i, [str(n) for n in d["cap_vocab"]], n_gt=4) for i in range(2)]
+    targets = [make_target(c, device, caption=not teacher) for c in cs]
+    model.eval()
+    with _ops(device), torch.no_grad():
+        dets = model(torch.stack([c["image"] for c in cs]).to(device), targets)
+    for i, det in enumerate(dets):
+        key = f"{'teacher' if teacher else 'student'}{i}_"
+        assert len(det) == len(targets[i]) == len(g[key + "labels"])
+        assert det.get_field("labels").cpu().tolist() == g[key + "labels"].tolist()   # class-major, same order
+        assert float(det.get_field("scores").min()) > 1.1 - 1e-6
+        matched, total = compare_detections(det, g, key, 1.0)
+        assert matched == total
+
+
+@pytest.mark.parametrize("teacher", [False, True])
+def test_ground_truth_box_evaluation_cpu_vs_reference_fixture(teacher):
+    run_gt_box_eval("cpu", teacher)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("teacher", [False, True])
+def test_ground_truth_box_evaluation_hip_vs_reference_fixture(teacher):
+    run_gt_box_eval("cuda", teacher)
 
 
 # ------------------------------------------------------------------------------------------------------------------
