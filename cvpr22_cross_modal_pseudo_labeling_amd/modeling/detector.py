@@ -334,5 +334,29 @@ class STGeneralizedRCNN(nn.Module):
 _META_ARCHITECTURES = {"GeneralizedRCNN": GeneralizedRCNN, "STGeneralizedRCNN": STGeneralizedRCNN}
 
 
+# Keys config.py carries so that the reference's yaml files merge, whose non-default values select reference subsystems
+# outside the training step this package replaces (SURVEY §2 "out of scope"): refuse them instead of building the default
+# silently.  (R-50-C4 / FPN switches are refused where the body and the RPN are built.)
+_ONLY_VALUE = {
+    "MODEL.RPN_ONLY": False, "MODEL.RETINANET_ON": False, "MODEL.KEYPOINT_ON": False,
+    "MODEL.RPN.RPN_HEAD": "SingleConvRPNHead",
+    "MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR": "ResNet50Conv5ROIFeatureExtractor",
+    "MODEL.ROI_MASK_HEAD.FEATURE_EXTRACTOR": "ResNet50Conv5ROIFeatureExtractor",
+    "MODEL.ROI_BOX_HEAD.PREDICTOR": "FastRCNNPredictor", "MODEL.ROI_MASK_HEAD.PREDICTOR": "MaskRCNNC4Predictor",
+    "MODEL.RESNETS.TRANS_FUNC": "BottleneckWithFixedBatchNorm", "MODEL.RESNETS.STEM_FUNC": "StemWithFixedBatchNorm",
+    "DTYPE": "float32",
+}
+
+
+def check_supported(cfg):
+    for key, only in _ONLY_VALUE.items():
+        node = cfg
+        for part in key.split("."):
+            node = getattr(node, part)
+        if node != only:
+            raise NotImplementedError(f"{key} = {node!r}: only {only!r} is built (the hot path of the shipped configurations)")
+
+
 def build_detection_model(cfg):
+    check_supported(cfg)
     return _META_ARCHITECTURES[cfg.MODEL.META_ARCHITECTURE](cfg)

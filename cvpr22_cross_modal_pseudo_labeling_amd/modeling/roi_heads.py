@@ -722,6 +722,12 @@ class ROIMaskHead(nn.Module):
         self.predictor = MaskRCNNC4Predictor(cfg, self.feature_extractor.out_channels)
         self.loss_evaluator = MaskRCNNLossComputation(cfg)
         self.cls_agnostic_mask = cfg.MODEL.CLS_AGNOSTIC_MASK
+        # MODEL.ROI_MASK_HEAD.POSTPROCESS_MASKS (mask_head/inference.py:207-213): the evaluation pass hands out the masks
+        # pasted into the image at POSTPROCESS_MASKS_THRESHOLD instead of the 14 x 14 probabilities
+        mh = cfg.MODEL.ROI_MASK_HEAD
+        self.masker = Masker(threshold=mh.POSTPROCESS_MASKS_THRESHOLD, padding=1) if mh.POSTPROCESS_MASKS else None
+        if self.masker is not None and self.masker.threshold < 0:
+            raise NotImplementedError("POSTPROCESS_MASKS_THRESHOLD < 0 (the reference's un-thresholded debugging paste)")
         self.log = "N/A"
         self.avg_uncertain = "N/A"
 
@@ -763,7 +769,7 @@ class ROIMaskHead(nn.Module):
             results = []
             for p, b in zip(prob.split([len(b) for b in proposals], 0), proposals):
                 out = b.copy_with_fields(b.fields())
-                out.add_field("mask", p)
+                out.add_field("mask", p if self.masker is None else self.masker(p, b))
                 results.append(out)
             return x, results, {}
         loss_mask = self.loss_evaluator(proposals, mask_logits, targets)

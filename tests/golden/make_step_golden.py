@@ -773,6 +773,22 @@ def gen_gt_box_eval():
         for f in ("scores", "labels", "mask"):
             out[f"teacher{i}_{f}"] = det.get_field(f).numpy()
         print("gt_box_eval teacher", i, det.get_field("labels").tolist(), det.get_field("scores").tolist())
+    # the same pass with MODEL.ROI_MASK_HEAD.POSTPROCESS_MASKS (mask_head/inference.py:56-57,207-213): masks pasted into the
+    # image at the threshold instead of the 14 x 14 probabilities
+    cfg = ref_import.reference_cfg("zeroshot_mask.yaml", opts + ["MODEL.ROI_MASK_HEAD.POSTPROCESS_MASKS", True,
+                                                                 "MODEL.ROI_MASK_HEAD.POSTPROCESS_MASKS_THRESHOLD", 0.45])
+    model = GeneralizedRCNN(cfg)
+    load_seeded(model)
+    model.roi_heads["box"].predictor.set_class_embeddings(case.text_embeddings())
+    model.eval()
+    with torch.no_grad():
+        dets = model(torch.stack([c["image"] for c in cases]), targets)
+    for i, det in enumerate(dets):
+        m = det.get_field("mask")
+        assert m.dtype == torch.bool and m.shape == (len(targets[i]), 1, case.IMAGE_H, case.IMAGE_W)
+        out[f"pasted{i}_mask_packed"] = np.packbits(m.numpy(), axis=-1)
+        out[f"pasted{i}_bbox"] = det.bbox.numpy()
+        print("pasted masks", i, m.flatten(1).sum(1).tolist())
     np.savez_compressed(os.path.join(HERE, "step_gt_box_eval.npz"), **out)
 
 
