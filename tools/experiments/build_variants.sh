@@ -8,6 +8,7 @@
 #     <file> = split_gemm | roi_align_bwd_plane | nms  ->  tools/experiments/variants/libovis_hip_<name>.so
 #     <patch file> (under tools/experiments/patches) replaces the file's default patch, e.g. split_gemm:tn_gmajor:"-DOVIS_TN_FORCE_GMAJOR=1":tn_tile_order.patch
 #   e.g.  split_gemm:gw16:"-DOVIS_SG_GW=16"  split_gemm:nbuf4:"-DOVIS_EPI_NBUF=4"  split_gemm:tn_noshift:"-DOVIS_TN_ABL_NOSHIFT"
+#         roi_align_bwd_plane:regplane:"":roi_bwd_register_plane.patch   (round 5: plane strips in the matrix core's accumulators)
 #         roi_align_bwd_plane:probe_time:"-DOVIS_ROI_PROBE_TIME"  roi_align_bwd_plane:kri6:"-DOVIS_ROI_KRI=6 -DOVIS_ROI_KRING=2"
 # tools/experiments/ab_bench.py lib:<name> loads such a library for a same-box A/B.
 set -euo pipefail
