@@ -516,7 +516,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=None,
                     help="ranks of the job (default: WORLD_SIZE under a launcher, else 1); N > 1 without a launcher environment "
                          "makes this process the launcher of its N ranks")
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=60,
+                    help="timed steps (default 60 = 2 s of student steps: a region long enough that the box-to-box spread, not its own noise, bounds the line)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="student", choices=["student", "teacher"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
