@@ -60,8 +60,9 @@ class BucketedGradReducer:
     st_generalized_rcnn.py:50): their hooks never fire, so they are left out of the per-bucket hook count (their slots
     of the flat buffer stay zero) -- otherwise their bucket, and every bucket behind it, would only be reduced in
     ``finish()``, after the backward.  Parameters whose ``requires_grad`` is turned off during the run (the student's
-    ``uncertain_pred`` at MODEL.UNCERTAINTY_TRAIN_ITER) are dropped from the count by the next ``zero_grad()`` and get
-    ``grad = None`` (no weight decay / momentum update on a frozen parameter)."""
+    ``uncertain_pred`` at MODEL.UNCERTAINTY_TRAIN_ITER) are dropped from the count by the next ``zero_grad()`` and keep a
+    ZERO gradient: the optimizer still applies weight decay and momentum to them, as the reference's loop does under its
+    pinned torch 1.7.1, whose ``zero_grad()`` zeroes gradients in place (pinned by tests/golden/step_student_freeze.npz)."""
 
     def __init__(self, model, bucket_bytes=32 << 20, never_used=None):
         self.world = get_world_size()
@@ -150,9 +151,11 @@ class BucketedGradReducer:
             self.launched[bi] = False
             off, base, esz = 0, flat.data_ptr(), flat.element_size()
             for p in bucket:  # pointer comparison only: no tensor op per parameter on the per-step path
-                if not p.requires_grad:
-                    p.grad = None  # frozen during the run: its slot stays zero on every rank, the optimizer skips it
-                elif p.grad is None or p.grad.data_ptr() != base + off * esz:
+                # (a parameter frozen during the run keeps its view: the slot stays zero on every rank, and the optimizer goes
+                # on applying weight decay and momentum to it -- what the reference's pinned torch 1.7.1 / apex
+                # ``zero_grad()``, which zeroes in place, does to ``uncertain_pred`` after MODEL.UNCERTAINTY_TRAIN_ITER;
+                # tests/golden/step_student_freeze.npz)
+                if p.grad is None or p.grad.data_ptr() != base + off * esz:
                     p.grad = flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
 

@@ -48,7 +48,7 @@ class GroupFusedSGD(torch.optim.SGD):
         params, grads, wds, lrs, moms = [], [], [], [], []
         for g in groups:
             for p in g["params"]:
-                if p.grad is None or not p.requires_grad:  # frozen during the run: no decay / momentum update either
+                if p.grad is None:  # (torch.optim.SGD's rule; a parameter frozen during the run keeps a zero gradient -- comm.py)
                     continue
                 if p.grad.is_sparse:
                     return super().step(closure)
@@ -131,7 +131,7 @@ class GroupFusedSGD(torch.optim.SGD):
         every = []
         for g in self.param_groups:
             for p in g["params"]:
-                live = p.grad is not None and p.requires_grad
+                live = p.grad is not None
                 b = used.get(id(p)) if live else None
                 every.append((p, p.data_ptr() if live else 0, p.grad.data_ptr() if live else 0, b, 0 if b is None else b.data_ptr()))
         cache["fast"] = (len(self.param_groups), every, launches)
@@ -150,7 +150,7 @@ class GroupFusedSGD(torch.optim.SGD):
         state = self.state
         for p, pptr, gptr, buf, bptr in every:
             g = p.grad
-            if g is None or not p.requires_grad:
+            if g is None:
                 if gptr != 0:
                     return False
                 continue

@@ -401,7 +401,7 @@ VARIANTS = {  # configuration switches of STGeneralizedRCNN.forward's loss compo
 }
 
 
-def reference_iteration(cfg, model, optimizer, scheduler, run_forward, iteration):
+def reference_iteration(cfg, model, optimizer, scheduler, run_forward, iteration, zero_grad=None):
     """One pass of the reference's loop body, engine/trainer.py:110-141 (amp at O0 is the identity)."""
     loss_dict = run_forward()
     losses = sum(loss for loss in loss_dict.values())
@@ -412,7 +412,7 @@ def reference_iteration(cfg, model, optimizer, scheduler, run_forward, iteration
             torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.SOLVER.CLIP_GRAD_NORM_AT)
         optimizer.step()
         scheduler.step()
-        optimizer.zero_grad()
+        (zero_grad or optimizer.zero_grad)()
     return loss_dict
 
 
@@ -726,6 +726,73 @@ def gen_checkpoint_map():
         json.dump(out, f, indent=0, sort_keys=True)
 
 
+def gen_uncertainty_freeze():
+    """MODEL.UNCERTAINTY_TRAIN_ITER (st_generalized_rcnn.py:77,197-199,402-406, defaults.py:45): the sigma branch stops training
+    when the model's own counter reaches it -- the counter is bumped twice by the first forward, so 3 means "inside the second
+    forward", whose backward still reaches the branch (its graph was built before the switch).  Four iterations of the reference
+    loop.  The reference's pinned torch 1.7.1 (and apex) zero gradients in place: ``optimizer.zero_grad()`` leaves the frozen
+    branch a ZERO gradient, so weight decay and momentum keep moving it; this container's torch would set the gradient to None
+    and skip it -- the loop below asks for the pinned behaviour explicitly (``set_to_none=False``)."""
+    from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+    from maskrcnn_benchmark.modeling.language_backbone import transformers as ref_lb
+    from maskrcnn_benchmark.solver import make_lr_scheduler, make_optimizer
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.segmentation_mask import SegmentationMask
+
+    ref_import._namespace_pkg("maskrcnn_benchmark.modeling.detector",
+                              os.path.join(ref_import.REF, "maskrcnn_benchmark/modeling/detector"))
+    if not getattr(ref_lb.BERT, "_seeded_stand_in", False):
+        ref_lb.BERT = make_bert_class(ref_lb.BERT)
+    from maskrcnn_benchmark.modeling.detector import st_generalized_rcnn as st_mod
+
+    opts = ["MODEL.UNCERTAINTY_TRAIN_ITER", 3]
+    cfg = ref_import.reference_cfg("student_teacher_mask_rcnn_uncertainty.yaml", list(case.COMMON_OPTS) + opts)
+    model = st_mod.STGeneralizedRCNN(cfg)
+    load_seeded(model)
+    model.class_names = list(case.SEEN_NAMES)
+    model.roi_heads["box"].predictor.set_class_embeddings(case.text_embeddings())
+    model.train()
+    c = case.image_case(0, model.cap_vocab)
+    target = make_target(BoxList, SegmentationMask, c, True)
+    optimizer = make_optimizer(cfg, model)
+    scheduler = make_lr_scheduler(cfg, optimizer)
+    watched = ["roi_heads_student.mask.predictor.uncertain_pred.weight", "roi_heads_student.mask.predictor.uncertain_pred.bias",
+               "roi_heads_student.mask.predictor.mask_fcn_logits.weight", "roi_heads_student.box.predictor.emb_pred.weight"]
+    params = dict(model.named_parameters())
+    out = {"opts": np.array([str(o) for o in opts]), "watched": np.array(watched), "iterations": np.int64(4)}
+    with Capture(BalancedPositiveNegativeSampler) as cap:
+        for it in range(1, 5):
+            state = {}
+
+            def run_forward():
+                losses = model(c["image"][None], [target])
+                state["flag"] = params[watched[0]].requires_grad      # after the forward, before the backward
+                state["iter"] = int(model.iter)
+                state["before"] = {n: params[n].detach().clone() for n in watched}   # (the first forward copies the teacher heads)
+                return losses
+
+            losses = reference_iteration(cfg, model, optimizer, scheduler, run_forward, it,
+                                         zero_grad=lambda: optimizer.zero_grad(set_to_none=False))
+            key = f"it{it}_"
+            out[key + "sigma_trainable_after_forward"] = np.bool_(state["flag"])
+            out[key + "model_iter_after_forward"] = np.int64(state["iter"])
+            for k, v in losses.items():
+                out[key + k] = np.float64(v.item())
+            out[key + "delta_names"] = np.array(watched)
+            for n in watched:
+                dd = case.grad_digest(n, params[n].detach() - state["before"][n], n=case.VARIANT_DIGEST)
+                out[f"{key}delta:{n}:values"], out[f"{key}delta:{n}:norm_sum"] = dd["values"], np.array([dd["norm"], dd["sum"]])
+            print("freeze it", it, "sigma trainable", state["flag"], "iter", state["iter"],
+                  "|d sigma.w|", float(out[f"{key}delta:{watched[0]}:norm_sum"][0]), {k: round(v.item(), 5) for k, v in losses.items()})
+    put_samples(out, "roi_sample", cap, cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE)
+    assert out["roi_sample_count"] == 8
+    eps = [r for r in cap.randn if r.dim() == 5]
+    assert len(eps) == 4
+    for i, e in enumerate(eps):
+        out[f"mask_eps{i}"] = e.numpy()
+    np.savez_compressed(os.path.join(HERE, "step_student_freeze.npz"), **out)
+
+
 def gen_gt_box_eval():
     """MODEL.GT_BOX_EVAL True (roi_heads.py:25-49, box_head/inference.py:82-89,177-181): the evaluation branch of both
     detectors with the ground-truth boxes as the proposals of the heads -- one detection per ground-truth box, scored
@@ -798,13 +865,13 @@ def main():
     ref_import.install()
     torch.Tensor.cuda = lambda self, *a, **k: self  # box_head/loss.py:42,173, language_backbone/transformers.py:60
     gens = [gen_student, gen_student_variants, gen_teacher, gen_teacher_variants, gen_teacher_fixed_rpn, gen_checkpoint_map,
-            gen_student_full, gen_teacher_full, gen_gt_box_eval]
+            gen_student_full, gen_teacher_full, gen_gt_box_eval, gen_uncertainty_freeze]
     only = sys.argv[1:]  # e.g. ``make_step_golden.py gen_gt_box_eval``: that file alone (each generator builds its own models)
     for g in gens:
         if not only or g.__name__ in only:
             g()
     for f in ("step_student.npz", "step_student_variants.npz", "step_teacher.npz", "step_teacher_fixed_rpn.npz", "step_student_full.npz",
-              "step_teacher_full.npz", "step_teacher_variants.npz", "step_gt_box_eval.npz"):
+              "step_teacher_full.npz", "step_teacher_variants.npz", "step_gt_box_eval.npz", "step_student_freeze.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 

@@ -200,8 +200,13 @@ def test_reducer_overlap_survives_frozen_and_never_used_parameters(tmp_path):
         for n in a["grads"]:
             ga, gb = a["grads"][n], b["grads"][n]
             assert (ga is None) == (gb is None) and (ga is None or torch.equal(ga, gb)), (step, n)
-        assert a["late_grad_none"] == (step >= 2)
-        assert a["late_moved"] == (step < 2)  # frozen: no weight decay / momentum update either
+        # frozen during the run: the gradient stays a ZERO view of its bucket and weight decay / momentum go on moving the
+        # parameter, identically on both ranks -- the reference's loop under its pinned torch 1.7.1, whose zero_grad()
+        # zeroes in place (tests/golden/step_student_freeze.npz pins it on the real model)
+        assert not a["late_grad_none"]
+        if step >= 2:
+            assert float(a["grads"]["late.weight"].abs().max()) == 0.0
+        assert a["late_moved"]
 
 
 class _FakeDetector(nn.Module):

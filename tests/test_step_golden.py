@@ -709,6 +709,59 @@ def test_step_switches_through_the_trainer_hip_vs_reference_fixture(name):
     run_variant("cuda", name)
 
 
+def run_uncertainty_freeze(device):
+    """MODEL.UNCERTAINTY_TRAIN_ITER (st_generalized_rcnn.py:77,197-199,402-406): four iterations of the loop through the
+    product's trainer against four of the reference's own loop -- when the sigma branch stops training (the model's counter
+    is bumped twice by the first forward), and what the optimizer does to it afterwards (under the reference's pinned torch
+    1.7.1 its gradient stays ZERO, so momentum and weight decay keep moving it: 0.9 x the previous update, + decay)."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm, solver, trainer
+
+    v = _fixture("step_student_freeze.npz")
+    model, d, cfg = build_student(device, _typed([str(o) for o in v["opts"]]))
+    c = case.image_case(0, [str(n) for n in d["cap_vocab"]])
+    images, targets = c["image"][None].to(device), [make_target(c, device)]
+    n_it = int(v["iterations"])
+    _replay(model.roi_heads_student["box"].loss_evaluator, v, "roi_sample", tuple(range(2 * n_it)))
+    eps = [torch.from_numpy(v[f"mask_eps{i}"]).to(device) for i in range(n_it)]
+    watched = [str(n) for n in v["watched"]]
+    params = dict(model.named_parameters())
+    state = {}
+    forward = model.forward
+
+    def recording_forward(im, tg):
+        losses = forward(im, tg, eps=eps.pop(0))
+        state["flag"], state["iter"] = params[watched[0]].requires_grad, int(model.iter)
+        state["before"] = {n: params[n].detach().clone() for n in watched}
+        return losses
+
+    model.forward = recording_forward
+    optimizer = solver.make_optimizer(cfg, model)
+    scheduler = solver.make_lr_scheduler(cfg, optimizer)
+    reducer = comm.BucketedGradReducer(model)
+    policy = trainer.StepPolicy.from_cfg(cfg)
+    with _ops(device):
+        for it in range(1, n_it + 1):
+            losses = trainer.train_step(model, optimizer, reducer, images, targets, scheduler, policy)
+            key = f"it{it}_"
+            assert state["flag"] == bool(v[key + "sigma_trainable_after_forward"]), it
+            assert state["iter"] == int(v[key + "model_iter_after_forward"]), it
+            for k in PSEUDO + SEEN:
+                assert _rel(losses[k], float(v[key + k])) <= 2e-3, (it, k, float(losses[k]), float(v[key + k]))
+            check_digests({n: params[n].detach() - state["before"][n] for n in watched}, v, key + "delta", 5e-3, case.VARIANT_DIGEST)
+    # the frozen branch went on moving (momentum + decay), by 0.9 x its previous update
+    assert float(v[f"it4_delta:{watched[0]}:norm_sum"][0]) > 0
+    reducer.remove()
+
+
+def test_uncertainty_branch_freeze_cpu_vs_reference_fixture():
+    run_uncertainty_freeze("cpu")
+
+
+@pytest.mark.gpu
+def test_uncertainty_branch_freeze_hip_vs_reference_fixture():
+    run_uncertainty_freeze("cuda")
+
+
 def test_lr_schedule_vs_reference_fixture():
     """WarmupMultiStepLR (solver/lr_scheduler.py:10-52) of the shipped student configuration at the iterations around the
     warm-up end and the two milestones."""
