@@ -25,31 +25,39 @@ def total_loss(loss_dict):
 
 class StepPolicy:
     """SOLVER.GRADIENT_ACCUMULATION_STEPS and SOLVER.CLIP_GRAD_NORM_AT of the reference loop (engine/trainer.py:117,
-    135-141): the summed loss is divided by the accumulation count, the optimizer (and the LR schedule) steps every k-th
-    iteration on the accumulated gradients, clipped to a total L2 norm first when the threshold is positive."""
+    135-141): the summed loss is divided by the accumulation count; the optimizer (and the LR schedule) steps on the
+    accumulated gradients, clipped to a total L2 norm first when the threshold is positive, at every iteration whose NUMBER is
+    a multiple of the count -- so a run resumed at an odd iteration, or a window with a skipped batch (trainer.py:96-98: the
+    batch is dropped before the check), steps where the reference's does.  Callers without iteration numbers (``iteration``
+    None) step every k-th call."""
 
     def __init__(self, accumulation_steps=1, clip_grad_norm_at=-1.0):
         self.accumulation_steps = max(int(accumulation_steps), 1)
         self.clip_grad_norm_at = float(clip_grad_norm_at)
-        self.micro = 0  # micro-steps since the last optimizer step
+        self.micro = 0     # micro-steps since the last optimizer step
+        self.fresh = True  # the gradient buffers hold nothing of an open window: the next micro-step starts from zero
 
     @classmethod
     def from_cfg(cls, cfg):
         return cls(cfg.SOLVER.GRADIENT_ACCUMULATION_STEPS, cfg.SOLVER.CLIP_GRAD_NORM_AT)
 
     def begin(self, reducer):
-        reducer.zero_grad(set_to_zero=self.micro == 0)
+        reducer.zero_grad(set_to_zero=self.fresh)
+        self.fresh = False
 
     def scale(self, losses):
         return losses / float(self.accumulation_steps) if self.accumulation_steps > 1 else losses
 
-    def end(self, reducer, optimizer, scheduler):
-        """After backward(): reduce, and -- on the last micro-step -- clip, step, advance the schedule."""
+    def end(self, reducer, optimizer, scheduler, iteration=None):
+        """After backward(): reduce, and -- when the window closes -- clip, step, advance the schedule.  ``iteration``: the
+        1-based number of this iteration in the run (None: count calls)."""
         reducer.finish()
         self.micro += 1
-        if self.micro < self.accumulation_steps:
+        due = self.micro >= self.accumulation_steps if iteration is None else iteration % self.accumulation_steps == 0
+        if not due:
             return False
         self.micro = 0
+        self.fresh = True
         if self.clip_grad_norm_at > 0:
             reducer.clip_grad_norm_(self.clip_grad_norm_at)
         optimizer.step()
@@ -58,7 +66,7 @@ class StepPolicy:
         return True
 
 
-def train_step(model, optimizer, reducer, images, targets, scheduler=None, policy=None):
+def train_step(model, optimizer, reducer, images, targets, scheduler=None, policy=None, iteration=None):
     """One iteration of the loop (an optimisation step unless ``policy`` accumulates); returns the (un-reduced) loss dict
     of this rank."""
     policy = policy or _default_policy(reducer)
@@ -66,7 +74,7 @@ def train_step(model, optimizer, reducer, images, targets, scheduler=None, polic
     loss_dict = model(images, targets)
     losses = policy.scale(total_loss(loss_dict))
     losses.backward()
-    policy.end(reducer, optimizer, scheduler)
+    policy.end(reducer, optimizer, scheduler, iteration)
     return loss_dict
 
 
@@ -183,11 +191,12 @@ class PipelinedTrainer:
             e, self.worker_error = self.worker_error, None
             raise e
 
-    def step(self, images, targets, next_batch=None):
+    def step(self, images, targets, next_batch=None, iteration=None):
         """One optimisation step on (images, targets); ``next_batch`` = the (images, targets) of the following call
-        (already resident on the device), whose frozen half is started before this call returns."""
+        (already resident on the device), whose frozen half is started before this call returns; ``iteration`` = the 1-based
+        number of this iteration (``StepPolicy.end``)."""
         if not self.enabled:
-            return train_step(self.model, self.optimizer, self.reducer, images, targets, self.scheduler, self.policy)
+            return train_step(self.model, self.optimizer, self.reducer, images, targets, self.scheduler, self.policy, iteration)
         main = torch.cuda.current_stream()
         inputs_ready = torch.cuda.Event()
         inputs_ready.record(main)  # uploads of this and the next batch precede this point on the main stream
@@ -204,7 +213,7 @@ class PipelinedTrainer:
         loss_dict = self.model.forward_student(frozen, targets)
         losses = self.policy.scale(total_loss(loss_dict))
         losses.backward()
-        self.policy.end(self.reducer, self.optimizer, self.scheduler)
+        self.policy.end(self.reducer, self.optimizer, self.scheduler, iteration)
         if next_batch is not None and not self.threaded:
             # the GPU now has the whole backward queued: overlap the next frozen half with it
             self._launch_frozen(next_batch[0], next_batch[1], inputs_ready)
@@ -250,7 +259,7 @@ def do_train(cfg, model, data_iter, optimizer, scheduler, max_iter, start_iter=0
             batch = nxt
             continue
         ok_next = nxt is not None and not any(len(t) < 1 for t in nxt[1])
-        loss_dict = pipe.step(images, targets, nxt if ok_next else None)
+        loss_dict = pipe.step(images, targets, nxt if ok_next else None, iteration=iteration + 1)
         completed = iteration + 1
         batch = nxt
         if (iteration + 1) % log_period == 0 or iteration + 1 == max_iter:

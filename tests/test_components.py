@@ -541,3 +541,54 @@ def test_project_masks_formula_on_crops_that_are_multiples_of_the_resolution():
     """The host side of tests/test_targets_gpu.py's case (crop sizes 14 k: exact-zero second-tap weights)."""
     from tests.test_targets_gpu import test_project_masks_on_crops_that_are_multiples_of_the_resolution as case
     case(False)
+
+
+def test_accumulation_windows_follow_iteration_numbers_like_the_reference_loop():
+    """engine/trainer.py:96-98,135-141: the optimizer steps at iterations whose NUMBER is a multiple of
+    SOLVER.GRADIENT_ACCUMULATION_STEPS -- a run resumed at an odd iteration, or a window that lost a batch to the empty-target
+    skip, steps where the reference's does -- against that loop written out on a copy of the model."""
+    import copy
+
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm, trainer
+
+    torch.manual_seed(0)
+    ref = torch.nn.Linear(4, 3)
+    mine = copy.deepcopy(ref)
+    xs = [torch.randn(5, 4) for _ in range(7)]
+    k = 3
+    # the reference loop: iterations 5 .. 11 of a resumed run, iteration 8 skipped (an image without targets)
+    opt_r = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9)
+    steps_r = []
+    for it, x in zip(range(5, 12), xs):
+        if it == 8:
+            continue
+        (ref(x).pow(2).mean() / k).backward()
+        if it % k == 0:
+            torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+            opt_r.step()
+            opt_r.zero_grad()
+            steps_r.append(it)
+
+    class Wrap(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, x, targets):
+            return {"loss": self.m(x).pow(2).mean()}
+
+    model = Wrap(mine)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    reducer = comm.BucketedGradReducer(model)
+    policy = trainer.StepPolicy(k, 0.5)
+    steps = []
+    for it, x in zip(range(5, 12), xs):
+        if it == 8:
+            continue
+        before = mine.weight.detach().clone()
+        trainer.train_step(model, opt, reducer, x, None, None, policy, iteration=it)
+        if not torch.equal(before, mine.weight.detach()):
+            steps.append(it)
+    reducer.remove()
+    assert steps == steps_r == [6, 9]
+    assert torch.allclose(mine.weight, ref.weight, rtol=1e-6, atol=1e-7) and torch.allclose(mine.bias, ref.bias, rtol=1e-6, atol=1e-7)
