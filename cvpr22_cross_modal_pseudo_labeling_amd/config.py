@@ -153,7 +153,7 @@ def get_defaults():
         "DATALOADER": {"NUM_WORKERS": 4, "SIZE_DIVISIBILITY": 0, "ASPECT_RATIO_GROUPING": True},
         "SOLVER": {  # :491-528
             "MAX_ITER": 40000, "BASE_LR": 0.001, "BIAS_LR_FACTOR": 2, "MOMENTUM": 0.9, "WEIGHT_DECAY": 0.0005,
-            "WEIGHT_DECAY_BIAS": 0.0, "GAMMA": 0.1, "STEPS": (30000,), "WARMUP_FACTOR": 1.0 / 3,
+            "WEIGHT_DECAY_BIAS": 0, "GAMMA": 0.1, "STEPS": (30000,), "WARMUP_FACTOR": 1.0 / 3,
             "WARMUP_ITERS": 500, "WARMUP_METHOD": "linear", "CHECKPOINT_PERIOD": 10000, "TEST_PERIOD": 10000,
             "LOG_PERIOD": 20, "IMS_PER_BATCH": 16, "CLIP_GRAD_NORM_AT": -1.0, "GRADIENT_ACCUMULATION_STEPS": 1,
             "SKIP_VAL_LOSS": False, "UNCERTAINTY_LR_FACTOR": 1.0,

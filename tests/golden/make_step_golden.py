@@ -869,6 +869,10 @@ def main():
     only = sys.argv[1:]  # e.g. ``make_step_golden.py gen_gt_box_eval``: that file alone (each generator builds its own models)
     for g in gens:
         if not only or g.__name__ in only:
+            if g is gen_uncertainty_freeze:
+                # its committed file was made by a run of this generator alone (fresh seed): the sampler draws and the mask
+                # noise it records follow the global generator, so a full run re-seeds here to reproduce it byte for byte
+                torch.manual_seed(20260101)
             g()
     for f in ("step_student.npz", "step_student_variants.npz", "step_teacher.npz", "step_teacher_fixed_rpn.npz", "step_student_full.npz",
               "step_teacher_full.npz", "step_teacher_variants.npz", "step_gt_box_eval.npz", "step_student_freeze.npz"):

@@ -11,6 +11,7 @@ Stand-ins (each only as wide as the reference's import statements / call sites n
   * ``maskrcnn_benchmark.data(.datasets(.helper))``  bare namespace packages so that ``helper/lvis_v1_categories.py``
     and ``helper/parser.py`` load without ``data/__init__`` (torchvision)
 """
+import ast
 import copy
 import importlib.util
 import os
@@ -52,30 +53,71 @@ class CfgNode(dict):
     def defrost(self):
         pass
 
-    def _merge(self, other):
+    # yacs semantics (yacs/config.py: _decode_cfg_value, _check_and_coerce_cfg_value_type, merge_from_list): string values are
+    # decoded with ast.literal_eval when they parse, a replacement must have the type of the value it replaces (tuple <->
+    # list is cast to the original's type), a key that does not exist is an error.  A value that would silently change a
+    # key's type -- and with it the configuration the fixture is generated for -- raises here as it does under yacs.
+    @staticmethod
+    def _decode(v):
+        if isinstance(v, dict):
+            return CfgNode(v)
+        if not isinstance(v, str):
+            return v
+        try:
+            return ast.literal_eval(v)
+        except (ValueError, SyntaxError):
+            return v
+
+    @staticmethod
+    def _check_and_coerce(replacement, original, key):
+        if type(replacement) is type(original):
+            return replacement
+        for from_type, to_type in ((list, tuple), (tuple, list)):
+            if type(replacement) is from_type and type(original) is to_type:
+                return to_type(replacement)
+        raise ValueError(f"Type mismatch ({type(original)} vs. {type(replacement)}) with values ({original!r} vs. "
+                         f"{replacement!r}) for config key: {key}")
+
+    def _merge(self, other, path=""):
         for k, v in other.items():
-            if isinstance(v, dict):
-                if k not in self:
-                    self[k] = CfgNode()
-                self[k]._merge(v)
+            full = path + k
+            if k not in self:
+                raise KeyError(f"Non-existent config key: {full}")
+            v = self._decode(copy.deepcopy(v))
+            if isinstance(self[k], CfgNode):
+                if not isinstance(v, dict):
+                    raise ValueError(f"{full} must be a mapping")
+                self[k]._merge(v, full + ".")
             else:
-                if k in self and isinstance(self[k], tuple) and isinstance(v, (list, str)):
-                    v = tuple(eval(v)) if isinstance(v, str) else tuple(v)  # yaml writes tuples as "(a, b)" strings
-                self[k] = v
+                self[k] = self._check_and_coerce(v, self[k], full)
 
     def merge_from_file(self, path):
         with open(path) as f:
-            self._merge(yaml.safe_load(f))
+            self._merge(yaml.safe_load(f) or {})
 
     def merge_from_list(self, opts):
-        assert len(opts) % 2 == 0
+        assert len(opts) % 2 == 0, "override list must be KEY VALUE pairs"
         for k, v in zip(opts[0::2], opts[1::2]):
             node = self
             parts = k.split(".")
             for p in parts[:-1]:
+                if p not in node:
+                    raise KeyError(f"Non-existent config key: {k}")
                 node = node[p]
-            assert parts[-1] in node, k
-            node[parts[-1]] = v
+            if parts[-1] not in node:
+                raise KeyError(f"Non-existent config key: {k}")
+            node[parts[-1]] = self._check_and_coerce(self._decode(v), node[parts[-1]], k)
+
+
+def flatten_cfg(node, prefix=""):
+    """{DOTTED.KEY: value} of a config tree; tuples as lists (JSON has one sequence type)."""
+    out = {}
+    for k, v in node.items():
+        if isinstance(v, dict):
+            out.update(flatten_cfg(v, prefix + k + "."))
+        else:
+            out[prefix + k] = list(v) if isinstance(v, tuple) else v
+    return out
 
 
 def _empty(name, **attrs):
