@@ -8,7 +8,9 @@ reference's torch-op formulas), DEVICE tensors to the HIP kernels -- never acros
 host tensors (the reference raises "Not implemented on the CPU", csrc/ROIAlign.h:44,
 csrc/SigmoidFocalLoss.h:23,40).
 """
+import contextlib
 import ctypes
+import threading
 
 import torch
 
@@ -204,6 +206,33 @@ def roi_align_backward_strided(grad, rois, spatial_scale, pooled_height, pooled_
     if rc == -3:  # OVIS_ERANGE
         return None
     _lib.check(rc, "roi_align_backward_strided")
+    return gin
+
+
+def roi_align_backward_strided_nhwc(grad_nhwc, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels,
+                                    height, width, sampling_ratio, bin_stride):
+    """Backward of ``roi_align_forward_strided_nhwc`` from the NHWC gradient itself: ``grad_nhwc`` [R, ceil(PH/s), ceil(PW/s), C]
+    contiguous (as the res5 head's data-gradient GEMM leaves it) -> grad_input [N, C, H, W].  The library re-lays it into
+    pre-split bf16 hi | lo tiles (no permute copy here, no split arithmetic in the plane-owner kernel).  Returns None when the
+    shape is not covered (tiles above 8 x 8, planes that do not fit): the caller uses ``roi_align_backward_strided``."""
+    grad_nhwc, rois = _dev(grad_nhwc, "grad"), _dev(rois, "rois")
+    r, th, tw, c = grad_nhwc.shape
+    if c != channels or r != rois.size(0):
+        raise RuntimeError(f"roi_align_backward_strided_nhwc: gradient {tuple(grad_nhwc.shape)} for {rois.size(0)} RoIs x {channels} channels")
+    if th > 8 or tw > 8:
+        return None
+    gin = torch.empty((batch_size, channels, height, width), dtype=grad_nhwc.dtype, device=grad_nhwc.device)
+    if gin.numel() == 0:
+        return gin
+    with _on(grad_nhwc.device):
+        nbytes = _L.ovis_roi_align_backward_strided_nhwc_workspace_bytes(r, batch_size, channels, height, width)
+        ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=grad_nhwc.device)
+        rc = _L.ovis_roi_align_backward_strided_nhwc_ws_f32(grad_nhwc.data_ptr(), rois.data_ptr(), gin.data_ptr(), r, batch_size,
+                                                            channels, height, width, pooled_height, pooled_width, bin_stride,
+                                                            spatial_scale, sampling_ratio, ws.data_ptr(), nbytes, _stream())
+    if rc == -3:  # OVIS_ERANGE
+        return None
+    _lib.check(rc, "roi_align_backward_strided_nhwc")
     return gin
 
 
@@ -795,6 +824,26 @@ def im2col_nchw_pair(x, kh, kw, stride, pad):
     return out, (ho, wo)
 
 
+_GEMM_TLS = threading.local()
+
+
+@contextlib.contextmanager
+def co_scheduled(on=True):
+    """Split-GEMM launches issued inside run BESIDE other work (the frozen half of the student-teacher step on its side stream,
+    ``engine/trainer.py``): the library then cuts K for least total work instead of least duration (config bit 16 of
+    ``ovis_split_gemm_pair*``).  Per thread: the look-ahead half may be issued by a worker thread."""
+    prev = getattr(_GEMM_TLS, "co", False)
+    _GEMM_TLS.co = bool(on)
+    try:
+        yield
+    finally:
+        _GEMM_TLS.co = prev
+
+
+def _gemm_cfg(config):
+    return config | (0x10000 if getattr(_GEMM_TLS, "co", False) else 0)
+
+
 def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f32=True, out_pair=False, conv=None,
                     config=0, a2_pair=None, residual_pair=None):
     """act(A @ B^T + bias + residual) with A [M, 2*ch] / B [N, 2*K] in pair layout (``split_pair``); fp32-accurate
@@ -836,7 +885,8 @@ def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f3
                 and residual_pair.stride(1) == 1 and residual_pair.shape == (m, 2 * n)):
             raise RuntimeError("split_gemm_pair: residual_pair must be [M, 2N] bfloat16 pair rows of a plain product")
         with _on(dev):
-            nbytes = _L.ovis_split_gemm_pair_workspace_bytes(m, n, ch, 0, 1, 1, 0) if not (config & 8) else 0
+            config = _gemm_cfg(config)
+            nbytes = _L.ovis_split_gemm_pair_workspace_bytes_ex(m, n, ch, 0, 1, 1, 0, config) if not (config & 8) else 0
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
             rc = _L.ovis_split_gemm_pair_rp(a_pair.data_ptr(), 2 * a_pair.stride(0), b_pair.data_ptr(), 2 * b_pair.stride(0),
                                             0 if c is None else c.data_ptr(), n, 0 if cp is None else cp.data_ptr(), 4 * n,
@@ -849,7 +899,8 @@ def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f3
                                      and residual.stride(1) == 1 and residual.shape == (m, n)):
         raise RuntimeError("split_gemm_pair: residual must be a float32 [M, N] HIP tensor with unit column stride")
     with _on(dev):
-        nbytes = _L.ovis_split_gemm_pair_workspace_bytes(m, n, ch, ch2, kh, kw, w) if not (config & 8) else 0
+        config = _gemm_cfg(config)
+        nbytes = _L.ovis_split_gemm_pair_workspace_bytes_ex(m, n, ch, ch2, kh, kw, w, config) if not (config & 8) else 0
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
         rc = _L.ovis_split_gemm_pair(a_pair.data_ptr(), 2 * a_pair.stride(0),
                                      0 if a2_pair is None else a2_pair.data_ptr(),
@@ -941,7 +992,8 @@ def split_gemm_pair_gated(a_pair, b_pair, gate_pair, conv=None, out_f32=False, o
         return c, cp
     with _on(dev):
         # under-filled grids take the plan's K slices (the slab reduction applies the gate)
-        nbytes = _L.ovis_split_gemm_pair_workspace_bytes(m, n, ch, 0, kh, kw, w) if not (config & 8) else 0
+        config = _gemm_cfg(config)
+        nbytes = _L.ovis_split_gemm_pair_workspace_bytes_ex(m, n, ch, 0, kh, kw, w, config) if not (config & 8) else 0
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
         rc = _L.ovis_split_gemm_pair_gated_ws(a_pair.data_ptr(), 2 * a_pair.stride(0), b_pair.data_ptr(),
                                               2 * b_pair.stride(0), 0 if c is None else c.data_ptr(), n,
@@ -1063,9 +1115,8 @@ def gemm_nt(a, b, bias=None):
     if bias is not None:
         bias = _dev(bias, "bias")
     with _on(a.device):
-        rc = _L.ovis_gemm_f32(a.data_ptr(), a.stride(0), a.stride(1), b.data_ptr(), b.stride(0), b.stride(1),
-                              0 if bias is None else bias.data_ptr(), out.data_ptr(), n, m, n, k, _stream())
-    _lib.check(rc, "gemm_f32")
+        _gemm_raw(a.data_ptr(), a.stride(0), a.stride(1), b.data_ptr(), b.stride(0), b.stride(1), out.data_ptr(), n, m, n, k,
+                  bias_ptr=0 if bias is None else bias.data_ptr(), device=a.device)
     return out
 
 
@@ -1190,10 +1241,15 @@ def mask_bce_stochastic_fwd_bwd(mu, sigma, eps, pos_index, targets, channel, nee
 
 # ---- deformable convolution (csrc/deform_conv.h:11-190; host loops deform_conv_cuda.cu:161-694) ---------
 def _gemm_raw(a_ptr, a_rs, a_ks, b_ptr, b_rs, b_ks, c_ptr, c_rs, m, n, k, bias_ptr=0, bias_per_row=0, alpha=1.0,
-              accumulate=0):
-    rc = _L.ovis_gemm_ex_f32(a_ptr, a_rs, a_ks, b_ptr, b_rs, b_ks, bias_ptr, bias_per_row, alpha, accumulate, c_ptr,
-                             c_rs, m, n, k, _stream())
-    _lib.check(rc, "gemm_ex_f32")
+              accumulate=0, device=None):
+    """C = alpha * A . B^T (+ C) + bias on raw pointers.  Products with too few tiles to fill the chip are cut along K
+    into slabs of a workspace allocated here (summed in slice order by the library: no atomics)."""
+    ws_bytes = _L.ovis_gemm_f32_workspace_bytes(m, n, k)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=device or torch.device("cuda", torch.cuda.current_device())) \
+        if ws_bytes else None
+    rc = _L.ovis_gemm_ex_ws_f32(a_ptr, a_rs, a_ks, b_ptr, b_rs, b_ks, bias_ptr, bias_per_row, alpha, accumulate, c_ptr,
+                                c_rs, m, n, k, 0 if ws is None else ws.data_ptr(), ws_bytes, _stream())
+    _lib.check(rc, "gemm_ex_ws_f32")
 
 
 dcn_implicit = True  # False: the column route (im2col + GEMM) also where the implicit GEMM applies (cross-check in the tests)

@@ -27,6 +27,8 @@ SIGNATURES = {
     "ovis_roi_align_backward_plane_supported": (_i, [_i, _i, _i, _i]),
     "ovis_roi_align_backward_ws_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "ovis_roi_align_backward_strided_ws_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
+    "ovis_roi_align_backward_strided_nhwc_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ovis_roi_align_backward_strided_nhwc_ws_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "ovis_roi_pool_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "ovis_roi_pool_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ovis_deform_psroi_pool_forward_f32": (_i, [_vp] * 5 + [_i] * 7 + [_f] + [_i] * 5 + [_f, _vp]),
@@ -61,6 +63,7 @@ SIGNATURES = {
     "ovis_split_gemm_pair_gated": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _l] + [_i] * 8 + [_vp]),
     "ovis_split_gemm_pair_gated_ws": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _l] + [_i] * 7 + [_vp, _sz, _i, _vp]),
     "ovis_split_gemm_pair_workspace_bytes": (_sz, [_l, _i, _i, _i, _i, _i, _i]),
+    "ovis_split_gemm_pair_workspace_bytes_ex": (_sz, [_l, _i, _i, _i, _i, _i, _i, _i]),
     "ovis_split_gemm_pair_rp_gated": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _l, _i, _i, _i, _vp]),
     "ovis_split_gemm_pair_pool_supported": (_i, [_l, _i, _i, _i]),
     "ovis_split_gemm_pair_rp_pool": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _l, _i, _i, _i, _vp, _i, _f, _vp]),
@@ -72,6 +75,8 @@ SIGNATURES = {
     "ovis_project_masks_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ovis_gemm_f32": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _i, _i, _i, _vp]),
     "ovis_gemm_ex_f32": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _i, _f, _i, _vp, _l, _i, _i, _i, _vp]),
+    "ovis_gemm_f32_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ovis_gemm_ex_ws_f32": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _i, _f, _i, _vp, _l, _i, _i, _i, _vp, _sz, _vp]),
     "ovis_deform_im2col_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
     "ovis_deform_col2im_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
     "ovis_deform_col2im_coord_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),

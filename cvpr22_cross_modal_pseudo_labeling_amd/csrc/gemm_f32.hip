@@ -72,9 +72,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                       const float* __restrict__ bias, float* __restrict__ C,
                                                       long c_rs, int M, int N, int K, int flags, float alpha,
                                                       int k_chunk) {
-  // split-K: slice z of the grid contracts k in [z * k_chunk, min(K, (z + 1) * k_chunk)) and adds its partial tile
-  // into C with fp32 atomics (C pre-zeroed by the launcher; bias from slice 0).  Small GEMMs of the head fill
-  // fewer than one workgroup per CU otherwise, and with one wave per SIMD nothing hides the LDS / barrier stalls.
+  // split-K: slice z of the grid contracts k in [z * k_chunk, min(K, (z + 1) * k_chunk)) and writes its partial tile
+  // (bias from slice 0) into its own fp32 slab [z][M][N] of the caller's workspace (`C` then points at the slabs and c_rs
+  // == N); gemm_f32_slab_sum_kernel adds the slabs in slice order -- no atomics, bit-reproducible.  Small GEMMs of the
+  // head fill fewer than one workgroup per CU otherwise, and with one wave per SIMD nothing hides the LDS / barrier stalls.
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDP];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDP];
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -119,11 +120,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
       if (row < M) {
         float v = alpha * acc[r] + bv;
         if (bias && row_bias) v += bias[row];
-        float* dst = C + (long)row * c_rs + col;
-        if (split) atomicAdd(dst, v);
-        else *dst = accumulate ? *dst + v : v;
+        float* dst = C + ((split ? (long)blockIdx.z * M : 0) + row) * c_rs + col;
+        *dst = (accumulate && !split) ? *dst + v : v;
       }
     }
+  }
+}
+
+// C = (C +) slab[0] + slab[1] + ... in slice order (4 columns per thread when N % 4 == 0, else one)
+__global__ __launch_bounds__(256) void gemm_f32_slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ C,
+                                                               long c_rs, int M, int N, int slices, int accumulate) {
+  const long total = (long)M * N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / N;
+    const int n = (int)(i - m * N);
+    float v = slabs[i];
+    for (int z = 1; z < slices; ++z) v += slabs[(long)z * total + i];
+    float* dst = C + m * c_rs + n;
+    *dst = accumulate ? *dst + v : v;
   }
 }
 
@@ -186,10 +200,30 @@ __global__ void region_noun_finalize_kernel(const unsigned long long* __restrict
 
 }  // namespace
 
-extern "C" int ovis_gemm_ex_f32(const float* A, long a_row_stride, long a_k_stride, const float* B,
-                                long b_row_stride, long b_k_stride, const float* bias, int bias_per_row,
-                                float alpha, int accumulate, float* C, long c_row_stride, int M, int N, int K,
-                                void* stream) {
+// split K until ~3 workgroups per CU are resident (12 waves / CU), keeping >= 8 k-steps per slice
+static int gemm_f32_slices(int M, int N, int K, int* k_chunk_out) {
+  const int tiles = ovis_ceil_div(N, BN) * ovis_ceil_div(M, BM);
+  int slices = 1;
+  while (slices < 8 && tiles * slices < 3 * OVIS_NUM_CU && K / (slices * 2) >= 8 * BK) slices *= 2;
+  int k_chunk = K;
+  if (slices > 1) {
+    k_chunk = ovis_ceil_div(ovis_ceil_div(K, slices), BK) * BK;
+    slices = ovis_ceil_div(K, k_chunk);
+  }
+  if (k_chunk_out) *k_chunk_out = k_chunk;
+  return slices;
+}
+
+extern "C" size_t ovis_gemm_f32_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int slices = gemm_f32_slices(M, N, K, nullptr);
+  return slices > 1 ? (size_t)slices * M * N * sizeof(float) : 0;
+}
+
+extern "C" int ovis_gemm_ex_ws_f32(const float* A, long a_row_stride, long a_k_stride, const float* B,
+                                   long b_row_stride, long b_k_stride, const float* bias, int bias_per_row,
+                                   float alpha, int accumulate, float* C, long c_row_stride, int M, int N, int K,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
   if (M < 0 || N < 0 || K < 0) return OVIS_EINVAL;
   if (M == 0 || N == 0) return OVIS_OK;
   if (!A || !B || !C) return OVIS_EINVAL;
@@ -201,31 +235,36 @@ extern "C" int ovis_gemm_ex_f32(const float* A, long a_row_stride, long a_k_stri
   else if (b_row_stride == 1 && b_k_stride % 4 == 0 && al16(B)) flags |= 8;
   if (accumulate) flags |= 16;
   if (bias_per_row) flags |= 32;
-  const int tiles = ovis_ceil_div(N, BN) * ovis_ceil_div(M, BM);
-  // split K until ~3 workgroups per CU are resident (12 waves / CU), keeping >= 8 k-steps per slice
-  int slices = 1;
-  if (c_row_stride >= N) {
-    while (slices < 8 && tiles * slices < 3 * OVIS_NUM_CU && K / (slices * 2) >= 8 * BK) slices *= 2;
-  }
+  // K is cut only when the caller brought the slabs' workspace (ovis_gemm_f32_workspace_bytes); without it: one slice
   int k_chunk = K;
-  if (slices > 1) {
-    k_chunk = ovis_ceil_div(ovis_ceil_div(K, slices), BK) * BK;
-    slices = ovis_ceil_div(K, k_chunk);
-  }
+  int slices = workspace ? gemm_f32_slices(M, N, K, &k_chunk) : 1;
+  if (slices > 1 && workspace_bytes < (size_t)slices * M * N * sizeof(float)) return OVIS_ENOSPC;
+  if (slices == 1) k_chunk = K;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(ovis_ceil_div(N, BN), ovis_ceil_div(M, BM), slices);
   if (slices > 1) {
     flags |= 64;
-    if (!accumulate) {  // partial tiles are added atomically: start from zeros
-      if (c_row_stride == N)
-        OVIS_HIP_TRY(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, (hipStream_t)stream));
-      else
-        OVIS_HIP_TRY(hipMemset2DAsync(C, sizeof(float) * c_row_stride, 0, sizeof(float) * N, M, (hipStream_t)stream));
-    }
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, A, a_row_stride, a_k_stride, B, b_row_stride, b_k_stride, bias,
+                       (float*)workspace, (long)N, M, N, K, flags, alpha, k_chunk);
+    OVIS_LAUNCH_CHECK();
+    const long total = (long)M * N;
+    hipLaunchKernelGGL(gemm_f32_slab_sum_kernel, dim3((unsigned)(total / 256 + 1 < 4L * OVIS_NUM_CU ? total / 256 + 1 : 4L * OVIS_NUM_CU)),
+                       dim3(256), 0, s, (const float*)workspace, C, c_row_stride, M, N, slices, accumulate);
+    OVIS_LAUNCH_CHECK();
+    return OVIS_OK;
   }
-  dim3 grid(ovis_ceil_div(N, BN), ovis_ceil_div(M, BM), slices);
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, a_row_stride, a_k_stride, B,
-                     b_row_stride, b_k_stride, bias, C, c_row_stride, M, N, K, flags, alpha, k_chunk);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, A, a_row_stride, a_k_stride, B, b_row_stride, b_k_stride, bias, C,
+                     c_row_stride, M, N, K, flags, alpha, k_chunk);
   OVIS_LAUNCH_CHECK();
   return OVIS_OK;
+}
+
+extern "C" int ovis_gemm_ex_f32(const float* A, long a_row_stride, long a_k_stride, const float* B,
+                                long b_row_stride, long b_k_stride, const float* bias, int bias_per_row,
+                                float alpha, int accumulate, float* C, long c_row_stride, int M, int N, int K,
+                                void* stream) {
+  return ovis_gemm_ex_ws_f32(A, a_row_stride, a_k_stride, B, b_row_stride, b_k_stride, bias, bias_per_row, alpha, accumulate,
+                             C, c_row_stride, M, N, K, nullptr, 0, stream);
 }
 
 extern "C" int ovis_gemm_f32(const float* A, long a_row_stride, long a_k_stride, const float* B,

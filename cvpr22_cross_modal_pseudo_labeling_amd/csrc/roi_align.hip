@@ -842,7 +842,8 @@ extern "C" int ovis_roi_align_forward_mfma_supported(int height, int width, int 
 int ovis_roi_align_backward_plane_launch(const float* grad_output, const float* rois, float* grad_input,
                                          int num_rois, int batch, int channels, int height, int width,
                                          int pooled_h, int pooled_w, int bin_stride, float spatial_scale,
-                                         int sampling_ratio, void* workspace, size_t workspace_bytes, hipStream_t s);
+                                         int sampling_ratio, void* workspace, size_t workspace_bytes, hipStream_t s,
+                                         int nhwc_small);
 extern "C" int ovis_roi_align_backward_plane_supported(int height, int width, int pooled_h, int pooled_w);
 
 extern "C" int ovis_roi_align_backward_f32(const float* grad_output, const float* rois,
@@ -895,7 +896,7 @@ extern "C" int ovis_roi_align_backward_ws_f32(const float* grad_output, const fl
     const int rc = ovis_roi_align_backward_plane_launch(grad_output, rois, grad_input, num_rois, batch, channels,
                                                         height, width, pooled_h, pooled_w, 1, spatial_scale,
                                                         sampling_ratio, workspace, workspace_bytes,
-                                                        (hipStream_t)stream);
+                                                        (hipStream_t)stream, 0);
     if (rc != -100) return rc;  // -100: offsets would not fit 32 bits -> atomic path below
   }
   return ovis_roi_align_backward_f32(grad_output, rois, grad_input, num_rois, batch, channels, height, width,
@@ -923,7 +924,33 @@ extern "C" int ovis_roi_align_backward_strided_ws_f32(const float* grad_output, 
   if (!grad_output || !rois) return OVIS_EINVAL;
   const int rc = ovis_roi_align_backward_plane_launch(grad_output, rois, grad_input, num_rois, batch, channels, height,
                                                       width, pooled_h, pooled_w, bin_stride, spatial_scale,
-                                                      sampling_ratio, workspace, workspace_bytes, (hipStream_t)stream);
+                                                      sampling_ratio, workspace, workspace_bytes, (hipStream_t)stream, 0);
+  return rc == -100 ? OVIS_ERANGE : rc;
+}
+
+// The same backward from the gradient AS THE PRODUCING GEMM LEAVES IT: NHWC [num_rois, th, tw, channels] fp32 (th, tw =
+// ceil(pooled / bin_stride) <= 8, e.g. the 7 x 7 tiles of the res5 head).  The layout change the plane-owner kernel needs
+// ([R, C, th, tw] tiles; a separate copy kernel before this entry point existed) hands every value over already split into
+// bf16 hi | lo, so the main kernel spends no vector arithmetic on the gradient operand and both stages are two matrix
+// instructions.  workspace: ovis_roi_align_backward_strided_nhwc_workspace_bytes.  Shapes it does not cover: OVIS_ERANGE.
+extern "C" int ovis_roi_align_backward_strided_nhwc_ws_f32(const float* grad_output_nhwc, const float* rois,
+                                                           float* grad_input, int num_rois, int batch, int channels,
+                                                           int height, int width, int pooled_h, int pooled_w,
+                                                           int bin_stride, float spatial_scale, int sampling_ratio,
+                                                           void* workspace, size_t workspace_bytes, void* stream) {
+  if (num_rois < 0 || batch < 0 || channels < 0 || height <= 0 || width <= 0 || pooled_h <= 0 || pooled_w <= 0 ||
+      bin_stride <= 0)
+    return OVIS_EINVAL;
+  if ((size_t)batch * channels == 0) return OVIS_OK;
+  if (!grad_input) return OVIS_EINVAL;
+  if (num_rois == 0)
+    return (int)hipMemsetAsync(grad_input, 0, (size_t)batch * channels * height * width * sizeof(float), (hipStream_t)stream);
+  const int th = (pooled_h + bin_stride - 1) / bin_stride, tw = (pooled_w + bin_stride - 1) / bin_stride;
+  if (th > 8 || tw > 8 || !ovis_roi_align_backward_plane_supported(height, width, th, tw)) return OVIS_ERANGE;
+  if (!grad_output_nhwc || !rois) return OVIS_EINVAL;
+  const int rc = ovis_roi_align_backward_plane_launch(grad_output_nhwc, rois, grad_input, num_rois, batch, channels, height,
+                                                      width, pooled_h, pooled_w, bin_stride, spatial_scale,
+                                                      sampling_ratio, workspace, workspace_bytes, (hipStream_t)stream, 1);
   return rc == -100 ? OVIS_ERANGE : rc;
 }
 

@@ -46,7 +46,7 @@ static_assert(kRing == 2 || kRing == 3, "ring depth");
 static_assert(kRing * kRoundBytes <= 24 * 1024, "the table ring has 24 KB");
 constexpr int kListPad = 4 * kGDepth;        // zero-contribution items after the last real one
 constexpr int kPlanThreads = 256;
-constexpr unsigned kReuseT = 2u;  // item flag, bit 1 of the footprint origin's byte offset
+constexpr unsigned kReuseT = 0x80000000u;  // item flag, top bit of the footprint origin's cell index
 
 // ---------------------------------------------------------------------------------------------------
 // Plan kernel.
@@ -71,7 +71,11 @@ __host__ __device__ inline long list_stride(int R, int NXB, int NYB) { return (l
 __global__ __launch_bounds__(kPlanThreads) void roi_bwd_plan_kernel(
     const float* __restrict__ rois, int R, int batch, int C, int H, int W, int PH, int PW, int bin_stride, float scale,
     int sampling_ratio, u4* __restrict__ list, int* __restrict__ counts, u4* __restrict__ tx,
-    u4* __restrict__ ty, int NXB, int NYB) {
+    u4* __restrict__ ty, int NXB, int NYB, int small) {
+  // small != 0 (tiles of at most 8 x 8 computed bins, gradient handed over as pre-split 256-byte tiles, see
+  // roi_bwd_tiles_from_nhwc_kernel): the k-slots of the lane groups s and s + 2 mean the SAME four bins 4 (s & 1) .. + 3 --
+  // the data operand carries its hi halves in groups 0, 1 and its lo halves in groups 2, 3, so ONE K = 16 product against the
+  // table's hi halves (in every group) is hi.hi + lo.hi, and one against its lo halves is hi.lo + lo.lo.
   // bin_stride > 1: grad_output holds only the bins (bin_stride * i, bin_stride * j) the strided pooler produced
   // (roi_align_fwd_strided_nhwc_kernel), as [R, C, TH, TW] tiles; the tables carry those bins' weights, every other
   // bin's gradient is zero by construction and is never read.
@@ -116,15 +120,14 @@ __global__ __launch_bounds__(kPlanThreads) void roi_bwd_plan_kernel(
       }
       int o = base + before + incl - nb;
       // A RoI's blocks are consecutive items, yb fastest.  An item's first stage depends on (RoI, xb) only -- T = G . Ax_xb --
-      // so bit 1 of the origin offset (a multiple of 4) tells the main kernel that the previous item was (xb, yb - 1) of the
+      // so the top bit of the origin's cell index tells the main kernel that the previous item was (xb, yb - 1) of the
       // same RoI: its split first-stage result, still in registers, IS this item's -- no G split, no stage 1, no T split
       // (20 vector + 3 matrix instructions of an item's ~56; one wave-uniform branch per item pays for it).  Re-using the
       // split G tile across xb as well costs a second branch per item and measured as a loss.
       for (int xb = 0; xb < nbx; ++xb)
         for (int yb = 0; yb < nby; ++yb)
-          my[o++] = (u4){(unsigned)r * (unsigned)(C * TH * TW) * 4u,
-                         (unsigned)(block_origin(g.wy0, yb, H) * W + block_origin(g.wx0, xb, W)) * 4u |
-                             (yb > 0 ? kReuseT : 0u),
+          my[o++] = (u4){small ? (unsigned)r * (unsigned)C * 256u : (unsigned)r * (unsigned)(C * TH * TW) * 4u,
+                         (unsigned)(block_origin(g.wy0, yb, H) * W + block_origin(g.wx0, xb, W)) | (yb > 0 ? kReuseT : 0u),
                          (unsigned)(r * NXB + xb) * 1024u, (unsigned)(r * NYB + yb) * 1024u};
       base += all;
       __syncthreads();
@@ -147,8 +150,9 @@ __global__ __launch_bounds__(kPlanThreads) void roi_bwd_plan_kernel(
     if (col >= g.wx0 + xb * kT && col <= min(g.wx0 + xb * kT + kT - 1, g.wx1)) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int j = min(4 * s, TW - 4) + e;  // the main kernel's k-slot -> bin-column map (pulled-back last group)
-        if (j >= 4 * s) v[e] = axis_weight(g.start_w, g.bin_w, g.gw, j * bin_stride, W, col);
+        // the main kernel's k-slot -> bin-column map: pulled-back last group / the same four bins in groups s and s + 2
+        const int j = small ? 4 * (s & 1) + e : min(4 * s, TW - 4) + e;
+        if (small ? j < TW : j >= 4 * s) v[e] = axis_weight(g.start_w, g.bin_w, g.gw, j * bin_stride, W, col);
       }
     }
     tx[((long)r * NXB + xb) * 64 + lane] = split_bf16(v);
@@ -159,11 +163,56 @@ __global__ __launch_bounds__(kPlanThreads) void roi_bwd_plan_kernel(
     if (row >= g.wy0 + yb * kT && row <= min(g.wy0 + yb * kT + kT - 1, g.wy1)) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int i = 4 * s + e;
+        const int i = small ? 4 * (s & 1) + e : 4 * s + e;
         if (i < TH) v[e] = axis_weight(g.start_h, g.bin_h, g.gh, i * bin_stride, H, row) / g.count;
       }
     }
-    ty[((long)r * NYB + yb) * 64 + lane] = split_bf16(v);
+    const u4 sp = split_bf16(v);
+    // small: the first-stage result arrives with its rows 0..7 repeated in rows 8..15 (lane groups 2, 3), so the table carries
+    // its hi halves in groups 0, 1 and its lo halves in groups 2, 3: one product per half of the split T covers all four terms
+    ty[((long)r * NYB + yb) * 64 + lane] = !small ? sp : (s < 2 ? (u4){sp.x, sp.y, 0u, 0u} : (u4){sp.z, sp.w, 0u, 0u});
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Pre-split gradient tiles of the strided pooler's backward (tiles of at most 8 x 8 computed bins): the gradient arrives
+// NHWC [R, TH, TW, C] fp32 from the producing data-gradient GEMM; this kernel is the layout change the plane-owner kernel
+// needs anyway ([R, C, TH, TW]: one contiguous tile per (RoI, channel)) and hands every value over ALREADY SPLIT:
+//   tile (r, c) = 256 bytes: hi[8][8] bf16 | lo[8][8] bf16, rows >= TH and columns >= TW zero
+// so the main kernel's lanes load MFMA operands as they lie (8 bytes per lane, no hi/lo arithmetic per item and channel).
+// One workgroup = (RoI, 64 channels): coalesced 256-byte row reads -> 2-byte LDS writes (tile stride 65 dwords: the 64 lanes
+// of a row hit 64 banks) -> 16-byte chunks written back in address order (4 tiles = 1 KB per wave instruction).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kTileBytes = 256;
+__global__ __launch_bounds__(256) void roi_bwd_tiles_from_nhwc_kernel(const float* __restrict__ g, char* __restrict__ tiles,
+                                                                     int C, int TH, int TW) {
+  __shared__ unsigned lds[64 * 65];
+  const int t = threadIdx.x;
+  const int groups = (C + 63) / 64;
+  const long r = blockIdx.x / groups;
+  const int c0 = (int)(blockIdx.x % groups) * 64;
+  for (int i = t; i < 64 * 65; i += 256) lds[i] = 0u;
+  __syncthreads();
+  const int c = t & 63;
+  unsigned short* mine = (unsigned short*)(lds + c * 65);
+  if (c0 + c < C) {
+    for (int p = t >> 6; p < TH * TW; p += 4) {
+      const float v = g[(r * TH * TW + p) * C + c0 + c];
+      const unsigned hl = pack_bf16(v, 0.f);                              // low half: bf16(v)
+      const unsigned lo = pack_bf16(v - __uint_as_float(hl << 16), 0.f);  // low half: bf16 of the exact remainder
+      const int pos = (p / TW) * 8 + p % TW;
+      mine[pos] = (unsigned short)hl;
+      mine[64 + pos] = (unsigned short)lo;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int chunk = t + 256 * k, tile = chunk >> 4, part = chunk & 15;
+    if (c0 + tile < C) {
+      const unsigned* src = lds + tile * 65 + part * 4;
+      *(u4*)(tiles + ((r * C + c0 + tile) * kTileBytes + part * 16)) = (u4){src[0], src[1], src[2], src[3]};
+    }
   }
 }
 
@@ -197,9 +246,14 @@ __global__ __launch_bounds__(kPlanThreads) void roi_bwd_plan_kernel(
 // G tile through a raw buffer descriptor over the channel's tiles: the item's byte offset is the SCALAR offset operand, so a
 // request costs no 64-bit address arithmetic (every instruction of the item loop is paid for in issue slots)
 typedef int i4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_f32;
 #define OVIS_BLOAD4(dst, voff, rsrc, soff) \
   asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory")
+#define OVIS_BLOAD2(dst, voff, rsrc, soff) \
+  asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory")
 #define OVIS_WAIT1(N, a) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "i"(N) : "memory")
+template <bool SMALL> struct GTile { typedef f4 type; };
+template <> struct GTile<true> { typedef u2 type; };
 
 __device__ __forceinline__ void lds_dma16(const void* gsrc_lane, unsigned lds_dst_wave) {
   unsigned keep;
@@ -210,7 +264,11 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc_lane, unsigned lds_ds
       : "memory");
 }
 
-template <int NW, bool FIT, int WC>
+// SMALL: the gradient comes as the pre-split 256-byte tiles of roi_bwd_tiles_from_nhwc_kernel (`gout` points at them): a lane
+// loads 8 bytes -- row q & 7, bins 4 (s & 1) .. + 3, hi halves in lane groups 0, 1 and lo halves in groups 2, 3 -- which IS the
+// first stage's data operand; both stages are two K = 16 products (all four hi/lo terms), the only vector arithmetic left per
+// item is the split of T: 39 instead of 53 instructions per item and channel.
+template <int NW, bool FIT, int WC, bool SMALL = false>
 __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
     const float* __restrict__ gout, const u4* __restrict__ list, const int* __restrict__ counts,
     const u4* __restrict__ tx, const u4* __restrict__ ty, float* __restrict__ gin, int R, int batch,
@@ -241,12 +299,15 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
   // Lane's slice of a G tile: row q, four columns starting at min(4s, PW - 4) -- the last k-group is pulled back
   // so that no lane reads past its row (the plan kernel zeroes the duplicated k-slots in tx).  Rows q >= PH re-read
   // row PH - 1: finite values that meet zero ty entries (i >= PH).
-  const unsigned g_lane = (unsigned)(min(q, PH - 1) * PW + min(4 * s, PW - 4)) * 4u;
-  const unsigned long long gb = (unsigned long long)(gout + (long)c * PHPW);
+  const unsigned g_lane = SMALL ? (unsigned)((s >> 1) * 128 + (q & 7) * 16 + (s & 1) * 8)
+                                : (unsigned)(min(q, PH - 1) * PW + min(4 * s, PW - 4)) * 4u;
+  const unsigned long long gb = SMALL ? (unsigned long long)((const char*)gout + (long)c * kTileBytes)
+                                      : (unsigned long long)(gout + (long)c * PHPW);
   const i4 rsrc = {(int)(unsigned)gb, (int)((unsigned)(gb >> 32) & 0xffffu), -1, 0x00020000};  // stride 0, no bound, 32-bit data
   const char* txl = (const char*)tx + lane * 16;
   const char* tyl = (const char*)ty + lane * 16;
-  const unsigned lane_cell = (unsigned)(4 * s * W + q) * 4u;  // byte offset of the lane's first footprint cell
+  // LDS byte address of the lane's first footprint cell for an origin at cell 0 (plane base included)
+  const unsigned lane_cell = (unsigned)wave * plane_stride + (unsigned)(4 * s * W + q) * 4u;
 
   // this wave's DMA duty for round `rr` into ring slot `slot`: blocks b = wave*P .. wave*P+P-1 (mod 2 kRI) of the round's
   // 2 kRI, block b = {tx, ty}[b / kRI] of item rr*kRI + b % kRI; lands at ring_base + slot*kRoundBytes + b*1024
@@ -260,14 +321,16 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
     }
   };
 
-  f4 rg[kGDepth];         // lane's 4 grad_output values G[i = min(q, PH-1)][j = min(4s, PW-4) + e] of the item in slot d
-  unsigned org[kGDepth];  // its footprint origin (LDS byte offset inside the plane)
+  // lane's 4 grad_output values G[i = min(q, PH-1)][j = min(4s, PW-4) + e] of the item in slot d (SMALL: 4 bf16 halves)
+  typename GTile<SMALL>::type rg[kGDepth];
+  unsigned org[kGDepth];  // its footprint origin (cell index | reuse flag)
 #pragma unroll
-  for (int d = 0; d < kGDepth; ++d) rg[d] = (f4){0.f, 0.f, 0.f, 0.f};
-#define OVIS_FETCH(d, e)                           \
-  do {                                             \
-    OVIS_BLOAD4(rg[d], g_lane, rsrc, (e).x);       \
-    org[d] = (e).y;                                \
+  for (int d = 0; d < kGDepth; ++d) rg[d] = (typename GTile<SMALL>::type)(0);
+#define OVIS_FETCH(d, e)                                        \
+  do {                                                          \
+    if constexpr (SMALL) OVIS_BLOAD2(rg[d], g_lane, rsrc, (e).x); \
+    else OVIS_BLOAD4(rg[d], g_lane, rsrc, (e).x);               \
+    org[d] = (e).y;                                             \
   } while (0)
 
   // prologue, in the steady-state issue order: DMA G(0 .. kRI-1) DMA G(kRI .. 2 kRI-1).  Ring of three: the tables of
@@ -292,7 +355,8 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
   unsigned slot = 0;     // ring slot of the round being consumed
 
   // cnt is a multiple of kGDepth; the list runs kListPad zero-contribution items past it
-  for (int k0 = 0; k0 < cnt; k0 += kGDepth) {
+  const u4* cur = my + kGDepth;  // entries of the items the running round requests; advanced once per kGDepth items
+  for (int k0 = 0; k0 < cnt; k0 += kGDepth, cur += kGDepth) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       {
@@ -304,13 +368,14 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
       }
       const char* tab = smem + ring_base + slot * kRoundBytes + lane * 16;
       // entries of the items this round requests (two rounds ahead): one base per round, constant offsets per item
-      const u4* ent = my + (k0 + half * kRI + kGDepth);
+      const u4* ent = cur + half * kRI;
 #pragma unroll
       for (int i = 0; i < kRI; ++i) {
         const int d = half * kRI + i;
-        const unsigned fl = org[d] & 3u;
-        const unsigned cell = (org[d] & ~3u) + lane_cell;
-        float* pp = (float*)((char*)plane + cell_prev);
+        const unsigned fl = org[d] & kReuseT;
+        unsigned cell;  // (origin << 2) + lane_cell in ONE instruction; the flag bit leaves through the shift
+        asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(cell) : "s"(org[d]), "v"(lane_cell));
+        lds_f32* pp = (lds_f32*)(unsigned long)cell_prev;  // an LDS address as such: no symbol base to add
         float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
         if (FIT) {
           v0 = pp[0]; v1 = pp[W]; v2 = pp[2 * W]; v3 = pp[3 * W];
@@ -324,8 +389,12 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
         // row = 4s + e -- is the B-operand layout of stage 2) -- unless the previous item (same RoI, same xb) left this
         // very operand in b2: ONE wave-uniform branch per item
         if (!(fl & kReuseT)) {
-          const u4 a1 = split_bf16(rg[d]);
-          b2 = split_bf16(mfma3(a1, bx, (f4){0.f, 0.f, 0.f, 0.f}));
+          if constexpr (SMALL) {
+            b2 = split_bf16(mfma2x2(rg[d], rg[d], (u2){bx.x, bx.y}, (u2){bx.z, bx.w}));
+          } else {
+            const u4 a1 = split_bf16(rg[d]);
+            b2 = split_bf16(mfma3(a1, bx, (f4){0.f, 0.f, 0.f, 0.f}));
+          }
         }
         // previous item's footprint (its reads were issued above, their latency is behind stage 1 by now)
         if (FIT) {
@@ -334,16 +403,17 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
           pp[2 * W] = v2 + w_prev.z;
           pp[3 * W] = v3 + w_prev.w;
         } else if (on_prev) {  // maps narrower / lower than one block: mask the footprint
-          const int y = (int)(cell_prev >> 2) / W;
+          const int y = (int)((cell_prev - (unsigned)wave * plane_stride) >> 2) / W;
           if (y + 0 < H) pp[0] += w_prev.x;
           if (y + 1 < H) pp[W] += w_prev.y;
           if (y + 2 < H) pp[2 * W] += w_prev.z;
           if (y + 3 < H) pp[3 * W] += w_prev.w;
         }
         // stage 2: dW[y][x] = sum_i Ay[i][y] T[i][x]
-        w_prev = mfma3(ay, b2, (f4){0.f, 0.f, 0.f, 0.f});
+        if constexpr (SMALL) w_prev = mfma2x2((u2){ay.x, ay.y}, (u2){ay.x, ay.y}, (u2){b2.x, b2.y}, (u2){b2.z, b2.w});
+        else w_prev = mfma3(ay, b2, (f4){0.f, 0.f, 0.f, 0.f});
         cell_prev = cell;
-        if (!FIT) on_prev = (int)(org[d] >> 2) % W + q < W;
+        if (!FIT) on_prev = (int)(org[d] & ~kReuseT) % W + q < W;
         // G slot d is dead from here: refill it in place, kGDepth items ahead
         __builtin_amdgcn_sched_barrier(0);
         OVIS_FETCH(d, epre);
@@ -361,14 +431,14 @@ __global__ __launch_bounds__(NW * 64) void roi_bwd_mfma_kernel(
     }
   }
   {  // drain the pipeline: the last item's footprint
-    float* pp = (float*)((char*)plane + cell_prev);
+    lds_f32* pp = (lds_f32*)(unsigned long)cell_prev;
     if (FIT) {
       pp[0] += w_prev.x;
       pp[W] += w_prev.y;
       pp[2 * W] += w_prev.z;
       pp[3 * W] += w_prev.w;
     } else if (on_prev) {
-      const int y = (int)(cell_prev >> 2) / W;
+      const int y = (int)((cell_prev - (unsigned)wave * plane_stride) >> 2) / W;
       if (y + 0 < H) pp[0] += w_prev.x;
       if (y + 1 < H) pp[W] += w_prev.y;
       if (y + 2 < H) pp[2 * W] += w_prev.z;
@@ -408,6 +478,15 @@ static int plane_waves(int height, int width) {
   return 0;
 }
 
+// The strided pooler's backward from an NHWC gradient (pre-split tiles, SMALL kernel): plan workspace + one 256-byte tile per
+// (RoI, channel)
+extern "C" size_t ovis_roi_align_backward_strided_nhwc_workspace_bytes(int num_rois, int batch, int channels, int height,
+                                                                       int width) {
+  const size_t plan = ovis_roi_align_backward_workspace_bytes(num_rois, batch, height, width);
+  if (plan == 0 || channels <= 0) return 0;
+  return align_up(plan, 256) + (size_t)num_rois * channels * kTileBytes;
+}
+
 // Whether the plane-owner kernel covers this shape (otherwise the caller falls back to the atomic kernels).
 extern "C" int ovis_roi_align_backward_plane_supported(int height, int width, int pooled_h, int pooled_w) {
   return pooled_h >= 1 && pooled_w >= 4 && pooled_h <= kT && pooled_w <= kT && height < 65536 && width < 32768 &&
@@ -417,14 +496,21 @@ extern "C" int ovis_roi_align_backward_plane_supported(int height, int width, in
 int ovis_roi_align_backward_plane_launch(const float* grad_output, const float* rois, float* grad_input,
                                          int num_rois, int batch, int channels, int height, int width,
                                          int pooled_h, int pooled_w, int bin_stride, float spatial_scale,
-                                         int sampling_ratio, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                                         int sampling_ratio, void* workspace, size_t workspace_bytes, hipStream_t s,
+                                         int nhwc_small) {
+  // nhwc_small: grad_output is the NHWC gradient [num_rois, tile_h, tile_w, channels] of at most 8 x 8 computed bins; it is
+  // re-laid into pre-split tiles behind the plan workspace and the SMALL kernel consumes those
   const int tile_h = (pooled_h + bin_stride - 1) / bin_stride, tile_w = (pooled_w + bin_stride - 1) / bin_stride;
+  if (nhwc_small && (tile_h > 8 || tile_w > 8 || !(height >= kT && width >= kT) || plane_waves(height, width) != 8))
+    return OVIS_PLANE_TOO_BIG;
   // item byte offsets are 32-bit: grad_output and the tables must each stay below 4 GiB (else: atomic path)
-  if ((double)num_rois * channels * tile_h * tile_w * 4.0 >= 4294967296.0 ||
+  if ((double)num_rois * channels * (nhwc_small ? 64.0 : (double)tile_h * tile_w) * 4.0 >= 4294967296.0 ||
       ((double)num_rois * ovis_ceil_div(width, kT) + 1) * 1024.0 >= 4294967296.0 ||
       ((double)num_rois * ovis_ceil_div(height, kT) + 1) * 1024.0 >= 4294967296.0)
     return OVIS_PLANE_TOO_BIG;
-  const size_t need = ovis_roi_align_backward_workspace_bytes(num_rois, batch, height, width);
+  const size_t plan_bytes = ovis_roi_align_backward_workspace_bytes(num_rois, batch, height, width);
+  const size_t need = nhwc_small ? ovis_roi_align_backward_strided_nhwc_workspace_bytes(num_rois, batch, channels, height, width)
+                                 : plan_bytes;
   if (!workspace || workspace_bytes < need) return OVIS_ENOSPC;
   if (((uintptr_t)workspace & 255) != 0) return OVIS_EINVAL;
   const int NXB = ovis_ceil_div(width, kT), NYB = ovis_ceil_div(height, kT);
@@ -444,11 +530,22 @@ int ovis_roi_align_backward_plane_launch(const float* grad_output, const float* 
   if (plan_blocks > 0x7fffffffL || blocks > 0x7fffffffL) return OVIS_ERANGE;
   hipLaunchKernelGGL(roi_bwd_plan_kernel, dim3((unsigned)plan_blocks), dim3(kPlanThreads), 0, s, rois, num_rois,
                      batch, channels, height, width, pooled_h, pooled_w, bin_stride, spatial_scale, sampling_ratio, list,
-                     counts, tx, ty, NXB, NYB);
+                     counts, tx, ty, NXB, NYB, nhwc_small);
   OVIS_LAUNCH_CHECK();
+  if (nhwc_small) {
+    char* tiles = (char*)workspace + align_up(plan_bytes, 256);
+    const long tblocks = (long)num_rois * ovis_ceil_div(channels, 64);
+    if (tblocks > 0x7fffffffL) return OVIS_ERANGE;
+    hipLaunchKernelGGL(roi_bwd_tiles_from_nhwc_kernel, dim3((unsigned)tblocks), dim3(256), 0, s, grad_output, tiles, channels,
+                       tile_h, tile_w);
+    OVIS_LAUNCH_CHECK();
+    grad_output = (const float*)tiles;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<8, true, 84>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<8, true, 84, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<8, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<8, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<8, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     OVIS_HIP_TRY(hipFuncSetAttribute((const void*)roi_bwd_mfma_kernel<4, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -460,7 +557,14 @@ int ovis_roi_align_backward_plane_launch(const float* grad_output, const float* 
   hipLaunchKernelGGL((roi_bwd_mfma_kernel<NW_, FIT_, WC_>), dim3((unsigned)blocks), dim3(NW_ * 64), lds, s, grad_output, \
                      list, counts, tx, ty, grad_input, num_rois, batch, channels, height, width, tile_h, tile_w,          \
                      NXB, NYB, stride)
-  if (nw == 8) {
+  if (nhwc_small) {
+#define OVIS_BWD_LAUNCH_SMALL(WC_)                                                                                           \
+  hipLaunchKernelGGL((roi_bwd_mfma_kernel<8, true, WC_, true>), dim3((unsigned)blocks), dim3(8 * 64), lds, s, grad_output,  \
+                     list, counts, tx, ty, grad_input, num_rois, batch, channels, height, width, tile_h, tile_w, NXB, NYB, \
+                     stride)
+    if (width == 84) OVIS_BWD_LAUNCH_SMALL(84); else OVIS_BWD_LAUNCH_SMALL(0);
+#undef OVIS_BWD_LAUNCH_SMALL
+  } else if (nw == 8) {
     if (fit && width == 84) OVIS_BWD_LAUNCH(8, true, 84);  // the C4 map of an 800 x 1333 batch
     else if (fit) OVIS_BWD_LAUNCH(8, true, 0);
     else OVIS_BWD_LAUNCH(8, false, 0);

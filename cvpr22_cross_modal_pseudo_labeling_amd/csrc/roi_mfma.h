@@ -48,6 +48,13 @@ static __device__ __forceinline__ f4 mfma3(u4 a, u4 b, f4 acc) {
   return acc;
 }
 
+// a0 . b0 + a1 . b1 as two K = 16 products into one accumulator (the pre-split small-tile form: the operands carry hi halves
+// in k-groups 0, 1 and lo halves in groups 2, 3 on one side, hi / lo halves on the other: all four hi/lo terms)
+static __device__ __forceinline__ f4 mfma2x2(u2 a0, u2 a1, u2 b0, u2 b1) {
+  f4 acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(as_s4(a0.x, a0.y), as_s4(b0.x, b0.y), (f4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(as_s4(a1.x, a1.y), as_s4(b1.x, b1.y), acc, 0, 0, 0);
+}
+
 // Summed weight the samples of bin `p` put on feature cell `cell` along one axis (the reference's
 // bilinear_interpolate_gradient set-up, ROIAlign_cuda.cu:125-175, reduced to one axis).
 static __device__ __forceinline__ float axis_weight(float start, float bin, int grid, int p, int size, int cell) {

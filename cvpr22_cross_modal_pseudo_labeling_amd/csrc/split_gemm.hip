@@ -1343,7 +1343,8 @@ struct SplitGemmPlan {
 };
 
 // config: 0 = choose; otherwise a bit set for tests / A-B probes: 1 = one LDS stage, 2 = two stages, 4 = never use
-// the halo form, 8 = no split-K.
+// the halo form, 8 = no split-K; bits 8..15: that many K slices (tools/experiments/slices_probe.py); bit 16: the launch is
+// co-scheduled with other work (choose slices for least total work, not least duration).
 SplitGemmPlan split_gemm_plan(long m, int n, int channels, int channels2, int taps_h, int taps_w, int width, int config) {
   SplitGemmPlan q;
   const int T = taps_h * taps_w;
@@ -1359,6 +1360,7 @@ SplitGemmPlan split_gemm_plan(long m, int n, int channels, int channels2, int ta
   // split-K: a grid that leaves most CUs idle while every workgroup walks a long K
   q.kslices = 1;
   q.steps_per_slice = units;
+  bool sliced_two_stage = false;   // the slice count below was chosen FOR the two-stage kernel
   if (!(config & 8) && !q.narrow && nb <= OVIS_NUM_CU / 2) {
     const int min_units = q.mode == HALO ? 1 : 8;
     long s = units / min_units;
@@ -1369,11 +1371,11 @@ SplitGemmPlan split_gemm_plan(long m, int n, int channels, int channels2, int ta
       q.steps_per_slice = (int)((units + s - 1) / s);
       q.kslices = (units + q.steps_per_slice - 1) / q.steps_per_slice;
     }
-  } else if (!(config & 8) && !q.narrow && q.mode != HALO) {
-    // Grids of one or two workgroups per CU that walk a long K (the 50 x 84 maps of layer3 and the RPN head: 66 row
-    // tiles): the CUs with one workgroup more than the others set the kernel's duration.  Cutting K in 2 / 4 makes the
-    // work items smaller, so they spread evenly (8400 x 256 x 2304: 132 workgroups on 256 CUs -> 528; the RPN head's
-    // 528 x 288 k-steps -> 1056 x 144); the slabs are small next to the K walk.
+  } else if (!(config & 8) && (config & 0x10000) && !q.narrow && q.mode != HALO) {
+    // CO-SCHEDULED launches (config bit 16: the frozen half of the student-teacher step, which runs on a side stream beside
+    // the student backward's full-machine GEMMs): another stream fills the CUs a tail leaves idle, so what counts is the
+    // launch's TOTAL work, not its duration alone -- the coarser cut of rounds 2-5 (fewer slabs to write and reduce).  Same-box
+    // A/B of the pipelined student step: 33.4 ms with this rule, 33.8 ms with the latency model below on every launch.
     int sl = 1;
     if (nb <= OVIS_NUM_CU && units >= 64) sl = 4;
     else if (nb <= OVIS_NUM_CU && units >= 32) sl = 2;
@@ -1382,6 +1384,37 @@ SplitGemmPlan split_gemm_plan(long m, int n, int channels, int channels2, int ta
       q.steps_per_slice = (units + sl - 1) / sl;
       q.kslices = (units + q.steps_per_slice - 1) / q.steps_per_slice;
     }
+  } else if (!(config & 8) && !q.narrow && q.mode != HALO && nb < 3L * OVIS_NUM_CU && units >= 16) {
+    // Grids of one or two workgroups per CU that walk a long K (the 50 x 84 maps of layer3 and the RPN head: 66 row tiles;
+    // the 100 x 167 maps of layer2: 261): the CUs with one workgroup more than the others set the kernel's duration, and a
+    // round of resident workgroups that overflows by a few items pays a whole extra item (528 tiles x 288 k-steps of the RPN
+    // head in two slices = 1056 items on 1024 one-stage slots: 509 us; in four slices on the 512 two-stage slots 421 us =
+    // the library's rate).  The slice count is chosen by a cost model of the TWO-STAGE kernel fitted to
+    // tools/experiments/slices_probe.py (profiles/r6_slices_probe.txt): an item of s k-steps takes 12.8 + 1.0 s us beside a
+    // second workgroup on its CU and 8 + 0.785 s us alone (a lone workgroup reaches 64 % of a CU's rate); a launch is
+    // floor(items / 512) full rounds plus one partial round, plus the slabs' write + reduce.
+    const double slab_unit = (double)m * n * 4.0 / 34.4e6;
+    double best = 1e30;
+    int best_sl = 1;
+    for (int sl : {1, 2, 3, 4, 6, 8}) {
+      const int steps = (units + sl - 1) / sl;
+      if (sl > 1 && steps < 8) break;
+      const long items = nb * ((units + steps - 1) / steps);
+      const long full = items / (2L * OVIS_NUM_CU), rest = items % (2L * OVIS_NUM_CU);
+      const double t2 = 12.8 + 1.0 * steps, t1 = 8.0 + 0.785 * steps;
+      const double t = full * t2 + (rest == 0 ? 0.0 : (rest > OVIS_NUM_CU ? t2 : t1)) + (sl > 1 ? 4.0 + 0.9 * sl * slab_unit : 0.0);
+      if (t < best) { best = t; best_sl = sl; }
+    }
+    if (best_sl > 1) {
+      q.steps_per_slice = (units + best_sl - 1) / best_sl;
+      q.kslices = (units + q.steps_per_slice - 1) / q.steps_per_slice;
+      sliced_two_stage = true;
+    }
+  }
+  if (const int forced = (config >> 8) & 0xff; forced > 0 && !q.narrow) {
+    const int sl = forced < units ? forced : units;
+    q.steps_per_slice = (units + sl - 1) / sl;
+    q.kslices = (units + q.steps_per_slice - 1) / q.steps_per_slice;
   }
   // Large grids: ONE LDS stage and three / four workgroups per CU instead of two double-buffered ones -- nothing
   // overlaps inside a workgroup, but more independent workgroups hide each other's load phases better (measured on
@@ -1391,10 +1424,13 @@ SplitGemmPlan split_gemm_plan(long m, int n, int channels, int channels2, int ta
   const long total = nb * q.kslices;
   q.stages = 2;
   if (q.mode == HALO || q.narrow) q.stages = 1;
+  else if (sliced_two_stage) q.stages = 2;
   else if (total >= 8L * OVIS_NUM_CU || (total >= 4L * OVIS_NUM_CU && (T > 1 || q.tiles_n >= 8))) q.stages = 1;
   else {
     const long slots2 = 2L * OVIS_NUM_CU, slots1 = 4L * OVIS_NUM_CU;
     if (total > slots2 && total <= slots2 + slots2 / 4 && total <= slots1) q.stages = 1;
+    // two two-stage rounds + a few items against one single-stage round + a few (33400 x 512 x 128: 1044 tiles, 26.5 vs 29.7 us)
+    if (total > slots1 && total <= slots1 + slots1 / 16) q.stages = 1;
   }
   if (config & 1) q.stages = 1;
   if ((config & 2) && q.mode != HALO && !q.narrow) q.stages = 2;
@@ -1402,11 +1438,16 @@ SplitGemmPlan split_gemm_plan(long m, int n, int channels, int channels2, int ta
 }
 }  // namespace
 
+extern "C" size_t ovis_split_gemm_pair_workspace_bytes_ex(long m, int n, int channels, int channels2, int taps_h,
+                                                          int taps_w, int width, int config) {
+  if (m <= 0 || n <= 0 || channels <= 0 || taps_h <= 0 || taps_w <= 0 || config < 0 || config > 0x1ffff) return 0;
+  const SplitGemmPlan q = split_gemm_plan(m, n, channels, channels2, taps_h, taps_w, width, config);
+  return q.kslices > 1 ? (size_t)q.kslices * (size_t)m * (size_t)n * sizeof(float) : 0;
+}
+
 extern "C" size_t ovis_split_gemm_pair_workspace_bytes(long m, int n, int channels, int channels2, int taps_h,
                                                        int taps_w, int width) {
-  if (m <= 0 || n <= 0 || channels <= 0 || taps_h <= 0 || taps_w <= 0) return 0;
-  const SplitGemmPlan q = split_gemm_plan(m, n, channels, channels2, taps_h, taps_w, width, 0);
-  return q.kslices > 1 ? (size_t)q.kslices * (size_t)m * (size_t)n * sizeof(float) : 0;
+  return ovis_split_gemm_pair_workspace_bytes_ex(m, n, channels, channels2, taps_h, taps_w, width, 0);
 }
 
 static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void* a2_pair, long a2_row_bytes,
@@ -1435,7 +1476,7 @@ static int split_gemm_pair_impl(const void* a_pair, long a_row_bytes, const void
       ((uintptr_t)residual & 15) || ((uintptr_t)workspace & 15) || ldc % 4 != 0 || ldr % 4 != 0 ||
       c_pair_row_bytes % 16 != 0)
     return OVIS_ERANGE;
-  if (config < 0 || config > 15) return OVIS_ERANGE;
+  if (config < 0 || config > 0x1ffff) return OVIS_ERANGE;
   SplitGemmPlan q = split_gemm_plan(m, n, channels, channels2, taps_h, taps_w, width, config);
   if (q.kslices > 1 && (!workspace || workspace_bytes < (size_t)q.kslices * (size_t)m * (size_t)n * sizeof(float))) {
     // no (or too small a) workspace: the un-split grid

@@ -22,15 +22,19 @@ def free_port():
         return s.getsockname()[1]
 
 
-def rank_env(rank, nproc, master_port, base=None, master_addr="127.0.0.1"):
-    """Environment of local rank ``rank`` of ``nproc`` (single node: RANK == LOCAL_RANK)."""
+def rank_env(rank, nproc, master_port, base=None, master_addr="127.0.0.1", gpu_ranks=True):
+    """Environment of local rank ``rank`` of ``nproc`` (single node: RANK == LOCAL_RANK).  ``gpu_ranks`` False (the CPU-only
+    configuration over gloo, whose step IS OpenMP / torch-CPU math): OMP_NUM_THREADS is left to the rank's core share."""
     env = dict(os.environ if base is None else base)
     env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(nproc), "LOCAL_WORLD_SIZE": str(nproc),
                 "MASTER_ADDR": master_addr, "MASTER_PORT": str(master_port)})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver: RCCL needs it
     # a SMALL OpenMP team per rank: the GPU path does almost no CPU math, and a team as wide as the rank's core share spins
     # after every host op and starves the rank's own staging / loader threads (profiles/r5_cli_input_path.txt)
-    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or 1) // max(nproc, 1) // 4))))
+    if gpu_ranks:
+        env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or 1) // max(nproc, 1) // 4))))
+    else:
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(nproc, 1))))
     return env
 
 
@@ -145,7 +149,12 @@ def format_cpus(cpus):
 def _visible_devices(env):
     """GPU indices behind local ranks 0, 1, ... when HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES re-orders or restricts them
     (None: rank r uses GPU r)."""
-    vis = env.get("HIP_VISIBLE_DEVICES") or env.get("ROCR_VISIBLE_DEVICES")
+    hip, rocr = env.get("HIP_VISIBLE_DEVICES"), env.get("ROCR_VISIBLE_DEVICES")
+    if hip and rocr:
+        # HIP's indices are then relative to the ROCR-filtered list: mapping them onto sysfs order would pin ranks to the
+        # wrong socket while the log says "numa" -- an empty list makes plan_affinity fall back to the even split
+        return []
+    vis = hip or rocr
     if vis and all(v.strip().isdigit() for v in vis.split(",")):
         return [int(v) for v in vis.split(",")]
     return None
@@ -167,7 +176,8 @@ def apply_rank_affinity(env=None, sysfs_root="/sys"):
             if world <= 1:
                 return {"cpus": format_cpus(os.sched_getaffinity(0)), "source": "single rank: unchanged"}
             cpus = plan_affinity(world, sysfs_root=sysfs_root, visible=_visible_devices(env))[rank]
-            source = "numa" if gpu_numa_nodes(sysfs_root) else "even split"
+            vis = _visible_devices(env)
+            source = "numa" if (gpu_numa_nodes(sysfs_root) and (vis is None or len(vis) >= world)) else "even split"
         cpus = set(cpus) & os.sched_getaffinity(0) or set(cpus)
         if len(cpus) < MIN_CORES_PER_RANK and len(cpus) < len(os.sched_getaffinity(0)):
             # a rank runs its training thread, the frozen-half worker, the staging thread and RCCL's proxy threads: squeezing
@@ -211,13 +221,16 @@ def _stop(children):
             c.wait()
 
 
-def spawn_ranks(argv, nproc, master_port=None, env=None, poll_seconds=0.2, python=None):
+def spawn_ranks(argv, nproc, master_port=None, env=None, poll_seconds=0.2, python=None, gpu_ranks=None):
     """Run ``python argv...`` as ``nproc`` ranks and wait for all of them.  Returns the job's exit code: 0 when every
     rank exited 0, else the code of the first rank seen failing (the others are terminated).  Whatever ends the wait --
     a failing rank, SIGTERM / SIGINT to the launcher, a ``Popen`` that raises half-way through the spawn -- no started
     rank is left behind holding its GPU and the rendezvous port."""
     if nproc < 1:
         raise ValueError("nproc must be >= 1")
+    if gpu_ranks is None:  # the CPU-only configuration (bench.py --device cpu, train_net.py MODEL.DEVICE cpu) does its math on the host
+        a = [str(x) for x in argv]
+        gpu_ranks = not any(a[i:i + 2] in (["--device", "cpu"], ["MODEL.DEVICE", "cpu"]) for i in range(len(a)))
     port = master_port or free_port()
     cmd = [python or sys.executable] + list(argv)
     children = []
@@ -239,7 +252,7 @@ def spawn_ranks(argv, nproc, master_port=None, env=None, poll_seconds=0.2, pytho
         for r in range(nproc):
             if got:
                 raise _Terminated(got[0])
-            renv = rank_env(r, nproc, port, env)
+            renv = rank_env(r, nproc, port, env, gpu_ranks=gpu_ranks)
             if plan is not None:
                 renv.setdefault("OVIS_RANK_CPUS", format_cpus(plan[r]))
             children.append(subprocess.Popen(cmd, env=renv, stdout=None if r == 0 else sys.stderr))
@@ -272,6 +285,17 @@ def spawn_ranks(argv, nproc, master_port=None, env=None, poll_seconds=0.2, pytho
                 break
             except BaseException as e:  # KeyboardInterrupt in the middle of a wait: try again, the ranks must go
                 sys.stderr.write(f"launch: clean-up interrupted ({type(e).__name__}); retrying\n")
+        # whatever interrupted the retries: no rank may outlive the launcher (it would keep its GPU and the rendezvous port)
+        for c in children:
+            try:
+                if c.poll() is None:
+                    c.kill()
+                    c.wait(timeout=10)
+            except BaseException as e:  # noqa: BLE001 -- keep going: the other ranks still have to go
+                sys.stderr.write(f"launch: could not reap pid {c.pid} ({type(e).__name__})\n")
+        for c in children:
+            if c.poll() is None:
+                sys.stderr.write(f"launch: rank process {c.pid} SURVIVED the clean-up\n")
         if old_term is not None:
             signal.signal(signal.SIGTERM, old_term)
     return code

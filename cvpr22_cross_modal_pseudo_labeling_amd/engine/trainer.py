@@ -12,6 +12,7 @@ import time
 import torch
 
 from . import comm
+from .. import _C
 
 
 def total_loss(loss_dict):
@@ -166,7 +167,8 @@ class PipelinedTrainer:
             with torch.cuda.stream(self.side):
                 if after_event is not None:
                     self.side.wait_event(after_event)
-                frozen = self.model.forward_frozen(images, targets)
+                with _C.co_scheduled():  # these launches run beside the student half: K cut for least total work
+                    frozen = self.model.forward_frozen(images, targets)
                 done = torch.cuda.Event()
                 done.record(self.side)
             self.pending = ((id(images), id(targets)), frozen, done)

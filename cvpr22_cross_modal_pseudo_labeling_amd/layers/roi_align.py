@@ -57,6 +57,11 @@ class _ROIAlignStridedNHWC(Function):
         bs, ch, h, w = ctx.input_shape
         ph, pw = ctx.output_size
         s = ctx.bin_stride
+        # the NHWC gradient as it is (tiles up to 8 x 8): the library re-lays it into pre-split per-(RoI, channel) tiles
+        grad_input = _C.roi_align_backward_strided_nhwc(grad_output.contiguous(), rois, ctx.spatial_scale, ph, pw, bs, ch, h, w,
+                                                        ctx.sampling_ratio, s) if grad_output.is_cuda else None
+        if grad_input is not None:
+            return grad_input, None, None, None, None, None
         # [R, oh, ow, C] -> [R, C, oh, ow] tiles of the computed bins only: a quarter of the bytes of the full tile
         grad_input = _C.roi_align_backward_strided(grad_output.permute(0, 3, 1, 2).contiguous(), rois, ctx.spatial_scale, ph, pw,
                                                    bs, ch, h, w, ctx.sampling_ratio, s)

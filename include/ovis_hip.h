@@ -131,6 +131,19 @@ int ovis_roi_align_backward_strided_ws_f32(const float* grad_output, const float
                                            int pooled_h, int pooled_w, int bin_stride, float spatial_scale,
                                            int sampling_ratio, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same backward from the gradient as the producing data-gradient GEMM leaves it: NHWC
+ * [num_rois, th, tw, channels] fp32 with th, tw = ceil(pooled / bin_stride) <= 8 (the 7 x 7 tiles of the res5 head;
+ * mb/csrc/cuda/ROIAlign_cuda.cu:178-254 restricted to the computed bins).  The layout change the plane-owner kernel
+ * needs hands every value over already split into bf16 hi | lo (one 256-byte tile per RoI and channel, kept behind the
+ * plan tables in `workspace`): no separate permute copy, no hi/lo arithmetic on the gradient operand per item and
+ * channel, two matrix instructions per stage.  OVIS_ERANGE for shapes it does not cover. */
+size_t ovis_roi_align_backward_strided_nhwc_workspace_bytes(int num_rois, int batch, int channels, int height, int width);
+int ovis_roi_align_backward_strided_nhwc_ws_f32(const float* grad_output_nhwc, const float* rois, float* grad_input,
+                                                int num_rois, int batch, int channels, int height, int width,
+                                                int pooled_h, int pooled_w, int bin_stride, float spatial_scale,
+                                                int sampling_ratio, void* workspace, size_t workspace_bytes,
+                                                void* stream);
+
 /* ------------------------------------------------------------------------------------
  * NMS                                        mb/csrc/nms.h:10-28, mb/csrc/cuda/nms.cu:13-131
  * boxes [K,4] f32 xyxy (+1 pixel area convention), scores [K] f32.
@@ -413,6 +426,10 @@ int ovis_im2col_nchw_pair_f32(const float* src, void* dst_pair, int num, int cha
  * channels % 32 == 0, channels2 % 32 == 0, n % 4 == 0, 16-byte aligned pointers and strides (else OVIS_ERANGE). */
 size_t ovis_split_gemm_pair_workspace_bytes(long m, int n, int channels, int channels2, int taps_h, int taps_w,
                                             int width);
+/* The same query for a launch with a non-zero `config` (bit 16 = co-scheduled launch: slices chosen for least total work;
+ * bits 8..15 = forced slice count): the plan, and with it the slabs' size, follows config. */
+size_t ovis_split_gemm_pair_workspace_bytes_ex(long m, int n, int channels, int channels2, int taps_h, int taps_w,
+                                               int width, int config);
 int ovis_split_gemm_pair(const void* a_pair, long a_row_bytes, const void* a2_pair, long a2_row_bytes,
                          const void* b_pair, long b_row_bytes, float* c, long ldc, void* c_pair,
                          long c_pair_row_bytes, const float* bias, const float* residual, long ldr, long m,
@@ -512,6 +529,17 @@ int ovis_gemm_ex_f32(const float* A, long a_row_stride, long a_k_stride, const f
                      long b_row_stride, long b_k_stride, const float* bias, int bias_per_row,
                      float alpha, int accumulate, float* C, long c_row_stride, int M, int N, int K,
                      void* stream);
+
+/* The same product with K cut into slices when the problem has too few tiles to fill the chip (the head's small
+ * GEMMs: a weight gradient contracts over ~1000 rows into a 768 x 2048 result): every slice writes its own fp32 slab
+ * in `workspace` and one kernel adds the slabs in slice order -- no atomics, bit-reproducible run to run.
+ * ovis_gemm_f32_workspace_bytes(M, N, K) = bytes the split needs (0: the problem is not cut); workspace NULL = never
+ * cut (what ovis_gemm_f32 / ovis_gemm_ex_f32 do); too small a workspace: OVIS_ENOSPC. */
+size_t ovis_gemm_f32_workspace_bytes(int M, int N, int K);
+int ovis_gemm_ex_ws_f32(const float* A, long a_row_stride, long a_k_stride, const float* B,
+                        long b_row_stride, long b_k_stride, const float* bias, int bias_per_row,
+                        float alpha, int accumulate, float* C, long c_row_stride, int M, int N, int K,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* Region <-> noun alignment of the teacher (mb/modeling/detector/st_generalized_rcnn.py:243-262):
  * for every noun w: raw_scores[w] = max_p <region_emb[p], noun_emb[w]>, best_region[w] = argmax_p

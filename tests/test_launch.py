@@ -25,6 +25,24 @@ def test_rank_env_is_env_rendezvous_on_loopback():
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["PATH"] == "/bin"
 
 
+def test_rank_env_small_openmp_team_only_for_gpu_ranks(monkeypatch):
+    """the min(8, cores / ranks / 4) OpenMP team is for ranks that compute on the GPU; the CPU-only configuration
+    (gloo, the step itself is OpenMP math) keeps its whole core share.  An explicit OMP_NUM_THREADS always wins."""
+    monkeypatch.setattr(launch.os, "cpu_count", lambda: 64)
+    assert launch.rank_env(0, 2, 1, base={})["OMP_NUM_THREADS"] == "8"
+    assert launch.rank_env(0, 2, 1, base={}, gpu_ranks=False)["OMP_NUM_THREADS"] == "32"
+    assert launch.rank_env(0, 2, 1, base={"OMP_NUM_THREADS": "3"}, gpu_ranks=False)["OMP_NUM_THREADS"] == "3"
+
+
+def test_both_visible_devices_variables_fall_back_to_the_even_split(tmp_path):
+    """with ROCR_VISIBLE_DEVICES and HIP_VISIBLE_DEVICES both set, HIP's indices are relative to the ROCR-filtered
+    list -- mapping them onto sysfs (PCI) order could pin a rank to the remote socket; the plan is then the even split."""
+    assert launch._visible_devices({"HIP_VISIBLE_DEVICES": "1,0"}) == [1, 0]
+    assert launch._visible_devices({"ROCR_VISIBLE_DEVICES": "2,3", "HIP_VISIBLE_DEVICES": "1,0"}) == []
+    plan = launch.plan_affinity(2, allowed=range(8), sysfs_root=str(tmp_path), visible=[])
+    assert [sorted(p) for p in plan] == [[0, 1, 2, 3], [4, 5, 6, 7]]
+
+
 def _run(script, nproc, tmp_path, extra_env=None):
     path = tmp_path / "child.py"
     path.write_text(textwrap.dedent(script))

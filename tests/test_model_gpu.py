@@ -207,11 +207,64 @@ def test_pipelined_trainer_runs_the_teacher_steps_frozen_trunk_prefix_ahead():
             assert set(a) == set(b)
             for k in b:
                 # Step 0 (same weights on both sides) is the statement about the split: equal to fp32 round-off.  Later steps
-                # compare trajectories, and the teacher's backward is not bit-reproducible (torch's gather / index backward
-                # accumulates with atomics): two PLAIN runs differ by 1e-5 at step 1 and up to 2e-4 at step 3
-                # (tools/experiments/dbg_prefix.py) -- a stale or foreign prefix would be an O(1) difference.
+                # compare trajectories of two DIFFERENT launch sequences (the prefix product runs as its own launches), whose
+                # round-off differs; a stale or foreign prefix would be an O(1) difference.  (Two runs of the SAME sequence
+                # are bit-identical since round 6: test_training_steps_are_bit_reproducible.)
                 tol = 1e-6 if i == 0 else 1e-3
                 assert abs(a[k] - b[k]) <= tol * max(abs(b[k]), 1e-3), (kind, i, k, a[k], b[k])
+
+
+@pytest.mark.parametrize("name", ["zeroshot_mask", "student_teacher_mask_rcnn_uncertainty"])
+def test_training_steps_are_bit_reproducible(name):
+    """Two runs of three optimisation steps (forward, backward, bucketed reduce, fused SGD) from the same weights, seeds and
+    batches give IDENTICAL losses, gradients and parameters -- bit for bit, both shipped configurations.  The reference cannot
+    (its RoIAlign backward adds with fp32 atomics, ROIAlign_cuda.cu:246-249); here no kernel of the step accumulates in an
+    order that depends on scheduling: the RoIAlign backward owns its planes, weight-gradient slabs and the fp32 head GEMM's
+    K slices (round 6: they were fp32 atomics until then -- the one source of run-to-run noise, 1e-5 .. 2e-4 on the losses)
+    are summed in a fixed order, the pooled-row atomics of the res5 epilogue add at most two addends onto zero."""
+    import copy
+
+    from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm, solver, trainer
+
+    model, e_vocab, e_seen, images, targets = _build(name)
+    cfg = get_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, f"configs/coco_cap_det/{name}.yaml"))
+    cfg.merge_from_list(["SOLVER.BASE_LR", 1e-4])
+    cfg.freeze()
+    images = images.cuda()
+    tg = [t.to("cuda") for t in targets]
+    batches = [(images, tg), (images.flip(-1).contiguous(), tg), (images * 0.5, tg)]
+
+    def run(pipelined):
+        m = copy.deepcopy(model).cuda()
+        m.set_class_embeddings(e_seen.cuda())
+        if hasattr(m, "set_caption_vocab"):
+            m.set_caption_vocab(e_vocab.cuda())
+        m.train()
+        opt = solver.make_optimizer(cfg, m)
+        red = comm.BucketedGradReducer(m)
+        pipe = trainer.PipelinedTrainer(m, opt, red)
+        pipe.enabled = pipe.enabled and pipelined
+        losses, grads = [], None
+        for i, (im, t) in enumerate(batches):
+            torch.manual_seed(100 + i)
+            nxt = batches[i + 1] if i + 1 < len(batches) else None
+            losses.append({k: float(v.detach()) for k, v in pipe.step(im, t, nxt).items()})
+            if i == 0:
+                grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+        pipe.drain()
+        red.remove()
+        return losses, grads, {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
+
+    for pipelined in (False, True):
+        l0, g0, w0 = run(pipelined)
+        l1, g1, w1 = run(pipelined)
+        assert l0 == l1, (pipelined, l0, l1)
+        assert len(g0) >= 10 and set(g0) == set(g1)
+        assert [n for n in g0 if not torch.equal(g0[n], g1[n])] == [], pipelined
+        assert [n for n in w0 if not torch.equal(w0[n], w1[n])] == [], pipelined
+        assert any(float(w0[n].sub(p.detach().cuda()).abs().max()) > 0 for n, p in model.named_parameters() if n in w0)  # it trained
 
 
 def test_rpn_shared_selection_matches_two_selections():
@@ -274,8 +327,7 @@ def test_batched_student_branches_match_sequential_branches():
 def test_do_train_checkpoint_cadence_and_resume(tmp_path):
     """do_train writes model_<iter>.pth every CHECKPOINT_PERIOD and model_final.pth (trainer.py:172-173, 252-253); a
     second run in the same directory resumes weights, momentum, LR schedule and the iteration counter from the tag file
-    EXACTLY (state equality -- loss trajectories of this step are not bit-reproducible run to run: fp32 atomics in the
-    RoIAlign backward) and continues with the remaining iterations."""
+    EXACTLY (state equality) and continues with the remaining iterations."""
     import copy
 
     from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults

@@ -60,7 +60,7 @@ def bench_rois(r, n_img, g, kind="uniform"):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--ops", default="roi_fwd,roi_bwd,nms,focal,gemm,dcn,res5,split_gemm")
+    ap.add_argument("--ops", default="roi_fwd,roi_bwd,roi_bwd_strided,nms,focal,gemm,dcn,res5,split_gemm")
     ap.add_argument("--lib", default="", help="path of an experiment build of libovis_hip.so (handled before the import)")
     ap.add_argument("--roi-kinds", default="uniform,rpn_like", help="RoI distributions of the RoIAlign micro-benchmarks")
     ap.add_argument("--iters", type=int, default=20)
@@ -69,7 +69,7 @@ def main():
     g = torch.Generator().manual_seed(1234)
     dev = "cuda"
     res = []
-    if "roi_fwd" in ops or "roi_bwd" in ops:
+    if "roi_fwd" in ops or "roi_bwd" in ops or "roi_bwd_strided" in ops:
         n, c, h, w, r = 2, 1024, 50, 84, 1024
         x = torch.randn(n, c, h, w, generator=g).to(dev)
         for kind in args.roi_kinds.split(","):
@@ -98,6 +98,18 @@ def main():
                 res.append({"op": "roi_align_backward", "rois": kind, "ms": ms, "alg_MB": alg / 1e6,
                             "GBps": alg / ms / 1e6, "frac_hbm": alg / ms / 1e6 / HBM_PEAK_GBS})
                 del go
+            if "roi_bwd_strided" in ops:
+                # the teacher step's form: gradient of the 7 x 7 computed bins, NHWC as the res5 data-gradient GEMM leaves it
+                gs = torch.randn(r, 7, 7, c, generator=g).to(dev)
+                alg_s = 4 * r * c * 49 + 4 * n * c * h * w + 20 * r
+                ms = timeit(lambda: _C.roi_align_backward_strided(gs.permute(0, 3, 1, 2).contiguous(), rois, 1 / 16, 14, 14, n, c, h, w, 0, 2), args.iters)
+                res.append({"op": "roi_align_backward_strided(s=2) after permute+contiguous", "rois": kind, "ms": ms,
+                            "alg_MB": alg_s / 1e6, "GBps": alg_s / ms / 1e6, "frac_hbm": alg_s / ms / 1e6 / HBM_PEAK_GBS})
+                if hasattr(_C, "roi_align_backward_strided_nhwc"):
+                    ms = timeit(lambda: _C.roi_align_backward_strided_nhwc(gs, rois, 1 / 16, 14, 14, n, c, h, w, 0, 2), args.iters)
+                    res.append({"op": "roi_align_backward_strided_nhwc(s=2, pre-split tiles)", "rois": kind, "ms": ms,
+                                "alg_MB": alg_s / 1e6, "GBps": alg_s / ms / 1e6, "frac_hbm": alg_s / ms / 1e6 / HBM_PEAK_GBS})
+                del gs
         del x
     if "res5" in ops:  # byte kernels of the NHWC res5 head at the student pass's shapes (R = 1024 -> M = 50176 rows)
         m = 1024 * 49

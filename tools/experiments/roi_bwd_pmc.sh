@@ -18,7 +18,7 @@ for v in "$@"; do
     i=$((i+1))
     have=""; for c in $grp; do grep -qx "$c" "$OUT/sq_counters_available.txt" || [ "$c" = GRBM_GUI_ACTIVE ] && have="$have $c"; done
     rm -rf /tmp/rbp_$i
-    timeout 300 rocprofv3 --kernel-trace --pmc $have --output-format csv -d /tmp/rbp_$i -o p -- python3 $ROOT/tools/bench_ops.py --ops roi_bwd --iters 3 --lib $LIB > /tmp/rbp_$i.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $have --output-format csv -d /tmp/rbp_$i -o p -- python3 $ROOT/tools/bench_ops.py --ops roi_bwd --roi-kinds uniform --iters 3 --lib $LIB > /tmp/rbp_$i.log 2>&1
     f=$(find /tmp/rbp_$i -name "*counter_collection.csv" | head -1)
     if [ -n "$f" ]; then python3 $ROOT/tools/pmc_reduce.py $f | grep roi_bwd_mfma >> "$OUT/$v.txt"; else echo "pass $i: no output" >> "$OUT/$v.txt"; tail -3 /tmp/rbp_$i.log >> "$OUT/$v.txt"; fi
   done
