@@ -239,16 +239,23 @@ def gen_student():
 FULL_OPTS = ["MODEL.DEVICE", "cpu"]   # the shipped configuration itself: full R-50-C4, 6000 -> 1000 / 12000 -> 2000 proposals, 512 RoIs
 
 
-def gen_student_full():
+def gen_student_full(index=0, out_name="step_student_full.npz", digests=True):
     """ONE image at BASELINE size (3 x 800 x 1333) through the reference's STGeneralizedRCNN with the SHIPPED configuration
     (full R-50-C4 -- 55 M seeded weights --, 1000 test-mode / 2000 train-mode proposals, 512 sampled RoIs per branch):
     proposals, aligned regions + margins, pseudo labels, sampler draws, mask noise, losses, gradient digests ->
     tests/golden/step_student_full.npz.  About a minute on 8 cores."""
     from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
-    from maskrcnn_benchmark.modeling.detector import st_generalized_rcnn as st_mod
+    from maskrcnn_benchmark.modeling.language_backbone import transformers as ref_lb
     from maskrcnn_benchmark.structures.bounding_box import BoxList
     from maskrcnn_benchmark.structures.image_list import to_image_list
     from maskrcnn_benchmark.structures.segmentation_mask import SegmentationMask
+
+    # (what gen_student sets up when the whole script runs; needed when this generator runs alone)
+    ref_import._namespace_pkg("maskrcnn_benchmark.modeling.detector",
+                              os.path.join(ref_import.REF, "maskrcnn_benchmark/modeling/detector"))
+    if not getattr(ref_lb.BERT, "_seeded_stand_in", False):
+        ref_lb.BERT = make_bert_class(ref_lb.BERT)
+    from maskrcnn_benchmark.modeling.detector import st_generalized_rcnn as st_mod
 
     torch.set_num_threads(os.cpu_count())
     cfg = ref_import.reference_cfg("student_teacher_mask_rcnn_uncertainty.yaml", FULL_OPTS)
@@ -257,14 +264,14 @@ def gen_student_full():
     model.class_names = list(case.SEEN_NAMES)
     model.roi_heads["box"].predictor.set_class_embeddings(case.text_embeddings())
     model.train()
-    c = case.image_case(0, model.cap_vocab, size=(case.FULL_H, case.FULL_W), n_gt=7, n_nouns=5)
+    c = case.image_case(index, model.cap_vocab, size=(case.FULL_H, case.FULL_W), n_gt=7, n_nouns=5)
     t = BoxList(c["boxes"].clone(), (case.FULL_W, case.FULL_H), mode="xyxy")
     t.add_field("labels", c["labels"].clone())
     t.add_field("masks", SegmentationMask(c["masks"].clone(), (case.FULL_W, case.FULL_H), mode="mask"))
     t.add_field("nn_caption", c["nn_caption"])
     t.add_field("ids_cap", c["ids_cap"].clone())
     t.add_field("is_det", "Yes")
-    out, key = {}, "img0_"
+    out, key = {}, f"img{index}_"
     with Capture(BalancedPositiveNegativeSampler) as cap:
         losses = model(c["image"][None], [t])
         with torch.no_grad():
@@ -303,15 +310,26 @@ def gen_student_full():
     out[key + "adaptive_lamb"] = np.float64(float(model.adaptive_lamb))
     for k, v in losses.items():
         out[key + k] = np.float64(v.item())
-    put_grads(out, model, key + "grad")
-    out["state_names"] = np.array([n for n, _, _ in names])
-    out["state_shapes"] = np.array([",".join(map(str, s)) for _, s, _ in names])
-    out["state_seeded_as"] = np.array([c_ for _, _, c_ in names])
+    if digests:   # (the second image's file serves the two-image combination test: outputs of the frozen half, draws, losses)
+        put_grads(out, model, key + "grad")
+        out["state_names"] = np.array([n for n, _, _ in names])
+        out["state_shapes"] = np.array([",".join(map(str, s)) for _, s, _ in names])
+        out["state_seeded_as"] = np.array([c_ for _, _, c_ in names])
     print("full size", {k: round(v.item(), 6) for k, v in losses.items()}, "proposals", len(props_test[0]), len(props_train[0]),
           "positives", [int(out[key + f"roi_sample{b}_pos"].sum()) for b in (0, 1)], "margins", out[key + "aligned_margin"],
           "features mean/std/max", out[key + "feature_stats"])
-    np.savez_compressed(os.path.join(HERE, "step_student_full.npz"), **out)
+    if not digests:
+        for k in [k for k in out if k.startswith(key + "feature_samples")]:
+            del out[k]
+    np.savez_compressed(os.path.join(HERE, out_name), **out)
     torch.set_num_threads(1)
+
+
+def gen_student_full_second():
+    """The SECOND image of the bench's two-image batch at BASELINE size through the reference's one-image-per-call class ->
+    tests/golden/step_student_full_img1.npz; with step_student_full.npz (image 0) the product's 2-image batch at 3 x 800 x 1333
+    is held to the combination of the two reference runs (tests/test_step_golden.py)."""
+    gen_student_full(index=1, out_name="step_student_full_img1.npz", digests=False)
 
 
 def gen_teacher_full():
@@ -865,17 +883,17 @@ def main():
     ref_import.install()
     torch.Tensor.cuda = lambda self, *a, **k: self  # box_head/loss.py:42,173, language_backbone/transformers.py:60
     gens = [gen_student, gen_student_variants, gen_teacher, gen_teacher_variants, gen_teacher_fixed_rpn, gen_checkpoint_map,
-            gen_student_full, gen_teacher_full, gen_gt_box_eval, gen_uncertainty_freeze]
+            gen_student_full, gen_teacher_full, gen_gt_box_eval, gen_uncertainty_freeze, gen_student_full_second]
     only = sys.argv[1:]  # e.g. ``make_step_golden.py gen_gt_box_eval``: that file alone (each generator builds its own models)
     for g in gens:
         if not only or g.__name__ in only:
-            if g is gen_uncertainty_freeze:
-                # its committed file was made by a run of this generator alone (fresh seed): the sampler draws and the mask
+            if g in (gen_uncertainty_freeze, gen_student_full_second):
+                # their committed files were made by runs of these generators alone (fresh seed): the sampler draws and the mask
                 # noise it records follow the global generator, so a full run re-seeds here to reproduce it byte for byte
                 torch.manual_seed(20260101)
             g()
     for f in ("step_student.npz", "step_student_variants.npz", "step_teacher.npz", "step_teacher_fixed_rpn.npz", "step_student_full.npz",
-              "step_teacher_full.npz", "step_teacher_variants.npz", "step_gt_box_eval.npz", "step_student_freeze.npz"):
+              "step_student_full_img1.npz", "step_teacher_full.npz", "step_teacher_variants.npz", "step_gt_box_eval.npz", "step_student_freeze.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 
