@@ -60,7 +60,7 @@ def test_shipped_library_is_a_product_build_without_experiment_switches():
                "tn_tile_order.patch": "split_gemm.hip", "nms_wide_stores.patch": "nms.hip",
                "roi_bwd_register_plane.patch": "roi_align_bwd_plane.hip", "roi_fwd_table_driven.patch": "roi_align.hip",
                "roi_bwd_round_entries.patch": "roi_align_bwd_plane.hip", "roi_bwd_fp32_stage1.patch": "roi_align_bwd_plane.hip",
-               "roi_bwd_drift_protocol.patch": "roi_align_bwd_plane.hip"}
+               "roi_bwd_drift_protocol.patch": "roi_align_bwd_plane.hip", "roi_bwd_software_pipeline.patch": "roi_align_bwd_plane.hip"}
     assert sorted(targets) == sorted(os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "tools", "experiments", "patches", "*.patch")))
     if shutil.which("patch"):
         for name, src in targets.items():
