@@ -12,6 +12,8 @@ step bash -c 'python bench.py --steps 20 --warmup 5 > "$0"/bench_student_default
 step bash -c 'python bench.py --secondary-steps 0 --steps 60 --warmup 5 --min-seconds 5 --per-shape-csv "$0"/per_shape_student.csv > "$0"/bench_student.json 2> "$0"/bench_student.err' "$OUT"
 step bash -c 'python bench.py --workload teacher --steps 60 --warmup 5 --min-seconds 5 --per-shape-csv "$0"/per_shape_teacher.csv > "$0"/bench_teacher.json 2> "$0"/bench_teacher.err' "$OUT"
 step bash -c 'python bench.py --no-pipeline --no-cpu-baseline --secondary-steps 0 --steps 30 > "$0"/bench_student_nopipe.json 2>/dev/null' "$OUT"
+# the rounds-1..4 protocol (one device batch throughout, 20 steps) beside the current default, so that lines stay comparable
+step bash -c 'python bench.py --resident-input --steps 20 --warmup 5 --no-cpu-baseline --no-roi-micro --secondary-steps 0 > "$0"/bench_student_resident20.json 2>/dev/null' "$OUT"
 step bash -c 'python tools/bench_ops.py > "$0"/bench_ops.txt 2>&1' "$OUT"
 step bash -c 'python tools/experiments/op_count.py > "$0"/op_count.txt 2>&1' "$OUT"
 step bash -c 'bash tools/prof_step.sh student "$0"/prof_student > "$0"/prof_student.txt 2>&1' "$OUT"

@@ -7,6 +7,7 @@ cpf $S/bench_student_default.json $D/${P}_bench_student_default.json
 cpf $S/bench_student.json $D/${P}_bench_student.json
 cpf $S/bench_teacher.json $D/${P}_bench_teacher.json
 cpf $S/bench_student_nopipe.json $D/${P}_bench_student_nopipe.json
+cpf $S/bench_student_resident20.json $D/${P}_bench_student_resident20.json
 cpf $S/per_shape_student.csv $D/${P}_split_gemm_per_shape_student.csv
 cpf $S/per_shape_teacher.csv $D/${P}_split_gemm_per_shape_teacher.csv
 cpf $S/bench_ops.txt $D/${P}_bench_ops.txt
