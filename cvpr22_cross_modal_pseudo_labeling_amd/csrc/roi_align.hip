@@ -182,10 +182,106 @@ __device__ __forceinline__ void fwd_batch_lds4(float* win, const float* __restri
   __syncthreads();
 }
 
+// ---- per-workgroup sample tables (round 6) ---------------------------------------------------------------------------
+// A RoI's sample geometry is the same for every channel, and per axis there are only PH * gh (PW * gw) distinct samples.
+// They are evaluated ONCE per workgroup into two LDS tables -- window-relative tap offsets + the low-side weight, 8 bytes
+// per entry -- by the very expressions of the per-lane code above (every bit of every weight is what it was), instead of
+// once per lane, sample, channel batch and wave (~55 of the ~160 vector instructions a lane spent per sample and batch).
+// The lane <-> bin mapping and the 16-channel batches (which amortise the tap addresses best) stay.
+constexpr int kTabMax = 64;                  // entries per axis table: larger sampling grids take the per-lane path
+struct AxisTap { short lo, hi; float l; };   // lo < 0: the sample lies outside the map (contributes nothing)
+
+template <bool FAST>
+__device__ __forceinline__ void fill_axis_table(AxisTap* tab, int P, int grid, float start, float bin, float inv_g, int size,
+                                                int w0, int scale_lo, int t) {
+  if (t >= 0 && t < P * grid) {
+    const int p = t / grid, i = t - p * grid;
+    const float v = sample_coord_t<FAST>(start, p, bin, i, grid, inv_g);
+    int lo, hi;
+    float l, h;
+    AxisTap e;
+    if (axis_sample(v, size, lo, hi, l, h)) {
+      e.lo = (short)((lo - w0) * scale_lo);
+      e.hi = (short)((hi - w0) * scale_lo);
+      e.l = l;
+    } else {
+      e.lo = -1; e.hi = -1; e.l = 0.f;
+    }
+    tab[t] = e;
+  }
+}
+
+// fwd_pool4 with the geometry read from the tables; `yrow` / `xrow` = the lane's first table entries (ph * gh, pw * gw)
+template <int NCS, bool FAST>
+__device__ __forceinline__ void fwd_pool4_tab(const f4* win4, const AxisTap* ytab, const AxisTap* xtab, int bin, int yrow,
+                                              int xrow, const RoiGeom& g, int PHPW, float* __restrict__ out_c0) {
+  constexpr int NG = NCS / 4;
+  constexpr int SG = kFwdLdsFloats / NCS;  // positions per channel group
+  if (bin >= PHPW) return;
+  f4 acc[NG];
+#pragma unroll
+  for (int k = 0; k < NG; ++k) acc[k] = (f4)(0.f);
+  for (int iy = 0; iy < g.gh; ++iy) {
+    const AxisTap ye = ytab[yrow + iy];
+    if (ye.lo < 0) continue;
+    const float ly = ye.l, hy = 1.f - ly;
+    for (int ix = 0; ix < g.gw; ++ix) {
+      const AxisTap xe = xtab[xrow + ix];
+      if (xe.lo < 0) continue;
+      const float lx = xe.l, hx = 1.f - lx;
+      const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+      const f4* p1 = win4 + (ye.lo + xe.lo);
+      const f4* p2 = win4 + (ye.lo + xe.hi);
+      const f4* p3 = win4 + (ye.hi + xe.lo);
+      const f4* p4 = win4 + (ye.hi + xe.hi);
+#pragma unroll
+      for (int k = 0; k < NG; ++k) {
+        acc[k] += w1 * p1[k * SG] + w2 * p2[k * SG] + w3 * p3[k * SG] + w4 * p4[k * SG];
+        if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NG; ++k) {
+    const f4 o = FAST ? acc[k] * g.inv_count : acc[k] / g.count;
+    (out_c0 + (long)(4 * k) * PHPW)[bin] = o.x;
+    (out_c0 + (long)(4 * k + 1) * PHPW)[bin] = o.y;
+    (out_c0 + (long)(4 * k + 2) * PHPW)[bin] = o.z;
+    (out_c0 + (long)(4 * k + 3) * PHPW)[bin] = o.w;
+  }
+}
+
+template <int NCS>
+__device__ __forceinline__ void fwd_batch_lds4_tab(float* win, const float* __restrict__ plane_c0, int HW, int W,
+                                                   const RoiGeom& g, int wh, int ww, int PHPW, const AxisTap* ytab,
+                                                   const AxisTap* xtab, int bin, int yrow, int xrow,
+                                                   float* __restrict__ out_c0) {
+  constexpr int NG = NCS / 4;
+  constexpr int SG = kFwdLdsFloats / NCS;
+  f4* win4 = (f4*)win;
+  const int warea = wh * ww;
+  const float inv_ww = 1.f / (float)ww;
+  for (int idx = threadIdx.x; idx < warea; idx += kThreads) {
+    const int y = (int)(((float)idx + 0.5f) * inv_ww);
+    const int x = idx - y * ww;
+    const int off = (g.wy0 + y) * W + (g.wx0 + x);
+    float v[NCS];
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) v[c] = (plane_c0 + (long)c * HW)[off];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) win4[k * SG + idx] = (f4){v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+  }
+  __syncthreads();  // (also publishes the tables before their first use)
+  if (g.pow2) fwd_pool4_tab<NCS, true>(win4, ytab, xtab, bin, yrow, xrow, g, PHPW, out_c0);
+  else fwd_pool4_tab<NCS, false>(win4, ytab, xtab, bin, yrow, xrow, g, PHPW, out_c0);
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_kernel(
     const float* __restrict__ in, const float* __restrict__ rois, float* __restrict__ out,
     int R, int batch, int C, int H, int W, int PH, int PW, float scale, int sampling_ratio) {
   __shared__ __attribute__((aligned(16))) float win[kFwdLdsFloats];
+  __shared__ AxisTap ytab[kTabMax], xtab[kTabMax];
   const int r = blockIdx.x % R;
   const int ct = blockIdx.x / R;
   const int c_begin = ct * kCPB;
@@ -207,12 +303,36 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_kernel(
   const float* img = in + (long)g.b * C * HW;
 
   int c = c_begin;
+  // table-driven batches: both axis tables fit, one pass of the workgroup covers the bins, tap offsets fit 16 bits
+  const bool tables = PH * g.gh <= kTabMax && PW * g.gw <= kTabMax && PHPW <= kThreads && warea <= 4352;
+  int t_bin = threadIdx.x, t_yrow = 0, t_xrow = 0;
+  if (tables) {
+    if (g.pow2) {
+      fill_axis_table<true>(ytab, PH, g.gh, g.start_h, g.bin_h, g.inv_gh, H, g.wy0, ww, threadIdx.x);
+      fill_axis_table<true>(xtab, PW, g.gw, g.start_w, g.bin_w, g.inv_gw, W, g.wx0, 1, (int)threadIdx.x - 128);
+    } else {
+      fill_axis_table<false>(ytab, PH, g.gh, g.start_h, g.bin_h, g.inv_gh, H, g.wy0, ww, threadIdx.x);
+      fill_axis_table<false>(xtab, PW, g.gw, g.start_w, g.bin_w, g.inv_gw, W, g.wx0, 1, (int)threadIdx.x - 128);
+    }
+    const int ph = (int)(((float)t_bin + 0.5f) * (1.f / (float)PW));  // exact for these sizes; once per lane, not per batch
+    t_yrow = ph * g.gh;
+    t_xrow = (t_bin - ph * PW) * g.gw;
+  }
   while (c < c_end) {
     const int left = c_end - c;
     const float* plane = img + (long)c * HW;
     float* o = out_r + (long)c * PHPW;
     const int n = min(left, cs_max);
-    if (n >= 16) {
+    if (tables && n >= 16) {
+      fwd_batch_lds4_tab<16>(win, plane, HW, W, g, wh, ww, PHPW, ytab, xtab, t_bin, t_yrow, t_xrow, o);
+      c += 16;
+    } else if (tables && n >= 8) {
+      fwd_batch_lds4_tab<8>(win, plane, HW, W, g, wh, ww, PHPW, ytab, xtab, t_bin, t_yrow, t_xrow, o);
+      c += 8;
+    } else if (tables && n >= 4) {
+      fwd_batch_lds4_tab<4>(win, plane, HW, W, g, wh, ww, PHPW, ytab, xtab, t_bin, t_yrow, t_xrow, o);
+      c += 4;
+    } else if (n >= 16) {
       fwd_batch_lds4<16>(win, plane, HW, W, H, g, wh, ww, PH, PW, o);
       c += 16;
     } else if (n >= 8) {
