@@ -137,3 +137,43 @@ def test_tn_slice_count_fills_the_rounds_of_resident_workgroups():
     s = f(25088, 512, 8192, 1)   # 256 tiles
     assert (s * 256) / (-(-(s * 256) // slots) * slots) >= 0.9 and s >= 2
     assert f(64, 128, 128, 1) == 1 and f(0, 128, 128, 1) == 1   # tiny / empty problems: one slice
+
+
+def test_co_scheduled_marks_launches_per_thread():
+    """``_C.co_scheduled()`` ORs config bit 16 (K cut for least total work) into the split-GEMM launches of the CALLING thread
+    only -- the look-ahead half of the pipelined step may be issued by a worker thread while the training thread launches the
+    student half."""
+    import threading
+
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+
+    assert _C._gemm_cfg(0) == 0 and _C._gemm_cfg(2) == 2
+    seen = {}
+
+    def worker():
+        seen["worker_outside"] = _C._gemm_cfg(0)
+        with _C.co_scheduled():
+            seen["worker_inside"] = _C._gemm_cfg(1)
+            ready.set()
+            done.wait(5)
+        seen["worker_after"] = _C._gemm_cfg(0)
+
+    ready, done = threading.Event(), threading.Event()
+    t = threading.Thread(target=worker)
+    t.start()
+    assert ready.wait(5)
+    seen["main_while_worker_inside"] = _C._gemm_cfg(0)
+    done.set()
+    t.join()
+    assert seen == {"worker_outside": 0, "worker_inside": 0x10001, "main_while_worker_inside": 0, "worker_after": 0}
+    with _C.co_scheduled():
+        with _C.co_scheduled(False):
+            assert _C._gemm_cfg(0) == 0
+        assert _C._gemm_cfg(0) == 0x10000
+    # the library accepts the bit and sizes the slabs for the plan it selects (round-5 rule: 2 slices for the RPN head's 3x3)
+    lib = _C._L
+    plain = lib.ovis_split_gemm_pair_workspace_bytes_ex(8400, 1024, 1024, 0, 3, 3, 84, 0)
+    co = lib.ovis_split_gemm_pair_workspace_bytes_ex(8400, 1024, 1024, 0, 3, 3, 84, 0x10000)
+    assert plain == 4 * 8400 * 1024 * 4 and co == 2 * 8400 * 1024 * 4
+    assert lib.ovis_split_gemm_pair_workspace_bytes(8400, 1024, 1024, 0, 3, 3, 84) == plain
+    assert lib.ovis_gemm_f32_workspace_bytes(768, 2048, 1024) > 0 and lib.ovis_gemm_f32_workspace_bytes(4096, 4096, 64) == 0
