@@ -267,6 +267,42 @@ def test_training_steps_are_bit_reproducible(name):
         assert any(float(w0[n].sub(p.detach().cuda()).abs().max()) > 0 for n, p in model.named_parameters() if n in w0)  # it trained
 
 
+def test_rpn_loss_beside_the_selection_equals_the_one_stream_order():
+    """Teacher step: the RPN loss is issued on a second stream beside the proposal selection (``RPNModule.forward``), its
+    backward beside the box head's.  Same kernels on the same operands, only the stream differs: losses and every gradient
+    are IDENTICAL to the one-stream order, bit for bit, three steps in a row."""
+    import copy
+
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import trainer
+
+    model, e_vocab, e_seen, images, targets = _build("zeroshot_mask")
+    images = images.cuda()
+    tg = [t.to("cuda") for t in targets]
+
+    def run(beside):
+        m = copy.deepcopy(model).cuda()
+        m.set_class_embeddings(e_seen.cuda())
+        m.train()
+        assert m.rpn.loss_beside_selection
+        m.rpn.loss_beside_selection = beside
+        out = []
+        for i in range(3):
+            torch.manual_seed(7 + i)
+            m.zero_grad(set_to_none=True)
+            loss_dict = m(images, tg)
+            trainer.total_loss(loss_dict).backward()
+            torch.cuda.synchronize()
+            out.append(({k: float(v.detach()) for k, v in loss_dict.items()},
+                        {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
+        return out
+
+    one, two = run(False), run(True)
+    for (la, ga), (lb, gb) in zip(one, two):
+        assert la == lb and "loss_objectness" in la and "loss_rpn_box_reg" in la
+        assert set(ga) == set(gb) and any(n.startswith("rpn.head") for n in ga)
+        assert [n for n in ga if not torch.equal(ga[n], gb[n])] == []
+
+
 def test_rpn_shared_selection_matches_two_selections():
     """RPNModule.proposals_train_and_test (one decode + NMS pass per image) returns exactly the proposals of the
     train-mode and the test-mode selection run separately."""
