@@ -321,6 +321,32 @@ def nms_presorted_batched(boxes, drop, threshold, below=0, ge_mode=False):
     return keep, counts
 
 
+def topk_sorted(scores, k):
+    """``scores.topk(k, dim=1, sorted=True)`` of a [N, A] score matrix in three launches (``ovis_topk_sorted_f32``: one device
+    radix sort of the batch; rpn/inference.py:95) -> (values [N, k] descending, indices [N, k] int64).  Equal scores come in
+    ascending index order."""
+    if not scores.is_cuda or scores.dtype != torch.float32 or scores.dim() != 2:
+        raise RuntimeError("topk_sorted: float32 HIP tensor [N, A] expected (the product path has no CPU fallback)")
+    n, a = scores.shape
+    if not 0 <= k <= a:
+        raise RuntimeError(f"topk_sorted: k = {k} out of range for rows of {a}")
+    if a > 1 and scores.stride(1) != 1:
+        scores = scores.contiguous()
+    vals = torch.empty((n, k), dtype=torch.float32, device=scores.device)
+    idx = torch.empty((n, k), dtype=torch.int64, device=scores.device)
+    if n == 0 or k == 0:
+        return vals, idx
+    need = _L.ovis_topk_sorted_workspace_bytes(n, a)
+    if need == 0:
+        raise RuntimeError(f"topk_sorted: unsupported size [{n}, {a}]")
+    ws = torch.empty((need,), dtype=torch.uint8, device=scores.device)
+    with _on(scores.device):
+        rc = _L.ovis_topk_sorted_f32(scores.data_ptr(), scores.stride(0) if n > 1 else a, n, a, k, vals.data_ptr(),
+                                     idx.data_ptr(), ws.data_ptr(), need, _stream())
+    _lib.check(rc, "topk_sorted")
+    return vals, idx
+
+
 def rpn_decode(box_regression, topk_idx, cell_anchors, image_wh, weights, xform_clip, min_size, anchor_stride):
     """Decode + clip + small-box flag of the top-k RPN candidates of a batch in one launch (``ovis_rpn_decode_f32``;
     rpn/inference.py:95-114).  box_regression [N, 4A, H, W] (any strides with stride(2) == W * stride(3): NCHW, or the

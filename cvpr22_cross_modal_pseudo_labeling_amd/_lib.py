@@ -45,6 +45,8 @@ SIGNATURES = {
     "ovis_gather_rows": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovis_rois_from_boxes_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "ovis_deform_conv_implicit_f32": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _l] + [_i] * 16 + [_vp]),
+    "ovis_topk_sorted_workspace_bytes": (_sz, [_i, _i]),
+    "ovis_topk_sorted_f32": (_i, [_vp, _l, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ovis_rpn_decode_f32": (_i, [_vp, _l, _l, _l, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp]),
     "ovis_sigmoid_focal_loss_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "ovis_sigmoid_focal_loss_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),

@@ -192,7 +192,7 @@ class RPNPostProcessor(nn.Module):  # inference.py:15-140 (single feature map)
         from .. import _C
         n, a, h, w = objectness.shape
         obj = permute_and_flatten(objectness, n, a, 1, h, w).view(n, -1).sigmoid()
-        scores, topk_idx = obj.topk(pre, dim=1, sorted=True)
+        scores, topk_idx = _C.topk_sorted(obj, pre)  # (torch.topk: ~80 launches for 12000 of 63000)
         ag = self.__dict__["anchor_generator"]
         boxes, drop = _C.rpn_decode(box_regression, topk_idx, ag.cell_anchors, ag.image_wh([b.size for b in anchors], obj.device),
                                     self.box_coder.weights, self.box_coder.bbox_xform_clip, self.min_size, ag.stride)

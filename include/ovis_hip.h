@@ -180,6 +180,18 @@ int ovis_nms_presorted_batched_f32(const float* boxes, const int32_t* drop, int 
                                    int64_t* keep_out, int32_t* num_keep, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Sorted top-k of the RPN scores             mb/modeling/rpn/inference.py:95
+ *   (`objectness.topk(pre_nms_top_n, dim=1, sorted=True)` on the sigmoid scores of the batch)
+ * scores [num_rows, row_len] (row stride row_stride, in floats) -> out_scores / out_idx [num_rows, k]: the k largest
+ * entries of every row in DESCENDING order and their positions in the row; equal scores come in ascending position
+ * (torch.topk leaves the order of ties open).  One key-building launch, one device radix sort of the whole batch
+ * (rocPRIM), one emitting launch.  num_rows <= 65535, num_rows * row_len < 2^31.
+ * ---------------------------------------------------------------------------------- */
+size_t ovis_topk_sorted_workspace_bytes(int num_rows, int row_len);
+int ovis_topk_sorted_f32(const float* scores, long row_stride, int num_rows, int row_len, int k, float* out_scores,
+                         int64_t* out_idx, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * RPN proposal decode                        mb/modeling/rpn/inference.py:95-114,
  *   mb/modeling/box_coder.py:49-95, mb/structures/bounding_box.py:214-225, mb/structures/boxlist_ops.py:34-49
  * For every image and every candidate k < num_candidates: anchor index topk_idx[image, k] = (y * feature_width + x) *

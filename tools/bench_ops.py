@@ -181,6 +181,11 @@ def main():
             keep, num = _C.nms_padded(boxes, scores, 0.7)
             res.append({"op": "nms", "K": k, "kept": int(num), "ms": ms, "alg_MB": alg / 1e6, "GBps": alg / ms / 1e6,
                         "MIoU_per_s": k * (k - 1) / 2 / ms / 1e3})
+    if "topk" in ops:  # the RPN's sorted top-k: 12000 of 50 * 84 * 15 = 63000 scores per image, two images
+        sc = torch.rand(2, 63000, generator=g).to(dev)
+        ms = timeit(lambda: _C.topk_sorted(sc, 12000), args.iters)
+        ms_t = timeit(lambda: sc.topk(12000, dim=1, sorted=True), args.iters)
+        res.append({"op": "topk_sorted", "shape": "[2,63000] k=12000", "ms": ms, "torch_topk_ms": ms_t})
     if "focal" in ops:
         m, c = 400000, 80
         logits = (torch.randn(m, c, generator=g) * 2).to(dev)
