@@ -65,7 +65,10 @@ class GeneralizedRCNN(nn.Module):
             self.rpn.eval()
         images = to_image_list(images)
         features = self.backbone(images.tensors) if prefix is None else self.backbone.body(images.tensors, prefix=prefix)
-        proposals, proposal_losses = self.rpn(images, features, targets)
+        if self.rpn.runs_ahead(features):  # trainable RPN on a device: its backward runs ahead on a second stream
+            proposals, proposal_losses, features = self.rpn.forward_ahead(images, features, targets)
+        else:
+            proposals, proposal_losses = self.rpn(images, features, targets)
         _, result, detector_losses = self.roi_heads(features, proposals, targets, is_eval_func=True)
         if self.training:
             losses = {}

@@ -375,6 +375,45 @@ class RPNLossComputation:  # loss.py:21-131
         return objectness_loss, box_loss
 
 
+class _BranchRunAhead(torch.autograd.Function):
+    """Joins a branch whose backward was already run (``RPNModule.forward_ahead``) to the graph: identity on the feature and on
+    the branch's (detached) loss values in the forward; the backward hands on the feature gradient PLUS the branch's
+    pre-computed one, and the branch's parameter gradients -- each times the gradient the loss values receive, which a sum
+    of loss terms hands to every term alike (``losses = sum(loss_dict.values())``, engine/trainer.py:96, also under
+    GRADIENT_ACCUMULATION_STEPS' 1 / k).  Two loss terms that receive DIFFERENT gradients cannot be served from one
+    pre-computed pass: the gradients turn NaN rather than silently wrong."""
+
+    @staticmethod
+    def forward(ctx, done, pre, feature, *loss_and_params):
+        ctx.done, ctx.pre = done, pre  # event on the branch's stream; [d/d feature, d/d parameter ...] for unit loss gradients
+        return (feature.view_as(feature),) + tuple(t.view_as(t) for t in loss_and_params[:2])
+
+    @staticmethod
+    def backward(ctx, g_feature, g_lo, g_lb):
+        main = torch.cuda.current_stream()
+        main.wait_event(ctx.done)
+        pre = ctx.pre
+        for t in pre:
+            if t is not None:
+                t.record_stream(main)
+        ref = next(t for t in pre if t is not None)
+        zero = ref.new_zeros(())
+        g_lo = zero if g_lo is None else g_lo.reshape(())
+        g_lb = zero if g_lb is None else g_lb.reshape(())
+        s = torch.where(g_lo == g_lb, g_lo, torch.full_like(g_lo, float("nan")))
+        out_feature = None
+        if ctx.needs_input_grad[2]:
+            if pre[0] is None:
+                out_feature = g_feature
+            elif g_feature is None:
+                out_feature = pre[0] * s
+            else:
+                out_feature = torch.addcmul(g_feature, pre[0], s)
+        live = [t for t in pre[1:] if t is not None]
+        scaled = iter(torch._foreach_mul(live, s) if live else [])
+        return (None, None, out_feature, None, None) + tuple(None if t is None else next(scaled) for t in pre[1:])
+
+
 class RPNModule(nn.Module):  # rpn.py:109-197
     def __init__(self, cfg, in_channels):
         super().__init__()
@@ -394,6 +433,7 @@ class RPNModule(nn.Module):  # rpn.py:109-197
             Matcher(r.FG_IOU_THRESHOLD, r.BG_IOU_THRESHOLD, allow_low_quality_matches=True),
             BalancedPositiveNegativeSampler(r.BATCH_SIZE_PER_IMAGE, r.POSITIVE_FRACTION), coder)
         self.loss_beside_selection = True  # False = one stream (the A/B switch of the measurement, and of the test)
+        self.backward_ahead = True         # ``forward_ahead``; False = the branch's backward inside the caller's
 
     def forward(self, images, features, targets=None, compute_loss=True, head_out=None):
         """``head_out``: (objectness, box_regression) of ``self.head`` on the same features, when the caller already
@@ -426,6 +466,45 @@ class RPNModule(nn.Module):  # rpn.py:109-197
                 lo, lb = self.loss_evaluator(anchors, objectness, box_regression, targets)
             return boxes, {"loss_objectness": lo, "loss_rpn_box_reg": lb}
         return self.box_selector_test(anchors, objectness, box_regression), {}
+
+    def forward_ahead(self, images, features, targets):
+        """Training step of a TRAINABLE RPN on a device, with the branch's backward run ahead: head, loss and the whole
+        backward of the two RPN losses (0.96 ms of 3x3 data / weight gradient GEMMs) are issued on a second stream as soon
+        as the trunk's feature exists, and run beside the proposal selection, its host read and the box head's sampling --
+        a stretch of single-workgroup kernels (NMS reduce 0.33 ms) and host round trips that leaves the machine empty.
+        Returns (proposals, losses, features): the caller continues from the RETURNED features -- the same values, joined
+        to the graph through ``_BranchRunAhead`` so that the trunk receives box-head + RPN gradient and the head's parameters
+        theirs when (and only if) the caller's backward arrives.  Same kernels on the same operands as ``forward``:
+        losses and gradients are bit-identical (tests/test_model_gpu.py)."""
+        from ..engine.trainer import side_stream
+        feature = features[0]
+        main, side = torch.cuda.current_stream(), side_stream(0)
+        anchors = self.anchor_generator(images.image_sizes, feature)
+        params = [p for p in self.head.parameters() if p.requires_grad]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            branch_in = feature.detach().requires_grad_(feature.requires_grad)
+            objectness, box_regression = self.head(branch_in)
+            head_done = torch.cuda.Event()
+            head_done.record(side)
+            lo, lb = self.loss_evaluator(anchors, objectness, box_regression, targets)
+            wrt = ([branch_in] if branch_in.requires_grad else []) + params
+            grads = list(torch.autograd.grad([lo + lb], wrt, allow_unused=True))
+            pre = grads if branch_in.requires_grad else [None] + grads
+            done = torch.cuda.Event()
+            done.record(side)
+        main.wait_event(head_done)
+        for t in (objectness, box_regression, lo, lb):
+            t.record_stream(main)
+        with torch.no_grad():
+            boxes = self.box_selector_train(anchors, objectness.detach(), box_regression.detach(), targets, add_gt=True)
+        joined, lo, lb = _BranchRunAhead.apply(done, pre, feature, lo.detach(), lb.detach(), *params)
+        return boxes, {"loss_objectness": lo, "loss_rpn_box_reg": lb}, [joined] + list(features[1:])
+
+    def runs_ahead(self, features):
+        """Whether ``forward_ahead`` serves this call: training with a loss to compute, on a device, something to train."""
+        return (self.training and self.backward_ahead and features[0].is_cuda and torch.is_grad_enabled()
+                and any(p.requires_grad for p in self.head.parameters()))
 
     @torch.no_grad()
     def proposals_train_and_test(self, images, features, targets, head_out=None):

@@ -267,10 +267,12 @@ def test_training_steps_are_bit_reproducible(name):
         assert any(float(w0[n].sub(p.detach().cuda()).abs().max()) > 0 for n, p in model.named_parameters() if n in w0)  # it trained
 
 
-def test_rpn_loss_beside_the_selection_equals_the_one_stream_order():
-    """Teacher step: the RPN loss is issued on a second stream beside the proposal selection (``RPNModule.forward``), its
-    backward beside the box head's.  Same kernels on the same operands, only the stream differs: losses and every gradient
-    are IDENTICAL to the one-stream order, bit for bit, three steps in a row."""
+def test_rpn_branch_on_a_second_stream_equals_the_one_stream_order():
+    """Teacher step.  (a) ``RPNModule.forward`` issues the RPN loss on a second stream beside the proposal selection;
+    (b) ``RPNModule.forward_ahead`` (what the detector calls) also runs the branch's whole BACKWARD ahead on that stream and
+    joins its gradients to the graph.  Same kernels on the same operands, only stream and order of issue differ: losses and
+    every gradient are IDENTICAL to the one-stream order, bit for bit, three steps in a row -- also under the 1 / 2 of a
+    gradient accumulation; two loss terms weighted differently cannot be served by the run-ahead pass and give NaN, loudly."""
     import copy
 
     from cvpr22_cross_modal_pseudo_labeling_amd.engine import trainer
@@ -279,28 +281,38 @@ def test_rpn_loss_beside_the_selection_equals_the_one_stream_order():
     images = images.cuda()
     tg = [t.to("cuda") for t in targets]
 
-    def run(beside):
+    def run(beside, ahead, scale=1.0, skew=False):
         m = copy.deepcopy(model).cuda()
         m.set_class_embeddings(e_seen.cuda())
         m.train()
-        assert m.rpn.loss_beside_selection
-        m.rpn.loss_beside_selection = beside
+        assert m.rpn.loss_beside_selection and m.rpn.backward_ahead
+        m.rpn.loss_beside_selection, m.rpn.backward_ahead = beside, ahead
         out = []
         for i in range(3):
             torch.manual_seed(7 + i)
             m.zero_grad(set_to_none=True)
             loss_dict = m(images, tg)
-            trainer.total_loss(loss_dict).backward()
+            total = trainer.total_loss(loss_dict) * scale
+            if skew:
+                total = total + loss_dict["loss_objectness"]
+            total.backward()
             torch.cuda.synchronize()
             out.append(({k: float(v.detach()) for k, v in loss_dict.items()},
                         {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
         return out
 
-    one, two = run(False), run(True)
-    for (la, ga), (lb, gb) in zip(one, two):
-        assert la == lb and "loss_objectness" in la and "loss_rpn_box_reg" in la
-        assert set(ga) == set(gb) and any(n.startswith("rpn.head") for n in ga)
-        assert [n for n in ga if not torch.equal(ga[n], gb[n])] == []
+    for scale in (1.0, 0.5):
+        one = run(False, False, scale)
+        for beside, ahead in ((True, False), (True, True)):
+            two = run(beside, ahead, scale)
+            for (la, ga), (lb, gb) in zip(one, two):
+                assert la == lb and "loss_objectness" in la and "loss_rpn_box_reg" in la
+                assert set(ga) == set(gb) and any(n.startswith("rpn.head") for n in ga) and any(n.startswith("backbone") for n in ga)
+                assert [n for n in ga if not torch.equal(ga[n], gb[n])] == [], (scale, beside, ahead)
+    _, g = run(True, True, skew=True)[0]
+    assert all(torch.isnan(g[n]).all() for n in g if n.startswith("rpn.head"))
+    _, g = run(True, False, skew=True)[0]   # ... which the in-graph backward serves
+    assert all(torch.isfinite(g[n]).all() for n in g)
 
 
 def test_rpn_shared_selection_matches_two_selections():
