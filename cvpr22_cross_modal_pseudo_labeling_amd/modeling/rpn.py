@@ -212,11 +212,21 @@ class RPNPostProcessor(nn.Module):  # inference.py:15-140 (single feature map)
     def forward(self, anchors, objectness, box_regression, targets=None, add_gt=False):
         if not self._on_device(objectness):
             return self.forward_tensor_ops(anchors, objectness, box_regression, targets, add_gt)
+        return self.finish(self.launch(anchors, objectness, box_regression), targets, add_gt)
+
+    def launch(self, anchors, objectness, box_regression):
+        """Device pipeline, first half: every launch of the selection, no host read -- the caller may issue independent work
+        (the RPN loss and its backward, on another stream) before ``finish`` waits for the survivor counts."""
         from .. import _C
         n, a, h, w = objectness.shape
         scores, boxes, drop = self._candidates(anchors, objectness, box_regression, min(self.pre_nms_top_n, a * h * w))
         keep, counts = _C.nms_presorted_batched(boxes, drop, self.nms_thresh)
         pb, ps = self._gather(boxes, scores, keep, self.post_nms_top_n)
+        return anchors, pb, ps, counts
+
+    def finish(self, launched, targets=None, add_gt=False):
+        anchors, pb, ps, counts = launched
+        n = pb.shape[0]
         cnt = counts[:, 0].tolist()  # the one host read of the selection
         result = []
         for i in range(n):
@@ -445,25 +455,30 @@ class RPNModule(nn.Module):  # rpn.py:109-197
         if self.training:
             # Loss and selection both start from the head's outputs and neither reads the other's result, and both are
             # chains of small launches around single-workgroup kernels (fg / bg sampler 2 x 113 us, NMS reduce 329 us):
-            # on a device the loss is issued first, on a second stream, and runs beside the selection (and its backward
-            # beside the box head's: autograd runs a node on the stream of its forward).
-            beside = compute_loss and objectness.is_cuda and self.loss_beside_selection
+            # on a device the loss goes to a second stream and runs beside the selection (and its backward beside the box
+            # head's: autograd runs a node on the stream of its forward); the selection's launches are issued first, its one
+            # host read last.
+            sel = self.box_selector_train
+            beside = compute_loss and objectness.is_cuda and self.loss_beside_selection and sel._on_device(objectness)
             if beside:
                 from ..engine.trainer import side_stream
                 main, side = torch.cuda.current_stream(), side_stream(0)
                 side.wait_stream(main)
+                with torch.no_grad():
+                    launched = sel.launch(anchors, objectness, box_regression)  # its launches first: they are the critical path
                 with torch.cuda.stream(side):
                     lo, lb = self.loss_evaluator(anchors, objectness, box_regression, targets)
-            with torch.no_grad():
-                boxes = self.box_selector_train(anchors, objectness, box_regression, targets, add_gt=True)
-            if not compute_loss:
-                return boxes, {}
-            if beside:
+                with torch.no_grad():
+                    boxes = sel.finish(launched, targets, add_gt=True)
                 main.wait_stream(side)
                 lo.record_stream(main)
                 lb.record_stream(main)
-            else:
-                lo, lb = self.loss_evaluator(anchors, objectness, box_regression, targets)
+                return boxes, {"loss_objectness": lo, "loss_rpn_box_reg": lb}
+            with torch.no_grad():
+                boxes = sel(anchors, objectness, box_regression, targets, add_gt=True)
+            if not compute_loss:
+                return boxes, {}
+            lo, lb = self.loss_evaluator(anchors, objectness, box_regression, targets)
             return boxes, {"loss_objectness": lo, "loss_rpn_box_reg": lb}
         return self.box_selector_test(anchors, objectness, box_regression), {}
 
@@ -487,17 +502,26 @@ class RPNModule(nn.Module):  # rpn.py:109-197
             objectness, box_regression = self.head(branch_in)
             head_done = torch.cuda.Event()
             head_done.record(side)
+        main.wait_event(head_done)
+        objectness.record_stream(main)
+        box_regression.record_stream(main)
+        sel = self.box_selector_train
+        on_device = sel._on_device(objectness)
+        if on_device:  # the selection's launches first (they are the critical path), its host read after the branch's launches
+            with torch.no_grad():
+                launched = sel.launch(anchors, objectness.detach(), box_regression.detach())
+        with torch.cuda.stream(side):
             lo, lb = self.loss_evaluator(anchors, objectness, box_regression, targets)
             wrt = ([branch_in] if branch_in.requires_grad else []) + params
             grads = list(torch.autograd.grad([lo + lb], wrt, allow_unused=True))
             pre = grads if branch_in.requires_grad else [None] + grads
             done = torch.cuda.Event()
             done.record(side)
-        main.wait_event(head_done)
-        for t in (objectness, box_regression, lo, lb):
-            t.record_stream(main)
+        lo.record_stream(main)
+        lb.record_stream(main)
         with torch.no_grad():
-            boxes = self.box_selector_train(anchors, objectness.detach(), box_regression.detach(), targets, add_gt=True)
+            boxes = (sel.finish(launched, targets, add_gt=True) if on_device else
+                     sel(anchors, objectness.detach(), box_regression.detach(), targets, add_gt=True))
         joined, lo, lb = _BranchRunAhead.apply(done, pre, feature, lo.detach(), lb.detach(), *params)
         return boxes, {"loss_objectness": lo, "loss_rpn_box_reg": lb}, [joined] + list(features[1:])
 
