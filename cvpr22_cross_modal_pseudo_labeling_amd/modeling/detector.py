@@ -44,6 +44,7 @@ class GeneralizedRCNN(nn.Module):
         if self.fix_rpn:
             for p in self.rpn.parameters():
                 p.requires_grad = False
+        self.heads_as_one_branch = True  # False = ``CombinedROIHeads.forward`` in training too (cross-check / A-B switch)
 
     def set_class_embeddings(self, embs):
         self.roi_heads["box"].predictor.set_class_embeddings(embs)
@@ -69,7 +70,18 @@ class GeneralizedRCNN(nn.Module):
             proposals, proposal_losses, features = self.rpn.forward_ahead(images, features, targets)
         else:
             proposals, proposal_losses = self.rpn(images, features, targets)
-        _, result, detector_losses = self.roi_heads(features, proposals, targets, is_eval_func=True)
+        heads = self.roi_heads
+        predictor = heads["box"].predictor
+        if (self.training and self.heads_as_one_branch and heads.branches_batchable(features[0])
+                and torch.is_tensor(getattr(predictor, "cls_score", None))):
+            # the student's batched-branch form with ONE branch: the last res5 block hands the positives' maps to the mask
+            # head itself, and their gradient enters its backward as dense maps -- no 411 MB zero tensor + scatter + dense
+            # read in front of the res5 backward
+            result = None
+            (detector_losses,) = heads.forward_branches(features[0], [dict(
+                image_ids=list(range(len(proposals))), proposals=proposals, targets=targets, cls_embs=predictor.cls_score)])
+        else:
+            _, result, detector_losses = heads(features, proposals, targets, is_eval_func=True)
         if self.training:
             losses = {}
             losses.update(detector_losses)

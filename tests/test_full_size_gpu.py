@@ -289,14 +289,14 @@ def test_teacher_step_at_baseline_size_matches_oracle_backed_cpu():
 
     # shared: proposals (recorded on the device, handed to the CPU side) and both samplers' draws
     proposals = []
-    select = model.rpn.box_selector_train.forward
+    select = model.rpn.box_selector_train.finish  # (the device selection = launch() + finish(); finish hands out the lists)
 
     def recording(*a, **k):
         out = select(*a, **k)
         proposals.append([b.to("cpu") for b in out])
         return out
 
-    model.rpn.box_selector_train.forward = recording
+    model.rpn.box_selector_train.finish = recording
     cpu_model.rpn.box_selector_train.forward = lambda *a, **k: proposals[0]
     drawn_rpn = _share_sampling(model, cpu_model, (model.rpn.loss_evaluator, cpu_model.rpn.loss_evaluator))
     drawn_box = _share_sampling(model, cpu_model, (model.roi_heads["box"].loss_evaluator, cpu_model.roi_heads["box"].loss_evaluator))

@@ -315,6 +315,40 @@ def test_rpn_branch_on_a_second_stream_equals_the_one_stream_order():
     assert all(torch.isfinite(g[n]).all() for n in g)
 
 
+def test_teacher_heads_as_one_batched_branch_match_the_plain_heads():
+    """Teacher step: ``GeneralizedRCNN.forward`` runs its heads through ``CombinedROIHeads.forward_branches`` with ONE branch
+    (the last res5 block hands the positives' maps to the mask head and takes their gradient as dense maps).  Same sampling,
+    same losses; the gradients agree with ``CombinedROIHeads.forward``'s to round-off (the mask gradient joins the pooled
+    one inside the gate kernel instead of through a scatter + add)."""
+    import copy
+
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import trainer
+
+    model, e_vocab, e_seen, images, targets = _build("zeroshot_mask")
+    images = images.cuda()
+    tg = [t.to("cuda") for t in targets]
+
+    def run(one_branch):
+        m = copy.deepcopy(model).cuda()
+        m.set_class_embeddings(e_seen.cuda())
+        m.train()
+        assert m.heads_as_one_branch
+        m.heads_as_one_branch = one_branch
+        torch.manual_seed(11)
+        loss_dict = m(images, tg)
+        trainer.total_loss(loss_dict).backward()
+        return ({k: float(v.detach()) for k, v in loss_dict.items()},
+                {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+
+    (la, ga), (lb, gb) = run(False), run(True)
+    assert set(la) == set(lb) == {"loss_classifier", "loss_box_reg", "loss_mask", "loss_objectness", "loss_rpn_box_reg"}
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-6 * max(abs(la[k]), 1.0), (k, la[k], lb[k])
+    assert set(ga) == set(gb)
+    for n in ga:
+        assert torch.allclose(ga[n], gb[n], rtol=1e-4, atol=1e-6 * float(ga[n].abs().max()) + 1e-12), n
+
+
 def test_rpn_shared_selection_matches_two_selections():
     """RPNModule.proposals_train_and_test (one decode + NMS pass per image) returns exactly the proposals of the
     train-mode and the test-mode selection run separately."""

@@ -138,6 +138,23 @@ def _draws(d, key, ids):
     return [(torch.from_numpy(d[f"{key}{k}_pos"]), torch.from_numpy(d[f"{key}{k}_neg"])) for k in ids]
 
 
+
+def _swap_rpn_proposals(model, swap):
+    """The RoI heads run on ``swap(the RPN's own train-mode proposals)``: hooks both entry points of the RPN the detector
+    uses in training (``forward``; on a device ``forward_ahead``, which also returns the features joined to its run-ahead
+    backward)."""
+    rpn_forward, rpn_ahead = model.rpn.forward, model.rpn.forward_ahead
+
+    def forward(*a, **k):
+        props, losses = rpn_forward(*a, **k)
+        return swap(props), losses
+
+    def forward_ahead(*a, **k):
+        props, losses, feats = rpn_ahead(*a, **k)
+        return swap(props), losses, feats
+
+    model.rpn.forward, model.rpn.forward_ahead = forward, forward_ahead
+
 def _replay(evaluator, d, key, ids):
     s = evaluator.sampler if hasattr(evaluator, "sampler") else evaluator.fg_bg_sampler
     r = ReplaySampler(s.batch_size_per_image, s.positive_fraction, _draws(d, key, ids))
@@ -562,17 +579,13 @@ def run_teacher(device, tol_feat, tol_grad, staged):
     with _ops(device):
         if staged:
             # the RoI heads on the fixture's proposals: swap the RPN's selected boxes for the reference's
-            rpn_forward = model.rpn.forward
-
-            def forward(*a, **k):
-                props, losses = rpn_forward(*a, **k)
+            def swap(props):
                 for i, p in enumerate(props):
                     assert boxes_match(p.bbox, torch.from_numpy(d[f"proposals_train{i}_bbox"]), 1.0 if device == "cpu" else 0.95)
-                props = [BoxList(torch.from_numpy(d[f"proposals_train{i}_bbox"]).to(device), (case.IMAGE_W, case.IMAGE_H))
-                         for i in range(2)]
-                return props, losses
+                return [BoxList(torch.from_numpy(d[f"proposals_train{i}_bbox"]).to(device), (case.IMAGE_W, case.IMAGE_H))
+                        for i in range(2)]
 
-            model.rpn.forward = forward
+            _swap_rpn_proposals(model, swap)
         losses = model(images, targets)
         sum(losses.values()).backward()
         with torch.no_grad():
@@ -1033,15 +1046,12 @@ def test_teacher_step_at_baseline_size_hip_vs_reference_fixture():
     else:
         ev.fg_bg_sampler = rep
     _replay(model.roi_heads["box"].loss_evaluator, d, "roi_sample", (0, 1))
-    rpn_forward = model.rpn.forward
-
-    def forward(*a, **k):   # the RoI heads run on the FIXTURE's proposals (2007 per image: 2000 + the 7 ground-truth boxes)
-        props, losses = rpn_forward(*a, **k)
+    def swap(props):   # the RoI heads run on the FIXTURE's proposals (2007 per image: 2000 + the 7 ground-truth boxes)
         for i, p in enumerate(props):
             assert boxes_match(p.bbox, torch.from_numpy(d[f"proposals_train{i}_bbox"]), 0.95)
-        return [BoxList(torch.from_numpy(d[f"proposals_train{i}_bbox"]).to(device), size) for i in range(2)], losses
+        return [BoxList(torch.from_numpy(d[f"proposals_train{i}_bbox"]).to(device), size) for i in range(2)]
 
-    model.rpn.forward = forward
+    _swap_rpn_proposals(model, swap)
     losses = model(images, targets)
     sum(losses.values()).backward()
     with torch.no_grad():
@@ -1083,16 +1093,13 @@ def run_teacher_variant(device, name):
     targets = [make_target(c, device, caption=False) for c in cs]
     _replay(model.rpn.loss_evaluator, v, key + "rpn_sample", (0, 1))
     _replay(model.roi_heads["box"].loss_evaluator, v, key + "roi_sample", (0, 1))
-    rpn_forward = model.rpn.forward
-
-    def forward(*a, **k):
-        props, losses = rpn_forward(*a, **k)
+    def swap(props):
         for i, p in enumerate(props):
             assert boxes_match(p.bbox, torch.from_numpy(v[f"{key}proposals_train{i}_bbox"]), 1.0 if device == "cpu" else 0.95)
         return [BoxList(torch.from_numpy(v[f"{key}proposals_train{i}_bbox"]).to(device), (case.IMAGE_W, case.IMAGE_H))
-                for i in range(2)], losses
+                for i in range(2)]
 
-    model.rpn.forward = forward
+    _swap_rpn_proposals(model, swap)
     with _ops(device):
         losses = model(images, targets)
         sum(losses.values()).backward()
