@@ -2,7 +2,7 @@
     python tools/experiments/ab_bench.py <patch> [bench args...]
 runs bench.py alternately unpatched (A) and with the named monkeypatch applied (B), three times each, and prints ms per step.
 Patches: nopool (the res5 head's average pooling as a separate pass), rpnloss_ops (the RPN loss as its tensor-op sequence;
-use with --workload teacher), lib:<variant> (a variant library of build_variants.sh), side_prio0 (the frozen half's stream at normal priority), no_prefix (teacher step without the frozen trunk prefix run ahead on the side stream; --workload teacher), gated_nosplit (gated data gradients never K-sliced, the form before round 4's _ws entry point; --workload teacher), rpnloss_one_stream (the teacher's RPN loss on the main stream, after the selection; --workload teacher), rpn_no_ahead (the teacher's RPN backward inside the step's backward instead of run ahead on the second stream; --workload teacher), teacher_heads_plain (the teacher's heads through CombinedROIHeads.forward instead of the one-branch batched form; --workload teacher), torch_topk (the RPN's sorted top-k through the tensor library instead of the one-radix-sort op), foreach_sgd (the optimizer step as six multi-tensor passes instead of the fused launch)."""
+use with --workload teacher), lib:<variant> (a variant library of build_variants.sh), side_prio0 (the frozen half's stream at normal priority), no_prefix (teacher step without the frozen trunk prefix run ahead on the side stream; --workload teacher), gated_nosplit (gated data gradients never K-sliced, the form before round 4's _ws entry point; --workload teacher), rpnloss_one_stream (the teacher's RPN loss on the main stream, after the selection; --workload teacher), rpn_no_ahead (the teacher's RPN backward inside the step's backward instead of run ahead on the second stream; --workload teacher), teacher_heads_plain (the teacher's heads through CombinedROIHeads.forward instead of the one-branch batched form; --workload teacher), drop_trunk_dw (WRONG RESULTS, a bound: the bottlenecks' weight gradients are computed but not handed to autograd -- what their AccumulateGrad adds cost), torch_topk (the RPN's sorted top-k through the tensor library instead of the one-radix-sort op), foreach_sgd (the optimizer step as six multi-tensor passes instead of the fused launch)."""
 import json
 import os
 import subprocess
@@ -27,6 +27,9 @@ PATCHES = {
     "teacher_heads_plain": ("from cvpr22_cross_modal_pseudo_labeling_amd.modeling import detector as _d; _i = _d.GeneralizedRCNN.__init__\n"
                             "def _init(self, *a, **k):\n    _i(self, *a, **k); self.heads_as_one_branch = False\n"
                             "_d.GeneralizedRCNN.__init__ = _init"),
+    "drop_trunk_dw": ("from cvpr22_cross_modal_pseudo_labeling_amd.layers import pair_bottleneck as _p; _b = _p._BottleneckPair.backward\n"
+                      "def _bw(ctx, *g):\n    out = list(_b(ctx, *g))\n    for i in (3, 6, 9, 12):\n        out[i] = None\n    return tuple(out)\n"
+                      "_p._BottleneckPair.backward = staticmethod(_bw)"),
     "torch_topk": "from cvpr22_cross_modal_pseudo_labeling_amd import _C; _C.topk_sorted = lambda s, k: s.topk(k, dim=1, sorted=True)",
     "foreach_sgd": "from cvpr22_cross_modal_pseudo_labeling_amd.engine import solver as _s; _s.GroupFusedSGD.native = False",
 }
