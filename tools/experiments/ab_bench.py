@@ -30,6 +30,8 @@ PATCHES = {
     "drop_trunk_dw": ("from cvpr22_cross_modal_pseudo_labeling_amd.layers import pair_bottleneck as _p; _b = _p._BottleneckPair.backward\n"
                       "def _bw(ctx, *g):\n    out = list(_b(ctx, *g))\n    for i in (3, 6, 9, 12):\n        out[i] = None\n    return tuple(out)\n"
                       "_p._BottleneckPair.backward = staticmethod(_bw)"),
+    # (needs tools/experiments/python_patches/trunk_dw_beside.patch applied)
+    "dw_beside": "from cvpr22_cross_modal_pseudo_labeling_amd.layers import pair_bottleneck as _p; _p.DW_BESIDE_ROWS = 40000",
     "torch_topk": "from cvpr22_cross_modal_pseudo_labeling_amd import _C; _C.topk_sorted = lambda s, k: s.topk(k, dim=1, sorted=True)",
     "foreach_sgd": "from cvpr22_cross_modal_pseudo_labeling_amd.engine import solver as _s; _s.GroupFusedSGD.native = False",
 }
