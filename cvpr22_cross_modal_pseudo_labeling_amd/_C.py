@@ -1485,6 +1485,21 @@ def modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, colu
 
 
 # ---- optimizer (engine/solver.py) ------------------------------------------------------------------------------------
+def weight_prep_tile():
+    return int(_L.ovis_weight_prep_tile())
+
+
+def weight_prep_pair_multi(items, blocks, max_taps):
+    """One launch of the weight preparation over the convolutions described by ``items`` (uint8 device table of 64-byte
+    records) and ``blocks`` (int32 [B, 2] = (item, 32 x 32 tile)); ``max_taps`` = the largest KH * KW in the table; see
+    include/ovis_hip.h and layers/pair_bottleneck.py::WeightPrepPlan, which builds the tables."""
+    if not (items.is_cuda and blocks.is_cuda and items.dtype == torch.uint8 and blocks.dtype == torch.int32):
+        raise RuntimeError("weight_prep_pair_multi: uint8 / int32 HIP device tables expected")
+    with _on(items.device):
+        rc = _L.ovis_weight_prep_pair_multi_f32(items.data_ptr(), blocks.data_ptr(), blocks.size(0), int(max_taps), _stream())
+    _lib.check(rc, "weight_prep_pair_multi")
+
+
 def sgd_chunk_elements():
     return int(_L.ovis_sgd_chunk_elements())
 

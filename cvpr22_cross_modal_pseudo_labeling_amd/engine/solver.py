@@ -40,6 +40,8 @@ class GroupFusedSGD(torch.optim.SGD):
 
     @torch.no_grad()
     def step(self, closure=None):
+        from ..layers.pair_bottleneck import note_weights_written
+        note_weights_written()  # the native launch writes parameters through raw pointers: no version counter moves
         groups = self.param_groups
         if closure is None and self.native and self._step_cached(groups):
             return None

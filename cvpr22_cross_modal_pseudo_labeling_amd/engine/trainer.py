@@ -35,6 +35,7 @@ class StepPolicy:
     def __init__(self, accumulation_steps=1, clip_grad_norm_at=-1.0):
         self.accumulation_steps = max(int(accumulation_steps), 1)
         self.clip_grad_norm_at = float(clip_grad_norm_at)
+        self.prepare_weights_ahead = True  # False = every block prepares its own weights in its forward (A/B switch)
         self.micro = 0     # micro-steps since the last optimizer step
         self.fresh = True  # the gradient buffers hold nothing of an open window: the next micro-step starts from zero
 
@@ -49,9 +50,10 @@ class StepPolicy:
     def scale(self, losses):
         return losses / float(self.accumulation_steps) if self.accumulation_steps > 1 else losses
 
-    def end(self, reducer, optimizer, scheduler, iteration=None):
+    def end(self, reducer, optimizer, scheduler, iteration=None, model=None):
         """After backward(): reduce, and -- when the window closes -- clip, step, advance the schedule.  ``iteration``: the
-        1-based number of this iteration in the run (None: count calls)."""
+        1-based number of this iteration in the run (None: count calls).  ``model``: its trainable bottlenecks' GEMM operands
+        are prepared right behind the optimizer step, in one launch (modeling/backbone.py::prepare_weights_ahead)."""
         reducer.finish()
         self.micro += 1
         due = self.micro >= self.accumulation_steps if iteration is None else iteration % self.accumulation_steps == 0
@@ -62,6 +64,9 @@ class StepPolicy:
         if self.clip_grad_norm_at > 0:
             reducer.clip_grad_norm_(self.clip_grad_norm_at)
         optimizer.step()
+        if model is not None and self.prepare_weights_ahead:
+            from ..modeling.backbone import prepare_weights_ahead
+            prepare_weights_ahead(model)
         if scheduler is not None:
             scheduler.step()
         return True
@@ -75,7 +80,7 @@ def train_step(model, optimizer, reducer, images, targets, scheduler=None, polic
     loss_dict = model(images, targets)
     losses = policy.scale(total_loss(loss_dict))
     losses.backward()
-    policy.end(reducer, optimizer, scheduler, iteration)
+    policy.end(reducer, optimizer, scheduler, iteration, model)
     return loss_dict
 
 
@@ -215,7 +220,7 @@ class PipelinedTrainer:
         loss_dict = self.model.forward_student(frozen, targets)
         losses = self.policy.scale(total_loss(loss_dict))
         losses.backward()
-        self.policy.end(self.reducer, self.optimizer, self.scheduler, iteration)
+        self.policy.end(self.reducer, self.optimizer, self.scheduler, iteration, self.model)
         if next_batch is not None and not self.threaded:
             # the GPU now has the whole backward queued: overlap the next frozen half with it
             self._launch_frozen(next_batch[0], next_batch[1], inputs_ready)

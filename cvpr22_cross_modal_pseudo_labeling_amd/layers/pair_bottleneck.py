@@ -65,6 +65,105 @@ def _dw(gp, xp, w, scale, conv=None):
     return d if scale is None else d * scale.view(-1, 1, 1, 1)
 
 
+# ---- weights prepared behind the optimizer step -----------------------------------------------------------------------
+_WEIGHTS_EPOCH = [0]
+
+
+def note_weights_written():
+    """Called by whatever writes parameters WITHOUT autograd's version counters noticing (the fused SGD launch writes
+    through raw pointers): everything a ``WeightPrepPlan`` prepared before is stale from here on."""
+    _WEIGHTS_EPOCH[0] += 1
+
+
+class WeightPrepPlan:
+    """The pair-layout operands (forward matrix, transposed matrix) of every trainable bottleneck convolution of a model,
+    prepared by ONE launch (``_C.weight_prep_pair_multi``, csrc/weight_prep_multi.hip) into buffers that live as long as the
+    plan -- instead of one ``_C.weight_prep_pair`` launch per convolution inside every block's forward (42 launches at the
+    head of the teacher step's GEMMs).  ``blocks``: [(key, [(w, scale) for conv1, conv2, conv3, (downsample)])]; the conv3
+    and downsample forward matrices of a projection block are written side by side into ONE [N, 2 (K3 + Kd)] matrix (the
+    operand of the fused conv3 + shortcut product).  ``run()`` after every optimizer step; ``lookup(key)`` hands a block its
+    ``wpairs`` dict while nothing has touched its weights since (``_WEIGHTS_EPOCH`` for raw-pointer writers, the tensors'
+    version counters for everything else) -- else None, and the block prepares its weights itself as before."""
+
+    def __init__(self, blocks):
+        import numpy as np
+        tile = _C.weight_prep_tile()
+        self.max_taps = 1
+        self.entries, self.tensors = {}, {}
+        rows, blk = [], []
+        dev = blocks[0][1][0][0].device
+        for key, convs in blocks:
+            ws = [w for w, _ in convs]
+            if not all(w.is_cuda and w.dtype == torch.float32 and w.dim() == 4 and w.is_contiguous() and w.device == dev
+                       and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0 for w in ws):
+                raise RuntimeError("WeightPrepPlan: contiguous float32 HIP weights with channel counts divisible by 32 expected")
+            (w1, _), (w2, _), (w3, _) = convs[:3]
+            wd = convs[3][0] if len(convs) > 3 else None
+            k3 = w3.shape[1] * w3.shape[2] * w3.shape[3]
+            kd = wd.shape[1] * wd.shape[2] * wd.shape[3] if wd is not None else 0
+            f1 = torch.empty((w1.shape[0], 2 * w1[0].numel()), dtype=torch.bfloat16, device=dev)
+            f2 = torch.empty((w2.shape[0], 2 * w2[0].numel()), dtype=torch.bfloat16, device=dev)
+            f3d = torch.empty((w3.shape[0], 2 * (k3 + kd)), dtype=torch.bfloat16, device=dev)
+            fwd = [(f1, f1.data_ptr()), (f2, f2.data_ptr()), (f3d, f3d.data_ptr())] + ([(f3d, f3d.data_ptr() + 4 * k3)] if wd is not None else [])
+            bwd = []
+            for (w, sc), (fbuf, fptr) in zip(convs, fwd):
+                n, c, t = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+                tb = torch.empty((c, 2 * t * n), dtype=torch.bfloat16, device=dev)
+                bwd.append(tb)
+                if sc is not None and not (sc.is_cuda and sc.dtype == torch.float32 and sc.is_contiguous() and sc.numel() == n):
+                    raise RuntimeError("WeightPrepPlan: scale must be a contiguous float32 [N] HIP tensor")
+                self.max_taps = max(self.max_taps, t)
+                rows.append((w.data_ptr(), 0 if sc is None else sc.data_ptr(), fptr, tb.data_ptr(), 2 * fbuf.stride(0),
+                             2 * tb.stride(0), n | (c << 32), t))
+                blk.extend((len(rows) - 1, ti) for ti in range((n // tile) * (c // tile)))
+            wp = {"w1": f1, "w2": f2, "w3": f3d[:, :2 * k3], "wd": f3d[:, 2 * k3:] if wd is not None else None,
+                  "wts": tuple(bwd) + ((None,) if wd is None else ())}
+            if wd is not None:
+                wp["w3d"] = f3d
+            self.entries[key] = [wp, tuple(w for w, _ in convs), tuple(sc for _, sc in convs), None]
+        table = np.zeros((len(rows), 8), dtype=np.int64)
+        for i, r in enumerate(rows):
+            table[i] = r
+        self.items = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(dev)
+        self.blocks = torch.tensor(blk, dtype=torch.int32, device=dev).reshape(-1, 2)
+        self._weights = [w for e in self.entries.values() for w in e[1]]
+        self._pointers = [w.data_ptr() for w in self._weights]
+        self.epoch = -1
+        self.event = self.stream = None
+        self.rebuild = False  # set by a lookup that found other FrozenBN scales than the tables hold
+
+    def describes(self):
+        """The device tables still point at the weights' storage (a ``.to()`` / ``.data`` swap moves it) and no block met
+        other scale tensors than it was built with."""
+        return not self.rebuild and self._pointers == [w.data_ptr() for w in self._weights]
+
+    def run(self):
+        """Prepare everything from the weights as they are now (one launch on the current stream)."""
+        _C.weight_prep_pair_multi(self.items, self.blocks, self.max_taps)
+        self.epoch = _WEIGHTS_EPOCH[0]
+        for e in self.entries.values():
+            e[3] = [w._version for w in e[1]]
+        self.stream = torch.cuda.current_stream()
+        self.event = torch.cuda.Event()
+        self.event.record(self.stream)
+
+    def lookup(self, key, scales):
+        """The block's ``wpairs`` (forward forms, ``"wts"`` = transposed forms), or None: prepare them yourself."""
+        ent = self.entries.get(key)
+        if ent is None or self.epoch != _WEIGHTS_EPOCH[0]:
+            return None
+        wp, ws, scs, versions = ent
+        if len(scales) != len(scs) or any(a is not b for a, b in zip(scales, scs)):
+            self.rebuild = True
+            return None
+        if versions != [w._version for w in ws]:
+            return None
+        cur = torch.cuda.current_stream()
+        if cur != self.stream:
+            cur.wait_event(self.event)
+        return wp
+
+
 _NAN_CELL = {}
 
 
@@ -123,6 +222,8 @@ class _BottleneckPair(Function):
             pd, td = _C.weight_prep_pair(wd, sd, need_bwd) if wd is not None else (None, None)
             wpairs = {"w1": p1, "w2": p2, "w3": p3, "wd": pd}
             wts = (t1, t2, t3, td)
+        elif need_bwd:
+            wts = wpairs.get("wts")  # prepared behind the optimizer step together with the forward forms (WeightPrepPlan)
         f32 = bool(want_f32 or pool or not want_pair)
         x_real = x is not None and not is_placeholder(x)
         _, o1p = _C.split_gemm_pair(xp, wpairs["w1"], b1, None, True, False, True)

@@ -177,6 +177,9 @@ class Bottleneck(nn.Module):
             wpairs, b3s = self._pair_cache[1], self._pair_cache[2]
         else:
             b3s = b3 if bd is None else b3 + bd
+            plan = self.__dict__.get("_prep_plan")  # trainable block: operands prepared behind the optimizer step, if still fresh
+            if plan is not None:
+                wpairs = plan.lookup(id(self), (s1, s2, s3) if sd is None else (s1, s2, s3, sd))
         res = bottleneck_pair(x2d, xp, (hs, ws), w1, b1, w2, b2, w3, b3s, wd, want_pair, wpairs, pool,
                               scales=(s1, s2, s3, sd),
                               want_f32=not (want_pair and pair_only and self.pair_only_chain), select=select,
@@ -514,3 +517,34 @@ class ResNetHead(nn.Module):
             if v is not None:
                 setattr(out, attr, v)
         return out
+
+
+def _trainable_pair_blocks(model):
+    out = []
+    for m in model.modules():
+        if isinstance(m, Bottleneck) and m.pair_gemm and m.pair_supported():
+            ws = [m.conv1.weight, m.conv2.weight, m.conv3.weight] + ([m.downsample[0].weight] if m.downsample is not None else [])
+            if any(w.requires_grad for w in ws) and all(w.is_cuda and w.is_contiguous() for w in ws):
+                bns = [m.bn1, m.bn2, m.bn3] + ([m.downsample[1]] if m.downsample is not None else [])
+                out.append((m, [(w, bn.fold()[0]) for w, bn in zip(ws, bns)]))  # the tensors _pair_node passes as scales
+    return out
+
+
+def prepare_weights_ahead(model):
+    """After an optimizer step: the pair-layout operands of every trainable bottleneck of ``model`` in ONE launch
+    (layers/pair_bottleneck.py::WeightPrepPlan) -- the next forward finds them instead of preparing 3-4 weights per block in
+    front of its GEMMs.  The plan (buffers + device tables) is built at the first call and rebuilt when a weight's storage or
+    a FrozenBN fold moved; a block whose weights were touched afterwards by anything else prepares them itself.  No-op on
+    hosts / without such blocks.  Returns the number of blocks served."""
+    from ..layers.pair_bottleneck import WeightPrepPlan
+    plan = model.__dict__.get("_ovis_prep_plan")
+    if plan is None or (plan and not plan.describes()):
+        blocks = _trainable_pair_blocks(model)  # (module walk + fold(): not per step)
+        plan = WeightPrepPlan([(id(m), convs) for m, convs in blocks]) if blocks else False
+        model.__dict__["_ovis_prep_plan"] = plan
+        for m, _ in blocks:
+            m.__dict__["_prep_plan"] = plan
+    if not plan:
+        return 0
+    plan.run()
+    return len(plan.entries)

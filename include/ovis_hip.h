@@ -694,6 +694,20 @@ int ovis_sgd_momentum_multi_f32(const void* items, const void* blocks, int num_b
                                 float momentum, int apply_weight_decay, void* stream);
 int ovis_sgd_chunk_elements(void);
 
+/* Weight preparation of MANY convolutions in one launch, behind the optimizer step (mb/engine/trainer.py:139; what
+ * ovis_weight_prep_pair_f32 does per convolution): items = device array of 64-byte records
+ *   {const float* w [N, C, T]; const float* scale [N] or NULL; void* fwd; void* bwd or NULL; long fwd_row_bytes;
+ *    long bwd_row_bytes; int N, C, T, pad}
+ * (fwd row n at fwd + n * fwd_row_bytes holds the pair form of w[n, :, :] * scale[n] tap-major, k = t * C + c; bwd row c at
+ * bwd + c * bwd_row_bytes the transposed matrix, k' = t * N + n; a row stride above 4 * T * C writes into a wider matrix:
+ * [w3 | wd] of a projection block), blocks = device array of int2 (item, tile): workgroup b converts tile (tile / (C / 32),
+ * tile % (C / 32)) of 32 output x 32 input channels (ovis_weight_prep_tile() = 32) of its item, all T taps; an item has
+ * (N / 32) * (C / 32) tiles.  max_taps = the largest T in the table (<= 15: the tile is staged in LDS).  N % 32 == 0,
+ * C % 32 == 0, buffers 16-byte aligned: the CALLER checks (the table is opaque here).  Bit-identical to the per-convolution
+ * entry. */
+int ovis_weight_prep_pair_multi_f32(const void* items, const void* blocks, int num_blocks, int max_taps, void* stream);
+int ovis_weight_prep_tile(void);
+
 #ifdef __cplusplus
 }
 #endif

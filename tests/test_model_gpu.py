@@ -267,6 +267,77 @@ def test_training_steps_are_bit_reproducible(name):
         assert any(float(w0[n].sub(p.detach().cuda()).abs().max()) > 0 for n, p in model.named_parameters() if n in w0)  # it trained
 
 
+@pytest.mark.parametrize("name", ["zeroshot_mask", "student_teacher_mask_rcnn_uncertainty"])
+def test_weights_prepared_behind_the_optimizer_step_equal_inline_preparation(name):
+    """The trainers prepare the GEMM operands of every trainable bottleneck in one launch right behind ``optimizer.step()``
+    (``prepare_weights_ahead`` / ``WeightPrepPlan``); the next forward's blocks find them instead of running 3-4 preparation
+    launches each.  Same bytes: losses, gradients and parameters over four iterations are IDENTICAL to the run whose blocks
+    prepare their own weights, the plan did serve the blocks (13 in the teacher's trunk + res5, 3 in the student's head), and
+    a weight edited between two steps is noticed (that block prepares its own operands, the result is that of the plain run)."""
+    import copy
+
+    from cvpr22_cross_modal_pseudo_labeling_amd.config import get_defaults
+    from cvpr22_cross_modal_pseudo_labeling_amd.engine import comm, solver, trainer
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers import pair_bottleneck
+
+    model, e_vocab, e_seen, images, targets = _build(name)
+    cfg = get_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, f"configs/coco_cap_det/{name}.yaml"))
+    cfg.merge_from_list(["SOLVER.BASE_LR", 1e-4])
+    cfg.freeze()
+    images = images.cuda()
+    tg = [t.to("cuda") for t in targets]
+    batches = [(images, tg), (images.flip(-1).contiguous(), tg), (images * 0.5, tg), (images, tg)]
+
+    def run(ahead):
+        m = copy.deepcopy(model).cuda()
+        m.set_class_embeddings(e_seen.cuda())
+        if hasattr(m, "set_caption_vocab"):
+            m.set_caption_vocab(e_vocab.cuda())
+        m.train()
+        opt = solver.make_optimizer(cfg, m)
+        red = comm.BucketedGradReducer(m)
+        policy = trainer.StepPolicy()
+        assert policy.prepare_weights_ahead
+        policy.prepare_weights_ahead = ahead
+        pipe = trainer.PipelinedTrainer(m, opt, red, policy=policy)
+        served = []
+        lookup = pair_bottleneck.WeightPrepPlan.lookup
+
+        def counting(self, key, scales):
+            out = lookup(self, key, scales)
+            served.append(out is not None)
+            return out
+
+        pair_bottleneck.WeightPrepPlan.lookup = counting
+        try:
+            losses, grads = [], []
+            for i, (im, t) in enumerate(batches):
+                torch.manual_seed(100 + i)
+                if i == 2:  # an edit behind the trainer's back, between two steps
+                    victim = [p for n, p in m.named_parameters() if p.requires_grad and n.endswith("conv2.weight")][0]
+                    with torch.no_grad():
+                        victim.mul_(1.0 + 2 ** -10)
+                nxt = batches[i + 1] if i + 1 < len(batches) else None
+                losses.append({k: float(v.detach()) for k, v in pipe.step(im, t, nxt).items()})
+                grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+        finally:
+            pair_bottleneck.WeightPrepPlan.lookup = lookup
+        pipe.drain()
+        red.remove()
+        return losses, grads, {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}, served
+
+    l0, g0, w0, s0 = run(False)
+    l1, g1, w1, s1 = run(True)
+    blocks = 13 if name == "zeroshot_mask" else 3
+    assert s0 == []                                           # no plan: nothing to look up
+    assert len(s1) == 3 * blocks and s1.count(False) == 1      # steps 2-4 look up; the edited block of step 3 is refused once
+    assert l0 == l1
+    for a, b in zip(g0, g1):
+        assert set(a) == set(b) and [n for n in a if not torch.equal(a[n], b[n])] == []
+    assert [n for n in w0 if not torch.equal(w0[n], w1[n])] == []
+
+
 def test_rpn_branch_on_a_second_stream_equals_the_one_stream_order():
     """Teacher step.  (a) ``RPNModule.forward`` issues the RPN loss on a second stream beside the proposal selection;
     (b) ``RPNModule.forward_ahead`` (what the detector calls) also runs the branch's whole BACKWARD ahead on that stream and

@@ -734,3 +734,52 @@ def test_split_gemm_full_size_properties():
     ref = (gy[:, i].double() * x[:, j].double()).sum(0)
     bound = (gy[:, i].abs().double() * x[:, j].abs().double()).sum(0) + 1
     assert ((center[i, j].double() - ref).abs() / bound).max().item() < TOL
+
+
+def test_weight_prep_plan_equals_per_weight_preparation():
+    """``WeightPrepPlan`` (every trainable bottleneck weight of a model in ONE launch, csrc/weight_prep_multi.hip) writes
+    exactly the bytes ``_C.weight_prep_pair`` writes per convolution: forward forms, transposed forms, the conv3 | shortcut
+    matrix of a projection block in place; scales folded or absent; and it notices every way a weight can change."""
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+    from cvpr22_cross_modal_pseudo_labeling_amd.layers.pair_bottleneck import WeightPrepPlan, note_weights_written
+
+    g = torch.Generator().manual_seed(5)
+
+    def conv(n, c, k, scaled=True):
+        w = (torch.randn(n, c, k, k, generator=g) * 0.1).cuda().requires_grad_()
+        return w, ((torch.rand(n, generator=g) + 0.5).cuda() if scaled else None)
+
+    proj = [conv(64, 256, 1), conv(64, 64, 3), conv(256, 64, 1), conv(256, 256, 1)]           # with a projection shortcut
+    plain = [conv(128, 512, 1, False), conv(128, 128, 3), conv(512, 128, 1, False)]           # identity shortcut, mixed scales
+    big = [conv(512, 2048, 1), conv(512, 512, 3), conv(2048, 512, 1)]                        # res5 sizes: many chunks per item
+    plan = WeightPrepPlan([("a", proj), ("b", plain), ("c", big)])
+    assert plan.lookup("a", tuple(s for _, s in proj)) is None                                # nothing prepared yet
+    plan.run()
+    for key, convs in (("a", proj), ("b", plain), ("c", big)):
+        wp = plan.lookup(key, tuple(s for _, s in convs))
+        assert wp is not None
+        want = [_C.weight_prep_pair(w, s, True) for w, s in convs]
+        for name, (f, _) in zip(("w1", "w2", "w3", "wd"), want):
+            assert torch.equal(wp[name].contiguous().view(torch.int16), f.view(torch.int16)), (key, name)
+        for i, (_, t) in enumerate(want):
+            assert torch.equal(wp["wts"][i].view(torch.int16), t.view(torch.int16)), (key, i)
+        if len(convs) == 4:
+            assert torch.equal(wp["w3d"].view(torch.int16), torch.cat([want[2][0], want[3][0]], 1).view(torch.int16))
+            assert wp["w3"].data_ptr() == wp["w3d"].data_ptr()
+        else:
+            assert wp["wd"] is None and wp["wts"][3] is None and "w3d" not in wp
+    scales_a = tuple(s for _, s in proj)
+    # (1) a raw-pointer writer announced itself, (2) an in-place update moved a version counter, (3) other scale tensors
+    note_weights_written()
+    assert plan.lookup("a", scales_a) is None
+    plan.run()
+    assert plan.lookup("a", scales_a) is not None
+    with torch.no_grad():
+        proj[1][0].mul_(2.0)
+    assert plan.lookup("a", scales_a) is None and plan.lookup("b", tuple(s for _, s in plain)) is not None
+    plan.run()
+    wp = plan.lookup("a", scales_a)
+    assert torch.equal(wp["w2"].view(torch.int16), _C.weight_prep_pair(proj[1][0], proj[1][1], True)[0].view(torch.int16))
+    assert plan.describes()
+    assert plan.lookup("a", (scales_a[0].clone(),) + scales_a[1:]) is None and not plan.describes()
+

@@ -2,7 +2,7 @@
     python tools/experiments/ab_bench.py <patch> [bench args...]
 runs bench.py alternately unpatched (A) and with the named monkeypatch applied (B), three times each, and prints ms per step.
 Patches: nopool (the res5 head's average pooling as a separate pass), rpnloss_ops (the RPN loss as its tensor-op sequence;
-use with --workload teacher), lib:<variant> (a variant library of build_variants.sh), side_prio0 (the frozen half's stream at normal priority), no_prefix (teacher step without the frozen trunk prefix run ahead on the side stream; --workload teacher), gated_nosplit (gated data gradients never K-sliced, the form before round 4's _ws entry point; --workload teacher), rpnloss_one_stream (the teacher's RPN loss on the main stream, after the selection; --workload teacher), rpn_no_ahead (the teacher's RPN backward inside the step's backward instead of run ahead on the second stream; --workload teacher), teacher_heads_plain (the teacher's heads through CombinedROIHeads.forward instead of the one-branch batched form; --workload teacher), drop_trunk_dw (WRONG RESULTS, a bound: the bottlenecks' weight gradients are computed but not handed to autograd -- what their AccumulateGrad adds cost), torch_topk (the RPN's sorted top-k through the tensor library instead of the one-radix-sort op), foreach_sgd (the optimizer step as six multi-tensor passes instead of the fused launch)."""
+use with --workload teacher), lib:<variant> (a variant library of build_variants.sh), side_prio0 (the frozen half's stream at normal priority), no_prefix (teacher step without the frozen trunk prefix run ahead on the side stream; --workload teacher), gated_nosplit (gated data gradients never K-sliced, the form before round 4's _ws entry point; --workload teacher), rpnloss_one_stream (the teacher's RPN loss on the main stream, after the selection; --workload teacher), rpn_no_ahead (the teacher's RPN backward inside the step's backward instead of run ahead on the second stream; --workload teacher), teacher_heads_plain (the teacher's heads through CombinedROIHeads.forward instead of the one-branch batched form; --workload teacher), drop_trunk_dw (WRONG RESULTS, a bound: the bottlenecks' weight gradients are computed but not handed to autograd -- what their AccumulateGrad adds cost), memo_weight_prep (WRONG RESULTS, a bound: pair forms of the trainable weights computed once and never again -- what the per-step weight preparation costs the step), inline_weight_prep (every trainable block prepares its own GEMM operands in its forward instead of finding them prepared behind the optimizer step), torch_topk (the RPN's sorted top-k through the tensor library instead of the one-radix-sort op), foreach_sgd (the optimizer step as six multi-tensor passes instead of the fused launch)."""
 import json
 import os
 import subprocess
@@ -32,6 +32,14 @@ PATCHES = {
                       "_p._BottleneckPair.backward = staticmethod(_bw)"),
     # (needs tools/experiments/python_patches/trunk_dw_beside.patch applied)
     "dw_beside": "from cvpr22_cross_modal_pseudo_labeling_amd.layers import pair_bottleneck as _p; _p.DW_BESIDE_ROWS = 40000",
+    "memo_weight_prep": ("from cvpr22_cross_modal_pseudo_labeling_amd import _C; _w = _C.weight_prep_pair; _m = {}\n"
+                         "def _memo(w, scale=None, want_transposed=False):\n"
+                         "    k = (w.data_ptr(), 0 if scale is None else scale.data_ptr(), bool(want_transposed))\n"
+                         "    if k not in _m:\n        _m[k] = _w(w, scale, want_transposed)\n    return _m[k]\n"
+                         "_C.weight_prep_pair = _memo"),
+    "inline_weight_prep": ("from cvpr22_cross_modal_pseudo_labeling_amd.engine import trainer as _t; _i = _t.StepPolicy.__init__\n"
+                           "def _init(self, *a, **k):\n    _i(self, *a, **k); self.prepare_weights_ahead = False\n"
+                           "_t.StepPolicy.__init__ = _init"),
     "torch_topk": "from cvpr22_cross_modal_pseudo_labeling_amd import _C; _C.topk_sorted = lambda s, k: s.topk(k, dim=1, sorted=True)",
     "foreach_sgd": "from cvpr22_cross_modal_pseudo_labeling_amd.engine import solver as _s; _s.GroupFusedSGD.native = False",
 }
