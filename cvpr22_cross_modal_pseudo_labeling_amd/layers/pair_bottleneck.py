@@ -79,7 +79,8 @@ class WeightPrepPlan:
     """The pair-layout operands (forward matrix, transposed matrix) of every trainable bottleneck convolution of a model,
     prepared by ONE launch (``_C.weight_prep_pair_multi``, csrc/weight_prep_multi.hip) into buffers that live as long as the
     plan -- instead of one ``_C.weight_prep_pair`` launch per convolution inside every block's forward (42 launches at the
-    head of the teacher step's GEMMs).  ``blocks``: [(key, [(w, scale) for conv1, conv2, conv3, (downsample)])]; the conv3
+    head of the teacher step's GEMMs).  ``blocks``: [(key, [(w, scale) for conv1, conv2, conv3, (downsample)])], or
+    [(key, [(w, scale)])] for a lone convolution (``conv_same_pair``: the RPN head's 3x3); the conv3
     and downsample forward matrices of a projection block are written side by side into ONE [N, 2 (K3 + Kd)] matrix (the
     operand of the fused conv3 + shortcut product).  ``run()`` after every optimizer step; ``lookup(key)`` hands a block its
     ``wpairs`` dict while nothing has touched its weights since (``_WEIGHTS_EPOCH`` for raw-pointer writers, the tensors'
@@ -97,6 +98,19 @@ class WeightPrepPlan:
             if not all(w.is_cuda and w.dtype == torch.float32 and w.dim() == 4 and w.is_contiguous() and w.device == dev
                        and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0 for w in ws):
                 raise RuntimeError("WeightPrepPlan: contiguous float32 HIP weights with channel counts divisible by 32 expected")
+            if len(convs) == 1:  # a lone convolution (the RPN head's 3x3): {"w": forward form, "wt": transposed form}
+                (w, sc), = convs
+                n, c, t = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+                f = torch.empty((n, 2 * t * c), dtype=torch.bfloat16, device=dev)
+                tb = torch.empty((c, 2 * t * n), dtype=torch.bfloat16, device=dev)
+                if sc is not None and not (sc.is_cuda and sc.dtype == torch.float32 and sc.is_contiguous() and sc.numel() == n):
+                    raise RuntimeError("WeightPrepPlan: scale must be a contiguous float32 [N] HIP tensor")
+                self.max_taps = max(self.max_taps, t)
+                rows.append((w.data_ptr(), 0 if sc is None else sc.data_ptr(), f.data_ptr(), tb.data_ptr(), 2 * f.stride(0),
+                             2 * tb.stride(0), n | (c << 32), t))
+                blk.extend((len(rows) - 1, ti) for ti in range((n // tile) * (c // tile)))
+                self.entries[key] = [{"w": f, "wt": tb}, (w,), (sc,), None]
+                continue
             (w1, _), (w2, _), (w3, _) = convs[:3]
             wd = convs[3][0] if len(convs) > 3 else None
             k3 = w3.shape[1] * w3.shape[2] * w3.shape[3]
@@ -375,11 +389,14 @@ class _ConvSamePair(Function):
     transpose-read GEMM for dW (csrc/split_gemm.hip).  Used for the RPN head's 3x3 (rpn.py:74-106) when it trains."""
 
     @staticmethod
-    def forward(ctx, x2d, geom, w, b, relu):
+    def forward(ctx, x2d, geom, w, b, relu, prepared=None):
         h, wd_ = geom
         n, c, kh, kw = w.shape
         xp = _C.split_pair(x2d)
-        wp, wt = _C.weight_prep_pair(w, None, ctx.needs_input_grad[0])
+        if prepared is not None:  # {"w", "wt"} of a WeightPrepPlan: written behind the optimizer step
+            wp, wt = prepared["w"], prepared["wt"]
+        else:
+            wp, wt = _C.weight_prep_pair(w, None, ctx.needs_input_grad[0])
         y, _ = _C.split_gemm_pair(xp, wp, b, None, relu, True, False, conv=(h, wd_, kh, kw, False))
         ctx.wt = wt
         ctx.save_for_backward(xp, y if relu else None, w)
@@ -402,9 +419,10 @@ class _ConvSamePair(Function):
             dw = _dw(gp, xp, w, None, (h, wd_, kh, kw))
         if need_b:
             db = g32.sum(0)
-        return dx, None, dw, db, None
+        return dx, None, dw, db, None, None
 
 
-def conv_same_pair(x2d, geom, w, b=None, relu=False):
-    """x2d [N*H*W, C] f32 NHWC rows of (H, W) maps -> [N*H*W, Cout] f32 (C, Cout % 32 == 0)."""
-    return _ConvSamePair.apply(x2d, geom, w, b, relu)
+def conv_same_pair(x2d, geom, w, b=None, relu=False, prepared=None):
+    """x2d [N*H*W, C] f32 NHWC rows of (H, W) maps -> [N*H*W, Cout] f32 (C, Cout % 32 == 0).  ``prepared``: the weight's
+    pair forms from a ``WeightPrepPlan`` lookup, or None (prepared here)."""
+    return _ConvSamePair.apply(x2d, geom, w, b, relu, prepared)

@@ -123,6 +123,17 @@ class Bottleneck(nn.Module):
                                    and d.stride == c1.stride))
                 and (d is not None or (c1.stride == (1, 1) and c1.in_channels == c3.out_channels)))
 
+    def prep_plan_convs(self):
+        """[(weight, scale)] of conv1, conv2, conv3 (, downsample) for ``prepare_weights_ahead`` when this block trains on the
+        pair GEMM of a device; the scales are the very tensors ``_pair_node`` passes on (``FrozenBatchNorm2d.fold``)."""
+        if not (self.pair_gemm and self.pair_supported()):
+            return None
+        ws = [self.conv1.weight, self.conv2.weight, self.conv3.weight] + ([self.downsample[0].weight] if self.downsample is not None else [])
+        if not (any(w.requires_grad for w in ws) and all(w.is_cuda and w.is_contiguous() for w in ws)):
+            return None
+        bns = [self.bn1, self.bn2, self.bn3] + ([self.downsample[1]] if self.downsample is not None else [])
+        return [(w, bn.fold()[0]) for w, bn in zip(ws, bns)]
+
     def takes_pair_only_input(self):
         """This block can consume an input that exists in pair layout only (conv1 operand and shortcut from the pair form):
         what a producer must check before it drops the fp32 copy of its output (``pair_only``)."""
@@ -520,13 +531,14 @@ class ResNetHead(nn.Module):
 
 
 def _trainable_pair_blocks(model):
+    """[(module, [(weight, scale) ...])] of the modules that offer ``prep_plan_convs()``: trainable bottlenecks on the pair
+    GEMM (three or four convolutions) and lone trainable convolutions on it (the RPN head's 3x3)."""
     out = []
     for m in model.modules():
-        if isinstance(m, Bottleneck) and m.pair_gemm and m.pair_supported():
-            ws = [m.conv1.weight, m.conv2.weight, m.conv3.weight] + ([m.downsample[0].weight] if m.downsample is not None else [])
-            if any(w.requires_grad for w in ws) and all(w.is_cuda and w.is_contiguous() for w in ws):
-                bns = [m.bn1, m.bn2, m.bn3] + ([m.downsample[1]] if m.downsample is not None else [])
-                out.append((m, [(w, bn.fold()[0]) for w, bn in zip(ws, bns)]))  # the tensors _pair_node passes as scales
+        offer = getattr(m, "prep_plan_convs", None)
+        convs = offer() if offer is not None else None
+        if convs:
+            out.append((m, convs))
     return out
 
 

@@ -118,13 +118,23 @@ class RPNHead(nn.Module):  # rpn.py:74-106
             from ..layers.cross_modal import linear_mfma
             from ..layers.pair_bottleneck import conv_same_pair
             n, ch, h, w = feature.shape
-            t = conv_same_pair(feature.permute(0, 2, 3, 1).reshape(-1, ch), (h, w), c.weight, c.bias, True)
+            plan = self.__dict__.get("_prep_plan")  # the 3x3's GEMM operands, prepared behind the optimizer step if still fresh
+            prepared = plan.lookup(id(self), (None,)) if plan is not None else None
+            t = conv_same_pair(feature.permute(0, 2, 3, 1).reshape(-1, ch), (h, w), c.weight, c.bias, True, prepared)
             a = self.cls_logits.out_channels
             cls = linear_mfma(t, self.cls_logits.weight.view(a, -1), self.cls_logits.bias)
             box = linear_mfma(t, self.bbox_pred.weight.view(4 * a, -1), self.bbox_pred.bias)
             return cls.view(n, h, w, a).permute(0, 3, 1, 2), box.view(n, h, w, 4 * a).permute(0, 3, 1, 2)
         t = F.relu(self.conv(feature))
         return self.cls_logits(t), self.bbox_pred(t)
+
+    def prep_plan_convs(self):
+        """[(weight, scale)] for ``modeling/backbone.py::prepare_weights_ahead``: the trainable 3x3 on the split GEMM."""
+        c = self.conv
+        if (self.split_gemm and c.weight.requires_grad and c.weight.is_cuda and c.in_channels % 128 == 0
+                and c.out_channels % 128 == 0 and c.kernel_size == (3, 3) and c.padding == (1, 1) and c.stride == (1, 1)):
+            return [(c.weight, None)]
+        return None
 
     def _gemm_ok(self, feature):
         c = self.conv

@@ -272,7 +272,7 @@ def test_weights_prepared_behind_the_optimizer_step_equal_inline_preparation(nam
     """The trainers prepare the GEMM operands of every trainable bottleneck in one launch right behind ``optimizer.step()``
     (``prepare_weights_ahead`` / ``WeightPrepPlan``); the next forward's blocks find them instead of running 3-4 preparation
     launches each.  Same bytes: losses, gradients and parameters over four iterations are IDENTICAL to the run whose blocks
-    prepare their own weights, the plan did serve the blocks (13 in the teacher's trunk + res5, 3 in the student's head), and
+    prepare their own weights, the plan did serve the blocks (13 bottlenecks of the teacher's trunk + res5 and its RPN 3x3, 3 in the student's head), and
     a weight edited between two steps is noticed (that block prepares its own operands, the result is that of the plain run)."""
     import copy
 
@@ -329,7 +329,7 @@ def test_weights_prepared_behind_the_optimizer_step_equal_inline_preparation(nam
 
     l0, g0, w0, s0 = run(False)
     l1, g1, w1, s1 = run(True)
-    blocks = 13 if name == "zeroshot_mask" else 3
+    blocks = 14 if name == "zeroshot_mask" else 3  # teacher: 10 trunk + 3 res5 bottlenecks + the RPN head's 3x3
     assert s0 == []                                           # no plan: nothing to look up
     assert len(s1) == 3 * blocks and s1.count(False) == 1      # steps 2-4 look up; the edited block of step 3 is refused once
     assert l0 == l1
