@@ -48,8 +48,8 @@ def record_gates(sites):
                 sites.append(g.view(-1, h, w, g.shape[1]).permute(0, 3, 1, 2).cpu())
         return res
 
-    def conv(x2d, geom, w, b=None, relu=False):
-        y = orig_c(x2d, geom, w, b, relu)
+    def conv(x2d, geom, w, b=None, relu=False, prepared=None):
+        y = orig_c(x2d, geom, w, b, relu, prepared)
         if relu and y.grad_fn is not None:
             g = y.detach() > 0
             sites.append(g.view(-1, geom[0], geom[1], g.shape[1]).permute(0, 3, 1, 2).cpu())
