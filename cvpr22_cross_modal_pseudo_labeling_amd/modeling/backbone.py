@@ -550,13 +550,20 @@ def prepare_weights_ahead(model):
     hosts / without such blocks.  Returns the number of blocks served."""
     from ..layers.pair_bottleneck import WeightPrepPlan
     plan = model.__dict__.get("_ovis_prep_plan")
-    if plan is None or (plan and not plan.describes()):
+    if isinstance(plan, torch.device):  # nothing to prepare when last looked: look again only when the model has moved
+        first = next(model.parameters(), None)
+        if first is None or first.device == plan:
+            return 0
+        plan = None
+    if plan is None or not plan.describes():
         blocks = _trainable_pair_blocks(model)  # (module walk + fold(): not per step)
-        plan = WeightPrepPlan([(id(m), convs) for m, convs in blocks]) if blocks else False
+        if not blocks:
+            first = next(model.parameters(), None)
+            model.__dict__["_ovis_prep_plan"] = first.device if first is not None else torch.device("cpu")
+            return 0
+        plan = WeightPrepPlan([(id(m), convs) for m, convs in blocks])
         model.__dict__["_ovis_prep_plan"] = plan
         for m, _ in blocks:
             m.__dict__["_prep_plan"] = plan
-    if not plan:
-        return 0
     plan.run()
     return len(plan.entries)
