@@ -1485,6 +1485,47 @@ def modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, colu
 
 
 # ---- optimizer (engine/solver.py) ------------------------------------------------------------------------------------
+_BB_WS = {}
+
+
+def bottleneck_identity_backward(g3p, xp, o1p, o2p, t1, t2, t3, scales, geom, weight_shapes, side_stream=None):
+    """The backward of an identity bottleneck of a pair-only chain in ONE native call (``ovis_bottleneck_identity_backward``:
+    the nine launches of the separate wrappers, the three weight gradients on ``side_stream`` beside the data-gradient chain).
+    g3p [M, 2C] gated output gradient, xp / o1p / o2p the block's input and conv1 / conv2 outputs, t1 / t2 / t3 the transposed
+    weight pair forms, scales (s1, s2, s3) or Nones, geom (h, w, kh, kw), weight_shapes (w1, w2, w3 shapes) ->
+    (gx pair [M, 2C], dw1, dw2, dw3).  Pair tensors: 2-D bfloat16 with unit column stride."""
+    for t in (g3p, xp, o1p, o2p, t1, t2, t3):
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1):
+            raise RuntimeError("bottleneck_identity_backward: 2-D bfloat16 HIP tensors in pair layout expected")
+    m, cin, mid = g3p.shape[0], g3p.shape[1] // 2, o1p.shape[1] // 2
+    h, w, kh, kw = geom
+    if (xp.shape != (m, 2 * cin) or o1p.shape[0] != m or o2p.shape != (m, 2 * mid) or t1.shape != (cin, 2 * mid)
+            or t2.shape != (mid, 2 * kh * kw * mid) or t3.shape != (mid, 2 * cin) or m % (h * w)):
+        raise RuntimeError("bottleneck_identity_backward: shape mismatch")
+    dev = g3p.device
+    g2p = torch.empty((m, 2 * mid), dtype=torch.bfloat16, device=dev)
+    g1p = torch.empty((m, 2 * mid), dtype=torch.bfloat16, device=dev)
+    gx = torch.empty((m, 2 * cin), dtype=torch.bfloat16, device=dev)
+    dw1, dw2, dw3 = (torch.empty(tuple(sh), dtype=torch.float32, device=dev) for sh in weight_shapes)
+    config = _gemm_cfg(0)
+    key = (m, cin, mid, kh, kw, w, config)
+    nbytes = _BB_WS.get(key)
+    if nbytes is None:
+        nbytes = _BB_WS[key] = int(_L.ovis_bottleneck_identity_backward_workspace_bytes(m, cin, mid, kh, kw, w, config))
+    ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
+    s1, s2, s3 = (None if s is None else _dev(s.detach(), "scale") for s in scales)
+    with _on(dev):
+        rc = _L.ovis_bottleneck_identity_backward(
+            g3p.data_ptr(), 2 * g3p.stride(0), xp.data_ptr(), 2 * xp.stride(0), o1p.data_ptr(), 2 * o1p.stride(0),
+            o2p.data_ptr(), 2 * o2p.stride(0), t1.data_ptr(), 2 * t1.stride(0), t2.data_ptr(), 2 * t2.stride(0),
+            t3.data_ptr(), 2 * t3.stride(0), 0 if s1 is None else s1.data_ptr(), 0 if s2 is None else s2.data_ptr(),
+            0 if s3 is None else s3.data_ptr(), m, cin, mid, kh, kw, h, w, g2p.data_ptr(), g1p.data_ptr(), gx.data_ptr(),
+            dw1.data_ptr(), dw2.data_ptr(), dw3.data_ptr(), ws.data_ptr(), ws.numel(), config, _stream(),
+            0 if side_stream is None else side_stream.cuda_stream)
+    _lib.check(rc, "bottleneck_identity_backward")
+    return gx, dw1, dw2, dw3
+
+
 def weight_prep_tile():
     return int(_L.ovis_weight_prep_tile())
 

@@ -88,6 +88,8 @@ SIGNATURES = {
     "ovis_text_embed_f32": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "ovis_project_polygon_masks_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ovis_sgd_momentum_multi_f32": (_i, [_vp, _vp, _i, _f, _f, _f, _i, _vp]),
+    "ovis_bottleneck_identity_backward_workspace_bytes": (_sz, [_l, _i, _i, _i, _i, _i, _i]),
+    "ovis_bottleneck_identity_backward": (_i, [_vp, _l] * 7 + [_vp] * 3 + [_l, _i, _i, _i, _i, _i, _i] + [_vp] * 7 + [_sz, _i, _vp, _vp]),
     "ovis_weight_prep_pair_multi_f32": (_i, [_vp, _vp, _i, _i, _vp]),
     "ovis_weight_prep_tile": (_i, []),
     "ovis_sgd_chunk_elements": (_i, []),

@@ -65,6 +65,12 @@ def _dw(gp, xp, w, scale, conv=None):
     return d if scale is None else d * scale.view(-1, 1, 1, 1)
 
 
+# Identity bottlenecks of a pair-only chain with at most this many rows run their backward through ONE native call with the
+# weight gradients on a second stream (``_C.bottleneck_identity_backward``): the trunk's blocks (M = 8400 / 33400), where a
+# block's kernels take 225 us and the host needs 150 us to issue them one by one.  0 = off (the A/B switch; the res5 head's
+# blocks, M = 50176 and full-machine GEMMs, gain nothing).
+ONE_CALL_BACKWARD_ROWS = 40000
+
 # ---- weights prepared behind the optimizer step -----------------------------------------------------------------------
 _WEIGHTS_EPOCH = [0]
 
@@ -330,6 +336,18 @@ class _BottleneckPair(Function):
             g3p, g3 = _C.gate_split_pair(None if dout is None else dout.reshape(-1, n3), out,
                                          want_f32=(wd is None and need_x and not to_link), pooled=dpooled, pool_rows=h * w,
                                          selected=sel_grad, group_slot=slot)
+        if (ONE_CALL_BACKWARD_ROWS and linked is not None and wd is None and to_link and need_w1 and need_w2 and need_w3
+                and 0 < g3p.shape[0] <= ONE_CALL_BACKWARD_ROWS and t1 is not None and t2 is not None and t3 is not None
+                and n3 % 128 == 0 and w1.shape[0] % 128 == 0 and kh % 2 == 1 and kw % 2 == 1):
+            # an identity block in the middle of a small pair-only chain (the trunk): its nine launches behind one native
+            # call, the three weight gradients on the second stream beside the data-gradient chain
+            from ..engine.trainer import side_stream
+            gx, dw1, dw2, dw3 = _C.bottleneck_identity_backward(g3p, xp, o1p, o2p, t1, t2, t3, (s1, s2, s3), (h, w, kh, kw),
+                                                               (w1.shape, w2.shape, w3.shape), side_stream(0))
+            link_in.grad_pair = gx
+            dx = nan_placeholder(gx.device, xp.shape[0], xp.shape[1] // 2)
+            return (dx, None, None, dw1, None, None, dw2, None, None, dw3, None, None, None, None, None, None, None, None, None,
+                    None, None, None)
         dw3 = _dw(g3p, o2p, w3, s3) if need_w3 else None
         _, g2p = _C.split_gemm_pair_gated(g3p, t3, o2p)                  # (dY W3) gated by relu(o2), split: one kernel
         dw2 = _dw(g2p, o1p, w2, s2, (h, w, kh, kw)) if need_w2 else None

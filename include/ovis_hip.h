@@ -694,6 +694,27 @@ int ovis_sgd_momentum_multi_f32(const void* items, const void* blocks, int num_b
                                 float momentum, int apply_weight_decay, void* stream);
 int ovis_sgd_chunk_elements(void);
 
+/* The backward of an identity bottleneck (mb/modeling/backbone/resnet.py:290-342: out = relu(conv3(relu(conv2(relu(conv1(x)))))
+ * + x); autograd derives the backward) inside a pair-only chain, behind ONE call: g3 [m, channels] = the gradient w.r.t. the
+ * block's output, already gated and in pair layout (what ovis_split_gemm_pair_rp_gated of the block above wrote); x / o1 / o2 =
+ * the block's input and its conv1 / conv2 outputs (post-ReLU) in pair layout; t1 [channels, mid], t2 [mid, taps * mid],
+ * t3 [mid, channels] = the transposed pair forms of the folded weights (ovis_weight_prep_pair_f32's second result);
+ * scale1..3 = the folded FrozenBN scales the raw weights' gradients are multiplied with (NULL: none).  Writes
+ *   g2 [m, mid], g1 [m, mid] (pair), gx [m, channels] (pair: the gated gradient for the block below),
+ *   dw1 [mid, channels, 1, 1], dw2 [mid, mid, taps_h, taps_w], dw3 [channels, mid, 1, 1] (fp32)
+ * by exactly the launches the separate entry points make (ovis_split_gemm_pair_gated_ws x 2, ovis_split_gemm_pair_rp_gated,
+ * ovis_split_gemm_pair_tn + ovis_slab_reduce_f32 x 3: bit-identical results), the data-gradient chain on `stream`, the three
+ * weight gradients on `side_stream` (NULL = `stream`) ordered against the chain by events; `stream` waits for them before
+ * whatever the caller enqueues next.  channels % 128 == 0, mid_channels % 128 == 0, odd taps. */
+size_t ovis_bottleneck_identity_backward_workspace_bytes(long m, int channels, int mid_channels, int taps_h, int taps_w,
+                                                         int width, int config);
+int ovis_bottleneck_identity_backward(
+    const void* g3_pair, long g3_row_bytes, const void* x_pair, long x_row_bytes, const void* o1_pair, long o1_row_bytes,
+    const void* o2_pair, long o2_row_bytes, const void* t1_pair, long t1_row_bytes, const void* t2_pair, long t2_row_bytes,
+    const void* t3_pair, long t3_row_bytes, const float* scale1, const float* scale2, const float* scale3, long m, int channels,
+    int mid_channels, int taps_h, int taps_w, int height, int width, void* g2_pair, void* g1_pair, void* gx_pair, float* dw1,
+    float* dw2, float* dw3, void* workspace, size_t workspace_bytes, int config, void* stream, void* side_stream);
+
 /* Weight preparation of MANY convolutions in one launch, behind the optimizer step (mb/engine/trainer.py:139; what
  * ovis_weight_prep_pair_f32 does per convolution): items = device array of 64-byte records
  *   {const float* w [N, C, T]; const float* scale [N] or NULL; void* fwd; void* bwd or NULL; long fwd_row_bytes;

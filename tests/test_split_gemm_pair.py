@@ -363,7 +363,7 @@ def test_bottleneck_chain_pair_only_vs_fp32_chain(train):
     assert not is_placeholder(both) and torch.equal(bothp, midp)
     from cvpr22_cross_modal_pseudo_labeling_amd import _C as C
     calls = {"rp_gated": 0, "gate_split": 0}
-    rp_gated, gate_split = C.split_gemm_pair_rp_gated, C.gate_split_pair
+    rp_gated, gate_split, one_call = C.split_gemm_pair_rp_gated, C.gate_split_pair, C.bottleneck_identity_backward
 
     def count(name, fn):
         def wrapped(*a, **k):
@@ -373,10 +373,11 @@ def test_bottleneck_chain_pair_only_vs_fp32_chain(train):
 
     ref = run(False)
     C.split_gemm_pair_rp_gated, C.gate_split_pair = count("rp_gated", rp_gated), count("gate_split", gate_split)
+    C.bottleneck_identity_backward = count("rp_gated", one_call)  # (the one-call backward of a linked identity block ends in it)
     try:
         got = run(True)
     finally:
-        C.split_gemm_pair_rp_gated, C.gate_split_pair = rp_gated, gate_split
+        C.split_gemm_pair_rp_gated, C.gate_split_pair, C.bottleneck_identity_backward = rp_gated, gate_split, one_call
     if train:
         # the two identity blocks hand their input gradient down gated and split (GradLink): one gate + split pass (the
         # gradient entering the chain) instead of three
@@ -782,4 +783,46 @@ def test_weight_prep_plan_equals_per_weight_preparation():
     assert torch.equal(wp["w2"].view(torch.int16), _C.weight_prep_pair(proj[1][0], proj[1][1], True)[0].view(torch.int16))
     assert plan.describes()
     assert plan.lookup("a", (scales_a[0].clone(),) + scales_a[1:]) is None and not plan.describes()
+
+
+@pytest.mark.parametrize("m_hw,cin,mid", [((3, 20, 24), 256, 128), ((2, 50, 84), 1024, 256), ((1, 7, 9), 128, 128)])
+def test_bottleneck_identity_backward_in_one_call_equals_the_separate_launches(m_hw, cin, mid):
+    """``_C.bottleneck_identity_backward`` (one native call: the data-gradient chain on the current stream, the three weight
+    gradients on a second stream) returns exactly what the nine separate wrapper calls of ``_BottleneckPair.backward`` return:
+    same entry points underneath, same plans -- bit for bit, with and without a second stream, with and without scales."""
+    from cvpr22_cross_modal_pseudo_labeling_amd import _C
+
+    r, h, w = m_hw
+    m = r * h * w
+    g = torch.Generator().manual_seed(m + cin)
+
+    def pair(rows, cols, scale=1.0, relu=False):
+        t = torch.randn(rows, cols, generator=g) * scale
+        return _C.split_pair((t.relu() if relu else t).cuda())
+
+    g3p, xp, o1p, o2p = pair(m, cin, 0.1), pair(m, cin, 1.0, True), pair(m, mid, 1.0, True), pair(m, mid, 1.0, True)
+    w1 = (torch.randn(mid, cin, 1, 1, generator=g) * 0.05).cuda()
+    w2 = (torch.randn(mid, mid, 3, 3, generator=g) * 0.05).cuda()
+    w3 = (torch.randn(cin, mid, 1, 1, generator=g) * 0.05).cuda()
+    side = torch.cuda.Stream()
+    for scaled in (True, False):
+        ss = tuple((torch.rand(n, generator=g) + 0.5).cuda() if scaled else None for n in (mid, mid, cin))
+        t1, t2, t3 = (_C.weight_prep_pair(wt, sc, True)[1] for wt, sc in zip((w1, w2, w3), ss))
+        # the separate launches, in the order of _BottleneckPair.backward
+        dw3 = _C.split_gemm_pair_tn(g3p, o2p, None, scale=ss[2], weight_shape=tuple(w3.shape))
+        _, g2p = _C.split_gemm_pair_gated(g3p, t3, o2p)
+        dw2 = _C.split_gemm_pair_tn(g2p, o1p, (h, w, 3, 3), scale=ss[1], weight_shape=tuple(w2.shape))
+        _, g1p = _C.split_gemm_pair_gated(g2p, t2, o1p, conv=(h, w, 3, 3, True))
+        dw1 = _C.split_gemm_pair_tn(g1p, xp, None, scale=ss[0], weight_shape=tuple(w1.shape))
+        _, gx = _C.split_gemm_pair_rp_gated(g1p, t1, g3p, xp)
+        for second in (side, None):
+            got = _C.bottleneck_identity_backward(g3p, xp, o1p, o2p, t1, t2, t3, ss, (h, w, 3, 3),
+                                                  (w1.shape, w2.shape, w3.shape), second)
+            torch.cuda.synchronize()
+            assert torch.equal(got[0].view(torch.int16), gx.view(torch.int16))
+            for a, b, name in zip(got[1:], (dw1, dw2, dw3), ("dw1", "dw2", "dw3")):
+                assert a.shape == b.shape and torch.equal(a, b), (name, scaled, second is not None)
+    with pytest.raises(RuntimeError):
+        _C.bottleneck_identity_backward(g3p, xp, o1p, o2p[:, :-2], t1, t2, t3, (None, None, None), (h, w, 3, 3),
+                                        (w1.shape, w2.shape, w3.shape))
 
