@@ -9,6 +9,7 @@ host tensors (the reference raises "Not implemented on the CPU", csrc/ROIAlign.h
 csrc/SigmoidFocalLoss.h:23,40).
 """
 import contextlib
+import functools
 import ctypes
 import threading
 
@@ -312,7 +313,7 @@ def nms_presorted_batched(boxes, drop, threshold, below=0, ge_mode=False):
         if drop.shape != (n, k):
             raise RuntimeError("nms_presorted_batched: drop must be [N,K] int32")
     with _on(boxes.device):
-        nbytes = _L.ovis_nms_presorted_workspace_bytes(n, k)
+        nbytes = _nms_presorted_ws_bytes(n, k)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=boxes.device)
         rc = _L.ovis_nms_presorted_batched_f32(boxes.data_ptr(), 0 if drop is None else drop.data_ptr(), n, k, threshold,
                                                int(bool(ge_mode)), int(below), ws.data_ptr(), nbytes, keep.data_ptr(),
@@ -336,7 +337,7 @@ def topk_sorted(scores, k):
     idx = torch.empty((n, k), dtype=torch.int64, device=scores.device)
     if n == 0 or k == 0:
         return vals, idx
-    need = _L.ovis_topk_sorted_workspace_bytes(n, a)
+    need = _topk_ws_bytes(n, a)
     if need == 0:
         raise RuntimeError(f"topk_sorted: unsupported size [{n}, {a}]")
     ws = torch.empty((need,), dtype=torch.uint8, device=scores.device)
@@ -866,6 +867,33 @@ def co_scheduled(on=True):
         _GEMM_TLS.co = prev
 
 
+# Size queries of the library are pure functions of their arguments (shape + config bits): asked once per distinct
+# argument tuple, not once per launch -- 98 ctypes round trips per student step for the split GEMM's workspace alone.
+@functools.lru_cache(maxsize=None)
+def _gemm_ws_bytes(m, n, ch, ch2, kh, kw, w, config):
+    return int(_L.ovis_split_gemm_pair_workspace_bytes_ex(m, n, ch, ch2, kh, kw, w, config))
+
+
+@functools.lru_cache(maxsize=None)
+def _tn_slices(m, n, ch, taps):
+    return int(_L.ovis_split_gemm_tn_slices(m, n, ch, taps))
+
+
+@functools.lru_cache(maxsize=None)
+def _gemm_f32_ws_bytes(m, n, k):
+    return int(_L.ovis_gemm_f32_workspace_bytes(m, n, k))
+
+
+@functools.lru_cache(maxsize=None)
+def _nms_presorted_ws_bytes(n, k):
+    return int(_L.ovis_nms_presorted_workspace_bytes(n, k))
+
+
+@functools.lru_cache(maxsize=None)
+def _topk_ws_bytes(n, a):
+    return int(_L.ovis_topk_sorted_workspace_bytes(n, a))
+
+
 def _gemm_cfg(config):
     return config | (0x10000 if getattr(_GEMM_TLS, "co", False) else 0)
 
@@ -912,7 +940,7 @@ def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f3
             raise RuntimeError("split_gemm_pair: residual_pair must be [M, 2N] bfloat16 pair rows of a plain product")
         with _on(dev):
             config = _gemm_cfg(config)
-            nbytes = _L.ovis_split_gemm_pair_workspace_bytes_ex(m, n, ch, 0, 1, 1, 0, config) if not (config & 8) else 0
+            nbytes = _gemm_ws_bytes(m, n, ch, 0, 1, 1, 0, config) if not (config & 8) else 0
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
             rc = _L.ovis_split_gemm_pair_rp(a_pair.data_ptr(), 2 * a_pair.stride(0), b_pair.data_ptr(), 2 * b_pair.stride(0),
                                             0 if c is None else c.data_ptr(), n, 0 if cp is None else cp.data_ptr(), 4 * n,
@@ -926,7 +954,7 @@ def split_gemm_pair(a_pair, b_pair, bias=None, residual=None, relu=False, out_f3
         raise RuntimeError("split_gemm_pair: residual must be a float32 [M, N] HIP tensor with unit column stride")
     with _on(dev):
         config = _gemm_cfg(config)
-        nbytes = _L.ovis_split_gemm_pair_workspace_bytes_ex(m, n, ch, ch2, kh, kw, w, config) if not (config & 8) else 0
+        nbytes = _gemm_ws_bytes(m, n, ch, ch2, kh, kw, w, config) if not (config & 8) else 0
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
         rc = _L.ovis_split_gemm_pair(a_pair.data_ptr(), 2 * a_pair.stride(0),
                                      0 if a2_pair is None else a2_pair.data_ptr(),
@@ -1019,7 +1047,7 @@ def split_gemm_pair_gated(a_pair, b_pair, gate_pair, conv=None, out_f32=False, o
     with _on(dev):
         # under-filled grids take the plan's K slices (the slab reduction applies the gate)
         config = _gemm_cfg(config)
-        nbytes = _L.ovis_split_gemm_pair_workspace_bytes_ex(m, n, ch, 0, kh, kw, w, config) if not (config & 8) else 0
+        nbytes = _gemm_ws_bytes(m, n, ch, 0, kh, kw, w, config) if not (config & 8) else 0
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
         rc = _L.ovis_split_gemm_pair_gated_ws(a_pair.data_ptr(), 2 * a_pair.stride(0), b_pair.data_ptr(),
                                               2 * b_pair.stride(0), 0 if c is None else c.data_ptr(), n,
@@ -1086,7 +1114,7 @@ def split_gemm_pair_tn(g_pair, x_pair, conv=None, scale=None, weight_shape=None)
     if m == 0:
         z = torch.zeros((n, kh * kw * ch), dtype=torch.float32, device=dev)
         return z if weight_shape is None else z.new_zeros(weight_shape)
-    slices = _L.ovis_split_gemm_tn_slices(m, n, ch, kh * kw)
+    slices = _tn_slices(m, n, ch, kh * kw)
     slabs = torch.empty((slices, n, kh * kw * ch), dtype=torch.float32, device=dev)
     with _on(dev):
         rc = _L.ovis_split_gemm_pair_tn(g_pair.data_ptr(), 2 * g_pair.stride(0), x_pair.data_ptr(), 2 * x_pair.stride(0),
@@ -1270,7 +1298,7 @@ def _gemm_raw(a_ptr, a_rs, a_ks, b_ptr, b_rs, b_ks, c_ptr, c_rs, m, n, k, bias_p
               accumulate=0, device=None):
     """C = alpha * A . B^T (+ C) + bias on raw pointers.  Products with too few tiles to fill the chip are cut along K
     into slabs of a workspace allocated here (summed in slice order by the library: no atomics)."""
-    ws_bytes = _L.ovis_gemm_f32_workspace_bytes(m, n, k)
+    ws_bytes = _gemm_f32_ws_bytes(m, n, k)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=device or torch.device("cuda", torch.cuda.current_device())) \
         if ws_bytes else None
     rc = _L.ovis_gemm_ex_ws_f32(a_ptr, a_rs, a_ks, b_ptr, b_rs, b_ks, bias_ptr, bias_per_row, alpha, accumulate, c_ptr,
