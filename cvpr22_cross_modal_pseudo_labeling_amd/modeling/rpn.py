@@ -405,7 +405,10 @@ class _BranchRunAhead(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, done, pre, feature, *loss_and_params):
-        ctx.done, ctx.pre = done, pre  # event on the branch's stream; [d/d feature, d/d parameter ...] for unit loss gradients
+        # done = (event behind the branch's loss forward, event behind its backward) on the branch's stream;
+        # pre = [d/d feature, d/d parameter ...] for unit loss gradients
+        ctx.done, ctx.pre = done[1], pre
+        torch.cuda.current_stream().wait_event(done[0])  # whoever reads the loss values from here on finds them written
         return (feature.view_as(feature),) + tuple(t.view_as(t) for t in loss_and_params[:2])
 
     @staticmethod
@@ -413,6 +416,8 @@ class _BranchRunAhead(torch.autograd.Function):
         main = torch.cuda.current_stream()
         main.wait_event(ctx.done)
         pre = ctx.pre
+        if all(t is None for t in pre):  # the branch reaches neither the feature nor a parameter
+            return (None, None, g_feature if ctx.needs_input_grad[2] else None, None, None) + (None,) * (len(pre) - 1)
         for t in pre:
             if t is not None:
                 t.record_stream(main)
@@ -522,6 +527,8 @@ class RPNModule(nn.Module):  # rpn.py:109-197
                 launched = sel.launch(anchors, objectness.detach(), box_regression.detach())
         with torch.cuda.stream(side):
             lo, lb = self.loss_evaluator(anchors, objectness, box_regression, targets)
+            loss_done = torch.cuda.Event()
+            loss_done.record(side)
             wrt = ([branch_in] if branch_in.requires_grad else []) + params
             grads = list(torch.autograd.grad([lo + lb], wrt, allow_unused=True))
             pre = grads if branch_in.requires_grad else [None] + grads
@@ -532,7 +539,7 @@ class RPNModule(nn.Module):  # rpn.py:109-197
         with torch.no_grad():
             boxes = (sel.finish(launched, targets, add_gt=True) if on_device else
                      sel(anchors, objectness.detach(), box_regression.detach(), targets, add_gt=True))
-        joined, lo, lb = _BranchRunAhead.apply(done, pre, feature, lo.detach(), lb.detach(), *params)
+        joined, lo, lb = _BranchRunAhead.apply((loss_done, done), pre, feature, lo.detach(), lb.detach(), *params)
         return boxes, {"loss_objectness": lo, "loss_rpn_box_reg": lb}, [joined] + list(features[1:])
 
     def runs_ahead(self, features):
