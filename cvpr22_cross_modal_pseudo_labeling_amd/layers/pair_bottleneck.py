@@ -88,15 +88,16 @@ class WeightPrepPlan:
     head of the teacher step's GEMMs).  ``blocks``: [(key, [(w, scale) for conv1, conv2, conv3, (downsample)])], or
     [(key, [(w, scale)])] for a lone convolution (``conv_same_pair``: the RPN head's 3x3); the conv3
     and downsample forward matrices of a projection block are written side by side into ONE [N, 2 (K3 + Kd)] matrix (the
-    operand of the fused conv3 + shortcut product).  ``run()`` after every optimizer step; ``lookup(key)`` hands a block its
-    ``wpairs`` dict while nothing has touched its weights since (``_WEIGHTS_EPOCH`` for raw-pointer writers, the tensors'
-    version counters for everything else) -- else None, and the block prepares its weights itself as before."""
+    operand of the fused conv3 + shortcut product).  ``run()`` after every optimizer step; ``lookup(key, scales)`` hands a
+    block its ``wpairs`` dict while nothing has touched its weights since (``_WEIGHTS_EPOCH`` for raw-pointer writers, the
+    tensors' version counters for everything else, identity of the FrozenBN scale tensors) -- else None, and the block
+    prepares its weights itself as before."""
 
     def __init__(self, blocks):
         import numpy as np
         tile = _C.weight_prep_tile()
         self.max_taps = 1
-        self.entries, self.tensors = {}, {}
+        self.entries = {}
         rows, blk = [], []
         dev = blocks[0][1][0][0].device
         for key, convs in blocks:
