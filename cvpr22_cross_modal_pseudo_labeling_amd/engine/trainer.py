@@ -129,6 +129,15 @@ def side_stream(priority):
     return _SIDE_STREAMS[key]
 
 
+def branch_stream():
+    """The stream a step's independent branches run on beside the main one (the teacher's RPN branch and its backward,
+    the trunk's weight gradients): the SAME side stream the look-ahead half of ``PipelinedTrainer`` uses -- that half is done
+    long before a step reaches its RPN, and with the copy stream and RCCL's own a process then stays at the four hardware
+    queues HIP multiplexes streams onto (a fifth stream shares the compute stream's queue: the 31-vs-23 ms lesson of round 5).
+    A/B against a stream of its own: equal (profiles/r6_ab_one_side_stream.txt)."""
+    return side_stream(-1)
+
+
 class PipelinedTrainer:
     """Student-teacher step, software-pipelined across iterations on two HIP streams.
 

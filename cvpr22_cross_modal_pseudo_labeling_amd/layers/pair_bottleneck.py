@@ -342,9 +342,9 @@ class _BottleneckPair(Function):
                 and n3 % 128 == 0 and w1.shape[0] % 128 == 0 and kh % 2 == 1 and kw % 2 == 1):
             # an identity block in the middle of a small pair-only chain (the trunk): its nine launches behind one native
             # call, the three weight gradients on the second stream beside the data-gradient chain
-            from ..engine.trainer import side_stream
+            from ..engine.trainer import branch_stream
             gx, dw1, dw2, dw3 = _C.bottleneck_identity_backward(g3p, xp, o1p, o2p, t1, t2, t3, (s1, s2, s3), (h, w, kh, kw),
-                                                               (w1.shape, w2.shape, w3.shape), side_stream(0))
+                                                               (w1.shape, w2.shape, w3.shape), branch_stream())
             link_in.grad_pair = gx
             dx = nan_placeholder(gx.device, xp.shape[0], xp.shape[1] // 2)
             return (dx, None, None, dw1, None, None, dw2, None, None, dw3, None, None, None, None, None, None, None, None, None,

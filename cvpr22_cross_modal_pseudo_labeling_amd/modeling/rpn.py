@@ -476,8 +476,8 @@ class RPNModule(nn.Module):  # rpn.py:109-197
             sel = self.box_selector_train
             beside = compute_loss and objectness.is_cuda and self.loss_beside_selection and sel._on_device(objectness)
             if beside:
-                from ..engine.trainer import side_stream
-                main, side = torch.cuda.current_stream(), side_stream(0)
+                from ..engine.trainer import branch_stream
+                main, side = torch.cuda.current_stream(), branch_stream()
                 side.wait_stream(main)
                 with torch.no_grad():
                     launched = sel.launch(anchors, objectness, box_regression)  # its launches first: they are the critical path
@@ -506,9 +506,9 @@ class RPNModule(nn.Module):  # rpn.py:109-197
         to the graph through ``_BranchRunAhead`` so that the trunk receives box-head + RPN gradient and the head's parameters
         theirs when (and only if) the caller's backward arrives.  Same kernels on the same operands as ``forward``:
         losses and gradients are bit-identical (tests/test_model_gpu.py)."""
-        from ..engine.trainer import side_stream
+        from ..engine.trainer import branch_stream
         feature = features[0]
-        main, side = torch.cuda.current_stream(), side_stream(0)
+        main, side = torch.cuda.current_stream(), branch_stream()
         anchors = self.anchor_generator(images.image_sizes, feature)
         params = [p for p in self.head.parameters() if p.requires_grad]
         side.wait_stream(main)
