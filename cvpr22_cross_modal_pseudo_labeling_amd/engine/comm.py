@@ -94,6 +94,7 @@ class BucketedGradReducer:
         self.flat, self.pending, self.handles, self.launched = [], [], [], []
         self._hooks = []
         self._next = 0  # first bucket whose all-reduce has not been issued yet
+        self._hook_streams = []  # per bucket: the streams its gradients were accumulated on this step (device runs, world > 1)
         for bi, bucket in enumerate(self.buckets):
             flat = torch.zeros(sum(p.numel() for p in bucket), dtype=bucket[0].dtype, device=bucket[0].device)
             off = 0
@@ -102,6 +103,7 @@ class BucketedGradReducer:
                 off += p.numel()
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
             self.flat.append(flat)
+            self._hook_streams.append(set())
             self.pending.append(self._expected(bucket))
             self.handles.append(None)
             self.launched.append(False)
@@ -117,6 +119,10 @@ class BucketedGradReducer:
                                        "its bucket was reduced")
                 return
             self.pending[bi] -= 1
+            if self.world > 1 and param.is_cuda:
+                # autograd accumulates a gradient on the stream its parameter was first used on in the forward (the teacher
+                # step's RPN head runs on the side stream): remember it, the bucket's collective must be ordered behind it
+                self._hook_streams[bi].add(torch.cuda.current_stream())
             before = self._next
             self._launch_ready()
             self.hook_launches += self._next - before
@@ -132,6 +138,13 @@ class BucketedGradReducer:
 
     def _launch(self, bi):
         self.launched[bi] = True
+        if self.world > 1 and self._hook_streams[bi]:
+            # The collective is ordered behind the stream it is issued from.  Gradients of this bucket that were accumulated
+            # on ANOTHER stream (see the hook) are only ordered against that one: make the issuing stream wait for each.
+            cur = torch.cuda.current_stream()
+            for st in self._hook_streams[bi]:
+                if st != cur:
+                    cur.wait_stream(st)
         if self.world > 1:
             op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
             self.handles[bi] = dist.all_reduce(self.flat[bi], op=op, async_op=True)
@@ -149,6 +162,7 @@ class BucketedGradReducer:
             self.pending[bi] = self._expected(bucket)
             self.handles[bi] = None
             self.launched[bi] = False
+            self._hook_streams[bi].clear()
             off, base, esz = 0, flat.data_ptr(), flat.element_size()
             for p in bucket:  # pointer comparison only: no tensor op per parameter on the per-step path
                 # (a parameter frozen during the run keeps its view: the slot stays zero on every rank, and the optimizer goes
