@@ -1,3 +1,7 @@
+"""Under which stream do the gradient reducer's accumulate hooks fire?  Tiny teacher model, two steps; prints, per probed
+parameter, "main" or the other stream -- the RPN head's (forward on the side stream since round 6) arrive under the side stream,
+which is why engine/comm.py orders a bucket's collective behind every stream its hooks fired under.
+python tools/experiments/hook_stream_probe.py"""
 import os, sys, torch, warnings
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT))

@@ -1,3 +1,6 @@
+"""Where the RPN's NMS survivors sit among the 12000 score-sorted candidates of the bench's teacher model and data: survivors
+per image, index of the 1000th / 2000th (what a scan that stops at post_nms_top_n could skip).
+python tools/experiments/nms_survivor_probe.py"""
 import os, sys, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT)
 from cvpr22_cross_modal_pseudo_labeling_amd import _C

@@ -1,3 +1,6 @@
+"""Kernel by kernel (start, end, us, queue, stream, name) through the trunk backward of one steady-state teacher step, from a
+rocprofv3 --kernel-trace CSV: shows which launches of the two streams actually overlap and what they cost beside each other.
+python tools/experiments/step_tail_trace.py trace.csv"""
 import csv, sys, re
 rows=[]
 with open(sys.argv[1], newline="") as f:
