@@ -47,10 +47,13 @@ __global__ __launch_bounds__(kPrepThreads) void weight_prep_pair_multi_kernel(co
   const int tiles_c = C / kPrepTile;
   const int n0 = (bc.y / tiles_c) * kPrepTile, c0 = (bc.y % tiles_c) * kPrepTile;
   const int row = kPrepTile * T, S = row + 1;
-  for (int idx = threadIdx.x; idx < kPrepTile * row; idx += kPrepThreads) {
-    const int r = idx / row, j = idx - r * row;
+  const int row4 = row >> 2;  // 32 T floats per output channel = 8 T 16-byte loads (c0 * T * 4 bytes is a multiple of 128)
+  for (int idx = threadIdx.x; idx < kPrepTile * row4; idx += kPrepThreads) {
+    const int r = idx / row4, j = (idx - r * row4) * 4;
     const float sc = it.scale ? it.scale[n0 + r] : 1.f;
-    tile[r * S + j] = it.w[((long)(n0 + r) * C + c0) * T + j] * sc;
+    const float4 v = *(const float4*)(it.w + ((long)(n0 + r) * C + c0) * T + j);
+    float* d = tile + r * S + j;
+    d[0] = v.x * sc; d[1] = v.y * sc; d[2] = v.z * sc; d[3] = v.w * sc;
   }
   __syncthreads();
   const int tasks = kPrepTile * T * 4;
