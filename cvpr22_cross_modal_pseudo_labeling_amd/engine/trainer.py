@@ -76,8 +76,12 @@ def train_step(model, optimizer, reducer, images, targets, scheduler=None, polic
     """One iteration of the loop (an optimisation step unless ``policy`` accumulates); returns the (un-reduced) loss dict
     of this rank."""
     policy = policy or _default_policy(reducer)
-    policy.begin(reducer)
     loss_dict = model(images, targets)
+    # (the reference zeroes the gradients right behind ``optimizer.step()``, engine/trainer.py:139-141; any point in front of
+    # the backward is equivalent.  Here: between forward and backward, so that the 0.4 ms of host time of re-arming the reducer
+    # -- 110 parameters' slots checked -- fall where the device has the forward queued, not at the step boundary; the step
+    # itself measured equal either way: tools/experiments/boundary_probe.py, ab_bench.py begin_first)
+    policy.begin(reducer)
     losses = policy.scale(total_loss(loss_dict))
     losses.backward()
     policy.end(reducer, optimizer, scheduler, iteration, model)
@@ -225,8 +229,8 @@ class PipelinedTrainer:
         _record_stream(frozen, main)
         if next_batch is not None and self.threaded:
             self._launch_frozen(next_batch[0], next_batch[1], inputs_ready, threaded=True)
-        self.policy.begin(self.reducer)
         loss_dict = self.model.forward_student(frozen, targets)
+        self.policy.begin(self.reducer)  # behind the forward's launches: see train_step
         losses = self.policy.scale(total_loss(loss_dict))
         losses.backward()
         self.policy.end(self.reducer, self.optimizer, self.scheduler, iteration, self.model)

@@ -2,7 +2,7 @@
     python tools/experiments/ab_bench.py <patch> [bench args...]
 runs bench.py alternately unpatched (A) and with the named monkeypatch applied (B), three times each, and prints ms per step.
 Patches: nopool (the res5 head's average pooling as a separate pass), rpnloss_ops (the RPN loss as its tensor-op sequence;
-use with --workload teacher), lib:<variant> (a variant library of build_variants.sh), side_prio0 (the frozen half's stream at normal priority), no_prefix (teacher step without the frozen trunk prefix run ahead on the side stream; --workload teacher), gated_nosplit (gated data gradients never K-sliced, the form before round 4's _ws entry point; --workload teacher), rpnloss_one_stream (the teacher's RPN loss on the main stream, after the selection; --workload teacher), rpn_no_ahead (the teacher's RPN backward inside the step's backward instead of run ahead on the second stream; --workload teacher), teacher_heads_plain (the teacher's heads through CombinedROIHeads.forward instead of the one-branch batched form; --workload teacher), drop_trunk_dw (WRONG RESULTS, a bound: the bottlenecks' weight gradients are computed but not handed to autograd -- what their AccumulateGrad adds cost), memo_weight_prep (WRONG RESULTS, a bound: pair forms of the trainable weights computed once and never again -- what the per-step weight preparation costs the step), inline_weight_prep (every trainable block prepares its own GEMM operands in its forward instead of finding them prepared behind the optimizer step), nms_full_scan (the RPN's NMS reduce over all 12000 candidates instead of stopping at post_nms_top_n survivors), block_backward_by_calls (the trunk's identity bottlenecks issue their backward launch by launch on one stream instead of through the one-call, two-stream entry point; --workload teacher), own_branch_stream (the RPN branch and the trunk's weight gradients on a side stream of their own instead of the look-ahead half's; --workload teacher), torch_topk (the RPN's sorted top-k through the tensor library instead of the one-radix-sort op), foreach_sgd (the optimizer step as six multi-tensor passes instead of the fused launch)."""
+use with --workload teacher), lib:<variant> (a variant library of build_variants.sh), side_prio0 (the frozen half's stream at normal priority), no_prefix (teacher step without the frozen trunk prefix run ahead on the side stream; --workload teacher), gated_nosplit (gated data gradients never K-sliced, the form before round 4's _ws entry point; --workload teacher), rpnloss_one_stream (the teacher's RPN loss on the main stream, after the selection; --workload teacher), rpn_no_ahead (the teacher's RPN backward inside the step's backward instead of run ahead on the second stream; --workload teacher), teacher_heads_plain (the teacher's heads through CombinedROIHeads.forward instead of the one-branch batched form; --workload teacher), drop_trunk_dw (WRONG RESULTS, a bound: the bottlenecks' weight gradients are computed but not handed to autograd -- what their AccumulateGrad adds cost), memo_weight_prep (WRONG RESULTS, a bound: pair forms of the trainable weights computed once and never again -- what the per-step weight preparation costs the step), inline_weight_prep (every trainable block prepares its own GEMM operands in its forward instead of finding them prepared behind the optimizer step), nms_full_scan (the RPN's NMS reduce over all 12000 candidates instead of stopping at post_nms_top_n survivors), block_backward_by_calls (the trunk's identity bottlenecks issue their backward launch by launch on one stream instead of through the one-call, two-stream entry point; --workload teacher), own_branch_stream (the RPN branch and the trunk's weight gradients on a side stream of their own instead of the look-ahead half's; --workload teacher), begin_first (the gradient buffers zeroed and the reducer re-armed in FRONT of the forward, the order until round 6, instead of behind its launches), torch_topk (the RPN's sorted top-k through the tensor library instead of the one-radix-sort op), foreach_sgd (the optimizer step as six multi-tensor passes instead of the fused launch)."""
 import json
 import os
 import subprocess
@@ -46,6 +46,15 @@ PATCHES = {
     "block_backward_by_calls": "from cvpr22_cross_modal_pseudo_labeling_amd.layers import pair_bottleneck as _p; _p.ONE_CALL_BACKWARD_ROWS = 0",
     "own_branch_stream": ("from cvpr22_cross_modal_pseudo_labeling_amd.engine import trainer as _t\n"
                           "_t.branch_stream = lambda: _t.side_stream(0)"),
+    "begin_first": ("from cvpr22_cross_modal_pseudo_labeling_amd.engine import trainer as _t; _P = _t.PipelinedTrainer; _i = _P.__init__\n"
+                    "def _init(self, model, *a, **k):\n"
+                    "    _i(self, model, *a, **k)\n"
+                    "    fs = model.forward_student\n"
+                    "    def first(frozen, targets, **kw):\n"
+                    "        self.policy.begin(self.reducer); self.policy.begin = lambda r: None\n"
+                    "        try:\n            return fs(frozen, targets, **kw)\n        finally:\n            del self.policy.begin\n"
+                    "    model.forward_student = first\n"
+                    "_P.__init__ = _init"),
     "torch_topk": "from cvpr22_cross_modal_pseudo_labeling_amd import _C; _C.topk_sorted = lambda s, k: s.topk(k, dim=1, sorted=True)",
     "foreach_sgd": "from cvpr22_cross_modal_pseudo_labeling_amd.engine import solver as _s; _s.GroupFusedSGD.native = False",
 }
