@@ -408,19 +408,21 @@ class _BranchRunAhead(torch.autograd.Function):
         # done = (event behind the branch's loss forward, event behind its backward) on the branch's stream;
         # pre = [d/d feature, d/d parameter ...] for unit loss gradients
         ctx.done, ctx.pre = done[1], pre
-        torch.cuda.current_stream().wait_event(done[0])  # whoever reads the loss values from here on finds them written
+        if done[0] is not None:  # (None, None): everything on one stream / host tensors -- the algebra alone, as the CPU test uses it
+            torch.cuda.current_stream().wait_event(done[0])  # whoever reads the loss values from here on finds them written
         return (feature.view_as(feature),) + tuple(t.view_as(t) for t in loss_and_params[:2])
 
     @staticmethod
     def backward(ctx, g_feature, g_lo, g_lb):
-        main = torch.cuda.current_stream()
-        main.wait_event(ctx.done)
         pre = ctx.pre
+        if ctx.done is not None:
+            main = torch.cuda.current_stream()
+            main.wait_event(ctx.done)
+            for t in pre:
+                if t is not None:
+                    t.record_stream(main)
         if all(t is None for t in pre):  # the branch reaches neither the feature nor a parameter
             return (None, None, g_feature if ctx.needs_input_grad[2] else None, None, None) + (None,) * (len(pre) - 1)
-        for t in pre:
-            if t is not None:
-                t.record_stream(main)
         ref = next(t for t in pre if t is not None)
         zero = ref.new_zeros(())
         g_lo = zero if g_lo is None else g_lo.reshape(())

@@ -592,3 +592,40 @@ def test_accumulation_windows_follow_iteration_numbers_like_the_reference_loop()
     reducer.remove()
     assert steps == steps_r == [6, 9]
     assert torch.allclose(mine.weight, ref.weight, rtol=1e-6, atol=1e-7) and torch.allclose(mine.bias, ref.bias, rtol=1e-6, atol=1e-7)
+
+
+def test_branch_run_ahead_joins_precomputed_gradients_to_the_graph():
+    """``modeling.rpn._BranchRunAhead`` (the node that joins the teacher step's run-ahead RPN branch to the graph), on host
+    tensors and without streams: identity on the feature and the loss values; the backward hands on the incoming feature
+    gradient plus the branch's pre-computed one and the parameters' pre-computed gradients, each times the gradient the loss
+    values receive (1 for a plain sum, 1 / k inside an accumulation window); two loss terms weighted differently give NaN
+    instead of silently wrong gradients; a branch that reaches no parameter at all passes the feature gradient through."""
+    from cvpr22_cross_modal_pseudo_labeling_amd.modeling.rpn import _BranchRunAhead
+
+    g = torch.Generator().manual_seed(3)
+    feature = torch.randn(2, 3, 4, 5, generator=g, requires_grad=True)
+    params = [torch.randn(4, 3, generator=g, requires_grad=True), torch.randn(4, generator=g, requires_grad=True),
+              torch.randn(2, generator=g, requires_grad=True)]
+    pre = [torch.randn(2, 3, 4, 5, generator=g), torch.randn(4, 3, generator=g), None, torch.randn(2, generator=g)]
+    lo, lb = torch.tensor(0.7), torch.tensor(1.9)
+
+    def run(scale_lo, scale_lb, pre_=pre):
+        for t in [feature] + params:
+            t.grad = None
+        joined, lo2, lb2 = _BranchRunAhead.apply((None, None), pre_, feature, lo, lb, *params)
+        assert torch.equal(joined, feature) and float(lo2.detach()) == float(lo) and float(lb2.detach()) == float(lb)
+        assert lo2.requires_grad and lb2.requires_grad
+        ((joined * 2.0).sum() + scale_lo * lo2 + scale_lb * lb2).backward()
+        return feature.grad, [p.grad for p in params]
+
+    for s in (1.0, 0.5):
+        gf, gp = run(s, s)
+        assert torch.equal(gf, 2.0 + s * pre[0])
+        assert torch.equal(gp[0], s * pre[1]) and gp[1] is None and torch.equal(gp[2], s * pre[3])
+    gf, gp = run(1.0, 0.25)
+    assert torch.isnan(gf).all() and torch.isnan(gp[0]).all() and torch.isnan(gp[2]).all()
+    gf, gp = run(1.0, 1.0, [None, None, None, None])
+    assert torch.equal(gf, torch.full_like(feature, 2.0)) and all(x is None for x in gp)
+    gf, gp = run(1.0, 1.0, [None] + pre[1:])   # a frozen trunk: only the head trains
+    assert torch.equal(gf, torch.full_like(feature, 2.0)) and torch.equal(gp[0], pre[1])
+
