@@ -278,3 +278,33 @@ def test_second_sigterm_does_not_cut_the_cleanup_short(tmp_path):
         except (ProcessLookupError, FileNotFoundError):
             alive = False
         assert not alive, pid
+
+
+def test_every_ab_bench_switch_is_valid_python_and_names_something_that_exists():
+    """``tools/experiments/ab_bench.py`` turns a product switch off by exec'ing a monkeypatch in front of ``bench.main()``: every
+    patch string compiles, and every ``from <package>... import X`` / attribute it touches exists (a renamed switch would
+    otherwise make the B side silently equal to the A side -- or fail only on the GPU box)."""
+    import importlib
+    import re
+    import sys as _sys
+
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "experiments")
+    _sys.path.insert(0, tools)
+    try:
+        ab_bench = importlib.import_module("ab_bench")
+    finally:
+        _sys.path.remove(tools)
+    assert len(ab_bench.PATCHES) >= 15
+    for name in ab_bench.PATCHES:
+        code = ab_bench._patch_code(name)
+        compile(code, name, "exec")
+        for mod, attr in re.findall(r"from (cvpr22_cross_modal_pseudo_labeling_amd[\w.]*) import (\w+)", code):
+            m = importlib.import_module(mod)
+            assert hasattr(m, attr) or importlib.util.find_spec(f"{mod}.{attr}") is not None, (name, mod, attr)
+    # the switches the shipped tree documents in DESIGN.md / profiles
+    for switch, where in (("loss_beside_selection", "modeling.rpn"), ("backward_ahead", "modeling.rpn"),
+                          ("heads_as_one_branch", "modeling.detector"), ("ONE_CALL_BACKWARD_ROWS", "layers.pair_bottleneck"),
+                          ("prepare_weights_ahead", "engine.trainer"), ("branch_stream", "engine.trainer")):
+        src = open(os.path.join(os.path.dirname(tools), "..", "cvpr22_cross_modal_pseudo_labeling_amd", *where.split(".")) + ".py").read()
+        assert switch in src, (switch, where)
+
