@@ -285,6 +285,7 @@ def test_every_ab_bench_switch_is_valid_python_and_names_something_that_exists()
     patch string compiles, and every ``from <package>... import X`` / attribute it touches exists (a renamed switch would
     otherwise make the B side silently equal to the A side -- or fail only on the GPU box)."""
     import importlib
+    import importlib.util
     import re
     import sys as _sys
 
